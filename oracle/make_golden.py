@@ -1,0 +1,343 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE itself on the CPU.
+
+Run in the build container only (``/root/reference`` never travels to the GPU box):
+
+    python oracle/make_golden.py            # writes tests/golden/*.npz and checks the oracle against them
+
+The reference's model modules import two packages that are not installed here:
+  * ``wandb`` (model_interface.py:9) -- logging only; an empty stand-in module is enough;
+  * ``rotary_embedding_torch`` (unet1d.py:16) -- carries arithmetic (RoPE on q/k of the bottleneck
+    attention).  The stand-in written below restates that package's published default behaviour; fixtures
+    are produced both with it and with RoPE disabled (identity) so that everything except RoPE is pinned by
+    the reference exactly.  RoPE itself stays "parity unpinned" (see oracle/dq_oracle.py header).
+Both stand-ins are written to a temporary directory outside the repository at run time.
+
+Fixtures are data only: seeded inputs, the weights the reference drew, and the reference's outputs.
+"""
+import os
+import sys
+import tempfile
+import textwrap
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("DQ_REFERENCE", "/root/reference")
+OUT = os.path.join(REPO, "tests", "golden")
+
+WANDB_STUB = """
+def init(*a, **k): return None
+def log(*a, **k): return None
+def finish(*a, **k): return None
+class Settings:
+    def __init__(self, *a, **k): pass
+class Table:
+    def __init__(self, *a, **k): pass
+    def add_data(self, *a, **k): pass
+class Image:
+    def __init__(self, *a, **k): pass
+class Html:
+    def __init__(self, *a, **k): pass
+"""
+
+ROPE_STUB = """
+import torch
+from torch import nn
+class RotaryEmbedding(nn.Module):
+    IDENTITY = False
+    def __init__(self, dim, theta=10000):
+        super().__init__()
+        freqs = 1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim))
+        self.freqs = nn.Parameter(freqs, requires_grad=False)
+    def rotate_queries_or_keys(self, t, seq_dim=-2):
+        if RotaryEmbedding.IDENTITY:
+            return t
+        n = t.shape[seq_dim]
+        pos = torch.arange(n, device=t.device, dtype=t.dtype)
+        f = torch.einsum("n,f->nf", pos, self.freqs.to(t.dtype)).repeat_interleave(2, dim=-1)
+        rot = f.shape[-1]
+        tm, tr = t[..., :rot], t[..., rot:]
+        x = tm.reshape(*tm.shape[:-1], rot // 2, 2)
+        rh = torch.stack((-x[..., 1], x[..., 0]), dim=-1).reshape(tm.shape)
+        return torch.cat((tm * f.cos() + rh * f.sin(), tr), dim=-1)
+"""
+
+
+def _import_reference():
+    stubs = tempfile.mkdtemp(prefix="dq_stubs_")
+    with open(os.path.join(stubs, "wandb.py"), "w") as f:
+        f.write(textwrap.dedent(WANDB_STUB))
+    with open(os.path.join(stubs, "rotary_embedding_torch.py"), "w") as f:
+        f.write(textwrap.dedent(ROPE_STUB))
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    sys.path.insert(0, stubs)
+    import rotary_embedding_torch as rope  # noqa
+    from dquartic.model import model as ref_model  # noqa
+    from dquartic.model import unet1d as ref_unet  # noqa
+
+    return ref_model, ref_unet, rope
+
+
+def npd(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def sd_np(module, prefix="w/"):
+    return {prefix + k: v.detach().cpu().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def randomize_(module, gen):
+    """Perturb every parameter (incl. the norm gains, which start at 1) so that no fixture hides a
+    transposed or ignored weight."""
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if n.endswith("rotary_emb.freqs"):
+                continue
+            p.add_(0.1 * torch.randn(p.shape, generator=gen))
+
+
+def main():
+    ref_model, U, rope = _import_reference()
+    os.makedirs(OUT, exist_ok=True)
+    sys.path.insert(0, REPO)
+    from oracle import dq_oracle as O
+
+    # ---------------------------------------------------------------- 1. schedules
+    sch = {}
+    for kind in ("cosine", "linear"):
+        betas = (ref_model.get_linear_beta_schedule(1000) if kind == "linear" else ref_model.get_cosine_beta_schedule(1000)).to(torch.float32)
+        alphas = ref_model.get_alphas(betas).to(torch.float32)
+        abar = ref_model.get_alpha_bars(alphas).to(torch.float32)
+        sch.update({f"{kind}/betas": betas, f"{kind}/alphas": alphas, f"{kind}/alpha_bars": abar})
+        mine = O.make_schedule(1000, kind)
+        for k in ("betas", "alphas", "alpha_bars"):
+            assert torch.equal(mine[k], sch[f"{kind}/{k}"]), (kind, k)
+    sch["timesteps50"] = torch.linspace(999, 0, 50, dtype=torch.long)
+    sch["timesteps5"] = torch.linspace(999, 0, 5, dtype=torch.long)
+    np.savez_compressed(os.path.join(OUT, "schedule.npz"), **npd(sch))
+
+    # ---------------------------------------------------------------- 2. per-block fixtures
+    g = torch.Generator().manual_seed(1234)
+    blk = {}
+
+    def rnd(*shape):
+        return torch.randn(*shape, generator=g)
+
+    # RMSNorm incl. an all-zero column (the eps clamp) -- unet1d.py:140
+    for C in (4, 12):
+        m = U.RMSNorm(C)
+        randomize_(m, g)
+        x = rnd(3, C, 8)
+        x[0, :, 2] = 0.0
+        blk.update({f"rmsnorm{C}/x": x, f"rmsnorm{C}/g": m.g, f"rmsnorm{C}/y": m(x)})
+    # time embedding + MLP -- unet1d.py:956-960
+    tm = torch.nn.Sequential(U.SinusoidalPosEmb(4), torch.nn.Linear(4, 16), torch.nn.GELU(), torch.nn.Linear(16, 16))
+    randomize_(tm, g)
+    tt = torch.tensor([0, 1, 20, 500, 999])
+    blk.update({"time/t": tt, "time/sinu": U.SinusoidalPosEmb(4)(tt), "time/out": tm(tt)})
+    blk.update({"time/" + k: v for k, v in tm.state_dict().items()})
+    # ConditionalScaleShift at B=1 -- unet1d.py:662-678
+    css = U.ConditionalScaleShift(16, 1)
+    randomize_(css, g)
+    x, te = rnd(5, 1, 8), rnd(1, 16)
+    blk.update({"css/x": x, "css/temb": te, "css/y": css(x, te)})
+    blk.update({"css/" + k: v for k, v in css.state_dict().items()})
+    # ResnetBlock with / without res_conv, with time embedding, B=1 -- unet1d.py:271-323
+    for name, (ci, co, n) in {"res_4_4_64": (4, 4, 64), "res_24_12_4": (24, 12, 4), "res_32_16_1": (32, 16, 1), "res_8_4_64": (8, 4, 64)}.items():
+        rb = U.ResnetBlock(ci, co, time_emb_dim=16)
+        randomize_(rb, g)
+        x, te = rnd(3, ci, n), rnd(1, 16)
+        blk.update({f"{name}/x": x, f"{name}/temb": te, f"{name}/y": rb(x, te)})
+        blk.update({f"{name}/w/" + k: v for k, v in rb.state_dict().items()})
+    # Residual(PreNorm(LinearAttention)) -- unet1d.py:446-496, 1017
+    for C, n in ((4, 64), (4, 32), (8, 16), (12, 4), (12, 2), (16, 1)):
+        la = U.Residual(U.PreNorm(C, U.LinearAttention(C)))
+        randomize_(la, g)
+        x = rnd(3, C, n)
+        blk.update({f"la_{C}_{n}/x": x, f"la_{C}_{n}/y": la(x)})
+        blk.update({f"la_{C}_{n}/w/" + k: v for k, v in la.state_dict().items()})
+    # Downsample / Upsample -- unet1d.py:82-110
+    dn = U.Downsample(4, 8)
+    up = U.Upsample(8, 4)
+    randomize_(dn, g), randomize_(up, g)
+    x = rnd(3, 4, 16)
+    blk.update({"down/x": x, "down/y": dn(x), "down/weight": dn.weight, "down/bias": dn.bias})
+    x = rnd(3, 8, 8)
+    blk.update({"up/x": x, "up/y": up(x), "up/weight": up[1].weight, "up/bias": up[1].bias})
+    np.savez_compressed(os.path.join(OUT, "blocks.npz"), **npd(blk))
+
+    # ---------------------------------------------------------------- 3. whole net, default config, RT=16
+    torch.manual_seed(7)
+    cfg_kw = dict(dim=4, channels=1, dim_mults=(1, 2, 2, 3, 3, 4, 4), conditional=True, init_cond_channels=1,
+                  attn_cond_channels=1, tfer_dim_mult=620, downsample_dim=64, simple=True)
+    net = U.UNet1d(**cfg_kw)
+    randomize_(net, g)
+    B, RT, MZ = 1, 16, 64
+    x = rnd(B, RT, MZ).requires_grad_(True)
+    c2 = rnd(B, RT, MZ).requires_grad_(True)
+    c1 = rnd(B, RT).requires_grad_(True)
+    t = torch.tensor([417])
+    wn = {"x": x, "init_cond": c2, "attn_cond": c1, "t": t}
+    gout = rnd(B, RT, MZ)
+    wn["gout"] = gout
+    for tag, ident in (("rope", False), ("norope", True)):
+        rope.RotaryEmbedding.IDENTITY = ident
+        net.zero_grad()
+        for v in (x, c2, c1):
+            v.grad = None
+        y = net(x, t, c2, c1)
+        (y * gout).sum().backward()
+        wn[f"{tag}/y"] = y
+        wn[f"{tag}/dx"], wn[f"{tag}/dinit_cond"], wn[f"{tag}/dattn_cond"] = x.grad.clone(), c2.grad.clone(), c1.grad.clone()
+        for n_, p_ in net.named_parameters():
+            if p_.grad is not None:
+                wn[f"{tag}/grad/{n_}"] = p_.grad.clone()
+    rope.RotaryEmbedding.IDENTITY = False
+    wn.update(sd_np(net))
+    np.savez_compressed(os.path.join(OUT, "unet_default_rt16.npz"), **npd(wn))
+
+    # oracle vs reference on the whole net (both RoPE modes)
+    cfg = O.UNetConfig(downsample_dim=64)
+    P = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    for tag, use in (("rope", True), ("norope", False)):
+        yo = O.unet_forward(P, cfg, x.detach(), t, c2.detach(), c1.detach(), use_rope=use)
+        ref_y = wn[f"{tag}/y"]
+        err = ((yo - ref_y).abs().max() / ref_y.abs().max()).item()
+        print(f"[check] whole-net oracle vs reference ({tag}): max err / max|y| = {err:.3e} (max|y| {ref_y.abs().max().item():.3f})")
+        assert err < 5e-6, err
+
+    # ---------------------------------------------------------------- 4. diffusion process on a tiny net
+    torch.manual_seed(11)
+    tiny_kw = dict(dim=4, channels=1, dim_mults=(1, 2), conditional=True, init_cond_channels=1,
+                   attn_cond_channels=1, tfer_dim_mult=620, downsample_dim=8, simple=True)
+    tnet = U.UNet1d(**tiny_kw)
+    randomize_(tnet, g)
+    dm = ref_model.DDIMDiffusionModel(model_class=tnet, num_timesteps=1000, beta_schedule_type="cosine",
+                                      pred_type="eps", auto_normalize=True, ms1_loss_weight=0.0, device="cpu")
+    RT, MZ = 12, 8
+    td = sd_np(tnet)
+    x0 = torch.rand(1, RT, MZ, generator=g)
+    ms2b = torch.rand(1, RT, MZ, generator=g)
+    ms1 = torch.rand(1, RT, generator=g)
+    ms2c = 0.5 * x0 + 0.5 * ms2b
+    td.update({"x0": x0, "ms2_cond": ms2c, "ms1_cond": ms1})
+    # q_sample
+    tq = torch.tensor([321])
+    nz = rnd(1, RT, MZ)
+    td.update({"q/t": tq, "q/noise": nz, "q/x_t": dm.q_sample(dm.normalize(x0), tq, nz)})
+    # p_sample at t = 999, 500, 1, 0 (conditions normalised as sample() does)
+    xt = rnd(1, RT, MZ)
+    td["p/x_t"] = xt
+    tnet.eval()
+    with torch.no_grad():
+        for tv in (999, 500, 1, 0):
+            xp, ep = dm.p_sample(xt, tv, dm.normalize(ms2c), dm.normalize(ms1))
+            td[f"p/{tv}/x_prev"], td[f"p/{tv}/eps"] = xp, ep
+        # sample(): per-step trajectory for 5 and 50 steps
+        for ns in (5, 50):
+            xx = xt.clone()
+            ts = torch.linspace(999, 0, ns, dtype=torch.long)
+            traj_x, traj_e = [], []
+            c2n, c1n = dm.normalize(ms2c), dm.normalize(ms1)
+            for tv in ts:
+                xx, ee = dm.p_sample(xx, tv.item(), c2n, c1n)
+                traj_x.append(xx.clone()), traj_e.append(ee.clone())
+            s, pn = dm.sample(xt.clone(), ms2c, ms1, num_steps=ns)
+            td[f"s{ns}/traj_x"], td[f"s{ns}/traj_eps"] = torch.stack(traj_x), torch.stack(traj_e)
+            td[f"s{ns}/sample"], td[f"s{ns}/pred_noise"] = s, pn
+            assert torch.allclose(dm.unnormalize(xx), s)
+    # train_step: the t and noise it draws under manual_seed(0) (randint first, then randn_like)
+    tnet.train()
+    torch.manual_seed(0)
+    loss = dm.train_step(x0, ms2c, ms1)
+    torch.manual_seed(0)
+    t_drawn = torch.randint(0, 1000, (1,)).long()
+    n_drawn = torch.randn_like(x0)
+    td.update({"train/t": t_drawn, "train/noise": n_drawn, "train/loss": loss.detach()})
+    # B > 1 goldens = per-sample loop of the B = 1 reference
+    Bn = 3
+    xb = torch.rand(Bn, RT, MZ, generator=g)
+    cb = torch.rand(Bn, RT, MZ, generator=g)
+    mb = torch.rand(Bn, RT, generator=g)
+    tb = torch.tensor([3, 640, 999])
+    with torch.no_grad():
+        yb = torch.cat([tnet(xb[i:i + 1], tb[i:i + 1], cb[i:i + 1], mb[i:i + 1]) for i in range(Bn)])
+    td.update({"batch/x": xb, "batch/init_cond": cb, "batch/attn_cond": mb, "batch/t": tb, "batch/y": yb})
+    nb = rnd(Bn, RT, MZ)
+    losses = []
+    for i in range(Bn):
+        xi, ci, mi = dm.normalize(xb[i:i + 1]), dm.normalize(cb[i:i + 1]), dm.normalize(mb[i:i + 1])
+        xti = dm.q_sample(xi, tb[i:i + 1], nb[i:i + 1])
+        with torch.no_grad():
+            losses.append(torch.nn.functional.mse_loss(tnet(xti, tb[i:i + 1], ci, mi), nb[i:i + 1]))
+    td.update({"batch/noise": nb, "batch/loss_mean": torch.stack(losses).mean()})
+
+    # _train_one_batch: params after 1 and 3 steps at lr=1e-5, losses, pre-clip grad norm
+    dm._set_optimizer(1e-5)
+    tnet.train()
+    torch.manual_seed(0)
+    step_losses, gnorms, drawn_t, drawn_n = [], [], [], []
+    rng_state = torch.get_rng_state()
+    for step in range(3):
+        st = torch.get_rng_state()
+        drawn_t.append(torch.randint(0, 1000, (1,)).long())
+        drawn_n.append(torch.randn_like(x0))
+        torch.set_rng_state(st)
+        # replicate _train_one_batch but record the pre-clip norm that clip_grad_norm_ returns
+        dm.optimizer.zero_grad()
+        ls = dm.train_step(x0, ms2_cond=ms2c, ms1_cond=ms1, noise=None, ms1_loss_weight=0.0)
+        ls.backward()
+        gn = torch.nn.utils.clip_grad_norm_(tnet.parameters(), max_norm=10.0)
+        dm.optimizer.step()
+        step_losses.append(ls.item()), gnorms.append(float(gn))
+        if step in (0, 2):
+            td.update({f"opt/after{step + 1}/" + k: v.detach().clone() for k, v in tnet.state_dict().items()})
+    td.update({"opt/losses": np.array(step_losses, np.float64), "opt/gnorms": np.array(gnorms, np.float64),
+               "opt/t": torch.cat(drawn_t), "opt/noise": torch.cat(drawn_n), "opt/lr": np.float64(1e-5)})
+    # also through the reference's own _train_one_batch (same seed => same numbers); cross-check
+    tnet2 = U.UNet1d(**tiny_kw)
+    tnet2.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in td.items() if isinstance(k, str) and k.startswith("w/")})
+    dm2 = ref_model.DDIMDiffusionModel(model_class=tnet2, device="cpu")
+    dm2._set_optimizer(1e-5)
+    torch.manual_seed(0)
+    l0 = dm2._train_one_batch(x0, ms2_cond=ms2c, ms1_cond=ms1, noise=None, ms1_loss_weight=0.0)
+    assert abs(l0 - step_losses[0]) < 1e-7, (l0, step_losses[0])
+    for k, v in tnet2.state_dict().items():
+        assert torch.allclose(v, td["opt/after1/" + k], atol=0, rtol=0), k
+    np.savez_compressed(os.path.join(OUT, "tiny_diffusion.npz"), **npd(td))
+
+    # ---------------------------------------------------------------- 5. _train_one_epoch triple + _predict_one_batch
+    ep = {}
+    a, b_ = torch.rand(2, RT, MZ, generator=g), torch.rand(2, RT, MZ, generator=g)
+    m1, m2 = torch.rand(2, RT, generator=g), torch.rand(2, RT, generator=g)
+    captured = {}
+
+    class Cap(ref_model.DDIMDiffusionModel):
+        def _train_one_batch(self, x_0, ms2_cond=None, ms1_cond=None, noise=None, ms1_loss_weight=0.0):
+            captured.update(x_0=x_0.clone(), ms2_cond=ms2_cond.clone(), ms1_cond=ms1_cond.clone())
+            return 0.0
+
+    cap = Cap(model_class=tnet, device="cpu")
+    cap._train_one_epoch(0, [(a, m1, b_, m2)])
+    ep.update({"in/ms2_1": a, "in/ms1_1": m1, "in/ms2_2": b_, "in/ms1_2": m2})
+    ep.update({"out/" + k: v for k, v in captured.items()})
+    # _predict_one_batch: x_T drawn under a fixed seed
+    tnet.eval()
+    pw = {k: v.detach().clone() for k, v in tnet.state_dict().items()}
+    torch.manual_seed(5)
+    xT = torch.randn_like(x0)
+    torch.manual_seed(5)
+    s0, pn0 = dm._predict_one_batch(x0, ms2_cond=ms2c, ms1_cond=ms1, num_steps=5)
+    ep.update({"pred/x_T": xT, "pred/x0": x0, "pred/ms2_cond": ms2c, "pred/ms1_cond": ms1, "pred/sample0": s0, "pred/pred_noise0": pn0})
+    ep.update({"pred/w/" + k: v for k, v in pw.items()})
+    np.savez_compressed(os.path.join(OUT, "harness.npz"), **npd(ep))
+
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
