@@ -1,0 +1,112 @@
+// Internal launch API of libdq_hip.so (host side).  Every launcher is asynchronous on the given stream,
+// allocates nothing and returns 0 on success (non-zero after dq::set_error()).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace dq {
+
+constexpr int MSE_MAX_BLOCKS = 1024;  // size of the partial-sum scratch used by the loss / grad-norm reductions
+
+// ---- k_stream.hip
+int launch_q_sample(const float* alpha_bars, const float* x0, const int64_t* t, const float* noise, float* x_t, int B,
+                    int64_t per_sample, int normalize, hipStream_t s);
+int launch_ddim_step(const float* x_t, const float* eps, float* x_prev, const float* coef_dev, int64_t n, hipStream_t s);
+int launch_sample_finish(const float* x, const float* ms2_cond, float* out_x, float* out_noise, int64_t n, int normalize,
+                         hipStream_t s);
+int launch_mse_fwd_bwd(const float* eps, const float* noise, float* loss_out, float* grad_out, float* partials, int64_t n,
+                       hipStream_t s);
+int launch_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, float* partials, float gscale, float max_norm,
+                      double lr, double b1, double b2, double eps, double wd, int step, float* gnorm_out, hipStream_t s);
+
+int launch_axpy(float* dst, const float* src, int64_t n, hipStream_t s);  // dst += src
+
+// ---- k_conv.hip
+enum ConvMode { CONV_S1 = 0, CONV_DOWN = 1, CONV_UP = 2 };  // stride-1 'same' | k4 s2 p1 | nearest x2 then k3 p1
+enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2 };
+
+struct ConvFwd {
+  // input = channel-concat of A (cinA) and B (cinB); tensors are (rows, C, n) with n contiguous
+  const float* inA = nullptr; const float* inB = nullptr; int cinA = 0, cinB = 0;
+  const float* w = nullptr;     // (cout, cinA+cinB, K)
+  const float* bias = nullptr;  // (cout) or null
+  int cout = 0, K = 1, mode = CONV_S1;
+  int rows = 0, n_in = 0, n_out = 0;
+  float* u_out = nullptr;       // pre-norm conv output (saved for backward) or null
+  float* y_out = nullptr;
+  const float* g = nullptr;     // RMSNorm gain (cout) or null => no norm
+  const float* ss = nullptr;    // per-sample [scale(cout) | shift(cout)] or null
+  int ss_stride = 0, rows_per_sample = 1;
+  int act = ACT_NONE;
+  // residual added after the activation: identity (resA has cout channels, res_w null) or 1x1 conv over cat(resA,resB)
+  const float* resA = nullptr; const float* resB = nullptr; int rcinA = 0, rcinB = 0;
+  const float* res_w = nullptr; const float* res_b = nullptr;
+};
+int launch_conv_fwd(const ConvFwd& a, hipStream_t s);
+
+// pointwise backward of [RMSNorm -> scale/shift -> act] (any of them optional): du from (u, dy)
+struct BlockBwd {
+  const float* u = nullptr; const float* dy = nullptr; float* du = nullptr;
+  int C = 0, rows = 0, n = 0, rows_per_sample = 1;
+  const float* g = nullptr; float* dg = nullptr;                           // norm gain and its grad (atomic +=)
+  const float* ss = nullptr; float* dss = nullptr; int ss_stride = 0;     // per-sample scale/shift and grads (atomic +=)
+  int act = ACT_NONE;
+};
+int launch_block_bwd(const BlockBwd& a, hipStream_t s);
+
+// dX (+=) of a conv: dinA/dinB receive the gradient of the concat input (either may be null => skipped)
+struct ConvBwdData {
+  const float* du = nullptr; const float* w = nullptr;
+  int cout = 0, K = 1, mode = CONV_S1, rows = 0, n_in = 0, n_out = 0;
+  float* dinA = nullptr; float* dinB = nullptr; int cinA = 0, cinB = 0;
+  int accumulate = 1;  // 1: += ; 0: =
+};
+int launch_conv_bwd_data(const ConvBwdData& a, hipStream_t s);
+
+// dW (+=, atomic) and dbias (+=, atomic; optional) of a conv
+struct ConvWgrad {
+  const float* du = nullptr; const float* inA = nullptr; const float* inB = nullptr; int cinA = 0, cinB = 0;
+  int cout = 0, K = 1, mode = CONV_S1, rows = 0, n_in = 0, n_out = 0;
+  float* dw = nullptr; float* dbias = nullptr;
+};
+int launch_conv_wgrad(const ConvWgrad& a, hipStream_t s);
+
+// standalone RMSNorm forward (PreNorm of the bottleneck attention)
+int launch_rmsnorm_fwd(const float* x, const float* g, float* y, int C, int rows, int n, hipStream_t s);
+
+// (rows=B*RT, C, n) <-> (B, C*n, RT) fold of the bottleneck (unet1d.py:1144-1148); add=1 accumulates
+int launch_fold(const float* in, float* out, int B, int RT, int cn, int to_mid, int add, hipStream_t s);
+
+// first layer inputs: cat0 = [cond_n*(scale+1)+shift, x] as (rows, 2, MZ); ms1n = ms1*cm+ca
+int launch_prep_inputs(const float* x, const float* cond, const float* ms1, const float* ss, int ss_stride, int ss_off, float cm,
+                       float ca, float* cat0, float* ms1n, int B, int RT, int MZ, hipStream_t s);
+// d(scale), d(shift) of init_cond_proj from dcat0 channel 0 (atomic += into dss)
+int launch_prep_inputs_bwd(const float* dcat0, const float* cond, float cm, float ca, float* dss, int ss_stride, int ss_off, int B,
+                           int RT, int MZ, hipStream_t s);
+
+// ---- k_time.hip (declared in dq_unet.h: needs the plan)
+
+// ---- k_linattn.hip
+struct LinAttn {
+  const float* x = nullptr; float* y = nullptr;  // (rows, C, n)
+  const float* w_qkv = nullptr; const float* w_out = nullptr; const float* b_out = nullptr;
+  const float* g_pre = nullptr; const float* g_out = nullptr;
+  int C = 0, rows = 0, n = 0;
+};
+int launch_linattn_fwd(const LinAttn& a, hipStream_t s);
+struct LinAttnBwd {
+  LinAttn f;
+  const float* dy = nullptr; float* dx = nullptr;  // dx +=
+  float* dw_qkv = nullptr; float* dw_out = nullptr; float* db_out = nullptr; float* dg_pre = nullptr; float* dg_out = nullptr;
+};
+int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s);
+
+// ---- k_attn.hip : softmax attention over RT of the bottleneck (q,k,v,o in (B, 128, RT) conv layout)
+int launch_rope(float* qk, const float* freqs, int B, int ch_total, int RT, float sign, hipStream_t s);
+int launch_attn_fwd(const float* q, int64_t q_bs, const float* k, int64_t k_bs, const float* v, int64_t v_bs, float* o, float* lse,
+                    int B, int RT, hipStream_t s);
+int launch_attn_bwd(const float* q, int64_t q_bs, const float* k, int64_t k_bs, const float* v, int64_t v_bs, const float* o,
+                    const float* d_o, const float* lse, float* delta, float* dq, int64_t dq_bs, float* dk, int64_t dk_bs, float* dv,
+                    int64_t dv_bs, int B, int RT, hipStream_t s);
+
+}  // namespace dq

@@ -1,0 +1,44 @@
+// Host-side state of one network instance: plan, device tables and the activation arena layout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <vector>
+#include "dq_plan.h"
+
+namespace dq {
+
+constexpr int TBUF_FLOATS = 100;  // per-sample scratch of the time-embedding kernels (see k_time.hip)
+
+struct DevTables {
+  int64_t* ss_w_off = nullptr;  // [ss_total] offset of row r's 16 weights in the flat parameter buffer
+  int64_t* ss_b_off = nullptr;  // [ss_total] offset of row r's bias
+};
+
+int launch_time_embed_fwd(const Plan& p, const DevTables& dt, const float* params, const int64_t* t, int t_scalar, float* tbuf,
+                          float* ss, int B, hipStream_t s);
+int launch_time_embed_bwd(const Plan& p, const DevTables& dt, const float* params, float* grads, float* tbuf, const float* dss,
+                          int B, hipStream_t s);
+
+// Activation arena: offsets (in floats) of every tensor the forward produces for a given (B, RT).  The backward's
+// gradient of a tensor lives at the same offset in a second arena of the same size ("twin").
+struct ResBuf { int64_t u1, a1, u2, out; };
+struct LevelBuf { ResBuf r0, r1; int64_t la, rs; };
+struct Arena {
+  int B = 0, RT = 0;
+  int64_t floats = 0;
+  int64_t tbuf, ss, cat0, ms1n, ms1_u, ms1_a, ms1f, h0;
+  std::vector<LevelBuf> downs, ups;
+  int64_t mid_in, xn, qv, kk, o, lse, delta, attn_out, mid_back, eps, partials, loss, coef, xa, xb;
+  ResBuf mid1, mid2, fin;
+};
+void layout_arena(const Plan& p, int B, int RT, Arena& a);
+
+}  // namespace dq
+
+struct dq_plan {
+  dq::Plan plan;
+  dq::DevTables dev;
+  float* alpha_bars_dev = nullptr;          // (T) fp32, for q_sample
+  std::vector<float> alpha_bars_host;
+  dq::Arena arena;                           // cached for the last (B, RT)
+};

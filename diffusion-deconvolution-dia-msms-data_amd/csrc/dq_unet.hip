@@ -1,0 +1,572 @@
+// Host orchestration of the U-Net forward/backward, the fused train step and the DDIM sampling loop, and the
+// C ABI (include/dq_hip.h).  Follows UNet1d.forward (dquartic/model/unet1d.py:1086-1166) op by op; the comments
+// name the reference lines each stage replaces.
+#include "dq_common.h"
+#include "dq_kernels.h"
+#include "dq_unet.h"
+#include "../../include/dq_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace dq {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// arena
+// ---------------------------------------------------------------------------------------------------------------
+void layout_arena(const Plan& p, int B, int RT, Arena& a) {
+  a = Arena();
+  a.B = B; a.RT = RT;
+  int64_t off = 0;
+  auto take = [&](int64_t n) { int64_t o = off; off += (n + 63) / 64 * 64; return o; };  // 256-B aligned
+  const int64_t R = (int64_t)B * RT;
+  auto res = [&](int64_t rows, int c, int n) {
+    ResBuf r;
+    r.u1 = take(rows * c * n); r.a1 = take(rows * c * n); r.u2 = take(rows * c * n); r.out = take(rows * c * n);
+    return r;
+  };
+  a.tbuf = take((int64_t)B * TBUF_FLOATS);
+  a.ss = take((int64_t)B * p.ss_total);
+  a.cat0 = take(R * 2 * p.mz);
+  a.ms1n = take(R);
+  a.ms1_u = take(R * p.cond_dim); a.ms1_a = take(R * p.cond_dim); a.ms1f = take(R * p.cond_dim);
+  a.h0 = take(R * p.dim * p.mz);
+  for (int lv = 0; lv < p.levels; ++lv) {
+    const LevelP& l = p.downs[lv];
+    LevelBuf b;
+    b.r0 = res(R, l.r0.cout, l.n); b.r1 = res(R, l.r1.cout, l.n);
+    b.la = take(R * l.la.C * l.n);
+    b.rs = take(R * l.resample.cout * l.n_next);
+    a.downs.push_back(b);
+  }
+  a.mid_in = take(R * p.mid_c);
+  a.mid1 = res(B, p.mid_c, RT);
+  a.xn = take(R * p.mid_c);
+  a.qv = take(R * 2 * HID); a.kk = take(R * HID); a.o = take(R * HID);
+  a.lse = take(R * HEADS); a.delta = take(R * HEADS);
+  a.attn_out = take(R * p.mid_c);
+  a.mid2 = res(B, p.mid_c, RT);
+  a.mid_back = take(R * p.mid_c);
+  for (int ui = 0; ui < p.levels; ++ui) {
+    const LevelP& l = p.ups[ui];
+    LevelBuf b;
+    b.r0 = res(R, l.r0.cout, l.n); b.r1 = res(R, l.r1.cout, l.n);
+    b.la = take(R * l.la.C * l.n);
+    b.rs = take(R * l.resample.cout * l.n_next);
+    a.ups.push_back(b);
+  }
+  a.fin = res(R, p.dim, p.mz);
+  a.eps = take(R * p.mz);
+  a.xa = take(R * p.mz);   // sampling ping-pong / train-step x_t
+  a.xb = take(R * p.mz);
+  a.partials = take(MSE_MAX_BLOCKS);
+  a.loss = take(64);
+  a.coef = take(4 * 1024);  // DDIM coefficient table (<= 1024 steps)
+  a.floats = off;
+}
+
+namespace {
+
+struct Ctx {
+  const Plan& p;
+  const Arena& ar;
+  const float* P;   // params
+  float* W;         // forward arena
+  float* G;         // gradient twin of the arena (null in inference)
+  float* dP;        // flat grads
+  int B, RT;
+  hipStream_t s;
+  float* w(int64_t off) const { return W + off; }
+  float* g(int64_t off) const { return G + off; }
+  const float* prm(int64_t off) const { return P + off; }
+  float* dprm(int64_t off) const { return dP + off; }
+};
+
+#define DQ_TRY(expr)            \
+  do {                          \
+    int _rc = (expr);           \
+    if (_rc) return _rc;        \
+  } while (0)
+
+// ResnetBlock forward (unet1d.py:302-323): input = cat(A, B)
+int res_fwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, int cinA, const float* inB, int cinB, int rows, int n,
+            int rows_per_sample) {
+  ConvFwd f;
+  f.inA = inA; f.inB = inB; f.cinA = cinA; f.cinB = cinB;
+  f.w = c.prm(r.c1.w); f.bias = c.prm(r.c1.b); f.cout = r.cout; f.K = 3; f.mode = CONV_S1;
+  f.rows = rows; f.n_in = n; f.n_out = n;
+  f.u_out = c.w(b.u1); f.y_out = c.w(b.a1);
+  f.g = c.prm(r.g1);
+  f.ss = c.w(c.ar.ss) + r.ss_off; f.ss_stride = c.p.ss_total; f.rows_per_sample = rows_per_sample;
+  f.act = ACT_SILU;
+  DQ_TRY(launch_conv_fwd(f, c.s));
+  ConvFwd f2;
+  f2.inA = c.w(b.a1); f2.cinA = r.cout;
+  f2.w = c.prm(r.c2.w); f2.bias = c.prm(r.c2.b); f2.cout = r.cout; f2.K = 3; f2.mode = CONV_S1;
+  f2.rows = rows; f2.n_in = n; f2.n_out = n;
+  f2.u_out = c.w(b.u2); f2.y_out = c.w(b.out);
+  f2.g = c.prm(r.g2); f2.act = ACT_SILU;
+  f2.resA = inA; f2.resB = inB; f2.rcinA = cinA; f2.rcinB = cinB;
+  if (r.res.cout) { f2.res_w = c.prm(r.res.w); f2.res_b = c.prm(r.res.b); }
+  DQ_TRY(launch_conv_fwd(f2, c.s));
+  return 0;
+}
+
+// ResnetBlock backward: d(out) is complete in the twin of b.out; adds into dA / dB (twins of the inputs; null => skipped)
+int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, float* dA, int cinA, const float* inB, float* dB, int cinB,
+            int rows, int n, int rows_per_sample) {
+  const float* dout = c.g(b.out);
+  // block2: norm -> silu
+  BlockBwd bb;
+  bb.u = c.w(b.u2); bb.dy = dout; bb.du = c.g(b.u2); bb.C = r.cout; bb.rows = rows; bb.n = n; bb.rows_per_sample = rows_per_sample;
+  bb.g = c.prm(r.g2); bb.dg = c.dprm(r.g2); bb.act = ACT_SILU;
+  DQ_TRY(launch_block_bwd(bb, c.s));
+  ConvWgrad wg;
+  wg.du = c.g(b.u2); wg.inA = c.w(b.a1); wg.cinA = r.cout; wg.cout = r.cout; wg.K = 3; wg.mode = CONV_S1;
+  wg.rows = rows; wg.n_in = n; wg.n_out = n; wg.dw = c.dprm(r.c2.w); wg.dbias = c.dprm(r.c2.b);
+  DQ_TRY(launch_conv_wgrad(wg, c.s));
+  ConvBwdData bd;
+  bd.du = c.g(b.u2); bd.w = c.prm(r.c2.w); bd.cout = r.cout; bd.K = 3; bd.mode = CONV_S1; bd.rows = rows; bd.n_in = n; bd.n_out = n;
+  bd.dinA = c.g(b.a1); bd.cinA = r.cout; bd.accumulate = 0;
+  DQ_TRY(launch_conv_bwd_data(bd, c.s));
+  // block1: norm -> scale/shift -> silu
+  BlockBwd b1;
+  b1.u = c.w(b.u1); b1.dy = c.g(b.a1); b1.du = c.g(b.u1); b1.C = r.cout; b1.rows = rows; b1.n = n; b1.rows_per_sample = rows_per_sample;
+  b1.g = c.prm(r.g1); b1.dg = c.dprm(r.g1); b1.act = ACT_SILU;
+  b1.ss = c.w(c.ar.ss) + r.ss_off; b1.dss = c.g(c.ar.ss) + r.ss_off; b1.ss_stride = c.p.ss_total;
+  DQ_TRY(launch_block_bwd(b1, c.s));
+  ConvWgrad w1;
+  w1.du = c.g(b.u1); w1.inA = inA; w1.inB = inB; w1.cinA = cinA; w1.cinB = cinB; w1.cout = r.cout; w1.K = 3; w1.mode = CONV_S1;
+  w1.rows = rows; w1.n_in = n; w1.n_out = n; w1.dw = c.dprm(r.c1.w); w1.dbias = c.dprm(r.c1.b);
+  DQ_TRY(launch_conv_wgrad(w1, c.s));
+  if (dA || dB) {
+    ConvBwdData d1;
+    d1.du = c.g(b.u1); d1.w = c.prm(r.c1.w); d1.cout = r.cout; d1.K = 3; d1.mode = CONV_S1; d1.rows = rows; d1.n_in = n; d1.n_out = n;
+    d1.dinA = dA; d1.dinB = dB; d1.cinA = cinA; d1.cinB = cinB; d1.accumulate = 1;
+    DQ_TRY(launch_conv_bwd_data(d1, c.s));
+  }
+  // residual path
+  if (r.res.cout) {
+    ConvWgrad wr;
+    wr.du = dout; wr.inA = inA; wr.inB = inB; wr.cinA = cinA; wr.cinB = cinB; wr.cout = r.cout; wr.K = 1; wr.mode = CONV_S1;
+    wr.rows = rows; wr.n_in = n; wr.n_out = n; wr.dw = c.dprm(r.res.w); wr.dbias = c.dprm(r.res.b);
+    DQ_TRY(launch_conv_wgrad(wr, c.s));
+    if (dA || dB) {
+      ConvBwdData dr;
+      dr.du = dout; dr.w = c.prm(r.res.w); dr.cout = r.cout; dr.K = 1; dr.mode = CONV_S1; dr.rows = rows; dr.n_in = n; dr.n_out = n;
+      dr.dinA = dA; dr.dinB = dB; dr.cinA = cinA; dr.cinB = cinB; dr.accumulate = 1;
+      DQ_TRY(launch_conv_bwd_data(dr, c.s));
+    }
+  } else if (dA) {
+    DQ_TRY(launch_axpy(dA, dout, (int64_t)rows * r.cout * n, c.s));
+  }
+  return 0;
+}
+
+int la_fwd(const Ctx& c, const LAP& l, const float* x, float* y, int rows, int n) {
+  LinAttn a;
+  a.x = x; a.y = y; a.w_qkv = c.prm(l.qkv_w); a.w_out = c.prm(l.out_w); a.b_out = c.prm(l.out_b);
+  a.g_pre = c.prm(l.g_pre); a.g_out = c.prm(l.g_out); a.C = l.C; a.rows = rows; a.n = n;
+  return launch_linattn_fwd(a, c.s);
+}
+
+int la_bwd(const Ctx& c, const LAP& l, const float* x, const float* dy, float* dx, int rows, int n) {
+  LinAttnBwd a;
+  a.f.x = x; a.f.w_qkv = c.prm(l.qkv_w); a.f.w_out = c.prm(l.out_w); a.f.b_out = c.prm(l.out_b);
+  a.f.g_pre = c.prm(l.g_pre); a.f.g_out = c.prm(l.g_out); a.f.C = l.C; a.f.rows = rows; a.f.n = n;
+  a.dy = dy; a.dx = dx;
+  a.dw_qkv = c.dprm(l.qkv_w); a.dw_out = c.dprm(l.out_w); a.db_out = c.dprm(l.out_b); a.dg_pre = c.dprm(l.g_pre);
+  a.dg_out = c.dprm(l.g_out);
+  return launch_linattn_bwd(a, c.s);
+}
+
+int conv_plain_fwd(const Ctx& c, const ConvP& cp, int mode, const float* in, float* out, int rows, int n_in, int n_out) {
+  ConvFwd f;
+  f.inA = in; f.cinA = cp.cin; f.w = c.prm(cp.w); f.bias = cp.b >= 0 ? c.prm(cp.b) : nullptr;
+  f.cout = cp.cout; f.K = cp.k; f.mode = mode; f.rows = rows; f.n_in = n_in; f.n_out = n_out; f.y_out = out;
+  return launch_conv_fwd(f, c.s);
+}
+
+int conv_plain_bwd(const Ctx& c, const ConvP& cp, int mode, const float* in, const float* dout, float* din, int rows, int n_in,
+                   int n_out, int accumulate) {
+  ConvWgrad wg;
+  wg.du = dout; wg.inA = in; wg.cinA = cp.cin; wg.cout = cp.cout; wg.K = cp.k; wg.mode = mode; wg.rows = rows; wg.n_in = n_in;
+  wg.n_out = n_out; wg.dw = c.dprm(cp.w); wg.dbias = cp.b >= 0 ? c.dprm(cp.b) : nullptr;
+  DQ_TRY(launch_conv_wgrad(wg, c.s));
+  if (din) {
+    ConvBwdData bd;
+    bd.du = dout; bd.w = c.prm(cp.w); bd.cout = cp.cout; bd.K = cp.k; bd.mode = mode; bd.rows = rows; bd.n_in = n_in; bd.n_out = n_out;
+    bd.dinA = din; bd.cinA = cp.cin; bd.accumulate = accumulate;
+    DQ_TRY(launch_conv_bwd_data(bd, c.s));
+  }
+  return 0;
+}
+
+ConvP proj(int64_t w, int cout, int cin) { ConvP c; c.w = w; c.b = -1; c.cout = cout; c.cin = cin; c.k = 1; return c; }
+
+int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t* t, int t_scalar, const float* init_cond,
+                 const float* attn_cond, float cm, float ca, const DevTables& dt, float* out) {
+  const Plan& p = c.p;
+  const Arena& a = c.ar;
+  const int B = c.B, RT = c.RT, R = B * RT, L = p.levels;
+  // K1: time embedding + every scale/shift head (unet1d.py:1105, 315-318, 677)
+  DQ_TRY(launch_time_embed_fwd(p, dt, c.P, t, t_scalar, c.w(a.tbuf), c.w(a.ss), B, c.s));
+  // K2: mixture conditioning + concat (unet1d.py:1107-1115), then init_conv k7 (:1117)
+  DQ_TRY(launch_prep_inputs(x, init_cond, attn_cond, c.w(a.ss), p.ss_total, p.ss_init, cm, ca, c.w(a.cat0), c.w(a.ms1n), B, RT, p.mz, c.s));
+  DQ_TRY(conv_plain_fwd(c, p.init_conv, CONV_S1, c.w(a.cat0), c.w(a.h0), R, p.mz, p.mz));
+  // K3: MS1 features (unet1d.py:1120-1130): (B,1,RT) -> conv k7 -> GELU -> conv k1
+  {
+    ConvFwd f;
+    f.inA = c.w(a.ms1n); f.cinA = 1; f.w = c.prm(p.ms1_c0.w); f.bias = c.prm(p.ms1_c0.b); f.cout = p.cond_dim; f.K = 7;
+    f.rows = B; f.n_in = RT; f.n_out = RT; f.u_out = c.w(a.ms1_u); f.y_out = c.w(a.ms1_a); f.act = ACT_GELU;
+    DQ_TRY(launch_conv_fwd(f, c.s));
+    DQ_TRY(conv_plain_fwd(c, p.ms1_c1, CONV_S1, c.w(a.ms1_a), c.w(a.ms1f), B, RT, RT));
+  }
+  // down path (unet1d.py:1134-1142)
+  const float* cur = c.w(a.h0);
+  for (int lv = 0; lv < L; ++lv) {
+    const LevelP& l = p.downs[lv];
+    const LevelBuf& b = a.downs[lv];
+    const int C = l.r0.cin;
+    DQ_TRY(res_fwd(c, l.r0, b.r0, cur, C, nullptr, 0, R, l.n, RT));
+    DQ_TRY(res_fwd(c, l.r1, b.r1, c.w(b.r0.out), C, nullptr, 0, R, l.n, RT));
+    DQ_TRY(la_fwd(c, l.la, c.w(b.r1.out), c.w(b.la), R, l.n));
+    DQ_TRY(conv_plain_fwd(c, l.resample, l.last ? CONV_S1 : CONV_DOWN, c.w(b.la), c.w(b.rs), R, l.n, l.n_next));
+    cur = c.w(b.rs);
+  }
+  // bottleneck (unet1d.py:1144-1148)
+  DQ_TRY(launch_fold(cur, c.w(a.mid_in), B, RT, p.mid_c, 1, 0, c.s));
+  DQ_TRY(res_fwd(c, p.mid1, a.mid1, c.w(a.mid_in), p.mid_c, nullptr, 0, B, RT, 1));
+  {
+    // Residual(PreNorm(Attention(use_xattn))) (unet1d.py:552-567)
+    DQ_TRY(launch_rmsnorm_fwd(c.w(a.mid1.out), c.prm(p.ag), c.w(a.xn), p.mid_c, B, RT, c.s));
+    DQ_TRY(conv_plain_fwd(c, proj(p.qv_w, 2 * HID, p.mid_c), CONV_S1, c.w(a.xn), c.w(a.qv), B, RT, RT));
+    DQ_TRY(conv_plain_fwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.w(a.kk), B, RT, RT));
+    if (rope) {
+      DQ_TRY(launch_rope(c.w(a.qv), rope, B * 2, HID, RT, 1.f, c.s));  // q = first 128 channels of each sample's 256
+      DQ_TRY(launch_rope(c.w(a.kk), rope, B, HID, RT, 1.f, c.s));
+    }
+    const int64_t qvbs = (int64_t)2 * HID * RT, kbs = (int64_t)HID * RT;
+    DQ_TRY(launch_attn_fwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.w(a.lse), B, RT, c.s));
+    ConvFwd f;
+    f.inA = c.w(a.o); f.cinA = HID; f.w = c.prm(p.ao_w); f.bias = c.prm(p.ao_b); f.cout = p.mid_c; f.K = 1;
+    f.rows = B; f.n_in = RT; f.n_out = RT; f.y_out = c.w(a.attn_out);
+    f.resA = c.w(a.mid1.out); f.rcinA = p.mid_c;
+    DQ_TRY(launch_conv_fwd(f, c.s));
+  }
+  DQ_TRY(res_fwd(c, p.mid2, a.mid2, c.w(a.attn_out), p.mid_c, nullptr, 0, B, RT, 1));
+  DQ_TRY(launch_fold(c.w(a.mid2.out), c.w(a.mid_back), B, RT, p.mid_c, 0, 0, c.s));
+  // up path (unet1d.py:1150-1158): first pop = post-attention skip, second pop = post-block1 skip
+  cur = c.w(a.mid_back);
+  for (int ui = 0; ui < L; ++ui) {
+    const LevelP& l = p.ups[ui];
+    const LevelBuf& b = a.ups[ui];
+    const int lv = L - 1 - ui;
+    const int cx = l.r0.cout, cs = l.r0.cin - l.r0.cout;
+    DQ_TRY(res_fwd(c, l.r0, b.r0, cur, cx, c.w(a.downs[lv].la), cs, R, l.n, RT));
+    DQ_TRY(res_fwd(c, l.r1, b.r1, c.w(b.r0.out), cx, c.w(a.downs[lv].r0.out), cs, R, l.n, RT));
+    DQ_TRY(la_fwd(c, l.la, c.w(b.r1.out), c.w(b.la), R, l.n));
+    DQ_TRY(conv_plain_fwd(c, l.resample, l.last ? CONV_S1 : CONV_UP, c.w(b.la), c.w(b.rs), R, l.n, l.n_next));
+    cur = c.w(b.rs);
+  }
+  // head (unet1d.py:1160-1166)
+  DQ_TRY(res_fwd(c, p.fin, a.fin, cur, p.dim, c.w(a.h0), p.dim, R, p.mz, RT));
+  DQ_TRY(conv_plain_fwd(c, p.final_conv, CONV_S1, c.w(a.fin.out), out, R, p.mz, p.mz));
+  return 0;
+}
+
+int unet_backward(const Ctx& c, const float* rope, const float* init_cond, float cm, float ca, const DevTables& dt,
+                  const float* grad_out, float* grad_x) {
+  const Plan& p = c.p;
+  const Arena& a = c.ar;
+  const int B = c.B, RT = c.RT, R = B * RT, L = p.levels;
+  DQ_HIP_OK(hipMemsetAsync(c.G, 0, sizeof(float) * a.floats, c.s));
+  // head
+  DQ_TRY(conv_plain_bwd(c, p.final_conv, CONV_S1, c.w(a.fin.out), grad_out, c.g(a.fin.out), R, p.mz, p.mz, 0));
+  const LevelBuf& lastup = a.ups[L - 1];
+  DQ_TRY(res_bwd(c, p.fin, a.fin, c.w(lastup.rs), c.g(lastup.rs), p.dim, c.w(a.h0), c.g(a.h0), p.dim, R, p.mz, RT));
+  // up path, reversed
+  for (int ui = L - 1; ui >= 0; --ui) {
+    const LevelP& l = p.ups[ui];
+    const LevelBuf& b = a.ups[ui];
+    const int lv = L - 1 - ui;
+    const int cx = l.r0.cout, cs = l.r0.cin - l.r0.cout;
+    const int64_t in_off = ui == 0 ? a.mid_back : a.ups[ui - 1].rs;
+    DQ_TRY(conv_plain_bwd(c, l.resample, l.last ? CONV_S1 : CONV_UP, c.w(b.la), c.g(b.rs), c.g(b.la), R, l.n, l.n_next, 1));
+    DQ_TRY(la_bwd(c, l.la, c.w(b.r1.out), c.g(b.la), c.g(b.r1.out), R, l.n));
+    DQ_TRY(res_bwd(c, l.r1, b.r1, c.w(b.r0.out), c.g(b.r0.out), cx, c.w(a.downs[lv].r0.out), c.g(a.downs[lv].r0.out), cs, R, l.n, RT));
+    DQ_TRY(res_bwd(c, l.r0, b.r0, c.w(in_off), c.g(in_off), cx, c.w(a.downs[lv].la), c.g(a.downs[lv].la), cs, R, l.n, RT));
+  }
+  // bottleneck
+  DQ_TRY(launch_fold(c.g(a.mid_back), c.g(a.mid2.out), B, RT, p.mid_c, 1, 1, c.s));
+  DQ_TRY(res_bwd(c, p.mid2, a.mid2, c.w(a.attn_out), c.g(a.attn_out), p.mid_c, nullptr, nullptr, 0, B, RT, 1));
+  {
+    const int64_t qvbs = (int64_t)2 * HID * RT, kbs = (int64_t)HID * RT;
+    // to_out (1x1 + bias) and the residual
+    ConvP ao = proj(p.ao_w, p.mid_c, HID);
+    ao.b = p.ao_b;
+    DQ_TRY(conv_plain_bwd(c, ao, CONV_S1, c.w(a.o), c.g(a.attn_out), c.g(a.o), B, RT, RT, 0));
+    DQ_TRY(launch_axpy(c.g(a.mid1.out), c.g(a.attn_out), (int64_t)R * p.mid_c, c.s));
+    DQ_TRY(launch_attn_bwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.g(a.o), c.w(a.lse), c.w(a.delta),
+                           c.g(a.qv), qvbs, c.g(a.kk), kbs, c.g(a.qv) + kbs, qvbs, B, RT, c.s));
+    if (rope) {
+      DQ_TRY(launch_rope(c.g(a.qv), rope, B * 2, HID, RT, -1.f, c.s));
+      DQ_TRY(launch_rope(c.g(a.kk), rope, B, HID, RT, -1.f, c.s));
+    }
+    DQ_TRY(conv_plain_bwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.g(a.kk), c.g(a.ms1f), B, RT, RT, 0));
+    DQ_TRY(conv_plain_bwd(c, proj(p.qv_w, 2 * HID, p.mid_c), CONV_S1, c.w(a.xn), c.g(a.qv), c.g(a.xn), B, RT, RT, 0));
+    // PreNorm backward: xn = rmsnorm(mid1.out) * g  (pointwise kernel, no scale/shift, no activation)
+    BlockBwd nb;
+    nb.u = c.w(a.mid1.out); nb.dy = c.g(a.xn); nb.du = c.g(a.xn); nb.C = p.mid_c; nb.rows = B; nb.n = RT; nb.rows_per_sample = 1;
+    nb.g = c.prm(p.ag); nb.dg = c.dprm(p.ag);
+    DQ_TRY(launch_block_bwd(nb, c.s));
+    DQ_TRY(launch_axpy(c.g(a.mid1.out), c.g(a.xn), (int64_t)R * p.mid_c, c.s));
+  }
+  DQ_TRY(res_bwd(c, p.mid1, a.mid1, c.w(a.mid_in), c.g(a.mid_in), p.mid_c, nullptr, nullptr, 0, B, RT, 1));
+  DQ_TRY(launch_fold(c.g(a.mid_in), c.g(a.downs[L - 1].rs), B, RT, p.mid_c, 0, 1, c.s));
+  // down path, reversed
+  for (int lv = L - 1; lv >= 0; --lv) {
+    const LevelP& l = p.downs[lv];
+    const LevelBuf& b = a.downs[lv];
+    const int C = l.r0.cin;
+    const int64_t in_off = lv == 0 ? a.h0 : a.downs[lv - 1].rs;
+    DQ_TRY(conv_plain_bwd(c, l.resample, l.last ? CONV_S1 : CONV_DOWN, c.w(b.la), c.g(b.rs), c.g(b.la), R, l.n, l.n_next, 1));
+    DQ_TRY(la_bwd(c, l.la, c.w(b.r1.out), c.g(b.la), c.g(b.r1.out), R, l.n));
+    DQ_TRY(res_bwd(c, l.r1, b.r1, c.w(b.r0.out), c.g(b.r0.out), C, nullptr, nullptr, 0, R, l.n, RT));
+    DQ_TRY(res_bwd(c, l.r0, b.r0, c.w(in_off), c.g(in_off), C, nullptr, nullptr, 0, R, l.n, RT));
+  }
+  // MS1 feature path
+  DQ_TRY(conv_plain_bwd(c, p.ms1_c1, CONV_S1, c.w(a.ms1_a), c.g(a.ms1f), c.g(a.ms1_a), B, RT, RT, 0));
+  {
+    BlockBwd gb;
+    gb.u = c.w(a.ms1_u); gb.dy = c.g(a.ms1_a); gb.du = c.g(a.ms1_u); gb.C = p.cond_dim; gb.rows = B; gb.n = RT; gb.rows_per_sample = 1;
+    gb.act = ACT_GELU;
+    DQ_TRY(launch_block_bwd(gb, c.s));
+    DQ_TRY(conv_plain_bwd(c, p.ms1_c0, CONV_S1, c.w(a.ms1n), c.g(a.ms1_u), nullptr, B, RT, RT, 0));
+  }
+  // init conv + mixture conditioning
+  DQ_TRY(conv_plain_bwd(c, p.init_conv, CONV_S1, c.w(a.cat0), c.g(a.h0), c.g(a.cat0), R, p.mz, p.mz, 0));
+  DQ_TRY(launch_prep_inputs_bwd(c.g(a.cat0), init_cond, cm, ca, c.g(a.ss), p.ss_total, p.ss_init, B, RT, p.mz, c.s));
+  if (grad_x) {
+    // channel 1 of d(cat0) is d loss / d x
+    DQ_HIP_OK(hipMemcpy2DAsync(grad_x, sizeof(float) * p.mz, c.g(a.cat0) + p.mz, sizeof(float) * 2 * p.mz, sizeof(float) * p.mz, R,
+                               hipMemcpyDeviceToDevice, c.s));
+  }
+  // time embedding: all scale/shift heads + the MLP
+  DQ_TRY(launch_time_embed_bwd(p, dt, c.P, c.dP, c.w(a.tbuf), c.g(a.ss), B, c.s));
+  return 0;
+}
+
+// Lays out the arena for (B, RT) and, on the first call of a plan, uploads the ~10 KB offset tables of the scale/shift
+// heads (the only device allocation the library ever makes; dq_plan_create itself never touches the GPU).
+int ensure_arena(dq_plan* plan, int B, int RT) {
+  if (plan->arena.B != B || plan->arena.RT != RT) layout_arena(plan->plan, B, RT, plan->arena);
+  if (!plan->dev.ss_w_off) {
+    const Plan& p = plan->plan;
+    std::vector<int64_t> woff(p.ss_total), boff(p.ss_total);
+    for (const auto& l : p.ss_lins)
+      for (int r = 0; r < l.rows; ++r) {
+        woff[l.ss_off + r] = l.w + (int64_t)r * p.time_dim;
+        boff[l.ss_off + r] = l.b + r;
+      }
+    DQ_HIP_OK(hipMalloc(&plan->dev.ss_w_off, sizeof(int64_t) * p.ss_total));
+    DQ_HIP_OK(hipMalloc(&plan->dev.ss_b_off, sizeof(int64_t) * p.ss_total));
+    DQ_HIP_OK(hipMemcpy(plan->dev.ss_w_off, woff.data(), sizeof(int64_t) * p.ss_total, hipMemcpyHostToDevice));
+    DQ_HIP_OK(hipMemcpy(plan->dev.ss_b_off, boff.data(), sizeof(int64_t) * p.ss_total, hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+}  // namespace
+}  // namespace dq
+
+using namespace dq;
+
+extern "C" {
+
+const char* dq_last_error(void) { return g_err.c_str(); }
+int dq_abi_version(void) { return 1; }
+
+dq_plan* dq_plan_create(int dim, int n_mults, const int* dim_mults, int mz, int num_timesteps) {
+  dq_plan* h = new dq_plan();
+  std::string err = build_plan(h->plan, dim, n_mults, dim_mults, mz, num_timesteps);
+  if (!err.empty()) {
+    set_error("dq_plan_create: " + err);
+    delete h;
+    return nullptr;
+  }
+  return h;
+}
+
+void dq_plan_destroy(dq_plan* plan) {
+  if (!plan) return;
+  if (plan->dev.ss_w_off) (void)hipFree(plan->dev.ss_w_off);
+  if (plan->dev.ss_b_off) (void)hipFree(plan->dev.ss_b_off);
+  delete plan;
+}
+
+int dq_plan_num_params(const dq_plan* plan) { return (int)plan->plan.params.size(); }
+int64_t dq_plan_param_floats(const dq_plan* plan) { return plan->plan.total_floats; }
+
+int dq_plan_param_info(const dq_plan* plan, int i, char* name, int name_cap, int64_t* offset, int* ndim, int64_t* shape) {
+  DQ_REQUIRE(plan && i >= 0 && i < (int)plan->plan.params.size(), "dq_plan_param_info: index out of range");
+  const ParamInfo& pi = plan->plan.params[i];
+  DQ_REQUIRE((int)pi.name.size() + 1 <= name_cap, "dq_plan_param_info: name buffer too small");
+  std::strcpy(name, pi.name.c_str());
+  *offset = pi.offset;
+  *ndim = pi.ndim;
+  for (int k = 0; k < 4; ++k) shape[k] = pi.shape[k];
+  return 0;
+}
+
+int64_t dq_unet_workspace_bytes(dq_plan* plan, int B, int RT, int training) {
+  if (!plan || B < 0 || RT < 0) return -1;
+  Arena a;
+  layout_arena(plan->plan, B, RT, a);
+  return (int64_t)sizeof(float) * a.floats * (training ? 2 : 1);
+}
+
+int dq_q_sample(const float* alpha_bars_dev, const float* x0, const int64_t* t, const float* noise, float* x_t, int B,
+                int64_t per_sample, int normalize_x0, void* stream) {
+  return launch_q_sample(alpha_bars_dev, x0, t, noise, x_t, B, per_sample, normalize_x0, (hipStream_t)stream);
+}
+
+int dq_ddim_step(const float* x_t, const float* eps, float* x_prev, const float* coef_dev, int64_t n, void* stream) {
+  return launch_ddim_step(x_t, eps, x_prev, coef_dev, n, (hipStream_t)stream);
+}
+
+int dq_unet_fwd(dq_plan* plan, const float* params, const float* rope_freqs, const float* x, const int64_t* t, int t_scalar,
+                const float* init_cond, const float* attn_cond, float cond_mul, float cond_add, float* out, void* workspace,
+                int64_t workspace_bytes, int B, int RT, void* stream) {
+  DQ_REQUIRE(plan && params && x && init_cond && attn_cond && out && workspace, "dq_unet_fwd: null argument");
+  DQ_REQUIRE(B > 0 && RT > 0, "dq_unet_fwd: B and RT must be positive");
+  DQ_TRY(ensure_arena(plan, B, RT));
+  DQ_REQUIRE(workspace_bytes >= (int64_t)sizeof(float) * plan->arena.floats, "dq_unet_fwd: workspace too small");
+  Ctx c{plan->plan, plan->arena, params, (float*)workspace, nullptr, nullptr, B, RT, (hipStream_t)stream};
+  return unet_forward(c, rope_freqs, x, t, t_scalar, init_cond, attn_cond, cond_mul, cond_add, plan->dev, out);
+}
+
+int dq_unet_bwd(dq_plan* plan, const float* params, const float* rope_freqs, const float* init_cond, float cond_mul,
+                float cond_add, const float* grad_out, float* grads, float* grad_x, void* workspace, int64_t workspace_bytes,
+                int B, int RT, void* stream) {
+  DQ_REQUIRE(plan && params && init_cond && grad_out && grads && workspace, "dq_unet_bwd: null argument");
+  DQ_TRY(ensure_arena(plan, B, RT));
+  DQ_REQUIRE(workspace_bytes >= 2 * (int64_t)sizeof(float) * plan->arena.floats, "dq_unet_bwd: workspace too small (training=1)");
+  float* W = (float*)workspace;
+  Ctx c{plan->plan, plan->arena, params, W, W + plan->arena.floats, grads, B, RT, (hipStream_t)stream};
+  return unet_backward(c, rope_freqs, init_cond, cond_mul, cond_add, plan->dev, grad_out, grad_x);
+}
+
+int dq_mse_loss_fwd_bwd(const float* eps, const float* noise, float* loss_out, float* grad_out, float* scratch, int64_t n,
+                        void* stream) {
+  DQ_REQUIRE(eps && noise && loss_out && scratch, "dq_mse_loss_fwd_bwd: null argument");
+  return launch_mse_fwd_bwd(eps, noise, loss_out, grad_out, scratch, n, (hipStream_t)stream);
+}
+
+int dq_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float* scratch,
+                       float grad_scale, float max_norm, double lr, double beta1, double beta2, double eps, double weight_decay,
+                       int step, float* gnorm_out, void* stream) {
+  DQ_REQUIRE(params && grads && exp_avg && exp_avg_sq && scratch, "dq_adamw_clip_step: null argument");
+  return launch_adamw_clip(params, grads, exp_avg, exp_avg_sq, n, scratch, grad_scale, max_norm, lr, beta1, beta2, eps,
+                           weight_decay, step, gnorm_out, (hipStream_t)stream);
+}
+
+int dq_train_step(dq_plan* plan, const float* params, const float* rope_freqs, const float* alpha_bars_dev, const float* x0,
+                  const float* ms2_cond, const float* ms1_cond, const int64_t* t, const float* noise, int auto_normalize,
+                  float* grads, float* loss_out, void* workspace, int64_t workspace_bytes, int B, int RT, void* stream) {
+  DQ_REQUIRE(plan && params && alpha_bars_dev && x0 && ms2_cond && ms1_cond && t && noise && grads && loss_out && workspace,
+             "dq_train_step: null argument");
+  DQ_REQUIRE(B > 0 && RT > 0, "dq_train_step: B and RT must be positive");
+  DQ_TRY(ensure_arena(plan, B, RT));
+  const Arena& a = plan->arena;
+  DQ_REQUIRE(workspace_bytes >= 2 * (int64_t)sizeof(float) * a.floats, "dq_train_step: workspace too small (training=1)");
+  hipStream_t s = (hipStream_t)stream;
+  float* W = (float*)workspace;
+  Ctx c{plan->plan, a, params, W, W + a.floats, grads, B, RT, s};
+  const int64_t per = (int64_t)RT * plan->plan.mz;
+  const float cm = auto_normalize ? 2.f : 1.f, ca = auto_normalize ? -1.f : 0.f;
+  DQ_TRY(launch_q_sample(alpha_bars_dev, x0, t, noise, c.w(a.xa), B, per, auto_normalize, s));               // model.py:349-352
+  DQ_TRY(unet_forward(c, rope_freqs, c.w(a.xa), t, 0, ms2_cond, ms1_cond, cm, ca, plan->dev, c.w(a.eps)));   // model.py:359
+  // the gradient twin is zeroed inside unet_backward, so the loss gradient goes to a forward-arena buffer (xb)
+  DQ_TRY(launch_mse_fwd_bwd(c.w(a.eps), noise, loss_out, c.w(a.xb), c.w(a.partials), B * per, s));           // model.py:361
+  DQ_TRY(unet_backward(c, rope_freqs, ms2_cond, cm, ca, plan->dev, c.w(a.xb), nullptr));
+  return 0;
+}
+
+int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, const float* alpha_bars_host, const float* x_T,
+                   const float* ms2_cond, const float* ms1_cond, int auto_normalize, const int32_t* timesteps_host,
+                   int num_steps, float* out_x, float* out_noise, float* traj_x, float* traj_eps, void* workspace,
+                   int64_t workspace_bytes, int B, int RT, void* stream) {
+  DQ_REQUIRE(plan && params && alpha_bars_host && x_T && ms2_cond && ms1_cond && timesteps_host && out_x && out_noise && workspace,
+             "dq_ddim_sample: null argument");
+  DQ_REQUIRE(B > 0 && RT > 0 && num_steps >= 1 && num_steps <= 1024, "dq_ddim_sample: need B, RT > 0 and 1 <= num_steps <= 1024");
+  DQ_TRY(ensure_arena(plan, B, RT));
+  const Arena& a = plan->arena;
+  DQ_REQUIRE(workspace_bytes >= (int64_t)sizeof(float) * a.floats, "dq_ddim_sample: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* W = (float*)workspace;
+  Ctx c{plan->plan, a, params, W, nullptr, nullptr, B, RT, s};
+  const int T = plan->plan.T;
+  const int64_t n = (int64_t)B * RT * plan->plan.mz;
+  const float cm = auto_normalize ? 2.f : 1.f, ca = auto_normalize ? -1.f : 0.f;
+  const int32_t* ts = timesteps_host;  // trunc(linspace(T-1, 0, num_steps)) formed by the caller exactly as model.py:313 does
+  // coefficient table (model.py:265-267, 284-286), fp32 like the reference
+  std::vector<float> coef(4 * (size_t)num_steps);
+  for (int i = 0; i < num_steps; ++i) {
+    const int t = ts[i];
+    DQ_REQUIRE(t >= 0 && t < T, "dq_ddim_sample: timestep out of range");
+    const float ab = alpha_bars_host[t];
+    coef[4 * i + 0] = std::sqrt(ab);
+    coef[4 * i + 1] = std::sqrt(1.0f - ab);
+    if (t > 0) {
+      const float abp = alpha_bars_host[t - 1];
+      coef[4 * i + 2] = std::sqrt(abp);
+      coef[4 * i + 3] = std::sqrt(1.0f - abp);
+    } else {
+      coef[4 * i + 2] = -1.f;
+      coef[4 * i + 3] = 0.f;
+    }
+  }
+  DQ_HIP_OK(hipMemcpyAsync(c.w(a.coef), coef.data(), sizeof(float) * coef.size(), hipMemcpyHostToDevice, s));
+  // the host vector must outlive the copy: pageable H2D copies are staged synchronously by the runtime, but make it explicit
+  DQ_HIP_OK(hipStreamSynchronize(s));
+  float* xa = c.w(a.xa);
+  float* xb = c.w(a.xb);
+  DQ_HIP_OK(hipMemcpyAsync(xa, x_T, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+  for (int i = 0; i < num_steps; ++i) {
+    float* eps = traj_eps ? traj_eps + (int64_t)i * n : c.w(a.eps);
+    DQ_TRY(unet_forward(c, rope_freqs, xa, nullptr, ts[i], ms2_cond, ms1_cond, cm, ca, plan->dev, eps));  // model.py:271
+    float* xn = traj_x ? traj_x + (int64_t)i * n : xb;
+    DQ_TRY(launch_ddim_step(xa, eps, xn, c.w(a.coef) + 4 * i, n, s));                                      // model.py:273-289
+    if (traj_x) {
+      DQ_HIP_OK(hipMemcpyAsync(xa, xn, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+    } else {
+      std::swap(xa, xb);
+    }
+  }
+  DQ_TRY(launch_sample_finish(xa, ms2_cond, out_x, out_noise, n, auto_normalize, s));  // model.py:319-322
+  return 0;
+}
+
+int dq_linattn_fwd(const float* x, float* y, const float* w_qkv, const float* w_out, const float* b_out, const float* g_pre,
+                   const float* g_out, int C, int rows, int n, void* stream) {
+  LinAttn a;
+  a.x = x; a.y = y; a.w_qkv = w_qkv; a.w_out = w_out; a.b_out = b_out; a.g_pre = g_pre; a.g_out = g_out; a.C = C; a.rows = rows; a.n = n;
+  return launch_linattn_fwd(a, (hipStream_t)stream);
+}
+
+int dq_linattn_bwd(const float* x, const float* dy, float* dx, const float* w_qkv, const float* w_out, const float* b_out,
+                   const float* g_pre, const float* g_out, float* dw_qkv, float* dw_out, float* db_out, float* dg_pre,
+                   float* dg_out, int C, int rows, int n, void* stream) {
+  LinAttnBwd a;
+  a.f.x = x; a.f.w_qkv = w_qkv; a.f.w_out = w_out; a.f.b_out = b_out; a.f.g_pre = g_pre; a.f.g_out = g_out; a.f.C = C; a.f.rows = rows;
+  a.f.n = n;
+  a.dy = dy; a.dx = dx; a.dw_qkv = dw_qkv; a.dw_out = dw_out; a.db_out = db_out; a.dg_pre = dg_pre; a.dg_out = dg_out;
+  return launch_linattn_bwd(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

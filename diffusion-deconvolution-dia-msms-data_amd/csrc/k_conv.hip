@@ -1,0 +1,572 @@
+// Conv-family kernels of the U-Net (K2, K3, K4, K6, K8 and the 1x1 projections of K7), forward and backward.
+// Reference arithmetic: dquartic/model/unet1d.py:223-323 (Block / ResnetBlock: Conv1d(k3,p1) -> RMSNorm ->
+// x*(scale+1)+shift -> SiLU, + res_conv), :82-110 (Upsample = nearest x2 + Conv1d(k3,p1); Downsample =
+// Conv1d(k4,s2,p1)), :113-140 (RMSNorm = F.normalize(dim=1) * g * sqrt(C)).
+//
+// Layout: every activation is (rows, C, n) fp32 with n (m/z, or RT in the bottleneck) contiguous.
+// Mapping: one thread per (row, output position); all output channels of that position live in registers, so the
+// RMSNorm over channels, the scale/shift, the activation and the residual are in-thread.  Consecutive lanes
+// are consecutive positions => coalesced 256-B wave accesses per channel.  Weights are read through
+// wave-uniform addresses (scalar loads).  No LDS.
+#include "dq_common.h"
+#include "dq_kernels.h"
+
+namespace dq {
+
+// input position feeding output position p through tap k, or -1 (zero padding)
+template <int MODE, int K>
+__device__ __forceinline__ int tap_pos(int p, int k, int n_in) {
+  if (MODE == CONV_S1) {
+    const int q = p + k - (K - 1) / 2;
+    return (q >= 0 && q < n_in) ? q : -1;
+  } else if (MODE == CONV_DOWN) {  // k4 s2 p1
+    const int q = 2 * p + k - 1;
+    return (q >= 0 && q < n_in) ? q : -1;
+  } else {  // nearest x2 then k3 p1
+    const int j = p + k - 1;
+    return (j >= 0 && j < 2 * n_in) ? (j >> 1) : -1;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// forward
+// -------------------------------------------------------------------------------------------------
+template <int COUT, int K, int MODE>
+__global__ void __launch_bounds__(256) k_conv_fwd(ConvFwd a) {
+  const int64_t item = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)a.rows * a.n_out;
+  if (item >= total) return;
+  const int row = (int)(item / a.n_out), p = (int)(item % a.n_out);
+  const int co_base = blockIdx.y * COUT;  // output-channel chunk (only for the norm-free 1x1 projections)
+  const int cin = a.cinA + a.cinB;
+
+  float acc[COUT];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) acc[co] = a.bias ? a.bias[co_base + co] : 0.f;
+
+  int q[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) q[k] = tap_pos<MODE, K>(p, k, a.n_in);
+
+  const float* w = a.w + (int64_t)co_base * cin * K;
+  for (int ci = 0; ci < cin; ++ci) {
+    const float* src = (ci < a.cinA) ? a.inA + ((int64_t)row * a.cinA + ci) * a.n_in
+                                     : a.inB + ((int64_t)row * a.cinB + (ci - a.cinA)) * a.n_in;
+    float xv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) xv[k] = q[k] >= 0 ? src[q[k]] : 0.f;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[co] = fmaf(w[((int64_t)co * cin + ci) * K + k], xv[k], acc[co]);
+    }
+  }
+
+  const int cout_total = gridDim.y * COUT;
+  if (a.u_out) {
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) a.u_out[((int64_t)row * cout_total + co_base + co) * a.n_out + p] = acc[co];
+  }
+  if (a.g) {  // RMSNorm over channels (chunking is never combined with a norm)
+    float ssq = 0.f;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) ssq = fmaf(acc[co], acc[co], ssq);
+    const float inv = sqrtf((float)COUT) / fmaxf(sqrtf(ssq), RMS_EPS);
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = acc[co] * inv * a.g[co];
+  }
+  if (a.ss) {
+    const float* ss = a.ss + (int64_t)(row / a.rows_per_sample) * a.ss_stride;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = fmaf(acc[co], ss[co] + 1.0f, ss[COUT + co]);
+  }
+  if (a.act == ACT_SILU) {
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = silu_f(acc[co]);
+  } else if (a.act == ACT_GELU) {
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = gelu_f(acc[co]);
+  }
+  if (a.resA) {
+    if (a.res_w) {
+      const int rcin = a.rcinA + a.rcinB;
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) acc[co] += a.res_b ? a.res_b[co] : 0.f;
+      for (int ci = 0; ci < rcin; ++ci) {
+        const float xv = (ci < a.rcinA) ? a.resA[((int64_t)row * a.rcinA + ci) * a.n_out + p]
+                                        : a.resB[((int64_t)row * a.rcinB + (ci - a.rcinA)) * a.n_out + p];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = fmaf(a.res_w[(int64_t)co * rcin + ci], xv, acc[co]);
+      }
+    } else {
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) acc[co] += a.resA[((int64_t)row * cout_total + co_base + co) * a.n_out + p];
+    }
+  }
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) a.y_out[((int64_t)row * cout_total + co_base + co) * a.n_out + p] = acc[co];
+}
+
+template <int COUT>
+static int conv_fwd_dispatch(const ConvFwd& a, int chunks, hipStream_t s) {
+  const int64_t total = (int64_t)a.rows * a.n_out;
+  if (total == 0) return 0;
+  dim3 grid(cdiv(total, 256), chunks), block(256);
+#define DQ_CF(KK, MM)                                                                   \
+  if (a.K == KK && a.mode == MM) {                                                       \
+    hipLaunchKernelGGL((k_conv_fwd<COUT, KK, MM>), grid, block, 0, s, a);                \
+    DQ_LAUNCH_CHECK();                                                                   \
+    return 0;                                                                            \
+  }
+  DQ_CF(1, CONV_S1)
+  DQ_CF(3, CONV_S1)
+  DQ_CF(7, CONV_S1)
+  DQ_CF(4, CONV_DOWN)
+  DQ_CF(3, CONV_UP)
+#undef DQ_CF
+  set_error("conv_fwd: unsupported (K, mode) = (" + std::to_string(a.K) + ", " + std::to_string(a.mode) + ")");
+  return 2;
+}
+
+int launch_conv_fwd(const ConvFwd& a, hipStream_t s) {
+  DQ_REQUIRE(a.inA && a.w && a.y_out && a.cout > 0 && a.cinA > 0, "conv_fwd: missing operand");
+  DQ_REQUIRE(a.cinB == 0 || a.inB, "conv_fwd: cinB > 0 needs inB");
+  if (a.mode == CONV_S1) DQ_REQUIRE(a.n_in == a.n_out && (a.K & 1), "conv_fwd: stride-1 conv needs n_in == n_out and odd K");
+  if (a.mode == CONV_DOWN) DQ_REQUIRE(a.n_in == 2 * a.n_out && a.K == 4, "conv_fwd: downsample needs n_in == 2*n_out, K == 4");
+  if (a.mode == CONV_UP) DQ_REQUIRE(2 * a.n_in == a.n_out && a.K == 3, "conv_fwd: upsample needs n_out == 2*n_in, K == 3");
+  if (a.resA && !a.res_w) DQ_REQUIRE(a.rcinA == a.cout && a.rcinB == 0, "conv_fwd: identity residual needs cout channels");
+  const bool chunkable = !a.g && !a.ss && !(a.resA && a.res_w);
+  switch (a.cout) {
+    case 1: return conv_fwd_dispatch<1>(a, 1, s);
+    case 4: return conv_fwd_dispatch<4>(a, 1, s);
+    case 8: return conv_fwd_dispatch<8>(a, 1, s);
+    case 12: return conv_fwd_dispatch<12>(a, 1, s);
+    case 16: return conv_fwd_dispatch<16>(a, 1, s);
+    case 32: return conv_fwd_dispatch<32>(a, 1, s);
+    case 64: return conv_fwd_dispatch<64>(a, 1, s);
+    default:
+      if (chunkable && a.cout % 32 == 0) return conv_fwd_dispatch<32>(a, a.cout / 32, s);
+      set_error("conv_fwd: unsupported cout " + std::to_string(a.cout));
+      return 2;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// pointwise backward of norm -> scale/shift -> act
+// grid (blocks_per_sample, B): a thread only ever touches items of one sample, so the per-sample
+// d(scale)/d(shift) sums are block-reduced and cost one atomic per (block, channel).
+// -------------------------------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(256) k_block_bwd(BlockBwd a) {
+  const int b = blockIdx.y;
+  const int64_t per_sample = (int64_t)a.rows_per_sample * a.n;  // items of one sample
+  const float sqC = sqrtf((float)C);
+  float g[C], sc[C], sh[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    g[c] = a.g ? a.g[c] : 1.f;
+    sc[c] = a.ss ? a.ss[(int64_t)b * a.ss_stride + c] + 1.0f : 1.f;
+    sh[c] = a.ss ? a.ss[(int64_t)b * a.ss_stride + C + c] : 0.f;
+  }
+  float dg[C], dsc[C], dsh[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) dg[c] = dsc[c] = dsh[c] = 0.f;
+
+  for (int64_t it = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; it < per_sample; it += (int64_t)gridDim.x * blockDim.x) {
+    const int row = b * a.rows_per_sample + (int)(it / a.n), p = (int)(it % a.n);
+    const int64_t base = (int64_t)row * C * a.n + p;
+    float u[C], d[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { u[c] = a.u[base + (int64_t)c * a.n]; d[c] = a.dy[base + (int64_t)c * a.n]; }
+    if (a.g) {
+      float ssq = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) ssq = fmaf(u[c], u[c], ssq);
+      const float nrm = sqrtf(ssq);
+      const float inv = 1.0f / fmaxf(nrm, RMS_EPS);
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float uh = u[c] * inv;            // normalised
+        const float z = uh * g[c] * sqC;        // after gain
+        const float w = fmaf(z, sc[c], sh[c]);  // after scale/shift
+        float dw = d[c];
+        if (a.act == ACT_SILU) dw *= silu_grad_f(w);
+        else if (a.act == ACT_GELU) dw *= gelu_grad_f(w);
+        dsh[c] += dw;
+        dsc[c] = fmaf(dw, z, dsc[c]);
+        const float dz = dw * sc[c];
+        dg[c] = fmaf(dz, uh * sqC, dg[c]);
+        const float gd = dz * g[c] * sqC;  // grad wrt the normalised value
+        d[c] = gd;
+        u[c] = uh;
+        dot = fmaf(gd, uh, dot);
+      }
+      const bool clamped = nrm < RMS_EPS;  // F.normalize clamps the norm: below eps the map is linear
+#pragma unroll
+      for (int c = 0; c < C; ++c) d[c] = clamped ? d[c] * inv : inv * (d[c] - u[c] * dot);
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float w = fmaf(u[c], sc[c], sh[c]);
+        float dw = d[c];
+        if (a.act == ACT_SILU) dw *= silu_grad_f(w);
+        else if (a.act == ACT_GELU) dw *= gelu_grad_f(w);
+        dsh[c] += dw;
+        dsc[c] = fmaf(dw, u[c], dsc[c]);
+        d[c] = dw * sc[c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) a.du[base + (int64_t)c * a.n] = d[c];
+  }
+
+  __shared__ float red[4][3 * C];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float s0 = wave_sum(dg[c]), s1 = wave_sum(dsc[c]), s2 = wave_sum(dsh[c]);
+    if (lane == 0) { red[wv][c] = s0; red[wv][C + c] = s1; red[wv][2 * C + c] = s2; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) {
+    const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    if (i < C) { if (a.dg) atomicAdd(a.dg + i, v); }
+    else if (a.dss) atomicAdd(a.dss + (int64_t)b * a.ss_stride + (i - C), v);  // [dscale(C) | dshift(C)]
+  }
+}
+
+int launch_block_bwd(const BlockBwd& a, hipStream_t s) {
+  DQ_REQUIRE(a.u && a.dy && a.du && a.rows > 0 && a.n > 0, "block_bwd: missing operand");
+  DQ_REQUIRE(a.rows % a.rows_per_sample == 0, "block_bwd: rows must be a multiple of rows_per_sample");
+  DQ_REQUIRE(!a.ss || a.dss, "block_bwd: scale/shift needs a gradient buffer");
+  const int B = a.rows / a.rows_per_sample;
+  const int64_t per_sample = (int64_t)a.rows_per_sample * a.n;
+  // ~4 items per thread, at most 64 blocks per sample
+  const int bps = std::max(1, std::min(64, cdiv(per_sample, 1024)));
+  dim3 grid(bps, B), block(256);
+#define DQ_BB(CC)                                                     \
+  case CC:                                                            \
+    hipLaunchKernelGGL((k_block_bwd<CC>), grid, block, 0, s, a);      \
+    break;
+  switch (a.C) {
+    DQ_BB(1) DQ_BB(4) DQ_BB(8) DQ_BB(12) DQ_BB(16) DQ_BB(32) DQ_BB(64)
+    default:
+      set_error("block_bwd: unsupported channel count " + std::to_string(a.C));
+      return 2;
+  }
+#undef DQ_BB
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// data gradient: thread = (row, input position m), NCI input channels per thread (grid.y = channel chunks)
+//   dX[ci][m] (+)= sum_co sum_(p,k : tap(p,k) == m) W[co][ci][k] * dU[co][p]
+// -------------------------------------------------------------------------------------------------
+template <int NCI, int K, int MODE>
+__global__ void __launch_bounds__(256) k_conv_bwd_data(ConvBwdData a) {
+  const int64_t item = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)a.rows * a.n_in;
+  if (item >= total) return;
+  const int row = (int)(item / a.n_in), m = (int)(item % a.n_in);
+  const int cin = a.cinA + a.cinB;
+  const int ci0 = blockIdx.y * NCI;
+
+  // contributing (p, k) pairs of input position m
+  constexpr int NT = (MODE == CONV_S1) ? K : (MODE == CONV_DOWN ? 2 : 6);
+  int tp[NT], tk[NT];
+  if (MODE == CONV_S1) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int p = m - k + (K - 1) / 2;
+      tk[k] = k;
+      tp[k] = (p >= 0 && p < a.n_out) ? p : -1;
+    }
+  } else if (MODE == CONV_DOWN) {  // 2p + k - 1 == m
+    const int par = (m + 1) & 1;   // k has the parity of m+1
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = par + 2 * j;
+      const int p2 = m + 1 - k;  // = 2p, even by construction
+      const int p = p2 >> 1;
+      tk[j] = k;
+      tp[j] = (p2 >= 0 && p < a.n_out) ? p : -1;
+    }
+  } else {  // upsampled positions j in {2m, 2m+1}; j == p + k - 1
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int p = 2 * m + jj + 1 - k;
+        tk[jj * 3 + k] = k;
+        tp[jj * 3 + k] = (p >= 0 && p < a.n_out) ? p : -1;
+      }
+    }
+  }
+
+  float acc[NCI];
+#pragma unroll
+  for (int i = 0; i < NCI; ++i) acc[i] = 0.f;
+  for (int co = 0; co < a.cout; ++co) {
+    const float* du = a.du + ((int64_t)row * a.cout + co) * a.n_out;
+    const float* w = a.w + (int64_t)co * cin * K;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float dv = tp[t] >= 0 ? du[tp[t]] : 0.f;
+#pragma unroll
+      for (int i = 0; i < NCI; ++i) {
+        const int ci = ci0 + i;
+        if (ci < cin) acc[i] = fmaf(w[(int64_t)ci * K + tk[t]], dv, acc[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NCI; ++i) {
+    const int ci = ci0 + i;
+    if (ci >= cin) continue;
+    float* dst;
+    if (ci < a.cinA) { if (!a.dinA) continue; dst = a.dinA + ((int64_t)row * a.cinA + ci) * a.n_in + m; }
+    else { if (!a.dinB) continue; dst = a.dinB + ((int64_t)row * a.cinB + (ci - a.cinA)) * a.n_in + m; }
+    *dst = a.accumulate ? *dst + acc[i] : acc[i];
+  }
+}
+
+int launch_conv_bwd_data(const ConvBwdData& a, hipStream_t s) {
+  DQ_REQUIRE(a.du && a.w && a.cout > 0 && a.cinA > 0, "conv_bwd_data: missing operand");
+  const int cin = a.cinA + a.cinB;
+  const int64_t total = (int64_t)a.rows * a.n_in;
+  if (total == 0) return 0;
+  constexpr int NCI = 4;
+  dim3 grid(cdiv(total, 256), cdiv(cin, NCI)), block(256);
+#define DQ_BD(KK, MM)                                                                     \
+  if (a.K == KK && a.mode == MM) {                                                         \
+    hipLaunchKernelGGL((k_conv_bwd_data<NCI, KK, MM>), grid, block, 0, s, a);              \
+    DQ_LAUNCH_CHECK();                                                                     \
+    return 0;                                                                              \
+  }
+  DQ_BD(1, CONV_S1)
+  DQ_BD(3, CONV_S1)
+  DQ_BD(7, CONV_S1)
+  DQ_BD(4, CONV_DOWN)
+  DQ_BD(3, CONV_UP)
+#undef DQ_BD
+  set_error("conv_bwd_data: unsupported (K, mode)");
+  return 2;
+}
+
+// -------------------------------------------------------------------------------------------------
+// weight gradient: block-y owns a (COB x CIB x K) sub-block of dW; threads stride over (row, p) items and keep the
+// sub-block in registers; one wave reduction + one atomic per (wave, element) at the end.
+// -------------------------------------------------------------------------------------------------
+template <int COB, int CIB, int K, int MODE>
+__global__ void __launch_bounds__(256) k_conv_wgrad(ConvWgrad a, int n_cib) {
+  const int cin = a.cinA + a.cinB;
+  const int co0 = (blockIdx.y / n_cib) * COB, ci0 = (blockIdx.y % n_cib) * CIB;
+  const int64_t total = (int64_t)a.rows * a.n_out;
+  float acc[COB][CIB][K];
+  float accb[COB];
+#pragma unroll
+  for (int i = 0; i < COB; ++i) {
+    accb[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < CIB; ++j)
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[i][j][k] = 0.f;
+  }
+  for (int64_t it = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(it / a.n_out), p = (int)(it % a.n_out);
+    float d[COB];
+#pragma unroll
+    for (int i = 0; i < COB; ++i) d[i] = (co0 + i < a.cout) ? a.du[((int64_t)row * a.cout + co0 + i) * a.n_out + p] : 0.f;
+    int q[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) q[k] = tap_pos<MODE, K>(p, k, a.n_in);
+#pragma unroll
+    for (int j = 0; j < CIB; ++j) {
+      const int ci = ci0 + j;
+      if (ci >= cin) continue;
+      const float* src = (ci < a.cinA) ? a.inA + ((int64_t)row * a.cinA + ci) * a.n_in
+                                       : a.inB + ((int64_t)row * a.cinB + (ci - a.cinA)) * a.n_in;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float xv = q[k] >= 0 ? src[q[k]] : 0.f;
+#pragma unroll
+        for (int i = 0; i < COB; ++i) acc[i][j][k] = fmaf(d[i], xv, acc[i][j][k]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < COB; ++i) accb[i] += d[i];
+  }
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < COB; ++i) {
+    const int co = co0 + i;
+#pragma unroll
+    for (int j = 0; j < CIB; ++j) {
+      const int ci = ci0 + j;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float v = wave_sum(acc[i][j][k]);
+        if (lane == 0 && co < a.cout && ci < cin) atomicAdd(a.dw + ((int64_t)co * cin + ci) * K + k, v);
+      }
+    }
+    if (a.dbias && ci0 == 0) {
+      const float v = wave_sum(accb[i]);
+      if (lane == 0 && co < a.cout) atomicAdd(a.dbias + co, v);
+    }
+  }
+}
+
+int launch_conv_wgrad(const ConvWgrad& a, hipStream_t s) {
+  DQ_REQUIRE(a.du && a.inA && a.dw && a.cout > 0 && a.cinA > 0, "conv_wgrad: missing operand");
+  const int cin = a.cinA + a.cinB;
+  const int64_t total = (int64_t)a.rows * a.n_out;
+  if (total == 0) return 0;
+  constexpr int COB = 4, CIB = 4;
+  const int n_cob = cdiv(a.cout, COB), n_cib = cdiv(cin, CIB);
+  // >= 16 items per thread where the problem allows it, but enough blocks to cover the chip
+  int gx = std::max(1, std::min(cdiv(total, 256 * 16), std::max(1, 2048 / (n_cob * n_cib))));
+  dim3 grid(gx, n_cob * n_cib), block(256);
+#define DQ_WG(KK, MM)                                                                          \
+  if (a.K == KK && a.mode == MM) {                                                              \
+    hipLaunchKernelGGL((k_conv_wgrad<COB, CIB, KK, MM>), grid, block, 0, s, a, n_cib);          \
+    DQ_LAUNCH_CHECK();                                                                          \
+    return 0;                                                                                   \
+  }
+  DQ_WG(1, CONV_S1)
+  DQ_WG(3, CONV_S1)
+  DQ_WG(7, CONV_S1)
+  DQ_WG(4, CONV_DOWN)
+  DQ_WG(3, CONV_UP)
+#undef DQ_WG
+  set_error("conv_wgrad: unsupported (K, mode)");
+  return 2;
+}
+
+// -------------------------------------------------------------------------------------------------
+// small helpers
+// -------------------------------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(256) k_rmsnorm_fwd(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ y,
+                                                     int rows, int n) {
+  const int64_t item = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (item >= (int64_t)rows * n) return;
+  const int row = (int)(item / n), p = (int)(item % n);
+  const int64_t base = (int64_t)row * C * n + p;
+  float v[C];
+  float ssq = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) { v[c] = x[base + (int64_t)c * n]; ssq = fmaf(v[c], v[c], ssq); }
+  const float inv = sqrtf((float)C) / fmaxf(sqrtf(ssq), RMS_EPS);
+#pragma unroll
+  for (int c = 0; c < C; ++c) y[base + (int64_t)c * n] = v[c] * inv * g[c];
+}
+
+int launch_rmsnorm_fwd(const float* x, const float* g, float* y, int C, int rows, int n, hipStream_t s) {
+  const int64_t total = (int64_t)rows * n;
+  if (total == 0) return 0;
+  dim3 grid(cdiv(total, 256)), block(256);
+  switch (C) {
+    case 16: hipLaunchKernelGGL((k_rmsnorm_fwd<16>), grid, block, 0, s, x, g, y, rows, n); break;
+    case 32: hipLaunchKernelGGL((k_rmsnorm_fwd<32>), grid, block, 0, s, x, g, y, rows, n); break;
+    case 64: hipLaunchKernelGGL((k_rmsnorm_fwd<64>), grid, block, 0, s, x, g, y, rows, n); break;
+    default: set_error("rmsnorm_fwd: unsupported channel count " + std::to_string(C)); return 2;
+  }
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// in: to_mid ? (B*RT, cn) rows : (B, cn, RT).  Tiny tensor (B*RT*cn floats); plain index transpose.
+__global__ void __launch_bounds__(256) k_fold(const float* __restrict__ in, float* __restrict__ out, int B, int RT, int cn, int to_mid,
+                                              int add) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * RT * cn;
+  if (i >= total) return;
+  // i indexes the OUTPUT contiguously
+  int64_t src;
+  if (to_mid) {  // out (B, cn, RT)
+    const int rt = (int)(i % RT);
+    const int c = (int)((i / RT) % cn);
+    const int b = (int)(i / ((int64_t)RT * cn));
+    src = ((int64_t)b * RT + rt) * cn + c;
+  } else {  // out (B*RT, cn)
+    const int c = (int)(i % cn);
+    const int rt = (int)((i / cn) % RT);
+    const int b = (int)(i / ((int64_t)RT * cn));
+    src = ((int64_t)b * cn + c) * RT + rt;
+  }
+  out[i] = add ? out[i] + in[src] : in[src];
+}
+
+int launch_fold(const float* in, float* out, int B, int RT, int cn, int to_mid, int add, hipStream_t s) {
+  const int64_t total = (int64_t)B * RT * cn;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(k_fold, dim3(cdiv(total, 256)), dim3(256), 0, s, in, out, B, RT, cn, to_mid, add);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// cat0[row][0][mz] = (cond*cm+ca)*(scale_b+1)+shift_b ; cat0[row][1][mz] = x ; ms1n = ms1*cm+ca
+// (reference unet1d.py:1107-1115 with the normalisation of model.py:310-311 / 350-351 folded in)
+__global__ void __launch_bounds__(256) k_prep_inputs(const float* __restrict__ x, const float* __restrict__ cond,
+                                                     const float* __restrict__ ms1, const float* __restrict__ ss, int ss_stride,
+                                                     int ss_off, float cm, float ca, float* __restrict__ cat0,
+                                                     float* __restrict__ ms1n, int B, int RT, int MZ) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * RT * MZ;
+  if (i < (int64_t)B * RT) ms1n[i] = fmaf(ms1[i], cm, ca);
+  if (i >= total) return;
+  const int mz = (int)(i % MZ);
+  const int64_t row = i / MZ;
+  const int b = (int)(row / RT);
+  const float sc = ss[(int64_t)b * ss_stride + ss_off], sh = ss[(int64_t)b * ss_stride + ss_off + 1];
+  const float cn = fmaf(cond[i], cm, ca);
+  cat0[(row * 2 + 0) * MZ + mz] = cn * (sc + 1.0f) + sh;
+  cat0[(row * 2 + 1) * MZ + mz] = x[i];
+}
+
+int launch_prep_inputs(const float* x, const float* cond, const float* ms1, const float* ss, int ss_stride, int ss_off, float cm,
+                       float ca, float* cat0, float* ms1n, int B, int RT, int MZ, hipStream_t s) {
+  const int64_t total = (int64_t)B * RT * MZ;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(k_prep_inputs, dim3(cdiv(total, 256)), dim3(256), 0, s, x, cond, ms1, ss, ss_stride, ss_off, cm, ca, cat0,
+                     ms1n, B, RT, MZ);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void __launch_bounds__(256) k_prep_inputs_bwd(const float* __restrict__ dcat0, const float* __restrict__ cond, float cm,
+                                                         float ca, float* __restrict__ dss, int ss_stride, int ss_off, int RT,
+                                                         int MZ) {
+  const int b = blockIdx.y;
+  const int64_t per = (int64_t)RT * MZ;
+  float dsc = 0.f, dsh = 0.f;
+  for (int64_t it = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; it < per; it += (int64_t)gridDim.x * blockDim.x) {
+    const int mz = (int)(it % MZ);
+    const int64_t row = (int64_t)b * RT + it / MZ;
+    const float d = dcat0[(row * 2 + 0) * MZ + mz];
+    dsh += d;
+    dsc = fmaf(d, fmaf(cond[(int64_t)b * per + it], cm, ca), dsc);
+  }
+  __shared__ float red[4][2];
+  dsc = wave_sum(dsc);
+  dsh = wave_sum(dsh);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = dsc; red[threadIdx.x >> 6][1] = dsh; }
+  __syncthreads();
+  if (threadIdx.x < 2)
+    atomicAdd(dss + (int64_t)b * ss_stride + ss_off + threadIdx.x,
+              red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+int launch_prep_inputs_bwd(const float* dcat0, const float* cond, float cm, float ca, float* dss, int ss_stride, int ss_off, int B,
+                           int RT, int MZ, hipStream_t s) {
+  const int64_t per = (int64_t)RT * MZ;
+  if (per == 0 || B == 0) return 0;
+  dim3 grid(std::max(1, std::min(32, cdiv(per, 1024))), B);
+  hipLaunchKernelGGL(k_prep_inputs_bwd, grid, dim3(256), 0, s, dcat0, cond, cm, ca, dss, ss_stride, ss_off, RT, MZ);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace dq

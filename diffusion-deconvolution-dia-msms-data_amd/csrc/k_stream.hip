@@ -1,0 +1,219 @@
+// Streaming (HBM-bound) kernels of the DDIM process: q_sample (K0), DDIM update (K9), MSE loss + its
+// gradient (K10), global-norm clip + AdamW on the flat parameter buffer (K11).
+// Reference arithmetic: dquartic/model/model.py:239-242 (q_sample), :265-289 (p_sample update),
+// :319-322 (sample epilogue), :361 (mse_loss); dquartic/model/model_interface.py:1121-1122
+// (clip_grad_norm_(10.0) + AdamW with torch defaults).
+// All kernels: 16 B per lane, grid-stride, no LDS.  Algorithmic bytes per element are stated per kernel.
+#include "dq_common.h"
+#include "dq_kernels.h"
+#include <algorithm>
+#include <cmath>
+
+namespace dq {
+
+// ---- K0: x_t = sqrt(ab[t_b]) * (2*x0-1) + sqrt(1-ab[t_b]) * noise : 12 B / element (2 reads + 1 write)
+__global__ void __launch_bounds__(256) k_q_sample(const float* __restrict__ alpha_bars, const float* __restrict__ x0,
+                                                  const int64_t* __restrict__ t, const float* __restrict__ noise,
+                                                  float* __restrict__ x_t, int B, int64_t per4, int normalize) {
+  const int64_t total = (int64_t)B * per4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per4);
+    const float ab = alpha_bars[t[b]];
+    const float sa = sqrtf(ab), sb = sqrtf(1.0f - ab);
+    float4 x = reinterpret_cast<const float4*>(x0)[i];
+    const float4 nz = reinterpret_cast<const float4*>(noise)[i];
+    if (normalize) { x.x = x.x * 2.f - 1.f; x.y = x.y * 2.f - 1.f; x.z = x.z * 2.f - 1.f; x.w = x.w * 2.f - 1.f; }
+    float4 o;
+    o.x = sa * x.x + sb * nz.x; o.y = sa * x.y + sb * nz.y; o.z = sa * x.z + sb * nz.z; o.w = sa * x.w + sb * nz.w;
+    reinterpret_cast<float4*>(x_t)[i] = o;
+  }
+}
+
+int launch_q_sample(const float* alpha_bars, const float* x0, const int64_t* t, const float* noise, float* x_t, int B,
+                    int64_t per_sample, int normalize, hipStream_t s) {
+  DQ_REQUIRE(per_sample % 4 == 0, "q_sample: RT*MZ must be a multiple of 4");
+  const int64_t per4 = per_sample / 4, total = B * per4;
+  if (total == 0) return 0;
+  const int grid = (int)std::min<int64_t>(cdiv(total, 256), 2048);
+  hipLaunchKernelGGL(k_q_sample, dim3(grid), dim3(256), 0, s, alpha_bars, x0, t, noise, x_t, B, per4, normalize);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- K9: x0 = (x_t - sb*eps)/sa ; x_prev = sap*x0 + sbp*eps (t>0) else x0 : 12 B / element
+// ``coef`` is a device table of 4 floats per step [sa, sb, sap, sbp]; sap < 0 marks the t == 0 step.
+__global__ void __launch_bounds__(256) k_ddim_step(const float* __restrict__ x_t, const float* __restrict__ eps,
+                                                   float* __restrict__ x_prev, const float* __restrict__ coef, int64_t n4) {
+  const float sa = coef[0], sb = coef[1], sap = coef[2], sbp = coef[3];
+  const bool last = sap < 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 x = reinterpret_cast<const float4*>(x_t)[i];
+    const float4 e = reinterpret_cast<const float4*>(eps)[i];
+    float4 o;
+    float x0;
+    x0 = (x.x - sb * e.x) / sa; o.x = last ? x0 : sap * x0 + sbp * e.x;
+    x0 = (x.y - sb * e.y) / sa; o.y = last ? x0 : sap * x0 + sbp * e.y;
+    x0 = (x.z - sb * e.z) / sa; o.z = last ? x0 : sap * x0 + sbp * e.z;
+    x0 = (x.w - sb * e.w) / sa; o.w = last ? x0 : sap * x0 + sbp * e.w;
+    reinterpret_cast<float4*>(x_prev)[i] = o;
+  }
+}
+
+int launch_ddim_step(const float* x_t, const float* eps, float* x_prev, const float* coef_dev, int64_t n, hipStream_t s) {
+  DQ_REQUIRE(n % 4 == 0, "ddim_step: element count must be a multiple of 4");
+  if (n == 0) return 0;
+  const int grid = (int)std::min<int64_t>(cdiv(n / 4, 256), 2048);
+  hipLaunchKernelGGL(k_ddim_step, dim3(grid), dim3(256), 0, s, x_t, eps, x_prev, coef_dev, n / 4);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- sample() epilogue (model.py:319-322): x = (x+1)/2 ; pred = ((2c-1)+1)/2 - x : 16 B / element
+__global__ void __launch_bounds__(256) k_sample_finish(const float* __restrict__ x, const float* __restrict__ ms2_cond,
+                                                       float* __restrict__ out_x, float* __restrict__ out_noise, int64_t n4,
+                                                       int normalize) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 c = reinterpret_cast<const float4*>(ms2_cond)[i];
+    float4 o, p;
+    if (!normalize) {  // identity normalisation: x stays, pred_noise = ms2_cond - x
+      p.x = c.x - v.x; p.y = c.y - v.y; p.z = c.z - v.z; p.w = c.w - v.w;
+      reinterpret_cast<float4*>(out_x)[i] = v;
+      reinterpret_cast<float4*>(out_noise)[i] = p;
+      continue;
+    }
+    o.x = (v.x + 1.f) * 0.5f; o.y = (v.y + 1.f) * 0.5f; o.z = (v.z + 1.f) * 0.5f; o.w = (v.w + 1.f) * 0.5f;
+    p.x = ((c.x * 2.f - 1.f) + 1.f) * 0.5f - o.x; p.y = ((c.y * 2.f - 1.f) + 1.f) * 0.5f - o.y;
+    p.z = ((c.z * 2.f - 1.f) + 1.f) * 0.5f - o.z; p.w = ((c.w * 2.f - 1.f) + 1.f) * 0.5f - o.w;
+    reinterpret_cast<float4*>(out_x)[i] = o;
+    reinterpret_cast<float4*>(out_noise)[i] = p;
+  }
+}
+
+int launch_sample_finish(const float* x, const float* ms2_cond, float* out_x, float* out_noise, int64_t n, int normalize,
+                         hipStream_t s) {
+  DQ_REQUIRE(n % 4 == 0, "sample_finish: element count must be a multiple of 4");
+  if (n == 0) return 0;
+  const int grid = (int)std::min<int64_t>(cdiv(n / 4, 256), 2048);
+  hipLaunchKernelGGL(k_sample_finish, dim3(grid), dim3(256), 0, s, x, ms2_cond, out_x, out_noise, n / 4, normalize);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- K10: loss = mean((eps-noise)^2) ; grad = 2*(eps-noise)*gscale : 12 B / element
+// partial sums go to ``partials`` (one per block, fixed order => deterministic); k_loss_final sums them.
+__global__ void __launch_bounds__(256) k_mse_fwd_bwd(const float* __restrict__ eps, const float* __restrict__ noise,
+                                                     float* __restrict__ grad, float* __restrict__ partials, int64_t n4,
+                                                     float gscale) {
+  float acc = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 e = reinterpret_cast<const float4*>(eps)[i];
+    const float4 z = reinterpret_cast<const float4*>(noise)[i];
+    float4 d;
+    d.x = e.x - z.x; d.y = e.y - z.y; d.z = e.z - z.z; d.w = e.w - z.w;
+    acc += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+    if (grad) {
+      float4 g;
+      g.x = d.x * gscale; g.y = d.y * gscale; g.z = d.z * gscale; g.w = d.w * gscale;
+      reinterpret_cast<float4*>(grad)[i] = g;
+    }
+  }
+  __shared__ float red[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(64) k_sum_partials(const float* __restrict__ partials, int n, float scale, float* __restrict__ out) {
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) acc += partials[i];
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) out[0] = acc * scale;
+}
+
+__global__ void __launch_bounds__(256) k_axpy(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+
+int launch_axpy(float* dst, const float* src, int64_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_axpy, dim3((int)std::min<int64_t>(cdiv(n, 256), 4096)), dim3(256), 0, s, dst, src, n);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_mse_fwd_bwd(const float* eps, const float* noise, float* loss_out, float* grad_out, float* partials, int64_t n,
+                       hipStream_t s) {
+  DQ_REQUIRE(n % 4 == 0 && n > 0, "mse: element count must be a positive multiple of 4");
+  const int grid = (int)std::min<int64_t>(cdiv(n / 4, 256), MSE_MAX_BLOCKS);
+  hipLaunchKernelGGL(k_mse_fwd_bwd, dim3(grid), dim3(256), 0, s, eps, noise, grad_out, partials, n / 4, 2.0f / (float)n);
+  DQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, s, partials, grid, 1.0f / (float)n, loss_out);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- K11: global L2 norm (two-stage, deterministic) + clip + AdamW, flat buffers.
+// norm pass: 4 B / param ; update pass: 28 B / param (read p,g,m,v ; write p,m,v).
+__global__ void __launch_bounds__(256) k_sumsq(const float* __restrict__ g, int64_t n, float gscale, float* __restrict__ partials) {
+  float acc = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = g[i] * gscale;
+    acc += v * v;
+  }
+  __shared__ float red[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(256) k_adamw_clip(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, const float* __restrict__ partials,
+                                                    int n_partials, float gscale, float max_norm, float decay, float step_size,
+                                                    float one_m_b1, float b2, float one_m_b2, float eps, float bc2_sqrt,
+                                                    float* __restrict__ gnorm_out) {
+  // every block re-derives the same clip coefficient from the same partials in the same order
+  __shared__ float s_coef;
+  if (threadIdx.x < 64) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n_partials; i += 64) acc += partials[i];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) {
+      const float nrm = sqrtf(acc);
+      const float c = max_norm / (nrm + 1e-6f);  // torch clip_grad_norm_: coef clamped to 1
+      s_coef = (max_norm > 0.f) ? fminf(c, 1.0f) : 1.0f;
+      if (blockIdx.x == 0 && gnorm_out) gnorm_out[0] = nrm;
+    }
+  }
+  __syncthreads();
+  const float coef = s_coef * gscale;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * coef;
+    float pi = p[i] * decay;
+    const float mo = m[i];
+    const float mi = mo + one_m_b1 * (gi - mo);          // torch: exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = fmaf(one_m_b2 * gi, gi, b2 * v[i]);  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+
+int launch_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, float* partials, float gscale, float max_norm,
+                      double lr, double b1, double b2, double eps, double wd, int step, float* gnorm_out, hipStream_t s) {
+  DQ_REQUIRE(n > 0 && step >= 1, "adamw: need n > 0 and step >= 1");
+  const int grid = (int)std::min<int64_t>(cdiv(n, 256), MSE_MAX_BLOCKS);
+  hipLaunchKernelGGL(k_sumsq, dim3(grid), dim3(256), 0, s, g, n, gscale, partials);
+  DQ_LAUNCH_CHECK();
+  const double bc1 = 1.0 - std::pow(b1, step), bc2 = 1.0 - std::pow(b2, step);
+  // scalar factors are formed in double like torch's Python-side arithmetic, then applied in fp32
+  hipLaunchKernelGGL(k_adamw_clip, dim3(grid), dim3(256), 0, s, p, g, m, v, n, partials, grid, gscale, max_norm,
+                     (float)(1.0 - lr * wd), (float)(lr / bc1), (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps,
+                     (float)std::sqrt(bc2), gnorm_out);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace dq

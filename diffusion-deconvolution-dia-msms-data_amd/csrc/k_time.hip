@@ -1,0 +1,160 @@
+// K1: timestep embedding MLP and every per-block scale/shift projection that hangs off it.
+// Reference arithmetic: dquartic/model/unet1d.py:196-218 (SinusoidalPosEmb), :956-960 (time_mlp: Linear ->
+// exact GELU -> Linear), :292-296 and :315-318 (ResnetBlock.mlp = SiLU -> Linear(time_dim, 2*C_out)), :662-678
+// (ConditionalScaleShift of the mixture input).  All the SiLU->Linear heads read the same silu(temb), so they are
+// evaluated as ONE (ss_total x 16) mat-vec per sample; row r of that virtual matrix is described by the device
+// tables ss_w_off[r] / ss_b_off[r] (offsets into the flat parameter buffer).
+// Launch-bound work (B x ~10 kFLOP): one wave per sample, everything in registers/LDS.
+#include "dq_common.h"
+#include "dq_kernels.h"
+#include "dq_plan.h"
+#include "dq_unet.h"
+
+namespace dq {
+
+// tbuf per sample: [0,4) sinu | [4,20) h_pre | [20,36) h_act | [36,52) temb | [52,68) silu(temb) | [68,84) dtemb | [84,100) dh_pre
+__global__ void __launch_bounds__(64) k_time_fwd(const float* __restrict__ P, const int64_t* __restrict__ t, int t_scalar,
+                                                 float* __restrict__ tbuf, float* __restrict__ ss, int ss_total,
+                                                 const int64_t* __restrict__ ss_w_off, const int64_t* __restrict__ ss_b_off,
+                                                 int64_t t1w, int64_t t1b, int64_t t2w, int64_t t2b, int dim, float theta) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float* tb = tbuf + (int64_t)b * TBUF_FLOATS;
+  __shared__ float sinu[4], hact[16], st[16];
+  const float tv = (float)(t ? t[b] : (int64_t)t_scalar);  // int64 * fp32 -> fp32 (unet1d.py:215)
+  const int half = dim / 2;
+  if (tid < dim) {
+    const int j = tid % half;
+    const float kf = (float)(-log((double)theta) / (double)(half - 1));
+    const float f = expf((float)j * kf);
+    const float e = tv * f;
+    const float v = tid < half ? sinf(e) : cosf(e);
+    sinu[tid] = v;
+    tb[tid] = v;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float h = P[t1b + tid];
+    for (int i = 0; i < dim; ++i) h = fmaf(P[t1w + tid * dim + i], sinu[i], h);
+    tb[4 + tid] = h;
+    const float a = gelu_f(h);
+    tb[20 + tid] = a;
+    hact[tid] = a;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float e = P[t2b + tid];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) e = fmaf(P[t2w + tid * 16 + i], hact[i], e);
+    tb[36 + tid] = e;
+    const float sv = silu_f(e);
+    tb[52 + tid] = sv;
+    st[tid] = sv;
+  }
+  __syncthreads();
+  for (int r = tid; r < ss_total; r += 64) {
+    const float* w = P + ss_w_off[r];
+    float v = P[ss_b_off[r]];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v = fmaf(w[i], st[i], v);
+    ss[(int64_t)b * ss_total + r] = v;
+  }
+}
+
+int launch_time_embed_fwd(const Plan& p, const DevTables& dt, const float* params, const int64_t* t, int t_scalar, float* tbuf,
+                          float* ss, int B, hipStream_t s) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(k_time_fwd, dim3(B), dim3(64), 0, s, params, t, t_scalar, tbuf, ss, p.ss_total, dt.ss_w_off, dt.ss_b_off,
+                     p.t1_w, p.t1_b, p.t2_w, p.t2_b, p.dim, 10000.0f);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- backward ----
+// (1) per ss row r: dW[r][:] += sum_b dss[b][r] * silu(temb_b) ; db[r] += sum_b dss[b][r]
+__global__ void __launch_bounds__(64) k_time_bwd_rows(float* __restrict__ G, const float* __restrict__ tbuf,
+                                                      const float* __restrict__ dss, int ss_total, int B,
+                                                      const int64_t* __restrict__ ss_w_off, const int64_t* __restrict__ ss_b_off) {
+  const int r = blockIdx.x * 64 + threadIdx.x;
+  if (r >= ss_total) return;
+  float dw[16], db = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dw[i] = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float d = dss[(int64_t)b * ss_total + r];
+    const float* st = tbuf + (int64_t)b * TBUF_FLOATS + 52;
+    db += d;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dw[i] = fmaf(d, st[i], dw[i]);
+  }
+  float* gw = G + ss_w_off[r];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) gw[i] += dw[i];
+  G[ss_b_off[r]] += db;
+}
+
+// (2) per sample: d silu(temb) = sum_r dss[b][r] W[r][:] -> dtemb -> dh_act -> dh_pre (stored in tbuf)
+__global__ void __launch_bounds__(64) k_time_bwd_sample(const float* __restrict__ P, float* __restrict__ tbuf,
+                                                        const float* __restrict__ dss, int ss_total,
+                                                        const int64_t* __restrict__ ss_w_off, int64_t t2w) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float* tb = tbuf + (int64_t)b * TBUF_FLOATS;
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int r = tid; r < ss_total; r += 64) {
+    const float d = dss[(int64_t)b * ss_total + r];
+    const float* w = P + ss_w_off[r];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = fmaf(d, w[i], acc[i]);
+  }
+  __shared__ float dtemb[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float v = wave_sum(acc[i]);
+    if (tid == i) {
+      const float dt = v * silu_grad_f(tb[36 + i]);
+      dtemb[i] = dt;
+      tb[68 + i] = dt;
+    }
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float dh = 0.f;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) dh = fmaf(dtemb[o], P[t2w + o * 16 + tid], dh);
+    tb[84 + tid] = dh * gelu_grad_f(tb[4 + tid]);
+  }
+}
+
+// (3) weights of the two time_mlp Linears: thread (o, i) loops over the batch
+__global__ void __launch_bounds__(256) k_time_bwd_mlp(float* __restrict__ G, const float* __restrict__ tbuf, int B, int64_t t1w,
+                                                      int64_t t1b, int64_t t2w, int64_t t2b, int dim) {
+  const int tid = threadIdx.x, o = tid >> 4, i = tid & 15;
+  float dw2 = 0.f, db2 = 0.f, dw1 = 0.f, db1 = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* tb = tbuf + (int64_t)b * TBUF_FLOATS;
+    const float dt = tb[68 + o], dh = tb[84 + o];
+    dw2 = fmaf(dt, tb[20 + i], dw2);
+    db2 += dt;
+    if (i < dim) dw1 = fmaf(dh, tb[i], dw1);
+    db1 += dh;
+  }
+  G[t2w + o * 16 + i] += dw2;
+  if (i < dim) G[t1w + o * dim + i] += dw1;
+  if (i == 0) { G[t2b + o] += db2; G[t1b + o] += db1; }
+}
+
+int launch_time_embed_bwd(const Plan& p, const DevTables& dt, const float* params, float* grads, float* tbuf, const float* dss,
+                          int B, hipStream_t s) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(k_time_bwd_rows, dim3(cdiv(p.ss_total, 64)), dim3(64), 0, s, grads, tbuf, dss, p.ss_total, B, dt.ss_w_off,
+                     dt.ss_b_off);
+  DQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_time_bwd_sample, dim3(B), dim3(64), 0, s, params, tbuf, dss, p.ss_total, dt.ss_w_off, p.t2_w);
+  DQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_time_bwd_mlp, dim3(1), dim3(256), 0, s, grads, tbuf, B, p.t1_w, p.t1_b, p.t2_w, p.t2_b, p.dim);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace dq

@@ -1,0 +1,72 @@
+"""ctypes binding of libdq_hip.so (include/dq_hip.h).  There is NO fallback: if the library is missing or a call
+fails, a RuntimeError is raised -- the product path never routes through PyTorch ops or the test oracle."""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("DQ_HIP_LIB", os.path.join(os.path.dirname(_HERE), "libdq_hip.so"))
+
+_lib = None
+
+# name -> (restype, argtypes); this table is checked against include/dq_hip.h by tests/test_abi.py
+PROTOTYPES = {
+    "dq_last_error": (c_char_p, []),
+    "dq_abi_version": (c_int, []),
+    "dq_plan_create": (c_void_p, [c_int, c_int, POINTER(c_int), c_int, c_int]),
+    "dq_plan_destroy": (None, [c_void_p]),
+    "dq_plan_num_params": (c_int, [c_void_p]),
+    "dq_plan_param_floats": (c_int64, [c_void_p]),
+    "dq_plan_param_info": (c_int, [c_void_p, c_int, c_char_p, c_int, POINTER(c_int64), POINTER(c_int), POINTER(c_int64)]),
+    "dq_unet_workspace_bytes": (c_int64, [c_void_p, c_int, c_int, c_int]),
+    "dq_q_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "dq_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dq_unet_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_float,
+                            c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "dq_unet_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                            c_int64, c_int, c_int, c_void_p]),
+    "dq_mse_loss_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dq_adamw_clip_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_double,
+                                   c_double, c_double, c_double, c_double, c_int, c_void_p, c_void_p]),
+    "dq_train_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                              c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "dq_ddim_sample": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_float), c_void_p, c_void_p, c_void_p, c_int,
+                               POINTER(c_int32), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                               c_void_p]),
+    "dq_linattn_fwd": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
+    "dq_linattn_bwd": (c_int, [c_void_p] * 13 + [c_int, c_int, c_int, c_void_p]),
+}
+
+
+def lib():
+    """Load (once) and return the shared library; raises RuntimeError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"libdq_hip.so not found at {LIB_PATH}: build it with `make -C diffusion-deconvolution-dia-msms-data_amd` "
+                "(or python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().dq_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device/host pointer of a contiguous torch tensor (None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

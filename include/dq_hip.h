@@ -1,0 +1,120 @@
+/* libdq_hip.so -- C ABI of the MI355X (gfx950) implementation of dquartic's DDIM hot path.
+ *
+ * The reference (Roestlab/diffusion-deconvolution-dia-msms-data, "dquartic") is pure PyTorch and has no FFI of
+ * its own; its boundary for this path is the Python object protocol of dquartic/model/model.py and
+ * dquartic/model/unet1d.py.  Each entry point below names the reference method whose arithmetic it replaces
+ * (file:line relative to the reference checkout).  The host-side mirror of that protocol
+ * (diffusion-deconvolution-dia-msms-data_amd/dquartic/) binds these symbols with ctypes; INTEGRATION.md shows the stub
+ * a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only: device pointers (float* / int64_t*), sizes, a HIP stream passed as void*;
+ *   - every call is asynchronous on the given stream, allocates no device memory and keeps no pointer after it
+ *     returns; the caller supplies the workspace (size from dq_unet_workspace_bytes);
+ *   - returns 0 on success; non-zero => dq_last_error() (thread-local text) says why;
+ *   - tensors are contiguous fp32; MS2 windows are (B, RT, MZ) with MZ contiguous, MS1 chromatograms (B, RT),
+ *     timesteps int64 (B);
+ *   - parameters/gradients/AdamW moments are single flat fp32 buffers whose layout is described by
+ *     dq_plan_param_info (tensor names == the reference's state_dict keys, reference registration order);
+ *   - calls that share a dq_plan must not run concurrently; distinct plans are independent.
+ */
+#ifndef DQ_HIP_H
+#define DQ_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dq_plan dq_plan;
+
+/* Text of the last error on this thread ("" if none). */
+const char* dq_last_error(void);
+/* ABI version of this header (bumped on any signature change). */
+int dq_abi_version(void);
+
+/* ---- network description -------------------------------------------------------------------------------------
+ * Replaces UNet1d.__init__ (unet1d.py:918-1084) for simple=True, conditional=True, channels=1,
+ * init_cond_channels=1, attn_cond_channels=1: builds the layer list and the flat parameter layout.
+ * mz == downsample_dim.  Returns NULL on an unsupported configuration (see dq_last_error). */
+dq_plan* dq_plan_create(int dim, int n_mults, const int* dim_mults, int mz, int num_timesteps);
+void dq_plan_destroy(dq_plan* plan);
+/* Number of trainable tensors / total trainable floats in the flat buffer. */
+int dq_plan_num_params(const dq_plan* plan);
+int64_t dq_plan_param_floats(const dq_plan* plan);
+/* Tensor i: state_dict key (NUL-terminated into name[name_cap]), offset in floats, ndim, shape[4]. */
+int dq_plan_param_info(const dq_plan* plan, int i, char* name, int name_cap, int64_t* offset, int* ndim, int64_t* shape);
+/* Bytes of workspace dq_unet_fwd / dq_unet_bwd / dq_train_step / dq_ddim_sample need for (B, RT).
+ * training != 0 adds the gradient twin of the activation arena. */
+int64_t dq_unet_workspace_bytes(dq_plan* plan, int B, int RT, int training);
+
+/* ---- K0: DDIMDiffusionModel.q_sample (model.py:225-242) ---------------------------------------------------------
+ * x_t = sqrt(ab[t_b]) * x0' + sqrt(1 - ab[t_b]) * noise, x0' = 2*x0-1 if normalize_x0 (model.py:349) else x0. */
+int dq_q_sample(const float* alpha_bars_dev, const float* x0, const int64_t* t, const float* noise, float* x_t, int B,
+                int64_t per_sample, int normalize_x0, void* stream);
+
+/* ---- K9: the update of DDIMDiffusionModel.p_sample (model.py:265-289, pred_type "eps") ---------------------------
+ * coef_dev: 4 device floats [sqrt(ab_t), sqrt(1-ab_t), sqrt(ab_{t-1}), sqrt(1-ab_{t-1})]; coef_dev[2] < 0 means t == 0
+ * (x_prev = x0_pred). */
+int dq_ddim_step(const float* x_t, const float* eps, float* x_prev, const float* coef_dev, int64_t n, void* stream);
+
+/* ---- K1-K8: UNet1d.forward (unet1d.py:1086-1166) ---------------------------------------------------------------
+ * params: flat parameter buffer; rope_freqs: the 8 non-trainable RoPE frequencies (device).
+ * x, init_cond (B,RT,MZ); attn_cond (B,RT); t (B) int64 or NULL => every sample uses t_scalar.
+ * init_cond/attn_cond are mapped v*cond_mul+cond_add on the fly (2,-1 reproduces model.py:310-311/350-351; 1,0 = raw).
+ * out (B,RT,MZ) receives the prediction.  The workspace keeps the activations dq_unet_bwd needs. */
+int dq_unet_fwd(dq_plan* plan, const float* params, const float* rope_freqs, const float* x, const int64_t* t, int t_scalar,
+                const float* init_cond, const float* attn_cond, float cond_mul, float cond_add, float* out, void* workspace,
+                int64_t workspace_bytes, int B, int RT, void* stream);
+/* Backward of the call above (same plan/workspace/arguments, workspace sized with training=1): accumulates
+ * d loss / d params into grads (+=; zero it first) given grad_out = d loss / d out.  grad_x (optional, may be NULL)
+ * receives d loss / d x.  Replaces loss.backward() through the network (model_interface.py:1120). */
+int dq_unet_bwd(dq_plan* plan, const float* params, const float* rope_freqs, const float* init_cond, float cond_mul,
+                float cond_add, const float* grad_out, float* grads, float* grad_x, void* workspace, int64_t workspace_bytes,
+                int B, int RT, void* stream);
+
+/* ---- K10: F.mse_loss(eps_pred, noise) and its gradient (model.py:361) ------------------------------------------
+ * loss_out: 1 device float (mean over all n elements); grad_out (nullable): 2*(eps-noise)/n.
+ * scratch: >= 1024 device floats. */
+int dq_mse_loss_fwd_bwd(const float* eps, const float* noise, float* loss_out, float* grad_out, float* scratch, int64_t n,
+                        void* stream);
+
+/* ---- K11: clip_grad_norm_(max_norm) + AdamW step (model_interface.py:1121-1122, torch defaults) ----------------
+ * grads are first multiplied by grad_scale (1/world_size after a summing all-reduce), the global L2 norm of the
+ * scaled grads goes to gnorm_out (nullable, 1 device float), then coef = min(1, max_norm/(norm+1e-6)) (max_norm <= 0
+ * disables clipping) and the decoupled-decay AdamW update with bias correction for `step` (1-based).
+ * scratch: >= 1024 device floats. */
+int dq_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float* scratch,
+                       float grad_scale, float max_norm, double lr, double beta1, double beta2, double eps, double weight_decay,
+                       int step, float* gnorm_out, void* stream);
+
+/* ---- DDIMDiffusionModel.train_step (model.py:326-406, eps objective) fused with its backward ------------------
+ * normalise x0/conds, q_sample, network forward, MSE loss, backward into grads (+=).  t (B) int64 and noise (B,RT,MZ) are
+ * drawn by the caller (the reference draws randint then randn_like, model.py:344-346).  loss_out: 1 device float =
+ * mean over the batch of the per-sample MSE. */
+int dq_train_step(dq_plan* plan, const float* params, const float* rope_freqs, const float* alpha_bars_dev, const float* x0,
+                  const float* ms2_cond, const float* ms1_cond, const int64_t* t, const float* noise, int auto_normalize,
+                  float* grads, float* loss_out, void* workspace, int64_t workspace_bytes, int B, int RT, void* stream);
+
+/* ---- DDIMDiffusionModel.sample (model.py:293-324) --------------------------------------------------------------
+ * Runs the whole strided loop natively over timesteps_host[num_steps] (host ints; the caller forms them as
+ * trunc(linspace(T-1, 0, num_steps)), model.py:313): each step = network forward + K9 (landing on alpha_bars[t-1],
+ * model.py:284), then the epilogue (model.py:319-322).  alpha_bars_host: T host floats.  x_T (B,RT,MZ) is not modified.  out_x = denoised in [0,1]; out_noise = mixture -
+ * denoised.  traj_x / traj_eps (nullable): (num_steps,B,RT,MZ) per-step x_{t-1} and eps. */
+int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, const float* alpha_bars_host, const float* x_T,
+                   const float* ms2_cond, const float* ms1_cond, int auto_normalize, const int32_t* timesteps_host,
+                   int num_steps, float* out_x, float* out_noise, float* traj_x, float* traj_eps, void* workspace,
+                   int64_t workspace_bytes, int B, int RT, void* stream);
+
+/* ---- building blocks exported for the per-block parity tests (tests/test_blocks_gpu.py) ------------------------
+ * Residual(PreNorm(LinearAttention)) (unet1d.py:446-496, 1017) on (rows, C, n). */
+int dq_linattn_fwd(const float* x, float* y, const float* w_qkv, const float* w_out, const float* b_out, const float* g_pre,
+                   const float* g_out, int C, int rows, int n, void* stream);
+int dq_linattn_bwd(const float* x, const float* dy, float* dx, const float* w_qkv, const float* w_out, const float* b_out,
+                   const float* g_pre, const float* g_out, float* dw_qkv, float* dw_out, float* db_out, float* dg_pre,
+                   float* dg_out, int C, int rows, int n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DQ_HIP_H */
