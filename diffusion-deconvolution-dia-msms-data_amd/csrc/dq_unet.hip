@@ -247,8 +247,8 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     DQ_TRY(conv_plain_fwd(c, proj(p.qv_w, 2 * HID, p.mid_c), CONV_S1, c.w(a.xn), c.w(a.qv), B, RT, RT));
     DQ_TRY(conv_plain_fwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.w(a.kk), B, RT, RT));
     if (rope) {
-      DQ_TRY(launch_rope(c.w(a.qv), rope, B * 2, HID, RT, 1.f, c.s));  // q = first 128 channels of each sample's 256
-      DQ_TRY(launch_rope(c.w(a.kk), rope, B, HID, RT, 1.f, c.s));
+      DQ_TRY(launch_rope(c.w(a.qv), rope, B, (int64_t)2 * HID * RT, RT, 1.f, c.s));  // q = first 128 channels of each sample's 256
+      DQ_TRY(launch_rope(c.w(a.kk), rope, B, (int64_t)HID * RT, RT, 1.f, c.s));
     }
     const int64_t qvbs = (int64_t)2 * HID * RT, kbs = (int64_t)HID * RT;
     DQ_TRY(launch_attn_fwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.w(a.lse), B, RT, c.s));
@@ -314,8 +314,8 @@ int unet_backward(const Ctx& c, const float* rope, const float* init_cond, float
     DQ_TRY(launch_attn_bwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.g(a.o), c.w(a.lse), c.w(a.delta),
                            c.g(a.qv), qvbs, c.g(a.kk), kbs, c.g(a.qv) + kbs, qvbs, B, RT, c.s));
     if (rope) {
-      DQ_TRY(launch_rope(c.g(a.qv), rope, B * 2, HID, RT, -1.f, c.s));
-      DQ_TRY(launch_rope(c.g(a.kk), rope, B, HID, RT, -1.f, c.s));
+      DQ_TRY(launch_rope(c.g(a.qv), rope, B, (int64_t)2 * HID * RT, RT, -1.f, c.s));
+      DQ_TRY(launch_rope(c.g(a.kk), rope, B, (int64_t)HID * RT, RT, -1.f, c.s));
     }
     DQ_TRY(conv_plain_bwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.g(a.kk), c.g(a.ms1f), B, RT, RT, 0));
     DQ_TRY(conv_plain_bwd(c, proj(p.qv_w, 2 * HID, p.mid_c), CONV_S1, c.w(a.xn), c.g(a.qv), c.g(a.xn), B, RT, RT, 0));
@@ -550,6 +550,37 @@ int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, 
   }
   DQ_TRY(launch_sample_finish(xa, ms2_cond, out_x, out_noise, n, auto_normalize, s));  // model.py:319-322
   return 0;
+}
+
+int64_t dq_debug_tensor_offset(dq_plan* plan, const char* name) {
+  if (!plan || !name) return -1;
+  const Arena& a = plan->arena;
+  const std::string n(name);
+  if (n == "tbuf") return a.tbuf;
+  if (n == "ss") return a.ss;
+  if (n == "cat0") return a.cat0;
+  if (n == "h0") return a.h0;
+  if (n == "ms1f") return a.ms1f;
+  if (n == "mid_in") return a.mid_in;
+  if (n == "mid1") return a.mid1.out;
+  if (n == "xn") return a.xn;
+  if (n == "qv") return a.qv;
+  if (n == "kk") return a.kk;
+  if (n == "o") return a.o;
+  if (n == "attn_out") return a.attn_out;
+  if (n == "mid2") return a.mid2.out;
+  if (n == "fin") return a.fin.out;
+  for (int i = 0; i < (int)a.downs.size(); ++i) {
+    if (n == "down" + std::to_string(i)) return a.downs[i].rs;
+    if (n == "down" + std::to_string(i) + ".r0") return a.downs[i].r0.out;
+    if (n == "down" + std::to_string(i) + ".r1") return a.downs[i].r1.out;
+    if (n == "down" + std::to_string(i) + ".la") return a.downs[i].la;
+    if (n == "up" + std::to_string(i)) return a.ups[i].rs;
+    if (n == "up" + std::to_string(i) + ".r0") return a.ups[i].r0.out;
+    if (n == "up" + std::to_string(i) + ".r1") return a.ups[i].r1.out;
+    if (n == "up" + std::to_string(i) + ".la") return a.ups[i].la;
+  }
+  return -1;
 }
 
 int dq_linattn_fwd(const float* x, float* y, const float* w_qkv, const float* w_out, const float* b_out, const float* g_pre,

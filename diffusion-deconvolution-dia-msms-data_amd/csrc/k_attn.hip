@@ -17,28 +17,29 @@ constexpr float ATT_SCALE = 0.17677669529663687f;  // 32^-0.5
 constexpr int TJ = 64;                              // rows per LDS tile
 
 // ---- RoPE, in place.  sign = +1 forward, -1 backward (transpose of the rotation).
-__global__ void __launch_bounds__(256) k_rope(float* __restrict__ t, const float* __restrict__ freqs, int heads_total, int RT,
+__global__ void __launch_bounds__(256) k_rope(float* __restrict__ t, const float* __restrict__ freqs, int64_t batch_stride, int RT,
                                               float sign, int64_t total) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int pos = (int)(i % RT);
   const int pr = (int)((i / RT) % 8);
-  const int64_t bh = i / ((int64_t)RT * 8);  // b * heads_total + head
+  const int64_t bh = i / ((int64_t)RT * 8);  // b * 4 + head
+  const int64_t b = bh >> 2, h = bh & 3;
   const float ang = (float)pos * freqs[pr];
   float sn, cs;
   sincosf(ang, &sn, &cs);
   sn *= sign;
-  float* pa = t + (bh * 32 + 2 * pr) * RT + pos;
+  float* pa = t + b * batch_stride + (h * 32 + 2 * pr) * RT + pos;
   const float xa = pa[0], xb = pa[RT];
   pa[0] = xa * cs - xb * sn;
   pa[RT] = xb * cs + xa * sn;
 }
 
-int launch_rope(float* qk, const float* freqs, int B, int ch_total, int RT, float sign, hipStream_t s) {
-  DQ_REQUIRE(ch_total % 32 == 0, "rope: channel count must be a multiple of 32");
-  const int64_t total = (int64_t)B * (ch_total / 32) * 8 * RT;
+int launch_rope(float* qk, const float* freqs, int B, int64_t batch_stride, int RT, float sign, hipStream_t s) {
+  // rotates the 4 heads x 32 channels that start at each sample's base (B, >=128, RT); batch_stride in floats
+  const int64_t total = (int64_t)B * 4 * 8 * RT;
   if (total == 0) return 0;
-  hipLaunchKernelGGL(k_rope, dim3(cdiv(total, 256)), dim3(256), 0, s, qk, freqs, ch_total / 32, RT, sign, total);
+  hipLaunchKernelGGL(k_rope, dim3(cdiv(total, 256)), dim3(256), 0, s, qk, freqs, batch_stride, RT, sign, total);
   DQ_LAUNCH_CHECK();
   return 0;
 }

@@ -114,6 +114,10 @@ int dq_linattn_bwd(const float* x, const float* dy, float* dx, const float* w_qk
                    const float* g_pre, const float* g_out, float* dw_qkv, float* dw_out, float* db_out, float* dg_pre,
                    float* dg_out, int C, int rows, int n, void* stream);
 
+/* Test hook: offset (in floats) of a named activation inside the workspace laid out by the last call on this plan
+ * ("h0", "ms1f", "down3", "down3.la", "mid1", "attn_out", "up0", "fin", ...), or -1. */
+int64_t dq_debug_tensor_offset(dq_plan* plan, const char* name);
+
 #ifdef __cplusplus
 }
 #endif

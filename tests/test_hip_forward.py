@@ -130,15 +130,16 @@ def test_q_sample_and_ddim_step(N, golden):
     x0, nz = torch.rand(B, RT, MZ, generator=gen), torch.randn(B, RT, MZ, generator=gen)
     t = torch.tensor([0, 1, 500, 998, 999])
     ref = O.q_sample(ab, O.normalize(x0), t, nz)
+    abd, x0d, td, nzd = ab.cuda(), x0.cuda(), t.cuda(), nz.cuda()  # keep the device tensors alive across the calls
     out = torch.empty(B, RT, MZ, device="cuda")
-    N.check(N.lib().dq_q_sample(N.ptr(ab.cuda()), N.ptr(x0.cuda()), N.ptr(t.cuda()), N.ptr(nz.cuda()), N.ptr(out), B, RT * MZ, 1,
-                                N.stream_ptr()), "dq_q_sample")
+    N.check(N.lib().dq_q_sample(N.ptr(abd), N.ptr(x0d), N.ptr(td), N.ptr(nzd), N.ptr(out), B, RT * MZ, 1, N.stream_ptr()), "dq_q_sample")
+    torch.cuda.synchronize()
     assert torch.equal(out.cpu(), ref) or rel_err(out, ref) < 2e-7
     for tv in (999, 500, 1, 0):
         refp = O.ddim_update(ab, x0, nz, tv)
         a = ab[tv]
-        coef = torch.tensor([a.sqrt(), (1 - a).sqrt(), ab[tv - 1].sqrt() if tv > 0 else -1.0, (1 - ab[tv - 1]).sqrt() if tv > 0 else 0.0])
+        coef = torch.tensor([a.sqrt(), (1 - a).sqrt(), ab[tv - 1].sqrt() if tv > 0 else -1.0, (1 - ab[tv - 1]).sqrt() if tv > 0 else 0.0]).cuda()
         o = torch.empty(B, RT, MZ, device="cuda")
-        N.check(N.lib().dq_ddim_step(N.ptr(x0.cuda()), N.ptr(nz.cuda()), N.ptr(o), N.ptr(coef.cuda()), B * RT * MZ, N.stream_ptr()),
-                "dq_ddim_step")
+        N.check(N.lib().dq_ddim_step(N.ptr(x0d), N.ptr(nzd), N.ptr(o), N.ptr(coef), B * RT * MZ, N.stream_ptr()), "dq_ddim_step")
+        torch.cuda.synchronize()
         assert rel_err(o, refp) < 1e-6
