@@ -1,0 +1,357 @@
+"""Training / prediction harness -- drop-in for the reference's ``dquartic.model.model_interface``
+(reference model_interface.py:64-236 schedulers/callbacks, :238-1150 ModelInterface).
+
+Kept: the public method names, signatures, checkpoint dictionary (``epoch, model_state_dict, optimizer_state_dict,
+scheduler_state_dict, best_loss``; reference :617-626), "latest" + "best" checkpoint cadence (:419-430), per-epoch
+warm-up + cosine LambdaLR (:149-155, :400), the ``(ms2_1, ms1_1, ms2_2, ms1_2)`` batch contract with
+``ms2_cond = 0.5*ms2_1 + 0.5*ms2_2`` (:1070-1075) and the step sequence of ``_train_one_batch`` (:1112-1123):
+zero_grad -> train_step -> backward -> clip_grad_norm_(10) -> AdamW -> loss float.
+
+Changed (DESIGN.md "deviations"): when the network is this package's ``UNet1d`` the step runs through two native
+calls on flat buffers (``dq_train_step`` + ``dq_adamw_clip_step``) instead of autograd; with ``torch.distributed``
+initialised the flat gradient is all-reduced (RCCL) between them; wandb / plotting are optional and imported lazily;
+the "latest" checkpoint goes next to ``checkpoint_path`` ('.' when it has no directory, not the filesystem root).
+"""
+import math
+import os
+from typing import List
+
+import numpy as np
+import torch
+
+from .. import _native as N
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# learning-rate schedule (reference model_interface.py:64-194)
+# ----------------------------------------------------------------------------------------------------------------
+class LR_SchedulerInterface(object):
+    def __init__(self, optimizer: torch.optim.Optimizer, **kwargs):
+        raise NotImplementedError
+
+    def step(self, epoch: int, loss: float):
+        raise NotImplementedError
+
+    def get_last_lr(self) -> float:
+        raise NotImplementedError
+
+
+class WarmupLR_Scheduler(LR_SchedulerInterface):
+    """Linear warm-up then cosine decay, stepped once per epoch."""
+
+    def __init__(self, optimizer, num_warmup_steps: int, num_training_steps: int, num_cycles: float = 0.5, last_epoch: int = -1):
+        self.optimizer = optimizer
+        self.lambda_lr = self.get_cosine_schedule_with_warmup(optimizer, num_warmup_steps, num_training_steps, num_cycles, last_epoch)
+
+    def step(self, epoch: int = None, loss=None):
+        return self.lambda_lr.step()
+
+    def get_last_lr(self) -> List[float]:
+        return self.lambda_lr.get_last_lr()
+
+    @staticmethod
+    def _lr_lambda(current_step: int, *, num_warmup_steps: int, num_training_steps: int, num_cycles: float):
+        if current_step < num_warmup_steps:
+            return float(current_step + 1) / float(max(1, num_warmup_steps))
+        progress = float(current_step - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
+        return max(1e-10, 0.5 * (1.0 + math.cos(math.pi * float(num_cycles) * 2.0 * progress)))
+
+    def get_cosine_schedule_with_warmup(self, optimizer, num_warmup_steps, num_training_steps, num_cycles=0.5, last_epoch=-1):
+        from functools import partial
+
+        fn = partial(self._lr_lambda, num_warmup_steps=num_warmup_steps, num_training_steps=num_training_steps, num_cycles=num_cycles)
+        return torch.optim.lr_scheduler.LambdaLR(optimizer, fn, last_epoch)
+
+
+class CallbackHandler:
+    """Hooks at epoch / batch end; ``epoch_callback`` returning False stops training (reference :196-236)."""
+
+    def epoch_callback(self, epoch: int, epoch_loss: float) -> bool:
+        return True
+
+    def batch_callback(self, batch: int, batch_loss: float):
+        pass
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# AdamW over the flat parameter buffer (K11)
+# ----------------------------------------------------------------------------------------------------------------
+class FlatAdamW(torch.optim.Optimizer):
+    """``torch.optim.AdamW`` semantics (torch defaults) executed by ``dq_adamw_clip_step`` on the network's flat
+    parameter / gradient buffers, with the global-norm clip of ``clip_grad_norm_`` folded in.  ``state_dict()`` has the
+    torch AdamW layout (per-parameter ``step, exp_avg, exp_avg_sq``), so checkpoints interchange with the reference."""
+
+    def __init__(self, net, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm=10.0):
+        self.net = net
+        params = [p for _, p in net.trainable_named()]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.max_norm = max_norm
+        self.grad_scale = 1.0
+        self._m = self._v = self._scratch = self._gnorm = None
+        self._step = 0
+
+    def _buffers(self):
+        flat = self.net.flat_params
+        if self._m is None or self._m.device != flat.device:
+            old_m, old_v = self._m, self._v
+            self._m = torch.zeros_like(flat) if old_m is None else old_m.to(flat.device)
+            self._v = torch.zeros_like(flat) if old_v is None else old_v.to(flat.device)
+            self._scratch = torch.empty(1024, dtype=torch.float32, device=flat.device)
+            self._gnorm = torch.zeros((), dtype=torch.float32, device=flat.device)
+            self._publish_state()
+        return flat
+
+    def _publish_state(self):
+        for (name, o, shape), p in zip(self.net._layout, self.param_groups[0]["params"]):
+            n = p.numel()
+            self.state[p] = {"step": torch.tensor(float(self._step)), "exp_avg": self._m[o:o + n].view(shape),
+                             "exp_avg_sq": self._v[o:o + n].view(shape)}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        flat = self._buffers()
+        grads = self.net.flat_grads()
+        g = self.param_groups[0]
+        self._step += 1
+        N.check(N.lib().dq_adamw_clip_step(N.ptr(flat), N.ptr(grads), N.ptr(self._m), N.ptr(self._v), flat.numel(), N.ptr(self._scratch),
+                                           float(self.grad_scale), float(self.max_norm), float(g["lr"]), float(g["betas"][0]),
+                                           float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), int(self._step),
+                                           N.ptr(self._gnorm), N.stream_ptr()), "dq_adamw_clip_step")
+        for st in self.state.values():
+            st["step"] = torch.tensor(float(self._step))
+        return None
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.net.flat_grads(zero=True)
+
+    @property
+    def last_grad_norm(self) -> torch.Tensor:
+        """Pre-clip global gradient norm of the last step (0-dim device tensor)."""
+        return self._gnorm
+
+    def load_state_dict(self, state_dict):
+        self._buffers()
+        super().load_state_dict(state_dict)
+        # copy the loaded moments back into the flat buffers and re-publish views
+        step = 0
+        for (name, o, shape), p in zip(self.net._layout, self.param_groups[0]["params"]):
+            st = self.state.get(p)
+            if st:
+                n = p.numel()
+                self._m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                self._v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                step = int(float(st["step"]))
+        self._step = step
+        self._publish_state()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# harness
+# ----------------------------------------------------------------------------------------------------------------
+class ModelInterface(object):
+    def __init__(self, device: str = torch.device("cuda" if torch.cuda.is_available() else "cpu"), min_pred_value: float = 0.0, **kwargs):
+        self.model: torch.nn.Module = None
+        self.optimizer = None
+        self.model_params: dict = {}
+        self.min_pred_value = min_pred_value
+        self.lr_scheduler_class = WarmupLR_Scheduler
+        self.callback_handler = CallbackHandler()
+        self.device = device
+        self.ms1_loss_weight = None
+        self.use_wandb = False
+        self.last_grad_norm = None
+
+    def __repr__(self):
+        return f"{self.__class__.__name__} with {self.model.__class__.__name__} model with {self.get_parameter_num()} parameters on {self.device}"
+
+    # ---- public
+    def build(self, model_class, **kwargs):
+        self.model = model_class
+        self._init_for_training()
+
+    def get_parameter_num(self):
+        return int(np.sum([p.numel() for p in self.model.parameters()]))
+
+    def train_step(self, x_0, ms2_cond=None, ms1_cond=None, noise=None, ms1_loss_weight=0.0):
+        raise NotImplementedError
+
+    def sample(self, x_t, ms2_cond=None, ms1_cond=None, num_steps=1000):
+        raise NotImplementedError
+
+    def train(self, dataloader, batch_size, epochs, warmup_epochs: int = 5, learning_rate: float = 1e-4, use_wandb: bool = False,
+              checkpoint_path: str = "best_model.ckpt", **kwargs):
+        """Epoch loop (reference :453-559).  ``warmup_epochs > 0`` uses the warm-up/cosine schedule, else a constant lr."""
+        self.train_with_warmup(dataloader, batch_size, epochs, max(0, int(warmup_epochs)), learning_rate, use_wandb, checkpoint_path,
+                               constant_lr=warmup_epochs <= 0, **kwargs)
+
+    def train_with_warmup(self, dataloader, batch_size, num_epochs, num_warmup_steps: int = 5, learning_rate: float = 1e-4,
+                          use_wandb: bool = False, checkpoint_path: str = "best_model.ckpt", log_every_n_epochs: int = 100,
+                          constant_lr: bool = False, **kwargs):
+        self.use_wandb_epoch = bool(use_wandb)
+        wandb = _wandb() if use_wandb else None
+        self._prepare_training(learning_rate)
+        lr_scheduler = None if constant_lr else self._get_lr_schedule_with_warmup(num_warmup_steps, num_epochs)
+        self.model.train()
+        ckpt_dir = os.path.dirname(checkpoint_path) or "."
+        latest = os.path.join(ckpt_dir, "dquartic_latest_checkpoint.ckpt")
+        start_epoch, best_loss, lr_scheduler = self.load_checkpoint(lr_scheduler, latest, self.device)
+        best_epoch = start_epoch
+        rank0 = _rank() == 0
+        for epoch in range(start_epoch, num_epochs):
+            if hasattr(dataloader.dataset, "reset_epoch"):
+                dataloader.dataset.reset_epoch()
+            batch_loss = self._train_one_epoch(epoch, dataloader)
+            if lr_scheduler is not None:
+                lr_scheduler.step(epoch, np.mean(batch_loss))
+            avg = float(np.mean(batch_loss))
+            lr_now = self.optimizer.param_groups[0]["lr"]
+            if wandb is not None and rank0:
+                wandb.log({"epoch": epoch, "train/loss": avg, "learning_rate": lr_now})
+            if rank0:
+                print(f"[Training] Epoch={epoch + 1}, lr={lr_now}, loss={avg}")
+                self.save_checkpoint(lr_scheduler, epoch, avg, latest)
+                if avg < best_loss:
+                    best_loss, best_epoch = avg, epoch + 1
+                    self.save_checkpoint(lr_scheduler, epoch, best_loss, checkpoint_path)
+            if not self.callback_handler.epoch_callback(epoch=epoch, epoch_loss=avg):
+                print(f"Training stopped at epoch {epoch}")
+                break
+        if rank0:
+            print(f"Best model checkpoint saved at epoch {best_epoch} with loss: {best_loss:.6f}")
+
+    def load_checkpoint(self, scheduler, checkpoint_path, device):
+        if os.path.exists(checkpoint_path):
+            print(f"Loading checkpoint from {checkpoint_path}...")
+            ck = torch.load(checkpoint_path, map_location=device, weights_only=False)
+            self.model.load_state_dict(ck["model_state_dict"])
+            if self.optimizer is not None and ck.get("optimizer_state_dict") is not None:
+                self.optimizer.load_state_dict(ck["optimizer_state_dict"])
+            if scheduler is not None and ck.get("scheduler_state_dict") is not None:
+                scheduler.lambda_lr.load_state_dict(ck["scheduler_state_dict"])
+            epoch, best_loss = ck["epoch"], ck["best_loss"]
+            print(f"Resumed from ({checkpoint_path}) epoch {epoch}, best loss {best_loss:.6f}")
+        else:
+            print(f"No checkpoint ({checkpoint_path}) found. Starting from scratch.")
+            epoch, best_loss = 0, float("inf")
+        return epoch, best_loss, scheduler
+
+    def save_checkpoint(self, scheduler, epoch, best_loss, checkpoint_path):
+        torch.save({"epoch": epoch, "model_state_dict": self.model.state_dict(), "optimizer_state_dict": self.optimizer.state_dict(),
+                    "scheduler_state_dict": (scheduler.lambda_lr.state_dict() if scheduler is not None else None),
+                    "best_loss": best_loss}, checkpoint_path)
+
+    def predict(self, dataloader, mixture_weights=(0.5, 0.5), num_steps=1000):
+        """Reference :630-668: one dict per batch with the first item's prediction (``_predict_one_batch`` returns item 0)."""
+        self.model.eval()
+        preds = []
+        for ms2_1, ms1_1, ms2_2, ms1_2 in dataloader:
+            x_0, ms1_cond = ms2_1.to(self.device), ms1_1.to(self.device)
+            ms2_cond = (ms2_1 * mixture_weights[0]).to(self.device) + (ms2_2 * mixture_weights[1]).to(self.device)
+            pred, _ = self._predict_one_batch(x_0, ms2_cond=ms2_cond, ms1_cond=ms1_cond, num_steps=num_steps)
+            preds.append({"ms2_1": ms2_1.cpu().numpy(), "ms1_1": ms1_1.cpu().numpy(), "mixture": ms2_cond.cpu().numpy(), "pred": pred})
+        return np.array(preds, dtype=object)
+
+    # ---- internals
+    def _init_for_training(self):
+        self.loss_func = torch.nn.MSELoss()
+
+    def _prepare_training(self, lr: float, **kwargs):
+        self.model.train()
+        self._set_lr(lr)
+
+    def _native_net(self) -> bool:
+        from .unet1d import UNet1d
+
+        return isinstance(self.model, UNet1d)
+
+    def _set_optimizer(self, lr):
+        """Reference :1011: AdamW(model.parameters(), lr) with torch defaults."""
+        if self._native_net():
+            self.optimizer = FlatAdamW(self.model, lr=lr)
+        else:
+            self.optimizer = torch.optim.AdamW(self.model.parameters(), lr=lr)
+
+    def _set_lr(self, lr: float):
+        if self.optimizer is None:
+            self._set_optimizer(lr)
+        else:
+            for g in self.optimizer.param_groups:
+                g["lr"] = lr
+
+    def _get_lr_schedule_with_warmup(self, warmup_epoch, epoch):
+        if warmup_epoch > epoch:
+            warmup_epoch = epoch // 2
+        return self.lr_scheduler_class(self.optimizer, num_warmup_steps=warmup_epoch, num_training_steps=epoch)
+
+    def _train_one_epoch(self, epoch, dataloader, mixture_weights=(0.5, 0.5)):
+        self.model.train()
+        batch_loss = []
+        for batch_idx, (ms2_1, ms1_1, ms2_2, ms1_2) in enumerate(dataloader):
+            x_0, ms1_cond = ms2_1.to(self.device), ms1_1.to(self.device)
+            # simulated mixed spectra from the target window and the other window (reference :1073-1075)
+            ms2_cond = (ms2_1 * mixture_weights[0]).to(self.device) + (ms2_2 * mixture_weights[1]).to(self.device)
+            loss = self._train_one_batch(x_0, ms2_cond=ms2_cond, ms1_cond=ms1_cond, noise=None, ms1_loss_weight=self.ms1_loss_weight)
+            batch_loss.append(loss)
+            self.callback_handler.batch_callback(batch_idx, loss)
+        return batch_loss
+
+    def _train_one_batch(self, x_0, ms2_cond=None, ms1_cond=None, noise=None, ms1_loss_weight=0.0, t=None, sync=True):
+        """Reference :1090-1123.  Returns the loss as a float (``sync=False``: a 0-dim device tensor, no host sync)."""
+        fused = self._native_net() and isinstance(self.optimizer, FlatAdamW) and x_0.is_cuda and hasattr(self, "train_step_fused") \
+            and not (ms1_loss_weight and ms1_loss_weight > 0.0)
+        if fused:
+            if noise is not None:
+                noise = self.normalize(noise)  # reference quirk: a passed noise is mapped 2n-1 (model.py:346)
+            loss = self.train_step_fused(x_0, ms2_cond, ms1_cond, t=t, noise=noise, zero_grads=True)
+            world = _world()
+            if world > 1:
+                torch.distributed.all_reduce(self.model.flat_grads())  # one flat RCCL all-reduce (sum)
+            self.optimizer.grad_scale = 1.0 / world
+            self.optimizer.step()
+            self.last_grad_norm = self.optimizer.last_grad_norm
+            return loss.item() if sync else loss
+        self.optimizer.zero_grad()
+        loss = self.train_step(x_0, ms2_cond=ms2_cond, ms1_cond=ms1_cond, noise=noise, ms1_loss_weight=ms1_loss_weight or 0.0)
+        if loss.dim() > 0:
+            loss = loss.mean()
+        loss.backward()
+        if isinstance(self.optimizer, FlatAdamW):
+            self.optimizer.grad_scale = 1.0
+            self.optimizer.step()  # clip folded in
+            self.last_grad_norm = self.optimizer.last_grad_norm
+        else:
+            self.last_grad_norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=10.0)
+            self.optimizer.step()
+        return loss.item() if sync else loss.detach()
+
+    def _predict_one_batch(self, x_0, ms2_cond=None, ms1_cond=None, num_steps=1000):
+        """Reference :1125-1150: eval + no_grad + sample(randn_like(x_0)); returns item 0 of the batch as numpy."""
+        self.model.eval()
+        with torch.no_grad():
+            sample, pred_noise = self.sample(torch.randn_like(x_0), ms2_cond=ms2_cond, ms1_cond=ms1_cond, num_steps=num_steps)
+        return sample[0].cpu().detach().numpy(), pred_noise[0].cpu().detach().numpy()
+
+    def log_single_prediction(self, *args, **kwargs):
+        raise NotImplementedError("wandb prediction tables / pyopenms_viz plots are outside the hot path (SURVEY section 2)")
+
+    plot_single_prediction = log_single_prediction
+
+
+def _wandb():
+    try:
+        import wandb
+
+        return wandb
+    except ImportError:
+        print("wandb is not installed; continuing without it")
+        return None
+
+
+def _world() -> int:
+    d = torch.distributed
+    return d.get_world_size() if d.is_available() and d.is_initialized() else 1
+
+
+def _rank() -> int:
+    d = torch.distributed
+    return d.get_rank() if d.is_available() and d.is_initialized() else 0
