@@ -51,6 +51,8 @@ struct BlockBwd {
   const float* g = nullptr; float* dg = nullptr;                           // norm gain and its grad (atomic +=)
   const float* ss = nullptr; float* dss = nullptr; int ss_stride = 0;     // per-sample scale/shift and grads (atomic +=)
   int act = ACT_NONE;
+  float* dbias = nullptr;  // optional: sum of du over rows and positions (atomic +=)
+  int accumulate = 0;      // 1: du += instead of du =
 };
 int launch_block_bwd(const BlockBwd& a, hipStream_t s);
 
@@ -92,11 +94,14 @@ struct LinAttn {
   const float* w_qkv = nullptr; const float* w_out = nullptr; const float* b_out = nullptr;
   const float* g_pre = nullptr; const float* g_out = nullptr;
   int C = 0, rows = 0, n = 0;
+  float* ypre = nullptr;  // optional: pre-norm output Wo*out + b (rows, C, n), saved for the backward
 };
 int launch_linattn_fwd(const LinAttn& a, hipStream_t s);
 struct LinAttnBwd {
   LinAttn f;
   const float* dy = nullptr; float* dx = nullptr;  // dx +=
+  const float* ypre = nullptr;                     // saved by the forward
+  float* dyp = nullptr; float* dxh = nullptr;      // scratch (rows, C, n) each
   float* dw_qkv = nullptr; float* dw_out = nullptr; float* db_out = nullptr; float* dg_pre = nullptr; float* dg_out = nullptr;
 };
 int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s);

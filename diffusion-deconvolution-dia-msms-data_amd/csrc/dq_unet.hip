@@ -39,7 +39,7 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
     const LevelP& l = p.downs[lv];
     LevelBuf b;
     b.r0 = res(R, l.r0.cout, l.n); b.r1 = res(R, l.r1.cout, l.n);
-    b.la = take(R * l.la.C * l.n);
+    b.la = take(R * l.la.C * l.n); b.la_pre = take(R * l.la.C * l.n); b.la_tmp = take(R * l.la.C * l.n);
     b.rs = take(R * l.resample.cout * l.n_next);
     a.downs.push_back(b);
   }
@@ -55,7 +55,7 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
     const LevelP& l = p.ups[ui];
     LevelBuf b;
     b.r0 = res(R, l.r0.cout, l.n); b.r1 = res(R, l.r1.cout, l.n);
-    b.la = take(R * l.la.C * l.n);
+    b.la = take(R * l.la.C * l.n); b.la_pre = take(R * l.la.C * l.n); b.la_tmp = take(R * l.la.C * l.n);
     b.rs = take(R * l.resample.cout * l.n_next);
     a.ups.push_back(b);
   }
@@ -167,15 +167,16 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
   return 0;
 }
 
-int la_fwd(const Ctx& c, const LAP& l, const float* x, float* y, int rows, int n) {
+int la_fwd(const Ctx& c, const LAP& l, const float* x, float* y, float* ypre, int rows, int n) {
   LinAttn a;
-  a.x = x; a.y = y; a.w_qkv = c.prm(l.qkv_w); a.w_out = c.prm(l.out_w); a.b_out = c.prm(l.out_b);
+  a.x = x; a.y = y; a.ypre = ypre; a.w_qkv = c.prm(l.qkv_w); a.w_out = c.prm(l.out_w); a.b_out = c.prm(l.out_b);
   a.g_pre = c.prm(l.g_pre); a.g_out = c.prm(l.g_out); a.C = l.C; a.rows = rows; a.n = n;
   return launch_linattn_fwd(a, c.s);
 }
 
-int la_bwd(const Ctx& c, const LAP& l, const float* x, const float* dy, float* dx, int rows, int n) {
+int la_bwd(const Ctx& c, const LAP& l, const LevelBuf& b, const float* x, const float* dy, float* dx, int rows, int n) {
   LinAttnBwd a;
+  a.ypre = c.w(b.la_pre); a.dyp = c.g(b.la_pre); a.dxh = c.g(b.la_tmp);
   a.f.x = x; a.f.w_qkv = c.prm(l.qkv_w); a.f.w_out = c.prm(l.out_w); a.f.b_out = c.prm(l.out_b);
   a.f.g_pre = c.prm(l.g_pre); a.f.g_out = c.prm(l.g_out); a.f.C = l.C; a.f.rows = rows; a.f.n = n;
   a.dy = dy; a.dx = dx;
@@ -234,7 +235,7 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     const int C = l.r0.cin;
     DQ_TRY(res_fwd(c, l.r0, b.r0, cur, C, nullptr, 0, R, l.n, RT));
     DQ_TRY(res_fwd(c, l.r1, b.r1, c.w(b.r0.out), C, nullptr, 0, R, l.n, RT));
-    DQ_TRY(la_fwd(c, l.la, c.w(b.r1.out), c.w(b.la), R, l.n));
+    DQ_TRY(la_fwd(c, l.la, c.w(b.r1.out), c.w(b.la), c.w(b.la_pre), R, l.n));
     DQ_TRY(conv_plain_fwd(c, l.resample, l.last ? CONV_S1 : CONV_DOWN, c.w(b.la), c.w(b.rs), R, l.n, l.n_next));
     cur = c.w(b.rs);
   }
@@ -269,7 +270,7 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     const int cx = l.r0.cout, cs = l.r0.cin - l.r0.cout;
     DQ_TRY(res_fwd(c, l.r0, b.r0, cur, cx, c.w(a.downs[lv].la), cs, R, l.n, RT));
     DQ_TRY(res_fwd(c, l.r1, b.r1, c.w(b.r0.out), cx, c.w(a.downs[lv].r0.out), cs, R, l.n, RT));
-    DQ_TRY(la_fwd(c, l.la, c.w(b.r1.out), c.w(b.la), R, l.n));
+    DQ_TRY(la_fwd(c, l.la, c.w(b.r1.out), c.w(b.la), c.w(b.la_pre), R, l.n));
     DQ_TRY(conv_plain_fwd(c, l.resample, l.last ? CONV_S1 : CONV_UP, c.w(b.la), c.w(b.rs), R, l.n, l.n_next));
     cur = c.w(b.rs);
   }
@@ -297,7 +298,7 @@ int unet_backward(const Ctx& c, const float* rope, const float* init_cond, float
     const int cx = l.r0.cout, cs = l.r0.cin - l.r0.cout;
     const int64_t in_off = ui == 0 ? a.mid_back : a.ups[ui - 1].rs;
     DQ_TRY(conv_plain_bwd(c, l.resample, l.last ? CONV_S1 : CONV_UP, c.w(b.la), c.g(b.rs), c.g(b.la), R, l.n, l.n_next, 1));
-    DQ_TRY(la_bwd(c, l.la, c.w(b.r1.out), c.g(b.la), c.g(b.r1.out), R, l.n));
+    DQ_TRY(la_bwd(c, l.la, b, c.w(b.r1.out), c.g(b.la), c.g(b.r1.out), R, l.n));
     DQ_TRY(res_bwd(c, l.r1, b.r1, c.w(b.r0.out), c.g(b.r0.out), cx, c.w(a.downs[lv].r0.out), c.g(a.downs[lv].r0.out), cs, R, l.n, RT));
     DQ_TRY(res_bwd(c, l.r0, b.r0, c.w(in_off), c.g(in_off), cx, c.w(a.downs[lv].la), c.g(a.downs[lv].la), cs, R, l.n, RT));
   }
@@ -335,7 +336,7 @@ int unet_backward(const Ctx& c, const float* rope, const float* init_cond, float
     const int C = l.r0.cin;
     const int64_t in_off = lv == 0 ? a.h0 : a.downs[lv - 1].rs;
     DQ_TRY(conv_plain_bwd(c, l.resample, l.last ? CONV_S1 : CONV_DOWN, c.w(b.la), c.g(b.rs), c.g(b.la), R, l.n, l.n_next, 1));
-    DQ_TRY(la_bwd(c, l.la, c.w(b.r1.out), c.g(b.la), c.g(b.r1.out), R, l.n));
+    DQ_TRY(la_bwd(c, l.la, b, c.w(b.r1.out), c.g(b.la), c.g(b.r1.out), R, l.n));
     DQ_TRY(res_bwd(c, l.r1, b.r1, c.w(b.r0.out), c.g(b.r0.out), C, nullptr, nullptr, 0, R, l.n, RT));
     DQ_TRY(res_bwd(c, l.r0, b.r0, c.w(in_off), c.g(in_off), C, nullptr, nullptr, 0, R, l.n, RT));
   }
@@ -583,19 +584,20 @@ int64_t dq_debug_tensor_offset(dq_plan* plan, const char* name) {
   return -1;
 }
 
-int dq_linattn_fwd(const float* x, float* y, const float* w_qkv, const float* w_out, const float* b_out, const float* g_pre,
-                   const float* g_out, int C, int rows, int n, void* stream) {
+int dq_linattn_fwd(const float* x, float* y, float* ypre, const float* w_qkv, const float* w_out, const float* b_out,
+                   const float* g_pre, const float* g_out, int C, int rows, int n, void* stream) {
   LinAttn a;
-  a.x = x; a.y = y; a.w_qkv = w_qkv; a.w_out = w_out; a.b_out = b_out; a.g_pre = g_pre; a.g_out = g_out; a.C = C; a.rows = rows; a.n = n;
+  a.x = x; a.y = y; a.ypre = ypre; a.w_qkv = w_qkv; a.w_out = w_out; a.b_out = b_out; a.g_pre = g_pre; a.g_out = g_out; a.C = C; a.rows = rows; a.n = n;
   return launch_linattn_fwd(a, (hipStream_t)stream);
 }
 
-int dq_linattn_bwd(const float* x, const float* dy, float* dx, const float* w_qkv, const float* w_out, const float* b_out,
-                   const float* g_pre, const float* g_out, float* dw_qkv, float* dw_out, float* db_out, float* dg_pre,
-                   float* dg_out, int C, int rows, int n, void* stream) {
+int dq_linattn_bwd(const float* x, const float* ypre, const float* dy, float* dx, const float* w_qkv, const float* w_out,
+                   const float* b_out, const float* g_pre, const float* g_out, float* dw_qkv, float* dw_out, float* db_out,
+                   float* dg_pre, float* dg_out, float* scratch, int C, int rows, int n, void* stream) {
   LinAttnBwd a;
   a.f.x = x; a.f.w_qkv = w_qkv; a.f.w_out = w_out; a.f.b_out = b_out; a.f.g_pre = g_pre; a.f.g_out = g_out; a.f.C = C; a.f.rows = rows;
   a.f.n = n;
+  a.ypre = ypre; a.dyp = scratch; a.dxh = scratch + (int64_t)rows * C * n;
   a.dy = dy; a.dx = dx; a.dw_qkv = dw_qkv; a.dw_out = dw_out; a.db_out = db_out; a.dg_pre = dg_pre; a.dg_out = dg_out;
   return launch_linattn_bwd(a, (hipStream_t)stream);
 }

@@ -159,7 +159,8 @@ int launch_conv_fwd(const ConvFwd& a, hipStream_t s) {
 template <int C>
 __global__ void __launch_bounds__(256) k_block_bwd(BlockBwd a) {
   const int b = blockIdx.y;
-  const int64_t per_sample = (int64_t)a.rows_per_sample * a.n;  // items of one sample
+  const int rows_here = min(a.rows_per_sample, a.rows - b * a.rows_per_sample);  // the last group may be ragged
+  const int64_t per_sample = (int64_t)rows_here * a.n;                            // items of this sample / group
   const float sqC = sqrtf((float)C);
   float g[C], sc[C], sh[C];
 #pragma unroll
@@ -168,9 +169,9 @@ __global__ void __launch_bounds__(256) k_block_bwd(BlockBwd a) {
     sc[c] = a.ss ? a.ss[(int64_t)b * a.ss_stride + c] + 1.0f : 1.f;
     sh[c] = a.ss ? a.ss[(int64_t)b * a.ss_stride + C + c] : 0.f;
   }
-  float dg[C], dsc[C], dsh[C];
+  float dg[C], dsc[C], dsh[C], dbs[C];
 #pragma unroll
-  for (int c = 0; c < C; ++c) dg[c] = dsc[c] = dsh[c] = 0.f;
+  for (int c = 0; c < C; ++c) dg[c] = dsc[c] = dsh[c] = dbs[c] = 0.f;
 
   for (int64_t it = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; it < per_sample; it += (int64_t)gridDim.x * blockDim.x) {
     const int row = b * a.rows_per_sample + (int)(it / a.n), p = (int)(it % a.n);
@@ -218,36 +219,44 @@ __global__ void __launch_bounds__(256) k_block_bwd(BlockBwd a) {
       }
     }
 #pragma unroll
-    for (int c = 0; c < C; ++c) a.du[base + (int64_t)c * a.n] = d[c];
+    for (int c = 0; c < C; ++c) {
+      dbs[c] += d[c];
+      float* dst = a.du + base + (int64_t)c * a.n;
+      *dst = a.accumulate ? *dst + d[c] : d[c];
+    }
   }
 
-  __shared__ float red[4][3 * C];
+  __shared__ float red[4][4 * C];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int c = 0; c < C; ++c) {
-    const float s0 = wave_sum(dg[c]), s1 = wave_sum(dsc[c]), s2 = wave_sum(dsh[c]);
-    if (lane == 0) { red[wv][c] = s0; red[wv][C + c] = s1; red[wv][2 * C + c] = s2; }
+    const float s0 = wave_sum(dg[c]), s1 = wave_sum(dsc[c]), s2 = wave_sum(dsh[c]), s3 = wave_sum(dbs[c]);
+    if (lane == 0) { red[wv][c] = s0; red[wv][C + c] = s1; red[wv][2 * C + c] = s2; red[wv][3 * C + c] = s3; }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) {
+  for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) {
     const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
     if (i < C) { if (a.dg) atomicAdd(a.dg + i, v); }
-    else if (a.dss) atomicAdd(a.dss + (int64_t)b * a.ss_stride + (i - C), v);  // [dscale(C) | dshift(C)]
+    else if (i < 3 * C) { if (a.dss) atomicAdd(a.dss + (int64_t)b * a.ss_stride + (i - C), v); }  // [dscale(C) | dshift(C)]
+    else if (a.dbias) atomicAdd(a.dbias + (i - 3 * C), v);
   }
 }
 
 int launch_block_bwd(const BlockBwd& a, hipStream_t s) {
   DQ_REQUIRE(a.u && a.dy && a.du && a.rows > 0 && a.n > 0, "block_bwd: missing operand");
-  DQ_REQUIRE(a.rows % a.rows_per_sample == 0, "block_bwd: rows must be a multiple of rows_per_sample");
+  DQ_REQUIRE(!a.ss || a.rows % a.rows_per_sample == 0, "block_bwd: rows must be a multiple of rows_per_sample");
   DQ_REQUIRE(!a.ss || a.dss, "block_bwd: scale/shift needs a gradient buffer");
-  const int B = a.rows / a.rows_per_sample;
-  const int64_t per_sample = (int64_t)a.rows_per_sample * a.n;
+  BlockBwd a2 = a;
+  if (!a.ss) a2.rows_per_sample = std::max(1, std::min(a.rows, 16384 / std::max(1, a.n)));  // no per-sample state: regroup freely
+  const BlockBwd& a_ = a2;
+  const int B = cdiv(a_.rows, a_.rows_per_sample);
+  const int64_t per_sample = (int64_t)a_.rows_per_sample * a_.n;
   // ~4 items per thread, at most 64 blocks per sample
   const int bps = std::max(1, std::min(64, cdiv(per_sample, 1024)));
   dim3 grid(bps, B), block(256);
 #define DQ_BB(CC)                                                     \
   case CC:                                                            \
-    hipLaunchKernelGGL((k_block_bwd<CC>), grid, block, 0, s, a);      \
+    hipLaunchKernelGGL((k_block_bwd<CC>), grid, block, 0, s, a_);     \
     break;
   switch (a.C) {
     DQ_BB(1) DQ_BB(4) DQ_BB(8) DQ_BB(12) DQ_BB(16) DQ_BB(32) DQ_BB(64)

@@ -225,6 +225,17 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
       ssq = fmaf(yv[c], yv[c], ssq);
     }
     const float inv = sqC / fmaxf(sqrtf(ssq), RMS_EPS);
+    if (a.ypre) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c0 = rowmap(j, 0), c1 = c0 + 4;
+        float lo = 0.f, hi = 0.f;
+        if (c0 < C) lo = yv[c0 < C ? c0 : 0];
+        if (c1 < C) hi = yv[c1 < C ? c1 : 0];
+        const int c = c0 + 4 * half;
+        if (row_ok && c < C) a.ypre[((int64_t)row * C + c) * N + pos] = half ? hi : lo;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int c0 = rowmap(j, 0), c1 = c0 + 4;  // this lane's channel is c0 + 4*half

@@ -1,9 +1,441 @@
-// placeholder until the backward kernel lands
+// K5 backward: gradient of Residual(PreNorm(LinearAttention)) (reference forward: dquartic/model/unet1d.py:446-496; the
+// reference's backward is autograd over those ops).  Same wave-per-row, all-in-registers MFMA scheme as the forward
+// (k_linattn.hip); derivation and lane-level check: oracle/wave_emu.py::la_bwd_unit.
+//
+// The backward is split in three launches (host: launch_linattn_bwd):
+//   (1) k_block_bwd (k_conv.hip) : post-norm backward on the saved pre-norm output  -> dYpre, d g_out, d b_out
+//   (2) k_linattn_bwd (here)     : everything between xh = rmsnorm(x)*g_pre and Ypre -> dXh (R,C,n), dWqkv, dWo
+//   (3) k_block_bwd              : pre-norm backward, accumulated into dx together with the residual
+//
+// (2): the HEAD loop is the outer loop of a wave and its rows the inner one, so the four per-head weight-gradient
+// tiles (dWq, dWk, dWv, dWo as 32x32 f32 MFMA accumulators, rows = channel) stay in registers across the wave's rows and
+// are flushed with one atomic per element per (wave, head).  Per head and 32-position block (recomputing the forward):
+//   kT, vT, q, v, do = Wo^T dYpre, doT           (projections, K = C)
+//   ctx = kT^T vT ; dctx = qT^T doT ; outT = q^T ctx ; dq = ctxT^T do ; dkT = v^T dctxT ; dv = dctx^T K
+//   softmax backward of q (over d, in-lane) and of k (over n, in-lane in the kT orientation), with
+//   sum_n dK K = rowsum(dctx o ctx) so that no cross-lane reduction over positions is ever needed
+//   dW* += XhT^T (.)T ; dXh via VALU from the (rows d/e, col n) tiles with Wqkv pre-permuted in LDS.
+// Orientation changes (q -> qT etc.) go through a wave-private 32x33 LDS tile (16 ds_write + 16 ds_read, conflict-free).
 #include "dq_common.h"
 #include "dq_kernels.h"
+
 namespace dq {
-int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s) {
-  set_error("linattn_bwd: not built yet");
-  return 2;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ f32x16 mfma32b(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ constexpr int rmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+__device__ __forceinline__ float swp32(float v) { return __shfl_xor(v, 32, 64); }
+
+// 32x32 transpose of an accumulator tile through a wave-private LDS tile [32][33]
+__device__ __forceinline__ f32x16 tr32(f32x16 a, float* tile, int col, int half) {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tile[rmap(r, half) * 33 + col] = a[r];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = tile[col * 33 + rmap(r, half)];
+  return o;
 }
+
+struct LinAttnBwdK {
+  const float* x; const float* dyp; float* dxh;  // (rows, C, n)
+  const float* w_qkv; const float* w_out; const float* g_pre;
+  float* dw_qkv; float* dw_out;
+  int rows; int units_per_wave;
+};
+
+template <int C, int N>
+__global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
+  constexpr int NB = N >= 32 ? N / 32 : 1;
+  constexpr int RW = N >= 32 ? 1 : 32 / N;
+  constexpr int NJ = C <= 8 ? 4 : 8;
+  constexpr int SEG = N >= 32 ? 16 : (N >= 8 ? N / 2 : N);
+  constexpr bool PARTNER = N >= 8;
+  static_assert(NB <= 2, "rows longer than 64 are not built");
+
+  __shared__ float wp_lds[3 * 4 * 2 * C * 16];  // [q|k|v][head][half][c][r] = Wqkv[m*128 + head*32 + rmap(r,half)][c]
+  __shared__ float tiles[4][32 * 33];
+  for (int i = threadIdx.x; i < 3 * 4 * 2 * C * 16; i += blockDim.x) {
+    const int r = i & 15, c = (i >> 4) % C, hh = (i / (16 * C)) & 1, hd = (i / (32 * C)) & 3, m = i / (128 * C);
+    wp_lds[i] = a.w_qkv[(m * 128 + hd * 32 + rmap(r, hh)) * C + c];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wv = threadIdx.x >> 6;
+  float* tile = tiles[wv];
+  const int wave_id = blockIdx.x * (blockDim.x >> 6) + wv;
+  const int n_units = (a.rows + RW - 1) / RW;
+  const int u0 = wave_id * a.units_per_wave;
+  if (u0 >= n_units) return;
+  const int u1 = min(n_units, u0 + a.units_per_wave);
+  const float sqC = sqrtf((float)C);
+  const float scale = 0.17677669529663687f;
+  const int rl = N >= 32 ? 0 : col / N;
+
+#pragma unroll 1
+  for (int hd = 0; hd < 4; ++hd) {
+    float wq[NJ], wk[NJ], wvv[NJ], wo[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = rmap(j, half);
+      const bool ok = c < C;
+      wq[j] = ok ? a.w_qkv[(hd * 32 + col) * C + c] : 0.f;
+      wk[j] = ok ? a.w_qkv[(128 + hd * 32 + col) * C + c] : 0.f;
+      wvv[j] = ok ? a.w_qkv[(256 + hd * 32 + col) * C + c] : 0.f;
+      wo[j] = ok ? a.w_out[c * 128 + hd * 32 + col] : 0.f;
+    }
+    f32x16 gq = {0}, gk = {0}, gv = {0}, go = {0};  // weight-gradient tiles of this head: rows c, cols d / e
+
+#pragma unroll 1
+    for (int u = u0; u < u1; ++u) {
+      const int row = u * RW + rl;
+      const bool row_ok = row < a.rows;
+      // ---- load x, dYpre; pre-norm recompute
+      float Xh[NB][NJ], DY[NB][NJ];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int pos = N >= 32 ? b * 32 + col : col % N;
+        float xv[NJ];
+        float ssq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int c = rmap(j, half);
+          const bool ok = row_ok && c < C;
+          xv[j] = ok ? a.x[((int64_t)row * C + c) * N + pos] : 0.f;
+          DY[b][j] = ok ? a.dyp[((int64_t)row * C + c) * N + pos] : 0.f;
+          ssq = fmaf(xv[j], xv[j], ssq);
+        }
+        ssq += swp32(ssq);
+        const float inv = sqC / fmaxf(sqrtf(ssq), RMS_EPS);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int c = rmap(j, half);
+          Xh[b][j] = xv[j] * inv * (c < C ? a.g_pre[c] : 0.f);
+        }
+      }
+      float part[NB][C];  // d xh partial sums of this lane-half (this head)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int c = 0; c < C; ++c) part[b][c] = 0.f;
+
+      // VALU: part[c] += sum_r W[m][hd][half][c][r] * t[r]
+      auto add_dxh = [&](int b, int m, const f32x16& t) {
+        const float* wl = wp_lds + ((m * 4 + hd) * 2 + half) * C * 16;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          float acc = part[b][c];
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const float4 w4 = *reinterpret_cast<const float4*>(wl + c * 16 + r4 * 4);
+            acc = fmaf(w4.x, t[r4 * 4 + 0], acc); acc = fmaf(w4.y, t[r4 * 4 + 1], acc);
+            acc = fmaf(w4.z, t[r4 * 4 + 2], acc); acc = fmaf(w4.w, t[r4 * 4 + 3], acc);
+          }
+          part[b][c] = acc;
+        }
+      };
+      auto as_acc = [&](const float* xr) {
+        f32x16 t = {0};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) t[j] = xr[j];
+        return t;
+      };
+
+      // ---- K^T (normalised over the positions of each row) and V^T
+      f32x16 kT[NB], vT[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        f32x16 ak = {0}, av = {0};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          ak = mfma32b(Xh[b][j], wk[j], ak);
+          av = mfma32b(Xh[b][j], wvv[j], av);
+        }
+        kT[b] = ak;
+        vT[b] = av;
+      }
+#pragma unroll
+      for (int s0 = 0; s0 < 16; s0 += SEG) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int r = s0; r < s0 + SEG; ++r) m = fmaxf(m, kT[b][r]);
+        if (PARTNER) m = fmaxf(m, swp32(m));
+        float ssum = 0.f;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int r = s0; r < s0 + SEG; ++r) {
+            const float e = expf(kT[b][r] - m);
+            kT[b][r] = e;
+            ssum += e;
+          }
+        if (PARTNER) ssum += swp32(ssum);
+        const float rs = 1.0f / ssum;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int r = s0; r < s0 + SEG; ++r) kT[b][r] *= rs;
+      }
+
+      // q (rows d, col n) with its softmax; returns the tile
+      auto make_q = [&](int b) {
+        f32x16 q = {0};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) q = mfma32b(wq[j], Xh[b][j], q);
+        float m = q[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m = fmaxf(m, q[r]);
+        m = fmaxf(m, swp32(m));
+        float ssum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          q[r] = expf(q[r] - m);
+          ssum += q[r];
+        }
+        ssum += swp32(ssum);
+        const float qs = scale / ssum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q[r] *= qs;
+        return q;
+      };
+      auto q_softmax_bwd = [&](const f32x16& q, const f32x16& dq) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t = fmaf(q[r], dq[r], t);
+        t = (t + swp32(t)) * (1.0f / scale);
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = q[r] * (dq[r] - t);
+        return o;
+      };
+
+      if (N >= 32) {
+        // ================= one row per wave, NB blocks: phased to keep few tiles live =================
+        f32x16 ctx = {0};
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ctx = mfma32b(kT[b][r], vT[b][r], ctx);
+        const f32x16 ctxT = tr32(ctx, tile, col, half);
+        f32x16 dctx = {0};
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const f32x16 q = make_q(b);
+          f32x16 dO = {0}, dOT = {0};
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            dO = mfma32b(wo[j], DY[b][j], dO);
+            dOT = mfma32b(DY[b][j], wo[j], dOT);
+          }
+          const f32x16 qT = tr32(q, tile, col, half);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dctx = mfma32b(qT[r], dOT[r], dctx);
+          f32x16 outT = {0}, dq = {0};
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            outT = mfma32b(q[r], ctx[r], outT);
+            dq = mfma32b(ctxT[r], dO[r], dq);
+          }
+          const f32x16 dypT = tr32(as_acc(DY[b]), tile, col, half);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) go = mfma32b(dypT[r], outT[r], go);
+          const f32x16 dq_raw = q_softmax_bwd(q, dq);
+          add_dxh(b, 0, dq_raw);
+          const f32x16 xhT = tr32(as_acc(Xh[b]), tile, col, half);
+          const f32x16 dq_rawT = tr32(dq_raw, tile, col, half);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gq = mfma32b(xhT[r], dq_rawT[r], gq);
+        }
+        const f32x16 dctxT = tr32(dctx, tile, col, half);
+        float delta = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) delta = fmaf(dctxT[r], ctxT[r], delta);
+        delta += swp32(delta);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          f32x16 v = {0};
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) v = mfma32b(wvv[j], Xh[b][j], v);
+          f32x16 dkT = {0};
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dkT = mfma32b(v[r], dctxT[r], dkT);
+          f32x16 dk_rawT;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dk_rawT[r] = kT[b][r] * (dkT[r] - delta);
+          const f32x16 xhT = tr32(as_acc(Xh[b]), tile, col, half);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gk = mfma32b(xhT[r], dk_rawT[r], gk);
+          add_dxh(b, 1, tr32(dk_rawT, tile, col, half));
+          const f32x16 Kd = tr32(kT[b], tile, col, half);
+          f32x16 dv = {0};
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dv = mfma32b(dctx[r], Kd[r], dv);
+          add_dxh(b, 2, dv);
+          const f32x16 dvT = tr32(dv, tile, col, half);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gv = mfma32b(xhT[r], dvT[r], gv);
+        }
+      } else {
+        // ================= 32/N rows per wave, one block: per-row ctx / dctx =================
+        const f32x16 q = make_q(0);
+        const f32x16 qT = tr32(q, tile, col, half);
+        f32x16 dO = {0}, dOT = {0}, v = {0};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          dO = mfma32b(wo[j], DY[0][j], dO);
+          dOT = mfma32b(DY[0][j], wo[j], dOT);
+          v = mfma32b(wvv[j], Xh[0][j], v);
+        }
+        const f32x16 Kd = tr32(kT[0], tile, col, half);
+        f32x16 outT = {0}, dq = {0}, dkT = {0}, dv = {0};
+        float delta[RW];
+#pragma unroll
+        for (int rho = 0; rho < RW; ++rho) {
+          f32x16 ctx = {0}, dctx = {0};
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool mine0 = rmap(r, 0) / N == rho, mine1 = rmap(r, 1) / N == rho;
+            if (mine0 || mine1) {
+              const bool msk = half ? mine1 : mine0;
+              ctx = mfma32b(msk ? kT[0][r] : 0.f, vT[0][r], ctx);
+              dctx = mfma32b(msk ? qT[r] : 0.f, dOT[r], dctx);
+            }
+          }
+          const f32x16 ctxT = tr32(ctx, tile, col, half);
+          const f32x16 dctxT = tr32(dctx, tile, col, half);
+          float dl = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dl = fmaf(dctxT[r], ctxT[r], dl);
+          delta[rho] = dl + swp32(dl);
+          const bool sel = rl == rho;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            outT = mfma32b(sel ? q[r] : 0.f, ctx[r], outT);
+            dq = mfma32b(ctxT[r], sel ? dO[r] : 0.f, dq);
+            dkT = mfma32b(sel ? v[r] : 0.f, dctxT[r], dkT);
+            dv = mfma32b(dctx[r], sel ? Kd[r] : 0.f, dv);
+          }
+        }
+        const f32x16 dypT = tr32(as_acc(DY[0]), tile, col, half);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) go = mfma32b(dypT[r], outT[r], go);
+        const f32x16 dq_raw = q_softmax_bwd(q, dq);
+        add_dxh(0, 0, dq_raw);
+        const f32x16 xhT = tr32(as_acc(Xh[0]), tile, col, half);
+        const f32x16 dq_rawT = tr32(dq_raw, tile, col, half);
+        f32x16 dk_rawT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d0 = delta[rmap(r, 0) / N < RW ? rmap(r, 0) / N : 0], d1 = delta[rmap(r, 1) / N < RW ? rmap(r, 1) / N : 0];
+          dk_rawT[r] = kT[0][r] * (dkT[r] - (half ? d1 : d0));
+        }
+        const f32x16 dvT = tr32(dv, tile, col, half);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          gq = mfma32b(xhT[r], dq_rawT[r], gq);
+          gk = mfma32b(xhT[r], dk_rawT[r], gk);
+          gv = mfma32b(xhT[r], dvT[r], gv);
+        }
+        add_dxh(0, 1, tr32(dk_rawT, tile, col, half));
+        add_dxh(0, 2, dv);
+      }
+
+      // ---- d xh of this head: both halves' partial sums, then each lane keeps its own channels
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int pos = N >= 32 ? b * 32 + col : col % N;
+        float full[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) full[c] = part[b][c] + swp32(part[b][c]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int c0 = rmap(j, 0), c1 = c0 + 4;
+          float lo = 0.f, hi = 0.f;
+          if (c0 < C) lo = full[c0 < C ? c0 : 0];
+          if (c1 < C) hi = full[c1 < C ? c1 : 0];
+          const int c = c0 + 4 * half;
+          if (row_ok && c < C) {
+            float* dst = a.dxh + ((int64_t)row * C + c) * N + pos;
+            const float val = half ? hi : lo;
+            *dst = hd == 0 ? val : *dst + val;  // head 0 initialises, heads 1..3 accumulate (same lane, same address)
+          }
+        }
+      }
+    }
+
+    // ---- flush this head's weight gradients: register r holds channel rmap(r, half), lane column = d / e
+#pragma unroll
+    for (int r = 0; r < NJ; ++r) {
+      const int c = rmap(r, half);
+      if (c < C) {
+        atomicAdd(a.dw_qkv + (int64_t)(hd * 32 + col) * C + c, gq[r]);
+        atomicAdd(a.dw_qkv + (int64_t)(128 + hd * 32 + col) * C + c, gk[r]);
+        atomicAdd(a.dw_qkv + (int64_t)(256 + hd * 32 + col) * C + c, gv[r]);
+        atomicAdd(a.dw_out + (int64_t)c * 128 + hd * 32 + col, go[r]);
+      }
+    }
+  }
+}
+
+template <int C>
+static int linattn_bwd_n(const LinAttnBwdK& k, int n, hipStream_t s) {
+#define DQ_LB(NN)                                                                                  \
+  case NN: {                                                                                       \
+    constexpr int RW = NN >= 32 ? 1 : 32 / NN;                                                     \
+    const int units = cdiv(k.rows, RW);                                                            \
+    LinAttnBwdK kk = k;                                                                            \
+    kk.units_per_wave = std::max(1, std::min(8, units / 4096));                                    \
+    const int waves = cdiv(units, kk.units_per_wave);                                              \
+    hipLaunchKernelGGL((k_linattn_bwd<C, NN>), dim3(cdiv(waves, 4)), dim3(256), 0, s, kk);         \
+    break;                                                                                         \
+  }
+  switch (n) {
+    DQ_LB(1) DQ_LB(2) DQ_LB(4) DQ_LB(8) DQ_LB(16) DQ_LB(32) DQ_LB(64)
+    default:
+      set_error("linattn_bwd: m/z length " + std::to_string(n) + " is not built (powers of two up to 64)");
+      return 2;
+  }
+#undef DQ_LB
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// a.f.y is unused; needs: a.ypre (saved pre-norm output), scratch dyp and dxh (rows, C, n)
+int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s) {
+  DQ_REQUIRE(a.f.x && a.dy && a.dx && a.ypre && a.dyp && a.dxh && a.dw_qkv && a.dw_out && a.db_out && a.dg_pre && a.dg_out,
+             "linattn_bwd: missing operand");
+  if (a.f.rows == 0) return 0;
+  const int C = a.f.C, rows = a.f.rows, n = a.f.n;
+  // (1) post-norm backward: dyp = d loss / d ypre, d g_out, d b_out
+  BlockBwd b2;
+  b2.u = a.ypre; b2.dy = a.dy; b2.du = a.dyp; b2.C = C; b2.rows = rows; b2.n = n; b2.rows_per_sample = rows;
+  b2.g = a.f.g_out; b2.dg = a.dg_out; b2.dbias = a.db_out;
+  if (int rc = launch_block_bwd(b2, s)) return rc;
+  // (2) attention core
+  LinAttnBwdK k;
+  k.x = a.f.x; k.dyp = a.dyp; k.dxh = a.dxh; k.w_qkv = a.f.w_qkv; k.w_out = a.f.w_out; k.g_pre = a.f.g_pre;
+  k.dw_qkv = a.dw_qkv; k.dw_out = a.dw_out; k.rows = rows; k.units_per_wave = 1;
+  int rc;
+  switch (C) {
+    case 4: rc = linattn_bwd_n<4>(k, n, s); break;
+    case 8: rc = linattn_bwd_n<8>(k, n, s); break;
+    case 12: rc = linattn_bwd_n<12>(k, n, s); break;
+    case 16: rc = linattn_bwd_n<16>(k, n, s); break;
+    default: set_error("linattn_bwd: unsupported channel count " + std::to_string(C)); return 2;
+  }
+  if (rc) return rc;
+  // (3) residual + pre-norm backward, accumulated into dx
+  if (int r2 = launch_axpy(a.dx, a.dy, (int64_t)rows * C * n, s)) return r2;
+  BlockBwd b1;
+  b1.u = a.f.x; b1.dy = a.dxh; b1.du = a.dx; b1.C = C; b1.rows = rows; b1.n = n; b1.rows_per_sample = rows;
+  b1.g = a.f.g_pre; b1.dg = a.dg_pre; b1.accumulate = 1;
+  return launch_block_bwd(b1, s);
+}
+
 }  // namespace dq

@@ -34,8 +34,8 @@ PROTOTYPES = {
                                POINTER(c_int32), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                c_void_p]),
     "dq_debug_tensor_offset": (c_int64, [c_void_p, c_char_p]),
-    "dq_linattn_fwd": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
-    "dq_linattn_bwd": (c_int, [c_void_p] * 13 + [c_int, c_int, c_int, c_void_p]),
+    "dq_linattn_fwd": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p]),
+    "dq_linattn_bwd": (c_int, [c_void_p] * 15 + [c_int, c_int, c_int, c_void_p]),
 }
 
 

@@ -254,7 +254,9 @@ class UNet1d(nn.Module):
         self._ensure_flat()
         need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for _, p in self.trainable_named()))
         if need_grad:
-            out = _UNetFn.apply(self, xs.requires_grad_(x.requires_grad), ts, ic, ac, *[p for _, p in self.trainable_named()])
+            x_in = x[None] if squeeze else x  # keep x's autograd history so that d loss / d x reaches the caller's tensor
+            x_in = x_in.to(torch.float32).contiguous() if x.requires_grad else xs
+            out = _UNetFn.apply(self, x_in, ts, ic, ac, *[p for _, p in self.trainable_named()])
         else:
             out = self._run_fwd(xs, ts, ic, ac, training=False)
         return out[0] if squeeze else out
@@ -279,7 +281,7 @@ class _UNetFn(torch.autograd.Function):
         ctx.save_for_backward(ic)
         ctx.shape = xs.shape
         ctx.x_needs = xs.requires_grad
-        return net._run_fwd(xs, ts, ic, ac, training=True)
+        return net._run_fwd(xs.detach(), ts, ic, ac, training=True)
 
     @staticmethod
     def backward(ctx, gout):

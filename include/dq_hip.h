@@ -108,11 +108,13 @@ int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, 
 
 /* ---- building blocks exported for the per-block parity tests (tests/test_blocks_gpu.py) ------------------------
  * Residual(PreNorm(LinearAttention)) (unet1d.py:446-496, 1017) on (rows, C, n). */
-int dq_linattn_fwd(const float* x, float* y, const float* w_qkv, const float* w_out, const float* b_out, const float* g_pre,
-                   const float* g_out, int C, int rows, int n, void* stream);
-int dq_linattn_bwd(const float* x, const float* dy, float* dx, const float* w_qkv, const float* w_out, const float* b_out,
-                   const float* g_pre, const float* g_out, float* dw_qkv, float* dw_out, float* db_out, float* dg_pre,
-                   float* dg_out, int C, int rows, int n, void* stream);
+int dq_linattn_fwd(const float* x, float* y, float* ypre /* nullable: pre-norm output saved for the backward */,
+                   const float* w_qkv, const float* w_out, const float* b_out, const float* g_pre, const float* g_out, int C,
+                   int rows, int n, void* stream);
+/* Backward: dx += d/dx, parameter gradients += (atomic).  ypre from the forward; scratch: 2*rows*C*n floats. */
+int dq_linattn_bwd(const float* x, const float* ypre, const float* dy, float* dx, const float* w_qkv, const float* w_out,
+                   const float* b_out, const float* g_pre, const float* g_out, float* dw_qkv, float* dw_out, float* db_out,
+                   float* dg_pre, float* dg_out, float* scratch, int C, int rows, int n, void* stream);
 
 /* Test hook: offset (in floats) of a named activation inside the workspace laid out by the last call on this plan
  * ("h0", "ms1f", "down3", "down3.la", "mid1", "attn_out", "up0", "fin", ...), or -1. */

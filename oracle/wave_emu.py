@@ -206,3 +206,222 @@ def la_fwd(x, Wqkv, Wo, bo, g_pre, g_out):
             xs = np.concatenate([xs, np.zeros((pad, C, n), F)])
         y[r0:r0 + rw] = la_fwd_block_rows(xs, Wqkv, Wo, bo, g_pre, g_out)[: rw - pad]
     return y
+
+
+# ======================================================================================================================
+# backward (mirrors k_linattn_bwd in csrc/k_linattn_bwd.hip)
+# ======================================================================================================================
+def to_mat(acc):
+    """accumulator (16, 64) -> logical 32x32 [row][col]"""
+    M = np.zeros((32, 32), F)
+    for r in range(16):
+        M[rowmap(r, HALF), COL] = acc[r]
+    return M
+
+
+def from_mat(M):
+    acc = np.zeros((16, 64), F)
+    for r in range(16):
+        acc[r] = M[rowmap(r, HALF), COL]
+    return acc
+
+
+def T(acc):
+    """32x32 transpose of an accumulator (done through a wave-private LDS tile in the kernel)"""
+    return from_mat(to_mat(acc).T.copy())
+
+
+def la_bwd_unit(x, dyp, Wqkv, Wo, g_pre, hd, dW):
+    """One wave, one head, one unit (1 row if n >= 32 else 32/n rows).  x, dyp: (RW, C, n); dyp = d loss / d y_pre.
+    Accumulates this head's weight gradients into dW (dict of logical matrices) and returns this head's contribution
+    to d loss / d xh (RW, C, n) where xh = rmsnorm(x)*g_pre."""
+    RW, C, n = x.shape
+    NB = max(1, n // 32)
+    NJ = 4 if C <= 8 else 8
+    sqC = F(np.sqrt(F(C)))
+    scale = F(32 ** -0.5)
+
+    def pos_of(blk):
+        if n >= 32:
+            return np.zeros(64, int), blk * 32 + COL
+        return COL // n, COL % n
+
+    def xload(t, blk):
+        rl, pp = pos_of(blk)
+        out = np.zeros((NJ, 64), F)
+        for j in range(NJ):
+            c = chan_of(j, HALF)
+            out[j] = np.where(c < C, t[rl, np.minimum(c, C - 1), pp], 0)
+        return out
+
+    def as_acc(xr):
+        a = acc_zero()
+        a[:NJ] = xr
+        return a
+
+    X = [xload(x, b) for b in range(NB)]
+    DYP = [xload(dyp, b) for b in range(NB)]
+    Xh = []
+    for b in range(NB):
+        ssq = (X[b] ** 2).sum(0)
+        ssq = ssq + shfl_xor32(ssq)
+        inv = sqC / np.maximum(np.sqrt(ssq), F(1e-12))
+        g = np.stack([np.where(chan_of(j, HALF) < C, g_pre[np.minimum(chan_of(j, HALF), C - 1)], 0) for j in range(NJ)])
+        Xh.append((X[b] * inv * g).astype(F))
+
+    def wfrag(o_base, j):
+        c = chan_of(j, HALF)
+        return np.where(c < C, Wqkv[o_base + COL, np.minimum(c, C - 1)], 0).astype(F)
+
+    def wofrag(j):
+        c = chan_of(j, HALF)
+        return np.where(c < C, Wo[np.minimum(c, C - 1), hd * 32 + COL], 0).astype(F)
+
+    if n >= 32:
+        SEG, PARTNER = 16, True
+    elif n >= 8:
+        SEG, PARTNER = n // 2, True
+    else:
+        SEG, PARTNER = max(n, 1), False
+
+    # ---------------- stage 0: recompute forward pieces
+    kT, vT, Kd, q, qT, do, doT, v = [], [], [], [], [], [], [], []
+    for b in range(NB):
+        ak, av, aq, avn, ado, adoT = (acc_zero() for _ in range(6))
+        for j in range(NJ):
+            ak = mfma(Xh[b][j], wfrag(128 + hd * 32, j), ak)
+            av = mfma(Xh[b][j], wfrag(256 + hd * 32, j), av)
+            aq = mfma(wfrag(hd * 32, j), Xh[b][j], aq)
+            avn = mfma(wfrag(256 + hd * 32, j), Xh[b][j], avn)
+            ado = mfma(wofrag(j), DYP[b][j], ado)
+            adoT = mfma(DYP[b][j], wofrag(j), adoT)
+        kT.append(ak), vT.append(av), v.append(avn), do.append(ado), doT.append(adoT)
+        m = aq.max(0)
+        m = np.maximum(m, shfl_xor32(m))
+        aq = np.exp(aq - m)
+        s = aq.sum(0)
+        s = s + shfl_xor32(s)
+        aq = aq * (scale / s)
+        q.append(aq), qT.append(T(aq))
+    for s0 in range(0, 16, SEG):
+        regs = range(s0, s0 + SEG)
+        m = np.full(64, -np.inf, F)
+        for b in range(NB):
+            for r in regs:
+                m = np.maximum(m, kT[b][r])
+        if PARTNER:
+            m = np.maximum(m, shfl_xor32(m))
+        ssum = np.zeros(64, F)
+        for b in range(NB):
+            for r in regs:
+                kT[b][r] = np.exp(kT[b][r] - m)
+                ssum = ssum + kT[b][r]
+        if PARTNER:
+            ssum = ssum + shfl_xor32(ssum)
+        for b in range(NB):
+            for r in regs:
+                kT[b][r] = kT[b][r] / ssum
+    Kd = [T(kT[b]) for b in range(NB)]
+
+    # ---------------- per row: ctx / dctx and their consumers
+    outT = [acc_zero() for _ in range(NB)]
+    dq = [acc_zero() for _ in range(NB)]
+    dkT = [acc_zero() for _ in range(NB)]
+    dv = [acc_zero() for _ in range(NB)]
+    delta = np.zeros((RW, 64), F)
+    for rho in range(RW):
+        ctx, dctx = acc_zero(), acc_zero()
+        for b in range(NB):
+            for r in range(16):
+                if n >= 32:
+                    mine0 = mine1 = True
+                else:
+                    mine0, mine1 = rowmap(r, 0) // n == rho, rowmap(r, 1) // n == rho
+                if not (mine0 or mine1):
+                    continue
+                msk = np.where(HALF == 0, mine0, mine1)
+                ctx = mfma(np.where(msk, kT[b][r], 0).astype(F), vT[b][r], ctx)
+                dctx = mfma(np.where(msk, qT[b][r], 0).astype(F), doT[b][r], dctx)
+        ctxT, dctxT = T(ctx), T(dctx)
+        dl = (dctxT * ctxT).sum(0)
+        delta[rho] = dl + shfl_xor32(dl)
+        for b in range(NB):
+            sel = np.ones(64, bool) if n >= 32 else (COL // n) == rho
+            for r in range(16):
+                outT[b] = mfma(np.where(sel, q[b][r], 0).astype(F), ctx[r], outT[b])
+                dq[b] = mfma(ctxT[r], np.where(sel, do[b][r], 0).astype(F), dq[b])
+                dkT[b] = mfma(np.where(sel, v[b][r], 0).astype(F), dctxT[r], dkT[b])
+                dv[b] = mfma(dctx[r], np.where(sel, Kd[b][r], 0).astype(F), dv[b])
+
+    # ---------------- softmax backward, weight gradients, d xh
+    dxh = np.zeros_like(x)
+    for b in range(NB):
+        t = (q[b] * dq[b]).sum(0)
+        t = (t + shfl_xor32(t)) / scale
+        dq_raw = q[b] * (dq[b] - t)
+        dk_rawT = acc_zero()
+        for r in range(16):
+            rho_r = np.zeros(64, int) if n >= 32 else rowmap(r, HALF) // n
+            dk_rawT[r] = kT[b][r] * (dkT[b][r] - delta[rho_r, LANES])
+        dvT = T(dv[b])
+        dq_rawT, dk_raw = T(dq_raw), T(dk_rawT)
+        XhT, DYPT = T(as_acc(Xh[b])), T(as_acc(DYP[b]))
+        aq, ak, av, ao = acc_zero(), acc_zero(), acc_zero(), acc_zero()
+        for r in range(16):
+            aq = mfma(XhT[r], dq_rawT[r], aq)   # rows c, col d
+            ak = mfma(XhT[r], dk_rawT[r], ak)
+            av = mfma(XhT[r], dvT[r], av)
+            ao = mfma(DYPT[r], outT[b][r], ao)  # rows c, col e
+        for nm, a in (("q", aq), ("k", ak), ("v", av), ("o", ao)):
+            dW[nm] += to_mat(a)[:C, :]
+        # d xh on the VALU: lane (n, half) holds rows rowmap(r, half) of dq_raw / dk_raw / dv
+        rl, pp = pos_of(b)
+        part = np.zeros((C, 64), F)
+        for c in range(C):
+            for r in range(16):
+                o = rowmap(r, HALF)
+                part[c] += Wqkv[hd * 32 + o, c] * dq_raw[r] + Wqkv[128 + hd * 32 + o, c] * dk_raw[r] + Wqkv[256 + hd * 32 + o, c] * dv[b][r]
+        full = part + np.stack([shfl_xor32(part[c]) for c in range(C)])
+        for l in range(32):  # half 0 lanes write (both halves hold the same sums)
+            dxh[rl[l], :, pp[l]] = full[:, l]
+    return dxh
+
+
+def la_bwd(x, dy, ypre, Wqkv, Wo, bo, g_pre, g_out):
+    """Full backward on (R, C, n) given the saved pre-norm output ypre.  Returns dict of gradients."""
+    R, C, n = x.shape
+    sqC = np.sqrt(F(C))
+    # (1) norm2 backward (k_block_bwd): y = ypre/max(||ypre||,eps)*g_out*sqrt(C)
+    nrm = np.sqrt((ypre ** 2).sum(1, keepdims=True))
+    inv = 1.0 / np.maximum(nrm, 1e-12)
+    uh = ypre * inv
+    gd = dy * g_out[None, :, None] * sqC
+    dyp = (inv * (gd - uh * (gd * uh).sum(1, keepdims=True))).astype(F)
+    out = {"g_out": (dy * uh * sqC).sum((0, 2)), "b_out": dyp.sum((0, 2))}
+    # (2) main kernel: head outer, units inner
+    rw = 1 if n >= 32 else 32 // n
+    dxh = np.zeros_like(x)
+    dWq, dWk, dWv, dWo = (np.zeros((128, C), F) for _ in range(3)), None, None, None
+    dWqkv = np.zeros((384, C), F)
+    dWo = np.zeros((C, 128), F)
+    for hd in range(4):
+        dW = {k: np.zeros((C, 32), F) for k in "qkvo"}
+        for r0 in range(0, R, rw):
+            xs, ds = x[r0:r0 + rw], dyp[r0:r0 + rw]
+            pad = rw - xs.shape[0]
+            if pad:
+                xs = np.concatenate([xs, np.zeros((pad, C, n), F)])
+                ds = np.concatenate([ds, np.zeros((pad, C, n), F)])
+            dxh[r0:r0 + rw] += la_bwd_unit(xs, ds, Wqkv, Wo, g_pre, hd, dW)[: rw - pad]
+        dWqkv[hd * 32:(hd + 1) * 32] += dW["q"].T
+        dWqkv[128 + hd * 32:128 + (hd + 1) * 32] += dW["k"].T
+        dWqkv[256 + hd * 32:256 + (hd + 1) * 32] += dW["v"].T
+        dWo[:, hd * 32:(hd + 1) * 32] += dW["o"]
+    # (3) norm1 backward + residual
+    nrm = np.sqrt((x ** 2).sum(1, keepdims=True))
+    inv = 1.0 / np.maximum(nrm, 1e-12)
+    uh = x * inv
+    gd = dxh * g_pre[None, :, None] * sqC
+    dx = inv * (gd - uh * (gd * uh).sum(1, keepdims=True)) + dy
+    out.update({"x": dx.astype(F), "g_pre": (dxh * uh * sqC).sum((0, 2)), "w_qkv": dWqkv, "w_out": dWo})
+    return out

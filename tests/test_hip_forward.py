@@ -41,7 +41,7 @@ def test_linattn_fwd_golden(N, golden, C, n):
     g1 = _dev(g[pre + "w/fn.norm.g"].reshape(-1))
     g2 = _dev(g[pre + "w/fn.fn.to_out.1.g"].reshape(-1))
     y = torch.empty_like(x)
-    N.check(N.lib().dq_linattn_fwd(N.ptr(x), N.ptr(y), N.ptr(w), N.ptr(wo), N.ptr(bo), N.ptr(g1), N.ptr(g2), C, x.shape[0], n,
+    N.check(N.lib().dq_linattn_fwd(N.ptr(x), N.ptr(y), None, N.ptr(w), N.ptr(wo), N.ptr(bo), N.ptr(g1), N.ptr(g2), C, x.shape[0], n,
                                    N.stream_ptr()), "dq_linattn_fwd")
     torch.cuda.synchronize()
     assert rel_err(y, g[pre + "y"]) < 1e-5  # fp32 tolerance: 1e-5 of the output scale
@@ -63,7 +63,7 @@ def test_linattn_fwd_oracle_ragged(N, C, n, rows):
     xd = x.cuda()
     y = torch.empty_like(xd)
     d = {k: v.cuda().reshape(v.shape[0] if v.dim() == 1 else -1).contiguous() for k, v in p.items()}
-    N.check(N.lib().dq_linattn_fwd(N.ptr(xd), N.ptr(y), N.ptr(d["la.fn.fn.to_qkv.weight"]), N.ptr(d["la.fn.fn.to_out.0.weight"]),
+    N.check(N.lib().dq_linattn_fwd(N.ptr(xd), N.ptr(y), None, N.ptr(d["la.fn.fn.to_qkv.weight"]), N.ptr(d["la.fn.fn.to_out.0.weight"]),
                                    N.ptr(d["la.fn.fn.to_out.0.bias"]), N.ptr(d["la.fn.norm.g"]), N.ptr(d["la.fn.fn.to_out.1.g"]),
                                    C, rows, n, N.stream_ptr()), "dq_linattn_fwd")
     torch.cuda.synchronize()

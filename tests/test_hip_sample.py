@@ -11,7 +11,10 @@ T = torch.from_numpy
 
 
 def rel_err(a, b):
-    a, b = torch.as_tensor(a).detach().float().cpu(), torch.as_tensor(np.array(b)).float()
+    def f(v):
+        return v.detach().float().cpu() if torch.is_tensor(v) else torch.as_tensor(np.asarray(v)).float()
+
+    a, b = f(a), f(b)
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
