@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""Benchmark of the DDIM hot path on MI355X (contract: see the task description / DESIGN.md "Measurement").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one optimiser step of the reference's ``_train_one_batch`` (zero_grad, train_step incl. drawing t and noise,
+backward, clip 10, AdamW) on one batch of 32 synthetic MS2+MS1 windows (RT=400 x MZ=64) per GPU -- BASELINE.json configs[1]
+("same model, 10k synthetic windows, batch=32, 1xMI355X"), computed in fp32 (the reference's precision; the bf16 in that
+config line is not used).  Inputs are resident in HBM before the timed region.  ``value`` = windows/s over all ranks
+(weak scaling: per-GPU batch fixed).  The same JSON line also carries the 50-step DDIM sampling throughput
+(configs[3], batch 512/GPU), the roofline of the dominant kernel, and the CPU baseline (oracle on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "diffusion-deconvolution-dia-msms-data_amd"))
+sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+
+RT, MZ = 400, 64
+TRAIN_BATCH = 32
+SAMPLE_BATCH = 512
+SAMPLE_STEPS = 50
+F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+# algorithmic FLOPs (2*MAC) of one LinearAttention forward per m/z row of n positions with C channels:
+#   to_qkv 2*384*C*n + ctx 2*4*32*32*n + out 2*4*32*32*n + to_out 2*128*C*n      
+
+
+def la_flops_fwd(C, n):
+    return 2 * 384 * C * n + 2 * 2 * 4 * 32 * 32 * n + 2 * 128 * C * n
+
+
+def build_model(device):
+    from dquartic.model.model import DDIMDiffusionModel
+    from dquartic.model.unet1d import UNet1d
+
+    net = UNet1d(dim=4, channels=1, dim_mults=(1, 2, 2, 3, 3, 4, 4), conditional=True, init_cond_channels=1,
+                 attn_cond_channels=1, tfer_dim_mult=620, downsample_dim=MZ, simple=True).to(device)
+    dm = DDIMDiffusionModel(model_class=net, num_timesteps=1000, beta_schedule_type="cosine", pred_type="eps",
+                            auto_normalize=True, ms1_loss_weight=0.0, device=device)
+    return net, dm
+
+
+def make_batches(n_batches, batch, rank, world, device):
+    """(x0, ms2_cond, ms1_cond) device batches from the synthetic pair dataset."""
+    from dquartic.utils.synthetic import SyntheticDIAMSDataset
+
+    ds = SyntheticDIAMSDataset(n_windows=64 * world, RT=RT, MZ=MZ, rank=rank, world=world, seed=0)
+    out = []
+    for _ in range(n_batches):
+        items = [ds[0] for _ in range(batch)]
+        a, m1, b, _ = (torch.stack([it[k] for it in items]) for k in range(4))
+        out.append((a.to(device), (0.5 * a + 0.5 * b).to(device), m1.to(device)))
+    return out
+
+
+def time_kernel(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters  # seconds per launch
+
+
+def roofline_linattn(device):
+    """Dominant kernel of the train step: k_linattn_bwd<4,64> (level-0 LinearAttention backward over 32*400 rows).
+    Timed live with HIP events on the launch stream; FLOPs are algorithmic (2x the forward's), not what the kernel
+    re-executes."""
+    from dquartic import _native as N
+
+    C, n, rows = 4, 64, TRAIN_BATCH * RT
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(rows, C, n, generator=g).to(device)
+    dy = torch.randn(rows, C, n, generator=g).to(device)
+    w = (torch.randn(384, C, generator=g) * 0.4).to(device)
+    wo = (torch.randn(C, 128, generator=g) * 0.2).to(device)
+    bo, g1, g2 = torch.zeros(C, device=device), torch.ones(C, device=device), torch.ones(C, device=device)
+    y, ypre, dx = torch.empty_like(x), torch.empty_like(x), torch.zeros_like(x)
+    dw, dwo, dbo, dg1, dg2 = (torch.zeros_like(t) for t in (w, wo, bo, g1, g2))
+    scratch = torch.empty(2 * x.numel(), device=device)
+    L = N.lib()
+
+    def fwd():
+        N.check(L.dq_linattn_fwd(N.ptr(x), N.ptr(y), N.ptr(ypre), N.ptr(w), N.ptr(wo), N.ptr(bo), N.ptr(g1), N.ptr(g2), C, rows, n,
+                                 N.stream_ptr()), "dq_linattn_fwd")
+
+    def bwd():
+        N.check(L.dq_linattn_bwd(N.ptr(x), N.ptr(ypre), N.ptr(dy), N.ptr(dx), N.ptr(w), N.ptr(wo), N.ptr(bo), N.ptr(g1), N.ptr(g2),
+                                 N.ptr(dw), N.ptr(dwo), N.ptr(dbo), N.ptr(dg1), N.ptr(dg2), N.ptr(scratch), C, rows, n,
+                                 N.stream_ptr()), "dq_linattn_bwd")
+
+    t_f = time_kernel(fwd)
+    t_b = time_kernel(bwd)  # includes the two small pointwise norm-backward launches (~3 % of it)
+    fl_f = la_flops_fwd(C, n) * rows
+    ach_f, ach_b = fl_f / t_f / 1e12, 2 * fl_f / t_b / 1e12
+    return {"bound": "mfma", "kernel": "k_linattn_bwd<4,64>", "achieved": round(ach_b, 3), "peak": F32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(ach_b / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "launch_us": round(t_b * 1e6, 2), "flops_per_launch": 2 * fl_f,
+            "fwd_kernel": {"kernel": "k_linattn_fwd<4,64>", "achieved": round(ach_f, 3), "frac": round(ach_f / F32_MFMA_PEAK_TFLOPS, 4),
+                           "launch_us": round(t_f * 1e6, 2), "flops_per_launch": fl_f}}
+
+
+def cpu_baseline(net):
+    """The oracle (CPU restatement of the reference, kind 'port') on this box's host cores: per-sample (B = 1) train steps
+    -- the only batch size the reference runs at -- incl. clip + AdamW, on a bounded sample of the same workload."""
+    from oracle import dq_oracle as O
+
+    # the GPU box gives one GPU a 16-CPU share; os.cpu_count() reports the whole host and oversubscribing it stalls OpenMP
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("DQ_CPU_BASELINE_THREADS", "16"))))
+    torch.set_num_threads(cores)
+    params = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    keys = O.trainable_keys(params)
+    for k in keys:
+        params[k].requires_grad_(True)
+    opt = torch.optim.AdamW([params[k] for k in keys], lr=1e-5)
+    d = O.Diffusion(params, O.UNetConfig(downsample_dim=MZ))
+    batches = make_batches(1, 8, 0, 1, "cpu")[0]
+    n_steps, t_train = 0, 0.0
+    for i in range(8):
+        x0, c2, c1 = (v[i:i + 1] for v in batches)
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        t = torch.randint(0, 1000, (1,))
+        nz = torch.randn_like(x0)
+        loss, _ = d.train_loss(x0, c2, c1, t, nz)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([params[k] for k in keys], 10.0)
+        opt.step()
+        dt = time.perf_counter() - t0
+        log(f"cpu baseline step {i}: {dt:.2f} s")
+        if i >= 2:  # 2 warm-up steps
+            n_steps += 1
+            t_train += dt
+    # sampling: 1 window, 5 of the 50 steps timed, extrapolated
+    with torch.no_grad():
+        x0, c2, c1 = (v[:1] for v in batches)
+        t0 = time.perf_counter()
+        d.sample(torch.randn_like(x0), c2, c1, 5)
+        t_s = (time.perf_counter() - t0) * (SAMPLE_STEPS / 5)
+    return {"value": round(n_steps / t_train, 4), "unit": "MS2 windows/s (train step)", "cores": cores, "kind": "port",
+            "sample": f"6 timed B=1 train steps (after 2 warm-up) of the same network/shape; sampling: 1 window x 5 steps x10",
+            "sample_windows_per_s": round(1.0 / t_s, 5)}
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-sample", action="store_true", help="skip the sampling leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--sample-batch", type=int, default=SAMPLE_BATCH)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+    elif args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    torch.manual_seed(rank)
+
+    net, dm = build_model(device)
+    dm._set_optimizer(1e-5)
+    log("building synthetic batches")
+    batches = make_batches(4, TRAIN_BATCH, rank, world, device)
+    log("train leg")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    # ------------------------------------------------------------------ train leg
+    for i in range(args.warmup):
+        x0, c2, c1 = batches[i % len(batches)]
+        dm._train_one_batch(x0, ms2_cond=c2, ms1_cond=c1, sync=False)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        x0, c2, c1 = batches[i % len(batches)]
+        loss = dm._train_one_batch(x0, ms2_cond=c2, ms1_cond=c1, sync=False)
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tt)
+    train_wps = world * TRAIN_BATCH * args.steps / dt
+    last_loss = float(loss)
+
+    # ------------------------------------------------------------------ sampling leg (no collective: batch shards)
+    log(f"train: {train_wps:.1f} windows/s; sampling leg")
+    sample = None
+    if not args.no_sample:
+        B = args.sample_batch
+        g = torch.Generator(device="cpu").manual_seed(rank)
+        xT = torch.randn(B, RT, MZ, generator=g).to(device)
+        reps = (B + TRAIN_BATCH - 1) // TRAIN_BATCH
+        c2 = torch.cat([batches[i % len(batches)][1] for i in range(reps)])[:B].contiguous()
+        c1 = torch.cat([batches[i % len(batches)][2] for i in range(reps)])[:B].contiguous()
+        dm.sample(xT[:8], c2[:8], c1[:8], num_steps=2)  # warm-up
+        barrier()
+        t0 = time.perf_counter()
+        dm.sample(xT, c2, c1, num_steps=SAMPLE_STEPS)
+        barrier()
+        ds = time.perf_counter() - t0
+        ts = torch.tensor([ds], device=device, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(ts, op=torch.distributed.ReduceOp.MAX)
+        sample = {"metric": "MS2 windows/s (50-step DDIM sample)", "value": round(world * B / float(ts), 2), "batch_per_gpu": B,
+                  "steps": SAMPLE_STEPS, "seconds": round(float(ts), 4)}
+
+    log("roofline leg")
+    roof = roofline_linattn(device) if rank == 0 else None
+    log("cpu baseline leg")
+    cpu = cpu_baseline(net) if (rank == 0 and world == 1 and not args.no_cpu) else None
+
+    if rank == 0:
+        out = {
+            "metric": "MS2 windows/s (train step: zero_grad + train_step + backward + clip 10 + AdamW)",
+            "value": round(train_wps, 2), "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: default UNet1d (dim 4, mults 1,2,2,3,3,4,4; 128,847 params), synthetic MS2+MS1 "
+                                   "windows 400 RT x 64 m/z, batch 32 per GPU, fp32", "global_batch": world * TRAIN_BATCH,
+                       "window": [RT, MZ], "parallelism": f"dp{world}"},
+            "last_loss": round(last_loss, 6),
+            "sample": sample, "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
