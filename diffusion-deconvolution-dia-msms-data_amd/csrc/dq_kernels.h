@@ -70,7 +70,9 @@ struct ConvWgrad {
   const float* du = nullptr; const float* inA = nullptr; const float* inB = nullptr; int cinA = 0, cinB = 0;
   int cout = 0, K = 1, mode = CONV_S1, rows = 0, n_in = 0, n_out = 0;
   float* dw = nullptr; float* dbias = nullptr;
+  float* scratch = nullptr; int64_t scratch_floats = 0;  // >= WGRAD_MAX_PARTS * (cout*cin*K + cout) floats
 };
+constexpr int WGRAD_MAX_PARTS = 64;
 int launch_conv_wgrad(const ConvWgrad& a, hipStream_t s);
 
 // standalone RMSNorm forward (PreNorm of the bottleneck attention)

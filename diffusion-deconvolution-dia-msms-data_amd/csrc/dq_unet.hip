@@ -66,6 +66,8 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
   a.partials = take(MSE_MAX_BLOCKS);
   a.loss = take(64);
   a.coef = take(4 * 1024);  // DDIM coefficient table (<= 1024 steps)
+  a.wg_floats = (int64_t)WGRAD_MAX_PARTS * (std::max({16 * 32 * 3, p.mid_c * p.mid_c * 3, 2 * HID * p.mid_c}) + 2 * HID);
+  a.wg = take(a.wg_floats);  // partial sums of the weight-gradient kernels
   a.floats = off;
 }
 
@@ -126,6 +128,7 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
   bb.g = c.prm(r.g2); bb.dg = c.dprm(r.g2); bb.act = ACT_SILU;
   DQ_TRY(launch_block_bwd(bb, c.s));
   ConvWgrad wg;
+  wg.scratch = c.w(c.ar.wg); wg.scratch_floats = c.ar.wg_floats;
   wg.du = c.g(b.u2); wg.inA = c.w(b.a1); wg.cinA = r.cout; wg.cout = r.cout; wg.K = 3; wg.mode = CONV_S1;
   wg.rows = rows; wg.n_in = n; wg.n_out = n; wg.dw = c.dprm(r.c2.w); wg.dbias = c.dprm(r.c2.b);
   DQ_TRY(launch_conv_wgrad(wg, c.s));
@@ -140,6 +143,7 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
   b1.ss = c.w(c.ar.ss) + r.ss_off; b1.dss = c.g(c.ar.ss) + r.ss_off; b1.ss_stride = c.p.ss_total;
   DQ_TRY(launch_block_bwd(b1, c.s));
   ConvWgrad w1;
+  w1.scratch = c.w(c.ar.wg); w1.scratch_floats = c.ar.wg_floats;
   w1.du = c.g(b.u1); w1.inA = inA; w1.inB = inB; w1.cinA = cinA; w1.cinB = cinB; w1.cout = r.cout; w1.K = 3; w1.mode = CONV_S1;
   w1.rows = rows; w1.n_in = n; w1.n_out = n; w1.dw = c.dprm(r.c1.w); w1.dbias = c.dprm(r.c1.b);
   DQ_TRY(launch_conv_wgrad(w1, c.s));
@@ -152,6 +156,8 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
   // residual path
   if (r.res.cout) {
     ConvWgrad wr;
+    wr.scratch = c.w(c.ar.wg); wr.scratch_floats = c.ar.wg_floats;
+  wr.scratch = c.w(c.ar.wg); wr.scratch_floats = c.ar.wg_floats;
     wr.du = dout; wr.inA = inA; wr.inB = inB; wr.cinA = cinA; wr.cinB = cinB; wr.cout = r.cout; wr.K = 1; wr.mode = CONV_S1;
     wr.rows = rows; wr.n_in = n; wr.n_out = n; wr.dw = c.dprm(r.res.w); wr.dbias = c.dprm(r.res.b);
     DQ_TRY(launch_conv_wgrad(wr, c.s));
@@ -195,6 +201,7 @@ int conv_plain_fwd(const Ctx& c, const ConvP& cp, int mode, const float* in, flo
 int conv_plain_bwd(const Ctx& c, const ConvP& cp, int mode, const float* in, const float* dout, float* din, int rows, int n_in,
                    int n_out, int accumulate) {
   ConvWgrad wg;
+  wg.scratch = c.w(c.ar.wg); wg.scratch_floats = c.ar.wg_floats;
   wg.du = dout; wg.inA = in; wg.cinA = cp.cin; wg.cout = cp.cout; wg.K = cp.k; wg.mode = mode; wg.rows = rows; wg.n_in = n_in;
   wg.n_out = n_out; wg.dw = c.dprm(cp.w); wg.dbias = cp.b >= 0 ? c.dprm(cp.b) : nullptr;
   DQ_TRY(launch_conv_wgrad(wg, c.s));

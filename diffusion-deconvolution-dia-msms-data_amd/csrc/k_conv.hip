@@ -365,14 +365,16 @@ int launch_conv_bwd_data(const ConvBwdData& a, hipStream_t s) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// weight gradient: block-y owns a (COB x CIB x K) sub-block of dW; threads stride over (row, p) items and keep the
-// sub-block in registers; one wave reduction + one atomic per (wave, element) at the end.
+// weight gradient, two deterministic stages (no atomics, fixed summation order => bitwise run-to-run repeatable):
+//  (1) block (x, y): y owns a (COB x CIB x K) sub-block of dW, x a strided share of the (row, p) items; the sub-block
+//      lives in registers, is reduced over the block (wave shuffles + LDS) and written to partials[x][element];
+//  (2) k_wgrad_reduce sums the <= 64 partials of every element in order and adds them to dW / dbias.
 // -------------------------------------------------------------------------------------------------
 template <int COB, int CIB, int K, int MODE>
-__global__ void __launch_bounds__(256) k_conv_wgrad(ConvWgrad a, int n_cib) {
+__global__ void __launch_bounds__(256) k_conv_wgrad(ConvWgrad a, int n_cib, int nelem_w) {
   const int cin = a.cinA + a.cinB;
   const int co0 = (blockIdx.y / n_cib) * COB, ci0 = (blockIdx.y % n_cib) * CIB;
-  const int64_t total = (int64_t)a.rows * a.n_out;
+  const int total = a.rows * a.n_out;  // < 2^31 (checked on the host)
   float acc[COB][CIB][K];
   float accb[COB];
 #pragma unroll
@@ -383,11 +385,12 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(ConvWgrad a, int n_cib) {
 #pragma unroll
       for (int k = 0; k < K; ++k) acc[i][j][k] = 0.f;
   }
-  for (int64_t it = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
-    const int row = (int)(it / a.n_out), p = (int)(it % a.n_out);
+  for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < total; it += gridDim.x * blockDim.x) {
+    const int row = it / a.n_out, p = it - row * a.n_out;
     float d[COB];
+    const float* dub = a.du + ((int64_t)row * a.cout + co0) * a.n_out + p;
 #pragma unroll
-    for (int i = 0; i < COB; ++i) d[i] = (co0 + i < a.cout) ? a.du[((int64_t)row * a.cout + co0 + i) * a.n_out + p] : 0.f;
+    for (int i = 0; i < COB; ++i) d[i] = (co0 + i < a.cout) ? dub[(int64_t)i * a.n_out] : 0.f;
     int q[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) q[k] = tap_pos<MODE, K>(p, k, a.n_in);
@@ -407,41 +410,68 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(ConvWgrad a, int n_cib) {
 #pragma unroll
     for (int i = 0; i < COB; ++i) accb[i] += d[i];
   }
-  const int lane = threadIdx.x & 63;
+  constexpr int NACC = COB * CIB * K + COB;
+  __shared__ float red[4][NACC];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < COB; ++i) {
-    const int co = co0 + i;
 #pragma unroll
-    for (int j = 0; j < CIB; ++j) {
-      const int ci = ci0 + j;
+    for (int j = 0; j < CIB; ++j)
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const float v = wave_sum(acc[i][j][k]);
-        if (lane == 0 && co < a.cout && ci < cin) atomicAdd(a.dw + ((int64_t)co * cin + ci) * K + k, v);
+        if (lane == 0) red[wv][(i * CIB + j) * K + k] = v;
       }
-    }
-    if (a.dbias && ci0 == 0) {
-      const float v = wave_sum(accb[i]);
-      if (lane == 0 && co < a.cout) atomicAdd(a.dbias + co, v);
+    const float vb = wave_sum(accb[i]);
+    if (lane == 0) red[wv][COB * CIB * K + i] = vb;
+  }
+  __syncthreads();
+  float* part = a.scratch + (int64_t)blockIdx.x * (nelem_w + a.cout);
+  for (int e = threadIdx.x; e < NACC; e += blockDim.x) {
+    const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    if (e < COB * CIB * K) {
+      const int i = e / (CIB * K), j = (e / K) % CIB, k = e % K;
+      const int co = co0 + i, ci = ci0 + j;
+      if (co < a.cout && ci < cin) part[((int64_t)co * cin + ci) * K + k] = v;
+    } else if (ci0 == 0) {
+      const int co = co0 + (e - COB * CIB * K);
+      if (co < a.cout) part[nelem_w + co] = v;
     }
   }
 }
 
+__global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ part, int nblk, int nelem_w, int cout,
+                                                      float* __restrict__ dw, float* __restrict__ dbias) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nelem = nelem_w + cout;
+  if (e >= nelem) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[(int64_t)b * nelem + e];
+  if (e < nelem_w) dw[e] += s;
+  else if (dbias) dbias[e - nelem_w] += s;
+}
+
 int launch_conv_wgrad(const ConvWgrad& a, hipStream_t s) {
-  DQ_REQUIRE(a.du && a.inA && a.dw && a.cout > 0 && a.cinA > 0, "conv_wgrad: missing operand");
+  DQ_REQUIRE(a.du && a.inA && a.dw && a.scratch && a.cout > 0 && a.cinA > 0, "conv_wgrad: missing operand");
   const int cin = a.cinA + a.cinB;
   const int64_t total = (int64_t)a.rows * a.n_out;
   if (total == 0) return 0;
+  DQ_REQUIRE(total < (1ll << 31), "conv_wgrad: rows*n must be below 2^31");
   constexpr int COB = 4, CIB = 4;
   const int n_cob = cdiv(a.cout, COB), n_cib = cdiv(cin, CIB);
-  // >= 16 items per thread where the problem allows it, but enough blocks to cover the chip
-  int gx = std::max(1, std::min(cdiv(total, 256 * 16), std::max(1, 2048 / (n_cob * n_cib))));
+  const int nelem_w = a.cout * cin * a.K;
+  // <= WGRAD_MAX_PARTS partial blocks per element; >= 8 items per thread where the problem allows it
+  const int gx = std::max(1, std::min({cdiv(total, 256 * 8), WGRAD_MAX_PARTS, std::max(1, 4096 / (n_cob * n_cib))}));
+  DQ_REQUIRE((int64_t)gx * (nelem_w + a.cout) <= a.scratch_floats, "conv_wgrad: scratch too small");
   dim3 grid(gx, n_cob * n_cib), block(256);
-#define DQ_WG(KK, MM)                                                                          \
-  if (a.K == KK && a.mode == MM) {                                                              \
-    hipLaunchKernelGGL((k_conv_wgrad<COB, CIB, KK, MM>), grid, block, 0, s, a, n_cib);          \
-    DQ_LAUNCH_CHECK();                                                                          \
-    return 0;                                                                                   \
+#define DQ_WG(KK, MM)                                                                                  \
+  if (a.K == KK && a.mode == MM) {                                                                      \
+    hipLaunchKernelGGL((k_conv_wgrad<COB, CIB, KK, MM>), grid, block, 0, s, a, n_cib, nelem_w);         \
+    DQ_LAUNCH_CHECK();                                                                                  \
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(nelem_w + a.cout, 256)), dim3(256), 0, s, a.scratch, gx, nelem_w, a.cout, a.dw, \
+                       a.dbias);                                                                        \
+    DQ_LAUNCH_CHECK();                                                                                  \
+    return 0;                                                                                           \
   }
   DQ_WG(1, CONV_S1)
   DQ_WG(3, CONV_S1)

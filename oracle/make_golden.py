@@ -335,6 +335,16 @@ def main():
     ep.update({"pred/w/" + k: v for k, v in pw.items()})
     np.savez_compressed(os.path.join(OUT, "harness.npz"), **npd(ep))
 
+    # ---------------------------------------------------------------- 6. default initialisation under a fixed seed
+    # (per-tensor checksums only: the drop-in UNet1d must consume the RNG in the reference's construction order)
+    torch.manual_seed(123)
+    inet = U.UNet1d(**cfg_kw)
+    init = {}
+    for k, v in inet.state_dict().items():
+        init[f"sum/{k}"] = np.float64(v.double().sum().item())
+        init[f"head/{k}"] = v.reshape(-1)[:4].clone()
+    np.savez_compressed(os.path.join(OUT, "init_seed123.npz"), **npd(init))
+
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
