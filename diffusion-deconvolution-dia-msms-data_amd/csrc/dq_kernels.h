@@ -72,7 +72,7 @@ struct ConvWgrad {
   float* dw = nullptr; float* dbias = nullptr;
   float* scratch = nullptr; int64_t scratch_floats = 0;  // >= WGRAD_MAX_PARTS * (cout*cin*K + cout) floats
 };
-constexpr int WGRAD_MAX_PARTS = 64;
+constexpr int WGRAD_MAX_PARTS = 512;
 int launch_conv_wgrad(const ConvWgrad& a, hipStream_t s);
 
 // standalone RMSNorm forward (PreNorm of the bottleneck attention)

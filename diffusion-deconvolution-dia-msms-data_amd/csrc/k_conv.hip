@@ -440,15 +440,20 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(ConvWgrad a, int n_cib, int 
   }
 }
 
+// one wave per element: lane l sums partials l, l+64, ... in order, then a fixed butterfly => deterministic
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ part, int nblk, int nelem_w, int cout,
                                                       float* __restrict__ dw, float* __restrict__ dbias) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   const int nelem = nelem_w + cout;
   if (e >= nelem) return;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[(int64_t)b * nelem + e];
-  if (e < nelem_w) dw[e] += s;
-  else if (dbias) dbias[e - nelem_w] += s;
+  for (int b = lane; b < nblk; b += 64) s += part[(int64_t)b * nelem + e];
+  s = wave_sum(s);
+  if (lane == 0) {
+    if (e < nelem_w) dw[e] += s;
+    else if (dbias) dbias[e - nelem_w] += s;
+  }
 }
 
 int launch_conv_wgrad(const ConvWgrad& a, hipStream_t s) {
@@ -460,15 +465,15 @@ int launch_conv_wgrad(const ConvWgrad& a, hipStream_t s) {
   constexpr int COB = 4, CIB = 4;
   const int n_cob = cdiv(a.cout, COB), n_cib = cdiv(cin, CIB);
   const int nelem_w = a.cout * cin * a.K;
-  // <= WGRAD_MAX_PARTS partial blocks per element; >= 8 items per thread where the problem allows it
-  const int gx = std::max(1, std::min({cdiv(total, 256 * 8), WGRAD_MAX_PARTS, std::max(1, 4096 / (n_cob * n_cib))}));
+  // <= WGRAD_MAX_PARTS partial blocks per element; ~4 items per thread, ~2048 blocks in flight where the problem allows it
+  const int gx = std::max(1, std::min({cdiv(total, 256 * 4), WGRAD_MAX_PARTS, std::max(1, 2048 / (n_cob * n_cib))}));
   DQ_REQUIRE((int64_t)gx * (nelem_w + a.cout) <= a.scratch_floats, "conv_wgrad: scratch too small");
   dim3 grid(gx, n_cob * n_cib), block(256);
 #define DQ_WG(KK, MM)                                                                                  \
   if (a.K == KK && a.mode == MM) {                                                                      \
     hipLaunchKernelGGL((k_conv_wgrad<COB, CIB, KK, MM>), grid, block, 0, s, a, n_cib, nelem_w);         \
     DQ_LAUNCH_CHECK();                                                                                  \
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(nelem_w + a.cout, 256)), dim3(256), 0, s, a.scratch, gx, nelem_w, a.cout, a.dw, \
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(nelem_w + a.cout, 4)), dim3(256), 0, s, a.scratch, gx, nelem_w, a.cout, a.dw, \
                        a.dbias);                                                                        \
     DQ_LAUNCH_CHECK();                                                                                  \
     return 0;                                                                                           \

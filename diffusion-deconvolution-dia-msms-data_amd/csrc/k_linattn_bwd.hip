@@ -390,7 +390,8 @@ static int linattn_bwd_n(const LinAttnBwdK& k, int n, hipStream_t s) {
     constexpr int RW = NN >= 32 ? 1 : 32 / NN;                                                     \
     const int units = cdiv(k.rows, RW);                                                            \
     LinAttnBwdK kk = k;                                                                            \
-    kk.units_per_wave = std::max(1, std::min(16, units / 2048));                                   \
+    /* 466 registers => one wave per SIMD, 1024 resident waves: size the grid to ONE resident round */ \
+    kk.units_per_wave = std::max(1, cdiv(units, 1024));                                            \
     const int waves = cdiv(units, kk.units_per_wave);                                              \
     hipLaunchKernelGGL((k_linattn_bwd<C, NN>), dim3(cdiv(waves, 4)), dim3(256), 0, s, kk);         \
     break;                                                                                         \
