@@ -19,10 +19,10 @@
 // Checked lane-for-lane on the CPU by oracle/wave_emu.py.
 #include "dq_common.h"
 #include "dq_kernels.h"
+#include "dq_mfma.h"
 
 namespace dq {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ constexpr int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
@@ -38,6 +38,8 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   static_assert(NB <= 2, "rows longer than 64 take the two-pass path (not built here)");
 
   __shared__ float wo_lds[4 * 2 * C * 16];  // [head][half][c][r] = Wo[c][head*32 + rowmap(r, half)]
+  __shared__ float tiles[(N > 1 && N < 32) ? 4 : 1][(N > 1 && N < 32) ? 32 * 33 : 1];  // wave-private transpose tiles (short rows only)
+  float* tile = tiles[(N > 1 && N < 32) ? (threadIdx.x >> 6) : 0];
   for (int i = threadIdx.x; i < 4 * 2 * C * 16; i += blockDim.x) {
     const int r = i & 15, c = (i >> 4) % C, hh = (i / (16 * C)) & 1, hd = i / (32 * C);
     wo_lds[i] = a.w_out[c * 128 + hd * 32 + rowmap(r, hh)];
@@ -173,24 +175,13 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) o = mfma32(ctx_row[r], q[r], o);
         } else {
-#pragma unroll
-          for (int rho = 0; rho < RW; ++rho) {
-            f32x16 ctx = {0};
-            if (N >= 8) {
-#pragma unroll
-              for (int r = rho * SEG; r < (rho + 1) * SEG; ++r) ctx = mfma32(kT[0][r], vT[0][r], ctx);
-            } else {
-              // N in {2, 4}: the two lane-halves of a register belong to different rows -> mask the A operand
-              const int g = N == 4 ? (rho >> 1) : (rho >> 2);
-              const int hsel = N == 4 ? (rho & 1) : ((rho >> 1) & 1);
-              const int r0 = N == 4 ? 4 * g : 4 * g + 2 * (rho & 1);
-#pragma unroll
-              for (int r = r0; r < r0 + N; ++r) ctx = mfma32(half == hsel ? kT[0][r] : 0.f, vT[0][r], ctx);
-            }
-            const bool sel = rl == rho;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o = mfma32(ctx[r], sel ? q[r] : 0.f, o);
-          }
+          // short rows (32/N rows share this block): "quadratic" form, no per-row loop and no wasted MFMAs:
+          //   S^T[n'][n] = sum_d K[d][n'] q[d][n], kept only for pairs of the same m/z row ; out[e][n] = sum_n' v[e][n'] S^T[n'][n]
+          const f32x16 Kd = transpose_tile(kT[0], tile, col, half);  // rows d, col n'
+          f32x16 st = {0};
+          st = xty(Kd, q, st);
+          st = mask_same_row<N>(st, col, half);
+          o = xty(vT[0], st, o);
         }
         out[blk] = o;
       }

@@ -18,14 +18,12 @@
 // Orientation changes (q -> qT etc.) go through a wave-private 32x33 LDS tile (16 ds_write + 16 ds_read, conflict-free).
 #include "dq_common.h"
 #include "dq_kernels.h"
+#include "dq_mfma.h"
 
 namespace dq {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ f32x16 mfma32b(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ constexpr int rmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
-__device__ __forceinline__ float swp32(float v) { return __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ f32x16 mfma32b(float a, float b, f32x16 c) { return mfma_f32(a, b, c); }
+__device__ __forceinline__ float swp32(float v) { return swap_half(v); }
 
 // 32x32 transpose of an accumulator tile through a wave-private LDS tile [32][33]
 __device__ __forceinline__ f32x16 tr32(f32x16 a, float* tile, int col, int half) {
@@ -293,34 +291,28 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
           v = mfma32b(wvv[j], Xh[0][j], v);
         }
         const f32x16 Kd = tr32(kT[0], tile, col, half);
-        f32x16 outT = {0}, dq = {0}, dkT = {0}, dv = {0};
-        float delta[RW];
+        // "quadratic" form (oracle/wave_emu.py::la_bwd_unit_quad): S[n][n'] = sum_d q[d][n] K[d][n'] restricted to pairs of
+        // the same m/z row replaces the per-row ctx tiles -- no loop over the 32/N rows, no 1/RW-utilised MFMAs.
+        f32x16 st = {0}, sm = {0}, dst = {0}, dsm = {0};
 #pragma unroll
-        for (int rho = 0; rho < RW; ++rho) {
-          f32x16 ctx = {0}, dctx = {0};
+        for (int r = 0; r < 16; ++r) {
+          st = mfma32b(Kd[r], q[r], st);     // S^T : rows n', col n
+          sm = mfma32b(q[r], Kd[r], sm);     // S   : rows n,  col n'
+          dst = mfma32b(v[r], dO[r], dst);   // dS^T: rows n', col n
+          dsm = mfma32b(dO[r], v[r], dsm);   // dS  : rows n,  col n'
+        }
+        st = mask_same_row<N>(st, col, half);
+        sm = mask_same_row<N>(sm, col, half);
+        dst = mask_same_row<N>(dst, col, half);
+        dsm = mask_same_row<N>(dsm, col, half);
+        f32x16 outT = {0}, dvT = {0}, dv = {0}, dq = {0}, dkT = {0};
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const bool mine0 = rmap(r, 0) / N == rho, mine1 = rmap(r, 1) / N == rho;
-            if (mine0 || mine1) {
-              const bool msk = half ? mine1 : mine0;
-              ctx = mfma32b(msk ? kT[0][r] : 0.f, vT[0][r], ctx);
-              dctx = mfma32b(msk ? qT[r] : 0.f, dOT[r], dctx);
-            }
-          }
-          const f32x16 ctxT = tr32(ctx, tile, col, half);
-          const f32x16 dctxT = tr32(dctx, tile, col, half);
-          float dl = 0.f;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) dl = fmaf(dctxT[r], ctxT[r], dl);
-          delta[rho] = dl + swp32(dl);
-          const bool sel = rl == rho;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            outT = mfma32b(sel ? q[r] : 0.f, ctx[r], outT);
-            dq = mfma32b(ctxT[r], sel ? dO[r] : 0.f, dq);
-            dkT = mfma32b(sel ? v[r] : 0.f, dctxT[r], dkT);
-            dv = mfma32b(dctx[r], sel ? Kd[r] : 0.f, dv);
-          }
+        for (int r = 0; r < 16; ++r) {
+          outT = mfma32b(st[r], vT[0][r], outT);  // rows n,  col e
+          dvT = mfma32b(sm[r], dOT[r], dvT);      // rows n', col e
+          dv = mfma32b(dOT[r], sm[r], dv);        // rows e,  col n'
+          dq = mfma32b(kT[0][r], dst[r], dq);     // rows d,  col n
+          dkT = mfma32b(dsm[r], qT[r], dkT);      // rows n', col d
         }
         const f32x16 dypT = tr32(as_acc(DY[0]), tile, col, half);
 #pragma unroll
@@ -329,13 +321,16 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
         add_dxh(0, 0, dq_raw);
         const f32x16 xhT = tr32(as_acc(Xh[0]), tile, col, half);
         const f32x16 dq_rawT = tr32(dq_raw, tile, col, half);
-        f32x16 dk_rawT;
+        f32x16 dk_rawT;  // softmax over the positions of each row: a lane's own register segment (+ lane^32)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float d0 = delta[rmap(r, 0) / N < RW ? rmap(r, 0) / N : 0], d1 = delta[rmap(r, 1) / N < RW ? rmap(r, 1) / N : 0];
-          dk_rawT[r] = kT[0][r] * (dkT[r] - (half ? d1 : d0));
+        for (int s0 = 0; s0 < 16; s0 += SEG) {
+          float dl = 0.f;
+#pragma unroll
+          for (int r = s0; r < s0 + SEG; ++r) dl = fmaf(dkT[r], kT[0][r], dl);
+          if (PARTNER) dl += swp32(dl);
+#pragma unroll
+          for (int r = s0; r < s0 + SEG; ++r) dk_rawT[r] = kT[0][r] * (dkT[r] - dl);
         }
-        const f32x16 dvT = tr32(dv, tile, col, half);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           gq = mfma32b(xhT[r], dq_rawT[r], gq);

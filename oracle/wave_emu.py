@@ -425,3 +425,158 @@ def la_bwd(x, dy, ypre, Wqkv, Wo, bo, g_pre, g_out):
     dx = inv * (gd - uh * (gd * uh).sum(1, keepdims=True)) + dy
     out.update({"x": dx.astype(F), "g_pre": (dxh * uh * sqC).sum((0, 2)), "w_qkv": dWqkv, "w_out": dWo})
     return out
+
+
+# ======================================================================================================================
+# "quadratic" form for short rows (n <= 32): S[n][n'] = sum_d q[d][n] k[d][n'] masked to pairs of the same m/z row,
+# out = v S^T.  One 32-position block holds 32/n rows; no per-row loop, no wasted MFMAs.  Mirrors the N < 32 paths of
+# k_linattn_fwd / k_linattn_bwd.
+# ======================================================================================================================
+def _common(x, Wqkv, g_pre, hd, C, n):
+    NJ = 4 if C <= 8 else 8
+    sqC = F(np.sqrt(F(C)))
+    rl, pp = COL // n, COL % n
+
+    def xload(t):
+        out = np.zeros((NJ, 64), F)
+        for j in range(NJ):
+            c = chan_of(j, HALF)
+            out[j] = np.where(c < C, t[rl, np.minimum(c, C - 1), pp], 0)
+        return out
+
+    X = xload(x)
+    ssq = (X ** 2).sum(0)
+    ssq = ssq + shfl_xor32(ssq)
+    inv = sqC / np.maximum(np.sqrt(ssq), F(1e-12))
+    g = np.stack([np.where(chan_of(j, HALF) < C, g_pre[np.minimum(chan_of(j, HALF), C - 1)], 0) for j in range(NJ)])
+    Xh = (X * inv * g).astype(F)
+
+    def wfrag(o_base, j):
+        c = chan_of(j, HALF)
+        return np.where(c < C, Wqkv[o_base + COL, np.minimum(c, C - 1)], 0).astype(F)
+
+    if n >= 8:
+        SEG, PARTNER = n // 2, True
+    else:
+        SEG, PARTNER = max(n, 1), False
+    kT, vT, q, v = acc_zero(), acc_zero(), acc_zero(), acc_zero()
+    for j in range(NJ):
+        kT = mfma(Xh[j], wfrag(128 + hd * 32, j), kT)
+        vT = mfma(Xh[j], wfrag(256 + hd * 32, j), vT)
+        q = mfma(wfrag(hd * 32, j), Xh[j], q)
+        v = mfma(wfrag(256 + hd * 32, j), Xh[j], v)
+    for s0 in range(0, 16, SEG):
+        regs = range(s0, s0 + SEG)
+        m = np.full(64, -np.inf, F)
+        for r in regs:
+            m = np.maximum(m, kT[r])
+        if PARTNER:
+            m = np.maximum(m, shfl_xor32(m))
+        ssum = np.zeros(64, F)
+        for r in regs:
+            kT[r] = np.exp(kT[r] - m)
+            ssum = ssum + kT[r]
+        if PARTNER:
+            ssum = ssum + shfl_xor32(ssum)
+        for r in regs:
+            kT[r] = kT[r] / ssum
+    m = q.max(0)
+    m = np.maximum(m, shfl_xor32(m))
+    q = np.exp(q - m)
+    s = q.sum(0)
+    s = s + shfl_xor32(s)
+    q = q * (F(32 ** -0.5) / s)
+    return X, Xh, xload, kT, vT, q, v, NJ, SEG, PARTNER
+
+
+def _mask_rows_vs_col(acc, n):
+    """keep element (row i in regs, col j on lane) iff i // n == j // n"""
+    out = acc.copy()
+    for r in range(16):
+        out[r] = np.where(rowmap(r, HALF) // n == COL // n, acc[r], 0)
+    return out
+
+
+def la_fwd_quad_head(x, Wqkv, g_pre, hd):
+    """out[e][n] (accumulator: rows e, col n) of one head for a 32-position block of 32/n rows"""
+    RW, C, n = x.shape
+    X, Xh, xload, kT, vT, q, v, NJ, SEG, PARTNER = _common(x, Wqkv, g_pre, hd, C, n)
+    Kd = T(kT)
+    ST = acc_zero()
+    for r in range(16):
+        ST = mfma(Kd[r], q[r], ST)  # rows n', col n
+    STm = _mask_rows_vs_col(ST, n)
+    out = acc_zero()
+    for r in range(16):
+        out = mfma(vT[r], STm[r], out)  # rows e, col n
+    return out
+
+
+def la_bwd_unit_quad(x, dyp, Wqkv, Wo, g_pre, hd, dW):
+    RW, C, n = x.shape
+    X, Xh, xload, kT, vT, q, v, NJ, SEG, PARTNER = _common(x, Wqkv, g_pre, hd, C, n)
+    scale = F(32 ** -0.5)
+    DYP = xload(dyp)
+
+    def wofrag(j):
+        c = chan_of(j, HALF)
+        return np.where(c < C, Wo[np.minimum(c, C - 1), hd * 32 + COL], 0).astype(F)
+
+    def as_acc(xr):
+        a = acc_zero()
+        a[:NJ] = xr
+        return a
+
+    do, doT = acc_zero(), acc_zero()
+    for j in range(NJ):
+        do = mfma(wofrag(j), DYP[j], do)
+        doT = mfma(DYP[j], wofrag(j), doT)
+    Kd, qT = T(kT), T(q)
+    ST, S, dST, dS = acc_zero(), acc_zero(), acc_zero(), acc_zero()
+    for r in range(16):
+        ST = mfma(Kd[r], q[r], ST)   # rows n', col n
+        S = mfma(q[r], Kd[r], S)     # rows n, col n'
+        dST = mfma(v[r], do[r], dST)  # rows n', col n
+        dS = mfma(do[r], v[r], dS)    # rows n, col n'
+    STm, Sm, dSTm, dSm = (_mask_rows_vs_col(a, n) for a in (ST, S, dST, dS))
+    outT, dvT, dv, dq, dkT = (acc_zero() for _ in range(5))
+    for r in range(16):
+        outT = mfma(STm[r], vT[r], outT)  # rows n, col e
+        dvT = mfma(Sm[r], doT[r], dvT)    # rows n', col e
+        dv = mfma(doT[r], Sm[r], dv)      # rows e, col n'
+        dq = mfma(kT[r], dSTm[r], dq)     # rows d, col n
+        dkT = mfma(dSm[r], qT[r], dkT)    # rows n', col d
+    t = (q * dq).sum(0)
+    t = (t + shfl_xor32(t)) / scale
+    dq_raw = q * (dq - t)
+    dk_rawT = acc_zero()
+    for s0 in range(0, 16, SEG):
+        regs = range(s0, s0 + SEG)
+        dl = np.zeros(64, F)
+        for r in regs:
+            dl = dl + dkT[r] * kT[r]
+        if PARTNER:
+            dl = dl + shfl_xor32(dl)
+        for r in regs:
+            dk_rawT[r] = kT[r] * (dkT[r] - dl)
+    dq_rawT, dk_raw = T(dq_raw), T(dk_rawT)
+    XhT, DYPT = T(as_acc(Xh)), T(as_acc(DYP))
+    aq, ak, av, ao = acc_zero(), acc_zero(), acc_zero(), acc_zero()
+    for r in range(16):
+        aq = mfma(XhT[r], dq_rawT[r], aq)
+        ak = mfma(XhT[r], dk_rawT[r], ak)
+        av = mfma(XhT[r], dvT[r], av)
+        ao = mfma(DYPT[r], outT[r], ao)
+    for nm, a in (("q", aq), ("k", ak), ("v", av), ("o", ao)):
+        dW[nm] += to_mat(a)[:C, :]
+    rl, pp = COL // n, COL % n
+    part = np.zeros((C, 64), F)
+    for c in range(C):
+        for r in range(16):
+            o = rowmap(r, HALF)
+            part[c] += Wqkv[hd * 32 + o, c] * dq_raw[r] + Wqkv[128 + hd * 32 + o, c] * dk_raw[r] + Wqkv[256 + hd * 32 + o, c] * dv[r]
+    full = part + np.stack([shfl_xor32(part[c]) for c in range(C)])
+    dxh = np.zeros_like(x)
+    for l in range(32):
+        dxh[rl[l], :, pp[l]] = full[:, l]
+    return dxh
