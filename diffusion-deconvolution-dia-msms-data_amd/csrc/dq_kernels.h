@@ -104,8 +104,10 @@ struct LinAttnBwd {
   const float* dy = nullptr; float* dx = nullptr;  // dx +=
   const float* ypre = nullptr;                     // saved by the forward
   float* dyp = nullptr; float* dxh = nullptr;      // scratch (rows, C, n) each
+  float* part = nullptr; int64_t part_floats = 0;  // per-wave dW partial slots: >= LA_MAX_WAVES * 512 * C floats
   float* dw_qkv = nullptr; float* dw_out = nullptr; float* db_out = nullptr; float* dg_pre = nullptr; float* dg_out = nullptr;
 };
+constexpr int LA_MAX_WAVES = 1024;  // the backward grid is one resident round: <= 1024 waves, one partial slot each
 int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s);
 
 // ---- k_attn.hip : softmax attention over RT of the bottleneck (q,k,v,o in (B, 128, RT) conv layout)

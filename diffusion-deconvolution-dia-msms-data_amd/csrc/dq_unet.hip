@@ -68,6 +68,8 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
   a.coef = take(4 * 1024);  // DDIM coefficient table (<= 1024 steps)
   a.wg_floats = (int64_t)WGRAD_MAX_PARTS * (std::max({16 * 32 * 3, p.mid_c * p.mid_c * 3, 2 * HID * p.mid_c}) + 2 * HID);
   a.wg = take(a.wg_floats);  // partial sums of the weight-gradient kernels
+  a.la_part_floats = (int64_t)LA_MAX_WAVES * 512 * 16;
+  a.la_part = take(a.la_part_floats);  // per-wave dW partial slots of the LinearAttention backward
   a.floats = off;
 }
 
@@ -183,6 +185,7 @@ int la_fwd(const Ctx& c, const LAP& l, const float* x, float* y, float* ypre, in
 int la_bwd(const Ctx& c, const LAP& l, const LevelBuf& b, const float* x, const float* dy, float* dx, int rows, int n) {
   LinAttnBwd a;
   a.ypre = c.w(b.la_pre); a.dyp = c.g(b.la_pre); a.dxh = c.g(b.la_tmp);
+  a.part = c.w(c.ar.la_part); a.part_floats = c.ar.la_part_floats;
   a.f.x = x; a.f.w_qkv = c.prm(l.qkv_w); a.f.w_out = c.prm(l.out_w); a.f.b_out = c.prm(l.out_b);
   a.f.g_pre = c.prm(l.g_pre); a.f.g_out = c.prm(l.g_out); a.f.C = l.C; a.f.rows = rows; a.f.n = n;
   a.dy = dy; a.dx = dx;
@@ -605,6 +608,7 @@ int dq_linattn_bwd(const float* x, const float* ypre, const float* dy, float* dx
   a.f.x = x; a.f.w_qkv = w_qkv; a.f.w_out = w_out; a.f.b_out = b_out; a.f.g_pre = g_pre; a.f.g_out = g_out; a.f.C = C; a.f.rows = rows;
   a.f.n = n;
   a.ypre = ypre; a.dyp = scratch; a.dxh = scratch + (int64_t)rows * C * n;
+  a.part = scratch + 2 * (int64_t)rows * C * n; a.part_floats = (int64_t)LA_MAX_WAVES * 512 * C;
   a.dy = dy; a.dx = dx; a.dw_qkv = dw_qkv; a.dw_out = dw_out; a.db_out = db_out; a.dg_pre = dg_pre; a.dg_out = dg_out;
   return launch_linattn_bwd(a, (hipStream_t)stream);
 }

@@ -43,6 +43,7 @@ struct LinAttnBwdK {
   const float* x; const float* dyp; float* dxh;  // (rows, C, n)
   const float* w_qkv; const float* w_out; const float* g_pre;
   float* dw_qkv; float* dw_out;
+  float* part;  // per-wave partial dW slots: [wave][512*C]
   int rows; int units_per_wave;
 };
 
@@ -364,17 +365,36 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
       }
     }
 
-    // ---- flush this head's weight gradients: register r holds channel rmap(r, half), lane column = d / e
+    // ---- flush this head's weight gradients to this wave's partial slot (plain stores; float atomics at this access
+    // shape -- one dword per lane, lanes C floats apart -- run ~17x below the store rate and made the flush the
+    // kernel's critical path).  Register r holds channel rmap(r, half), lane column = d / e.
+    float* slot = a.part + (int64_t)wave_id * (512 * C);
 #pragma unroll
     for (int r = 0; r < NJ; ++r) {
       const int c = rmap(r, half);
       if (c < C) {
-        atomicAdd(a.dw_qkv + (int64_t)(hd * 32 + col) * C + c, gq[r]);
-        atomicAdd(a.dw_qkv + (int64_t)(128 + hd * 32 + col) * C + c, gk[r]);
-        atomicAdd(a.dw_qkv + (int64_t)(256 + hd * 32 + col) * C + c, gv[r]);
-        atomicAdd(a.dw_out + (int64_t)c * 128 + hd * 32 + col, go[r]);
+        slot[(hd * 32 + col) * C + c] = gq[r];
+        slot[(128 + hd * 32 + col) * C + c] = gk[r];
+        slot[(256 + hd * 32 + col) * C + c] = gv[r];
+        slot[384 * C + c * 128 + hd * 32 + col] = go[r];
       }
     }
+  }
+}
+
+// dW[e] += sum over the wave slots, one wave per element, fixed order (deterministic)
+__global__ void __launch_bounds__(256) k_linattn_dw_reduce(const float* __restrict__ part, int nslots, int C,
+                                                           float* __restrict__ dw_qkv, float* __restrict__ dw_out) {
+  const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int nelem = 512 * C;
+  if (e >= nelem) return;
+  float s = 0.f;
+  for (int b = lane; b < nslots; b += 64) s += part[(int64_t)b * nelem + e];
+  s = wave_sum(s);
+  if (lane == 0) {
+    if (e < 384 * C) dw_qkv[e] += s;
+    else dw_out[e - 384 * C] += s;
   }
 }
 
@@ -389,6 +409,7 @@ static int linattn_bwd_n(const LinAttnBwdK& k, int n, hipStream_t s) {
     kk.units_per_wave = std::max(1, cdiv(units, 1024));                                            \
     const int waves = cdiv(units, kk.units_per_wave);                                              \
     hipLaunchKernelGGL((k_linattn_bwd<C, NN>), dim3(cdiv(waves, 4)), dim3(256), 0, s, kk);         \
+    hipLaunchKernelGGL(k_linattn_dw_reduce, dim3(cdiv(512 * C, 4)), dim3(256), 0, s, kk.part, waves, C, kk.dw_qkv, kk.dw_out); \
     break;                                                                                         \
   }
   switch (n) {
@@ -417,6 +438,8 @@ int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s) {
   LinAttnBwdK k;
   k.x = a.f.x; k.dyp = a.dyp; k.dxh = a.dxh; k.w_qkv = a.f.w_qkv; k.w_out = a.f.w_out; k.g_pre = a.f.g_pre;
   k.dw_qkv = a.dw_qkv; k.dw_out = a.dw_out; k.rows = rows; k.units_per_wave = 1;
+  DQ_REQUIRE(a.part && a.part_floats >= (int64_t)LA_MAX_WAVES * 512 * C, "linattn_bwd: partial-sum scratch missing or too small");
+  k.part = a.part;
   int rc;
   switch (C) {
     case 4: rc = linattn_bwd_n<4>(k, n, s); break;
