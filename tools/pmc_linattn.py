@@ -1,0 +1,25 @@
+"""PMC driver: a few launches of the level-0 LinearAttention forward/backward (C=4, n=64, 12800 rows) and of a plain
+device copy of known size (calibration of FETCH_SIZE / WRITE_SIZE for this access pattern)."""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "diffusion-deconvolution-dia-msms-data_amd"))
+import torch
+from dquartic import _native as N
+C, n, rows = 4, 64, 12800
+g = torch.Generator().manual_seed(0)
+x = torch.randn(rows, C, n, generator=g).cuda(); dy = torch.randn(rows, C, n, generator=g).cuda()
+w = (torch.randn(384, C, generator=g) * .4).cuda(); wo = (torch.randn(C, 128, generator=g) * .2).cuda()
+bo, g1, g2 = torch.zeros(C).cuda(), torch.ones(C).cuda(), torch.ones(C).cuda()
+y, ypre, dx = torch.empty_like(x), torch.empty_like(x), torch.zeros_like(x)
+dw, dwo, dbo, dg1, dg2 = (torch.zeros_like(t) for t in (w, wo, bo, g1, g2))
+scratch = torch.empty(2 * x.numel() + 1024 * 512 * C, device="cuda")
+L = N.lib()
+for _ in range(5):
+    N.check(L.dq_linattn_fwd(N.ptr(x), N.ptr(y), N.ptr(ypre), N.ptr(w), N.ptr(wo), N.ptr(bo), N.ptr(g1), N.ptr(g2), C, rows, n, N.stream_ptr()), "f")
+    N.check(L.dq_linattn_bwd(N.ptr(x), N.ptr(ypre), N.ptr(dy), N.ptr(dx), N.ptr(w), N.ptr(wo), N.ptr(bo), N.ptr(g1), N.ptr(g2), N.ptr(dw), N.ptr(dwo), N.ptr(dbo), N.ptr(dg1), N.ptr(dg2), N.ptr(scratch), C, rows, n, N.stream_ptr()), "b")
+# calibration: q_sample streams 3 tensors of rows*C*n floats (2 reads + 1 write) with 16 B per lane
+ab = torch.linspace(0.9, 0.1, 1000).cuda(); t = torch.zeros(50, dtype=torch.long).cuda()
+for _ in range(5):
+    N.check(L.dq_q_sample(N.ptr(ab), N.ptr(x), N.ptr(t), N.ptr(dy), N.ptr(y), 50, x.numel() // 50, 0, N.stream_ptr()), "q")
+torch.cuda.synchronize()
+print("bytes per tensor", x.numel() * 4)
