@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
         for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
           for (int r = s0; r < s0 + SEG; ++r) {
-            const float e = expf(kT[blk][r] - m);
+            const float e = __expf(kT[blk][r] - m);
             kT[blk][r] = e;
             ssum += e;
           }
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
         float ssum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          q[r] = expf(q[r] - m);
+          q[r] = __expf(q[r] - m);
           ssum += q[r];
         }
         ssum += swap32(ssum);

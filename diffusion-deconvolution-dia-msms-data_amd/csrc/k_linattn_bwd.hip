@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
         for (int b = 0; b < NB; ++b)
 #pragma unroll
           for (int r = s0; r < s0 + SEG; ++r) {
-            const float e = expf(kT[b][r] - m);
+            const float e = __expf(kT[b][r] - m);
             kT[b][r] = e;
             ssum += e;
           }
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
         float ssum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          q[r] = expf(q[r] - m);
+          q[r] = __expf(q[r] - m);
           ssum += q[r];
         }
         ssum += swp32(ssum);
