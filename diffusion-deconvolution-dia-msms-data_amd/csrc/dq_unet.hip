@@ -84,6 +84,7 @@ struct Ctx {
   float* dP;        // flat grads
   int B, RT;
   hipStream_t s;
+  bool save = true;  // keep what the backward needs (pre-norm conv outputs, LinearAttention pre-norm output)
   float* w(int64_t off) const { return W + off; }
   float* g(int64_t off) const { return G + off; }
   const float* prm(int64_t off) const { return P + off; }
@@ -103,7 +104,7 @@ int res_fwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, int 
   f.inA = inA; f.inB = inB; f.cinA = cinA; f.cinB = cinB;
   f.w = c.prm(r.c1.w); f.bias = c.prm(r.c1.b); f.cout = r.cout; f.K = 3; f.mode = CONV_S1;
   f.rows = rows; f.n_in = n; f.n_out = n;
-  f.u_out = c.w(b.u1); f.y_out = c.w(b.a1);
+  f.u_out = c.save ? c.w(b.u1) : nullptr; f.y_out = c.w(b.a1);
   f.g = c.prm(r.g1);
   f.ss = c.w(c.ar.ss) + r.ss_off; f.ss_stride = c.p.ss_total; f.rows_per_sample = rows_per_sample;
   f.act = ACT_SILU;
@@ -112,7 +113,7 @@ int res_fwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, int 
   f2.inA = c.w(b.a1); f2.cinA = r.cout;
   f2.w = c.prm(r.c2.w); f2.bias = c.prm(r.c2.b); f2.cout = r.cout; f2.K = 3; f2.mode = CONV_S1;
   f2.rows = rows; f2.n_in = n; f2.n_out = n;
-  f2.u_out = c.w(b.u2); f2.y_out = c.w(b.out);
+  f2.u_out = c.save ? c.w(b.u2) : nullptr; f2.y_out = c.w(b.out);
   f2.g = c.prm(r.g2); f2.act = ACT_SILU;
   f2.resA = inA; f2.resB = inB; f2.rcinA = cinA; f2.rcinB = cinB;
   if (r.res.cout) { f2.res_w = c.prm(r.res.w); f2.res_b = c.prm(r.res.b); }
@@ -233,7 +234,7 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
   {
     ConvFwd f;
     f.inA = c.w(a.ms1n); f.cinA = 1; f.w = c.prm(p.ms1_c0.w); f.bias = c.prm(p.ms1_c0.b); f.cout = p.cond_dim; f.K = 7;
-    f.rows = B; f.n_in = RT; f.n_out = RT; f.u_out = c.w(a.ms1_u); f.y_out = c.w(a.ms1_a); f.act = ACT_GELU;
+    f.rows = B; f.n_in = RT; f.n_out = RT; f.u_out = c.save ? c.w(a.ms1_u) : nullptr; f.y_out = c.w(a.ms1_a); f.act = ACT_GELU;
     DQ_TRY(launch_conv_fwd(f, c.s));
     DQ_TRY(conv_plain_fwd(c, p.ms1_c1, CONV_S1, c.w(a.ms1_a), c.w(a.ms1f), B, RT, RT));
   }
@@ -245,7 +246,7 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     const int C = l.r0.cin;
     DQ_TRY(res_fwd(c, l.r0, b.r0, cur, C, nullptr, 0, R, l.n, RT));
     DQ_TRY(res_fwd(c, l.r1, b.r1, c.w(b.r0.out), C, nullptr, 0, R, l.n, RT));
-    DQ_TRY(la_fwd(c, l.la, c.w(b.r1.out), c.w(b.la), c.w(b.la_pre), R, l.n));
+    DQ_TRY(la_fwd(c, l.la, c.w(b.r1.out), c.w(b.la), c.save ? c.w(b.la_pre) : nullptr, R, l.n));
     DQ_TRY(conv_plain_fwd(c, l.resample, l.last ? CONV_S1 : CONV_DOWN, c.w(b.la), c.w(b.rs), R, l.n, l.n_next));
     cur = c.w(b.rs);
   }
@@ -280,7 +281,7 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     const int cx = l.r0.cout, cs = l.r0.cin - l.r0.cout;
     DQ_TRY(res_fwd(c, l.r0, b.r0, cur, cx, c.w(a.downs[lv].la), cs, R, l.n, RT));
     DQ_TRY(res_fwd(c, l.r1, b.r1, c.w(b.r0.out), cx, c.w(a.downs[lv].r0.out), cs, R, l.n, RT));
-    DQ_TRY(la_fwd(c, l.la, c.w(b.r1.out), c.w(b.la), c.w(b.la_pre), R, l.n));
+    DQ_TRY(la_fwd(c, l.la, c.w(b.r1.out), c.w(b.la), c.save ? c.w(b.la_pre) : nullptr, R, l.n));
     DQ_TRY(conv_plain_fwd(c, l.resample, l.last ? CONV_S1 : CONV_UP, c.w(b.la), c.w(b.rs), R, l.n, l.n_next));
     cur = c.w(b.rs);
   }
@@ -451,13 +452,14 @@ int dq_ddim_step(const float* x_t, const float* eps, float* x_prev, const float*
 }
 
 int dq_unet_fwd(dq_plan* plan, const float* params, const float* rope_freqs, const float* x, const int64_t* t, int t_scalar,
-                const float* init_cond, const float* attn_cond, float cond_mul, float cond_add, float* out, void* workspace,
-                int64_t workspace_bytes, int B, int RT, void* stream) {
+                const float* init_cond, const float* attn_cond, float cond_mul, float cond_add, float* out, int save_for_bwd,
+                void* workspace, int64_t workspace_bytes, int B, int RT, void* stream) {
   DQ_REQUIRE(plan && params && x && init_cond && attn_cond && out && workspace, "dq_unet_fwd: null argument");
   DQ_REQUIRE(B > 0 && RT > 0, "dq_unet_fwd: B and RT must be positive");
   DQ_TRY(ensure_arena(plan, B, RT));
   DQ_REQUIRE(workspace_bytes >= (int64_t)sizeof(float) * plan->arena.floats, "dq_unet_fwd: workspace too small");
   Ctx c{plan->plan, plan->arena, params, (float*)workspace, nullptr, nullptr, B, RT, (hipStream_t)stream};
+  c.save = save_for_bwd != 0;
   return unet_forward(c, rope_freqs, x, t, t_scalar, init_cond, attn_cond, cond_mul, cond_add, plan->dev, out);
 }
 
@@ -521,6 +523,7 @@ int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, 
   hipStream_t s = (hipStream_t)stream;
   float* W = (float*)workspace;
   Ctx c{plan->plan, a, params, W, nullptr, nullptr, B, RT, s};
+  c.save = false;
   const int T = plan->plan.T;
   const int64_t n = (int64_t)B * RT * plan->plan.mz;
   const float cm = auto_normalize ? 2.f : 1.f, ca = auto_normalize ? -1.f : 0.f;

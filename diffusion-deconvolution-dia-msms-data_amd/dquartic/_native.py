@@ -22,7 +22,7 @@ PROTOTYPES = {
     "dq_q_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "dq_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "dq_unet_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_float,
-                            c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+                            c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "dq_unet_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_int64, c_int, c_int, c_void_p]),
     "dq_mse_loss_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

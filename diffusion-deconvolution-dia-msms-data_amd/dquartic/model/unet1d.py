@@ -267,7 +267,8 @@ class UNet1d(nn.Module):
         out = torch.empty_like(xs)
         fr = self.rope_freqs()
         N.check(N.lib().dq_unet_fwd(self._plan, N.ptr(self._flat), N.ptr(fr), N.ptr(xs), N.ptr(ts), 0, N.ptr(ic), N.ptr(ac),
-                                    cond_mul, cond_add, N.ptr(out), N.ptr(ws), ws.numel(), B, RT, N.stream_ptr()), "dq_unet_fwd")
+                                    cond_mul, cond_add, N.ptr(out), 1 if training else 0, N.ptr(ws), ws.numel(), B, RT,
+                                    N.stream_ptr()), "dq_unet_fwd")
         return out
 
 

@@ -62,10 +62,10 @@ int dq_ddim_step(const float* x_t, const float* eps, float* x_prev, const float*
  * params: flat parameter buffer; rope_freqs: the 8 non-trainable RoPE frequencies (device).
  * x, init_cond (B,RT,MZ); attn_cond (B,RT); t (B) int64 or NULL => every sample uses t_scalar.
  * init_cond/attn_cond are mapped v*cond_mul+cond_add on the fly (2,-1 reproduces model.py:310-311/350-351; 1,0 = raw).
- * out (B,RT,MZ) receives the prediction.  The workspace keeps the activations dq_unet_bwd needs. */
+ * out (B,RT,MZ) receives the prediction.  save_for_bwd != 0 also keeps the pre-norm tensors dq_unet_bwd reads. */
 int dq_unet_fwd(dq_plan* plan, const float* params, const float* rope_freqs, const float* x, const int64_t* t, int t_scalar,
-                const float* init_cond, const float* attn_cond, float cond_mul, float cond_add, float* out, void* workspace,
-                int64_t workspace_bytes, int B, int RT, void* stream);
+                const float* init_cond, const float* attn_cond, float cond_mul, float cond_add, float* out, int save_for_bwd,
+                void* workspace, int64_t workspace_bytes, int B, int RT, void* stream);
 /* Backward of the call above (same plan/workspace/arguments, workspace sized with training=1): accumulates
  * d loss / d params into grads (+=; zero it first) given grad_out = d loss / d out.  grad_x (optional, may be NULL)
  * receives d loss / d x.  Replaces loss.backward() through the network (model_interface.py:1120). */
