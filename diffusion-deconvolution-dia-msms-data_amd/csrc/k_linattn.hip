@@ -262,6 +262,7 @@ static int linattn_fwd_n(const LinAttn& a, hipStream_t s) {
 int launch_linattn_fwd(const LinAttn& a, hipStream_t s) {
   DQ_REQUIRE(a.x && a.y && a.w_qkv && a.w_out && a.b_out && a.g_pre && a.g_out, "linattn_fwd: missing operand");
   if (a.rows == 0) return 0;
+  if (a.n > 64) return launch_linattn_fwd_long(a, s);
   switch (a.C) {
     case 4: return linattn_fwd_n<4>(a, s);
     case 8: return linattn_fwd_n<8>(a, s);

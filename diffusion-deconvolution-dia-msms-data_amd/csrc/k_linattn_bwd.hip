@@ -441,6 +441,13 @@ int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s) {
   DQ_REQUIRE(a.part && a.part_floats >= (int64_t)LA_MAX_WAVES * 512 * C, "linattn_bwd: partial-sum scratch missing or too small");
   k.part = a.part;
   int rc;
+  if (n > 64) {
+    int waves = 0;
+    rc = launch_linattn_bwd_long(a.f.x, a.dyp, a.dxh, a.f.w_qkv, a.f.w_out, a.f.g_pre, a.part, C, rows, n, &waves, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_linattn_dw_reduce, dim3(cdiv(512 * C, 4)), dim3(256), 0, s, a.part, waves, C, a.dw_qkv, a.dw_out);
+    DQ_LAUNCH_CHECK();
+  } else
   switch (C) {
     case 4: rc = linattn_bwd_n<4>(k, n, s); break;
     case 8: rc = linattn_bwd_n<8>(k, n, s); break;

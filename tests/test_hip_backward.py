@@ -27,7 +27,7 @@ def N():
 
 
 @pytest.mark.parametrize("C,n,rows", [(4, 64, 37), (4, 32, 9), (8, 32, 70), (8, 16, 13), (8, 8, 22), (12, 8, 5), (12, 4, 50), (12, 2, 33),
-                                      (16, 2, 16), (16, 1, 77), (4, 64, 1300)])
+                                      (16, 2, 16), (16, 1, 77), (4, 64, 1300), (4, 128, 21), (4, 256, 9), (8, 128, 6)])
 def test_linattn_bwd_vs_autograd(N, C, n, rows):
     from oracle import dq_oracle as O
 
@@ -181,3 +181,34 @@ def test_adamw_clip_matches_torch(N):
         torch.cuda.synchronize()
         assert abs(float(gn) - float(tn)) < 1e-4 * float(tn)
         assert float((p.cpu() - ref.detach()).abs().max()) < 2e-6
+
+
+def test_large_window_config_forward_and_grads_vs_oracle():
+    """BASELINE configs[4] family: MZ = 256 (downsample_dim 256 -> LinearAttention rows of 256/128 positions, bottleneck width
+    64), reduced RT so that the oracle finishes in seconds.  Loss and all parameter gradients against oracle autograd."""
+    from dquartic.model.model import DDIMDiffusionModel
+    from dquartic.model.unet1d import UNet1d
+    from oracle import dq_oracle as O
+
+    torch.manual_seed(3)
+    net = UNet1d(dim=4, channels=1, dim_mults=(1, 2, 2, 3, 3, 4, 4), conditional=True, init_cond_channels=1,
+                 attn_cond_channels=1, downsample_dim=256, simple=True)
+    params = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    dm = DDIMDiffusionModel(model_class=net.cuda(), device="cuda")
+    B, RT, MZ = 2, 24, 256
+    g = torch.Generator().manual_seed(1)
+    x0, c2, c1 = torch.rand(B, RT, MZ, generator=g), torch.rand(B, RT, MZ, generator=g), torch.rand(B, RT, generator=g)
+    t, nz = torch.tensor([11, 871]), torch.randn(B, RT, MZ, generator=g)
+    loss = dm.train_step_fused(x0.cuda(), c2.cuda(), c1.cuda(), t=t.cuda(), noise=nz.cuda())
+    grads = net.flat_grads().clone()
+    po = {k: v.clone().requires_grad_(not k.endswith("freqs")) for k, v in params.items()}
+    lo, eps_o = O.Diffusion(po, O.UNetConfig(downsample_dim=256)).train_loss(x0, c2, c1, t, nz)
+    lo.backward()
+    assert abs(float(loss) - float(lo)) < 2e-5 * abs(float(lo))
+    ref = torch.cat([po[n].grad.reshape(-1) for n, _ in net.trainable_named()])
+    assert rel_err(grads, ref) < 2e-4
+    # forward alone (inference path) at the same shape
+    with torch.no_grad():
+        xt = O.q_sample(O.make_schedule()["alpha_bars"], O.normalize(x0), t, nz)
+        y = net(xt.cuda(), t.cuda(), O.normalize(c2).cuda(), O.normalize(c1).cuda())
+    assert rel_err(y, eps_o) < 5e-5
