@@ -11,7 +11,9 @@ constexpr int MSE_MAX_BLOCKS = 1024;  // size of the partial-sum scratch used by
 // ---- k_stream.hip
 int launch_q_sample(const float* alpha_bars, const float* x0, const int64_t* t, const float* noise, float* x_t, int B,
                     int64_t per_sample, int normalize, hipStream_t s);
-int launch_ddim_step(const float* x_t, const float* eps, float* x_prev, const float* coef_dev, int64_t n, hipStream_t s);
+int launch_ddim_step(const float* x_t, const float* eps, float* x_prev, const float* coef_dev, int64_t n, const int* step_ptr,
+                     hipStream_t s);  // x_prev may alias x_t (element-wise); step_ptr (nullable): row index into coef_dev
+int launch_inc_step(int* p, hipStream_t s);
 int launch_sample_finish(const float* x, const float* ms2_cond, float* out_x, float* out_noise, int64_t n, int normalize,
                          hipStream_t s);
 int launch_mse_fwd_bwd(const float* eps, const float* noise, float* loss_out, float* grad_out, float* partials, int64_t n,

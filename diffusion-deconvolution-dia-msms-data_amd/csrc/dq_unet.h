@@ -15,7 +15,7 @@ struct DevTables {
 };
 
 int launch_time_embed_fwd(const Plan& p, const DevTables& dt, const float* params, const int64_t* t, int t_scalar, float* tbuf,
-                          float* ss, int B, hipStream_t s);
+                          float* ss, int B, const int* step_tab, const int* step_ptr, hipStream_t s);
 int launch_time_embed_bwd(const Plan& p, const DevTables& dt, const float* params, float* grads, float* tbuf, const float* dss,
                           int B, hipStream_t s);
 
@@ -28,7 +28,7 @@ struct Arena {
   int64_t floats = 0;
   int64_t tbuf, ss, cat0, ms1n, ms1_u, ms1_a, ms1f, h0;
   std::vector<LevelBuf> downs, ups;
-  int64_t mid_in, xn, qv, kk, o, lse, delta, attn_out, mid_back, eps, partials, loss, coef, xa, xb, wg, wg_floats, la_part, la_part_floats;
+  int64_t mid_in, xn, qv, kk, o, lse, delta, attn_out, mid_back, eps, partials, loss, coef, xa, xb, wg, wg_floats, la_part, la_part_floats, ts_tab, step, c2_stage, c1_stage;
   ResBuf mid1, mid2, fin;
 };
 void layout_arena(const Plan& p, int B, int RT, Arena& a);
@@ -41,4 +41,11 @@ struct dq_plan {
   float* alpha_bars_dev = nullptr;          // (T) fp32, for q_sample
   std::vector<float> alpha_bars_host;
   dq::Arena arena;                           // cached for the last (B, RT)
+  // hipGraph of ONE sampling step (network forward + DDIM update + step counter), replayed num_steps times; valid while
+  // every pointer baked into its kernel arguments is unchanged
+  hipGraphExec_t step_exec = nullptr;
+  hipGraph_t step_graph = nullptr;
+  hipStream_t cap_stream = nullptr;  // capture-only stream (the caller's may be the uncapturable legacy default stream)
+  const void* g_params = nullptr; const void* g_rope = nullptr; const void* g_ws = nullptr;
+  int g_B = 0, g_RT = 0, g_norm = -1;
 };

@@ -70,6 +70,8 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
   a.wg = take(a.wg_floats);  // partial sums of the weight-gradient kernels
   a.la_part_floats = (int64_t)LA_MAX_WAVES * 512 * 16;
   a.la_part = take(a.la_part_floats);  // per-wave dW partial slots of the LinearAttention backward
+  a.ts_tab = take(1024); a.step = take(64);  // graph replay: timestep table (int32) and the device-side step counter
+  a.c2_stage = take(R * p.mz); a.c1_stage = take(R);  // conditions staged at fixed addresses for the captured step
   a.floats = off;
 }
 
@@ -221,12 +223,13 @@ int conv_plain_bwd(const Ctx& c, const ConvP& cp, int mode, const float* in, con
 ConvP proj(int64_t w, int cout, int cin) { ConvP c; c.w = w; c.b = -1; c.cout = cout; c.cin = cin; c.k = 1; return c; }
 
 int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t* t, int t_scalar, const float* init_cond,
-                 const float* attn_cond, float cm, float ca, const DevTables& dt, float* out) {
+                 const float* attn_cond, float cm, float ca, const DevTables& dt, float* out, const int* step_tab = nullptr,
+                 const int* step_ptr = nullptr) {
   const Plan& p = c.p;
   const Arena& a = c.ar;
   const int B = c.B, RT = c.RT, R = B * RT, L = p.levels;
   // K1: time embedding + every scale/shift head (unet1d.py:1105, 315-318, 677)
-  DQ_TRY(launch_time_embed_fwd(p, dt, c.P, t, t_scalar, c.w(a.tbuf), c.w(a.ss), B, c.s));
+  DQ_TRY(launch_time_embed_fwd(p, dt, c.P, t, t_scalar, c.w(a.tbuf), c.w(a.ss), B, step_tab, step_ptr, c.s));
   // K2: mixture conditioning + concat (unet1d.py:1107-1115), then init_conv k7 (:1117)
   DQ_TRY(launch_prep_inputs(x, init_cond, attn_cond, c.w(a.ss), p.ss_total, p.ss_init, cm, ca, c.w(a.cat0), c.w(a.ms1n), B, RT, p.mz, c.s));
   DQ_TRY(conv_plain_fwd(c, p.init_conv, CONV_S1, c.w(a.cat0), c.w(a.h0), R, p.mz, p.mz));
@@ -418,6 +421,9 @@ void dq_plan_destroy(dq_plan* plan) {
   if (!plan) return;
   if (plan->dev.ss_w_off) (void)hipFree(plan->dev.ss_w_off);
   if (plan->dev.ss_b_off) (void)hipFree(plan->dev.ss_b_off);
+  if (plan->step_exec) (void)hipGraphExecDestroy(plan->step_exec);
+  if (plan->step_graph) (void)hipGraphDestroy(plan->step_graph);
+  if (plan->cap_stream) (void)hipStreamDestroy(plan->cap_stream);
   delete plan;
 }
 
@@ -448,7 +454,7 @@ int dq_q_sample(const float* alpha_bars_dev, const float* x0, const int64_t* t, 
 }
 
 int dq_ddim_step(const float* x_t, const float* eps, float* x_prev, const float* coef_dev, int64_t n, void* stream) {
-  return launch_ddim_step(x_t, eps, x_prev, coef_dev, n, (hipStream_t)stream);
+  return launch_ddim_step(x_t, eps, x_prev, coef_dev, n, nullptr, (hipStream_t)stream);
 }
 
 int dq_unet_fwd(dq_plan* plan, const float* params, const float* rope_freqs, const float* x, const int64_t* t, int t_scalar,
@@ -512,7 +518,7 @@ int dq_train_step(dq_plan* plan, const float* params, const float* rope_freqs, c
 
 int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, const float* alpha_bars_host, const float* x_T,
                    const float* ms2_cond, const float* ms1_cond, int auto_normalize, const int32_t* timesteps_host,
-                   int num_steps, float* out_x, float* out_noise, float* traj_x, float* traj_eps, void* workspace,
+                   int num_steps, float* out_x, float* out_noise, float* traj_x, float* traj_eps, int use_graph, void* workspace,
                    int64_t workspace_bytes, int B, int RT, void* stream) {
   DQ_REQUIRE(plan && params && alpha_bars_host && x_T && ms2_cond && ms1_cond && timesteps_host && out_x && out_noise && workspace,
              "dq_ddim_sample: null argument");
@@ -551,11 +557,48 @@ int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, 
   float* xa = c.w(a.xa);
   float* xb = c.w(a.xb);
   DQ_HIP_OK(hipMemcpyAsync(xa, x_T, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+  if (use_graph && !traj_x && !traj_eps) {
+    // ---- hipGraph path: one step captured once (all pointers inside the arena / parameter buffers), replayed per step.
+    // The step index lives on the device: k_time_fwd reads ts_tab[*step], k_ddim_step its coefficient row, k_inc_step bumps it.
+    int* ts_tab = reinterpret_cast<int*>(c.w(a.ts_tab));
+    int* step = reinterpret_cast<int*>(c.w(a.step));
+    DQ_HIP_OK(hipMemcpyAsync(ts_tab, ts, sizeof(int32_t) * num_steps, hipMemcpyHostToDevice, s));
+    DQ_HIP_OK(hipMemsetAsync(step, 0, sizeof(int), s));
+    DQ_HIP_OK(hipMemcpyAsync(c.w(a.c2_stage), ms2_cond, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+    DQ_HIP_OK(hipMemcpyAsync(c.w(a.c1_stage), ms1_cond, sizeof(float) * (int64_t)B * RT, hipMemcpyDeviceToDevice, s));
+    DQ_HIP_OK(hipStreamSynchronize(s));  // ts is caller memory; also keeps the capture below free of pending copies
+    const bool valid = plan->step_exec && plan->g_params == params && plan->g_rope == rope_freqs && plan->g_ws == workspace &&
+                       plan->g_B == B && plan->g_RT == RT && plan->g_norm == auto_normalize;
+    if (!valid) {
+      if (plan->step_exec) { (void)hipGraphExecDestroy(plan->step_exec); plan->step_exec = nullptr; }
+      if (plan->step_graph) { (void)hipGraphDestroy(plan->step_graph); plan->step_graph = nullptr; }
+      // the caller's stream may be the legacy default stream, which cannot be captured: capture on a stream of our own
+      // (nothing executes during capture) and launch the instantiated graph on the caller's stream
+      if (!plan->cap_stream) DQ_HIP_OK(hipStreamCreateWithFlags(&plan->cap_stream, hipStreamNonBlocking));
+      hipStream_t cs = plan->cap_stream;
+      Ctx cc{plan->plan, a, params, W, nullptr, nullptr, B, RT, cs};
+      cc.save = false;
+      DQ_HIP_OK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+      int rc = unet_forward(cc, rope_freqs, xa, nullptr, 0, c.w(a.c2_stage), c.w(a.c1_stage), cm, ca, plan->dev, c.w(a.eps), ts_tab, step);
+      if (!rc) rc = launch_ddim_step(xa, c.w(a.eps), xa, c.w(a.coef), n, step, cs);  // in place: element-wise
+      if (!rc) rc = launch_inc_step(step, cs);
+      hipGraph_t g = nullptr;
+      const hipError_t ce = hipStreamEndCapture(cs, &g);
+      if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+      DQ_HIP_OK(ce);
+      plan->step_graph = g;
+      DQ_HIP_OK(hipGraphInstantiate(&plan->step_exec, g, nullptr, nullptr, 0));
+      plan->g_params = params; plan->g_rope = rope_freqs; plan->g_ws = workspace; plan->g_B = B; plan->g_RT = RT; plan->g_norm = auto_normalize;
+    }
+    for (int i = 0; i < num_steps; ++i) DQ_HIP_OK(hipGraphLaunch(plan->step_exec, s));
+    DQ_TRY(launch_sample_finish(xa, ms2_cond, out_x, out_noise, n, auto_normalize, s));
+    return 0;
+  }
   for (int i = 0; i < num_steps; ++i) {
     float* eps = traj_eps ? traj_eps + (int64_t)i * n : c.w(a.eps);
     DQ_TRY(unet_forward(c, rope_freqs, xa, nullptr, ts[i], ms2_cond, ms1_cond, cm, ca, plan->dev, eps));  // model.py:271
     float* xn = traj_x ? traj_x + (int64_t)i * n : xb;
-    DQ_TRY(launch_ddim_step(xa, eps, xn, c.w(a.coef) + 4 * i, n, s));                                      // model.py:273-289
+    DQ_TRY(launch_ddim_step(xa, eps, xn, c.w(a.coef) + 4 * i, n, nullptr, s));                             // model.py:273-289
     if (traj_x) {
       DQ_HIP_OK(hipMemcpyAsync(xa, xn, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
     } else {

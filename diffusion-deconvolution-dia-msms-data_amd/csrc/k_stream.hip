@@ -43,7 +43,9 @@ int launch_q_sample(const float* alpha_bars, const float* x0, const int64_t* t, 
 // ---- K9: x0 = (x_t - sb*eps)/sa ; x_prev = sap*x0 + sbp*eps (t>0) else x0 : 12 B / element
 // ``coef`` is a device table of 4 floats per step [sa, sb, sap, sbp]; sap < 0 marks the t == 0 step.
 __global__ void __launch_bounds__(256) k_ddim_step(const float* __restrict__ x_t, const float* __restrict__ eps,
-                                                   float* __restrict__ x_prev, const float* __restrict__ coef, int64_t n4) {
+                                                   float* __restrict__ x_prev, const float* __restrict__ coef, int64_t n4,
+                                                   const int* __restrict__ step_ptr) {
+  if (step_ptr) coef += 4 * step_ptr[0];  // graph replay: this step's row of the coefficient table
   const float sa = coef[0], sb = coef[1], sap = coef[2], sbp = coef[3];
   const bool last = sap < 0.f;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -59,11 +61,20 @@ __global__ void __launch_bounds__(256) k_ddim_step(const float* __restrict__ x_t
   }
 }
 
-int launch_ddim_step(const float* x_t, const float* eps, float* x_prev, const float* coef_dev, int64_t n, hipStream_t s) {
+__global__ void k_inc_step(int* p) { p[0] += 1; }
+
+int launch_inc_step(int* p, hipStream_t s) {
+  hipLaunchKernelGGL(k_inc_step, dim3(1), dim3(1), 0, s, p);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ddim_step(const float* x_t, const float* eps, float* x_prev, const float* coef_dev, int64_t n, const int* step_ptr,
+                     hipStream_t s) {
   DQ_REQUIRE(n % 4 == 0, "ddim_step: element count must be a multiple of 4");
   if (n == 0) return 0;
   const int grid = (int)std::min<int64_t>(cdiv(n / 4, 256), 2048);
-  hipLaunchKernelGGL(k_ddim_step, dim3(grid), dim3(256), 0, s, x_t, eps, x_prev, coef_dev, n / 4);
+  hipLaunchKernelGGL(k_ddim_step, dim3(grid), dim3(256), 0, s, x_t, eps, x_prev, coef_dev, n / 4, step_ptr);
   DQ_LAUNCH_CHECK();
   return 0;
 }

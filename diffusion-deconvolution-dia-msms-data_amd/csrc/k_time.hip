@@ -16,11 +16,13 @@ namespace dq {
 __global__ void __launch_bounds__(64) k_time_fwd(const float* __restrict__ P, const int64_t* __restrict__ t, int t_scalar,
                                                  float* __restrict__ tbuf, float* __restrict__ ss, int ss_total,
                                                  const int64_t* __restrict__ ss_w_off, const int64_t* __restrict__ ss_b_off,
-                                                 int64_t t1w, int64_t t1b, int64_t t2w, int64_t t2b, int dim, float theta) {
+                                                 int64_t t1w, int64_t t1b, int64_t t2w, int64_t t2b, int dim, float theta,
+                                                 const int* __restrict__ step_tab, const int* __restrict__ step_ptr) {
   const int b = blockIdx.x, tid = threadIdx.x;
   float* tb = tbuf + (int64_t)b * TBUF_FLOATS;
   __shared__ float sinu[4], hact[16], st[16];
-  const float tv = (float)(t ? t[b] : (int64_t)t_scalar);  // int64 * fp32 -> fp32 (unet1d.py:215)
+  // timestep: per-sample tensor, or a scalar, or (graph replay) table[*step] read on the device
+  const float tv = (float)(t ? t[b] : (int64_t)(step_tab ? step_tab[*step_ptr] : t_scalar));  // int64 * fp32 -> fp32 (unet1d.py:215)
   const int half = dim / 2;
   if (tid < dim) {
     const int j = tid % half;
@@ -61,10 +63,10 @@ __global__ void __launch_bounds__(64) k_time_fwd(const float* __restrict__ P, co
 }
 
 int launch_time_embed_fwd(const Plan& p, const DevTables& dt, const float* params, const int64_t* t, int t_scalar, float* tbuf,
-                          float* ss, int B, hipStream_t s) {
+                          float* ss, int B, const int* step_tab, const int* step_ptr, hipStream_t s) {
   if (B == 0) return 0;
   hipLaunchKernelGGL(k_time_fwd, dim3(B), dim3(64), 0, s, params, t, t_scalar, tbuf, ss, p.ss_total, dt.ss_w_off, dt.ss_b_off,
-                     p.t1_w, p.t1_b, p.t2_w, p.t2_b, p.dim, 10000.0f);
+                     p.t1_w, p.t1_b, p.t2_w, p.t2_b, p.dim, 10000.0f, step_tab, step_ptr);
   DQ_LAUNCH_CHECK();
   return 0;
 }

@@ -12,6 +12,7 @@ samples of the reference's B = 1 loss); ``ms1_loss_weight > 0`` and ``pred_type=
 """
 import ctypes
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -88,6 +89,7 @@ class DDIMDiffusionModel(ModelInterface):
         self.pred_type = pred_type
         self.ms1_loss_weight = ms1_loss_weight
         self._ab_host = None
+        self.use_graph = os.environ.get("DQ_NO_GRAPH", "0") != "1"  # sample(): replay one hipGraph-captured step per timestep
 
     # ------------------------------------------------------------------ helpers
     @property
@@ -187,7 +189,8 @@ class DDIMDiffusionModel(ModelInterface):
         traj_e = torch.empty((num_steps, B, RT, MZ), device=x_T.device) if return_trajectory else None
         N.check(N.lib().dq_ddim_sample(net._plan, N.ptr(flat), N.ptr(net.rope_freqs()), self._alpha_bars_host(), N.ptr(x_T), N.ptr(c2),
                                        N.ptr(c1), 1 if self.auto_normalize else 0, ts_c, num_steps, N.ptr(out_x), N.ptr(out_n),
-                                       N.ptr(traj_x), N.ptr(traj_e), N.ptr(ws), ws.numel(), B, RT, N.stream_ptr()), "dq_ddim_sample")
+                                       N.ptr(traj_x), N.ptr(traj_e), 1 if (self.use_graph and not return_trajectory) else 0, N.ptr(ws),
+                                       ws.numel(), B, RT, N.stream_ptr()), "dq_ddim_sample")
         if return_trajectory:
             return out_x, out_n, traj_x, traj_e
         return out_x, out_n

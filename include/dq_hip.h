@@ -100,10 +100,12 @@ int dq_train_step(dq_plan* plan, const float* params, const float* rope_freqs, c
  * Runs the whole strided loop natively over timesteps_host[num_steps] (host ints; the caller forms them as
  * trunc(linspace(T-1, 0, num_steps)), model.py:313): each step = network forward + K9 (landing on alpha_bars[t-1],
  * model.py:284), then the epilogue (model.py:319-322).  alpha_bars_host: T host floats.  x_T (B,RT,MZ) is not modified.  out_x = denoised in [0,1]; out_noise = mixture -
- * denoised.  traj_x / traj_eps (nullable): (num_steps,B,RT,MZ) per-step x_{t-1} and eps. */
+ * denoised.  traj_x / traj_eps (nullable): (num_steps,B,RT,MZ) per-step x_{t-1} and eps.  use_graph != 0 (and no trajectory
+ * requested): one step is captured into a hipGraph (cached in the plan while params/workspace/B/RT stay the same) and
+ * replayed num_steps times; the conditions are staged inside the workspace, the step index lives on the device. */
 int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, const float* alpha_bars_host, const float* x_T,
                    const float* ms2_cond, const float* ms1_cond, int auto_normalize, const int32_t* timesteps_host,
-                   int num_steps, float* out_x, float* out_noise, float* traj_x, float* traj_eps, void* workspace,
+                   int num_steps, float* out_x, float* out_noise, float* traj_x, float* traj_eps, int use_graph, void* workspace,
                    int64_t workspace_bytes, int B, int RT, void* stream);
 
 /* ---- building blocks exported for the per-block parity tests (tests/test_blocks_gpu.py) ------------------------
