@@ -77,6 +77,30 @@ struct ConvWgrad {
 constexpr int WGRAD_MAX_PARTS = 512;
 int launch_conv_wgrad(const ConvWgrad& a, hipStream_t s);
 
+// ---- k_res.hip : fused ResnetBlock over m/z rows whose length divides 256
+struct ResFwd {
+  const float* inA = nullptr; const float* inB = nullptr; int cinA = 0, cinB = 0;  // input = cat(A, B)
+  const float* w1 = nullptr; const float* b1 = nullptr; const float* g1 = nullptr;   // block1 conv (C, cin, 3), bias, norm gain
+  const float* w2 = nullptr; const float* b2 = nullptr; const float* g2 = nullptr;   // block2 conv (C, C, 3)
+  const float* wr = nullptr; const float* br = nullptr;                              // res_conv (C, cin) or null => identity
+  const float* ss = nullptr; int ss_stride = 0;                                      // per-sample [scale(C) | shift(C)] of block1
+  float* u1 = nullptr; float* a1 = nullptr; float* u2 = nullptr;                     // saved for the backward (nullable)
+  float* out = nullptr;
+  int C = 0, rows = 0, n = 0, rows_per_sample = 1;
+};
+struct ResBwd {
+  const float* dout = nullptr; const float* u1 = nullptr; const float* u2 = nullptr;
+  const float* w1 = nullptr; const float* w2 = nullptr; const float* wr = nullptr;
+  const float* g1 = nullptr; const float* g2 = nullptr; const float* ss = nullptr; int ss_stride = 0;
+  float* du1 = nullptr; float* du2 = nullptr;          // written (the weight-gradient kernels read them)
+  float* dA = nullptr; float* dB = nullptr; int cinA = 0, cinB = 0;  // += gradient of the block input (nullable)
+  float* dg1 = nullptr; float* dg2 = nullptr; float* dss = nullptr;  // atomic +=
+  int C = 0, rows = 0, n = 0, rows_per_sample = 1;
+};
+bool res_fusable(int n, int C);
+int launch_res_fwd(const ResFwd& a, hipStream_t s);
+int launch_res_bwd(const ResBwd& a, hipStream_t s);
+
 // standalone RMSNorm forward (PreNorm of the bottleneck attention)
 int launch_rmsnorm_fwd(const float* x, const float* g, float* y, int C, int rows, int n, hipStream_t s);
 

@@ -102,6 +102,18 @@ struct Ctx {
 // ResnetBlock forward (unet1d.py:302-323): input = cat(A, B)
 int res_fwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, int cinA, const float* inB, int cinB, int rows, int n,
             int rows_per_sample) {
+  if (rows_per_sample > 1 && res_fusable(n, r.cout)) {  // m/z levels: one fused launch
+    ResFwd k;
+    k.inA = inA; k.inB = inB; k.cinA = cinA; k.cinB = cinB;
+    k.w1 = c.prm(r.c1.w); k.b1 = c.prm(r.c1.b); k.g1 = c.prm(r.g1);
+    k.w2 = c.prm(r.c2.w); k.b2 = c.prm(r.c2.b); k.g2 = c.prm(r.g2);
+    if (r.res.cout) { k.wr = c.prm(r.res.w); k.br = c.prm(r.res.b); }
+    k.ss = c.w(c.ar.ss) + r.ss_off; k.ss_stride = c.p.ss_total;
+    if (c.save) { k.u1 = c.w(b.u1); k.a1 = c.w(b.a1); k.u2 = c.w(b.u2); }
+    k.out = c.w(b.out);
+    k.C = r.cout; k.rows = rows; k.n = n; k.rows_per_sample = rows_per_sample;
+    return launch_res_fwd(k, c.s);
+  }
   ConvFwd f;
   f.inA = inA; f.inB = inB; f.cinA = cinA; f.cinB = cinB;
   f.w = c.prm(r.c1.w); f.bias = c.prm(r.c1.b); f.cout = r.cout; f.K = 3; f.mode = CONV_S1;
@@ -127,6 +139,31 @@ int res_fwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, int 
 int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, float* dA, int cinA, const float* inB, float* dB, int cinB,
             int rows, int n, int rows_per_sample) {
   const float* dout = c.g(b.out);
+  if (rows_per_sample > 1 && res_fusable(n, r.cout)) {
+    // m/z levels: the whole data path in one launch, then the three weight-gradient launches
+    ResBwd k;
+    k.dout = dout; k.u1 = c.w(b.u1); k.u2 = c.w(b.u2);
+    k.w1 = c.prm(r.c1.w); k.w2 = c.prm(r.c2.w); k.wr = r.res.cout ? c.prm(r.res.w) : nullptr;
+    k.g1 = c.prm(r.g1); k.g2 = c.prm(r.g2); k.ss = c.w(c.ar.ss) + r.ss_off; k.ss_stride = c.p.ss_total;
+    k.du1 = c.g(b.u1); k.du2 = c.g(b.u2); k.dA = dA; k.dB = dB; k.cinA = cinA; k.cinB = cinB;
+    k.dg1 = c.dprm(r.g1); k.dg2 = c.dprm(r.g2); k.dss = c.g(c.ar.ss) + r.ss_off;
+    k.C = r.cout; k.rows = rows; k.n = n; k.rows_per_sample = rows_per_sample;
+    DQ_TRY(launch_res_bwd(k, c.s));
+    ConvWgrad w2;
+    w2.scratch = c.w(c.ar.wg); w2.scratch_floats = c.ar.wg_floats;
+    w2.du = c.g(b.u2); w2.inA = c.w(b.a1); w2.cinA = r.cout; w2.cout = r.cout; w2.K = 3; w2.mode = CONV_S1;
+    w2.rows = rows; w2.n_in = n; w2.n_out = n; w2.dw = c.dprm(r.c2.w); w2.dbias = c.dprm(r.c2.b);
+    DQ_TRY(launch_conv_wgrad(w2, c.s));
+    ConvWgrad w1 = w2;
+    w1.du = c.g(b.u1); w1.inA = inA; w1.inB = inB; w1.cinA = cinA; w1.cinB = cinB; w1.dw = c.dprm(r.c1.w); w1.dbias = c.dprm(r.c1.b);
+    DQ_TRY(launch_conv_wgrad(w1, c.s));
+    if (r.res.cout) {
+      ConvWgrad wr = w1;
+      wr.du = dout; wr.K = 1; wr.dw = c.dprm(r.res.w); wr.dbias = c.dprm(r.res.b);
+      DQ_TRY(launch_conv_wgrad(wr, c.s));
+    }
+    return 0;
+  }
   // block2: norm -> silu
   BlockBwd bb;
   bb.u = c.w(b.u2); bb.dy = dout; bb.du = c.g(b.u2); bb.C = r.cout; bb.rows = rows; bb.n = n; bb.rows_per_sample = rows_per_sample;

@@ -1,0 +1,278 @@
+// Fused ResnetBlock kernels for the m/z levels (reference dquartic/model/unet1d.py:271-323):
+//   forward : conv3 -> RMSNorm -> (scale+1, shift) -> SiLU -> conv3 -> RMSNorm -> SiLU, + res_conv(x) | x      (one launch)
+//   backward: the whole data path  d out -> dU2 -> d a1 -> dU1 -> d x  incl. the residual branch, d g1/g2 and the per-sample
+//             d(scale)/d(shift)                                                                                 (one launch)
+// instead of 2 and 5-6 launches of the generic kernels in k_conv.hip.  Thread = (row, position), all channels in
+// registers; the +-1 neighbours a k=3 conv needs of an intermediate (a1 forward; dU2, dU1 backward) are exchanged through
+// LDS inside the 256-thread block.  A block covers 256 consecutive positions of ONE sample (grid = (blocks per sample, B)),
+// rows never straddle blocks because the row length divides 256 -- the launcher refuses anything else (the bottleneck's
+// RT-long rows keep the unfused path).  Weight gradients stay in k_conv_wgrad (they read dU1 / dU2 written here).
+#include "dq_common.h"
+#include "dq_kernels.h"
+
+namespace dq {
+
+namespace {
+__device__ __forceinline__ float ldg(const float* p) { return *p; }
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) k_res_fwd(ResFwd a) {
+  __shared__ float sh[C][256 + 2];
+  const int b = blockIdx.y;
+  const int per_sample = a.rows_per_sample * a.n;
+  const int it = blockIdx.x * 256 + threadIdx.x;
+  const bool live = it < per_sample;
+  const int row = b * a.rows_per_sample + (live ? it / a.n : 0), p = live ? it % a.n : 0;
+  const int cin = a.cinA + a.cinB;
+  const float sqC = sqrtf((float)C);
+  float acc[C];
+  // ---- conv1 (k3, zero padding) over cat(A, B)
+#pragma unroll
+  for (int co = 0; co < C; ++co) acc[co] = a.b1[co];
+  if (live) {
+    for (int ci = 0; ci < cin; ++ci) {
+      const float* src = (ci < a.cinA) ? a.inA + ((int64_t)row * a.cinA + ci) * a.n : a.inB + ((int64_t)row * a.cinB + (ci - a.cinA)) * a.n;
+      const float x0 = p > 0 ? src[p - 1] : 0.f, x1 = src[p], x2 = p + 1 < a.n ? src[p + 1] : 0.f;
+#pragma unroll
+      for (int co = 0; co < C; ++co) {
+        const float* w = a.w1 + ((int64_t)co * cin + ci) * 3;
+        acc[co] = fmaf(w[0], x0, fmaf(w[1], x1, fmaf(w[2], x2, acc[co])));
+      }
+    }
+  }
+  const int64_t obase = ((int64_t)row * C) * a.n + p;
+  if (live && a.u1) {
+#pragma unroll
+    for (int co = 0; co < C; ++co) a.u1[obase + (int64_t)co * a.n] = acc[co];
+  }
+  {
+    float ssq = 0.f;
+#pragma unroll
+    for (int co = 0; co < C; ++co) ssq = fmaf(acc[co], acc[co], ssq);
+    const float inv = sqC / fmaxf(sqrtf(ssq), RMS_EPS);
+    const float* ss = a.ss + (int64_t)b * a.ss_stride;
+#pragma unroll
+    for (int co = 0; co < C; ++co) acc[co] = silu_f(fmaf(acc[co] * inv * a.g1[co], ss[co] + 1.0f, ss[C + co]));
+  }
+  if (live && a.a1) {
+#pragma unroll
+    for (int co = 0; co < C; ++co) a.a1[obase + (int64_t)co * a.n] = acc[co];
+  }
+  // ---- neighbours of a1 through LDS (zero outside the row)
+#pragma unroll
+  for (int co = 0; co < C; ++co) sh[co][threadIdx.x + 1] = live ? acc[co] : 0.f;
+  __syncthreads();
+  float o[C];
+#pragma unroll
+  for (int co = 0; co < C; ++co) o[co] = a.b2[co];
+  const bool hasL = p > 0, hasR = p + 1 < a.n;
+#pragma unroll 1
+  for (int ci = 0; ci < C; ++ci) {  // not unrolled: C*C*3 weights would not fit in registers
+    const float x0 = hasL ? sh[ci][threadIdx.x] : 0.f, x1 = sh[ci][threadIdx.x + 1], x2 = hasR ? sh[ci][threadIdx.x + 2] : 0.f;
+    const float* w = a.w2 + (int64_t)ci * 3;
+#pragma unroll
+    for (int co = 0; co < C; ++co) o[co] = fmaf(w[co * C * 3 + 0], x0, fmaf(w[co * C * 3 + 1], x1, fmaf(w[co * C * 3 + 2], x2, o[co])));
+  }
+  if (!live) return;
+  if (a.u2) {
+#pragma unroll
+    for (int co = 0; co < C; ++co) a.u2[obase + (int64_t)co * a.n] = o[co];
+  }
+  {
+    float ssq = 0.f;
+#pragma unroll
+    for (int co = 0; co < C; ++co) ssq = fmaf(o[co], o[co], ssq);
+    const float inv = sqC / fmaxf(sqrtf(ssq), RMS_EPS);
+#pragma unroll
+    for (int co = 0; co < C; ++co) o[co] = silu_f(o[co] * inv * a.g2[co]);
+  }
+  // ---- residual: 1x1 conv over cat(A, B) or identity
+  if (a.wr) {
+#pragma unroll
+    for (int co = 0; co < C; ++co) o[co] += a.br[co];
+    for (int ci = 0; ci < cin; ++ci) {
+      const float xv = (ci < a.cinA) ? a.inA[((int64_t)row * a.cinA + ci) * a.n + p] : a.inB[((int64_t)row * a.cinB + (ci - a.cinA)) * a.n + p];
+#pragma unroll
+      for (int co = 0; co < C; ++co) o[co] = fmaf(a.wr[(int64_t)co * cin + ci], xv, o[co]);
+    }
+  } else {
+#pragma unroll
+    for (int co = 0; co < C; ++co) o[co] += a.inA[obase + (int64_t)co * a.n];
+  }
+#pragma unroll
+  for (int co = 0; co < C; ++co) a.out[obase + (int64_t)co * a.n] = o[co];
+}
+
+bool res_fusable(int n, int C) { return n >= 1 && n <= 256 && (256 % n) == 0 && (C == 4 || C == 8 || C == 12 || C == 16); }
+
+int launch_res_fwd(const ResFwd& a, hipStream_t s) {
+  DQ_REQUIRE(res_fusable(a.n, a.C), "res_fwd: row length must divide 256 and C be 4/8/12/16");
+  DQ_REQUIRE(a.rows % a.rows_per_sample == 0, "res_fwd: rows must be a multiple of rows_per_sample");
+  DQ_REQUIRE(a.wr || (a.cinA == a.C && a.cinB == 0), "res_fwd: identity residual needs C input channels");
+  const int B = a.rows / a.rows_per_sample;
+  dim3 grid(cdiv((int64_t)a.rows_per_sample * a.n, 256), B), block(256);
+  switch (a.C) {
+    case 4: hipLaunchKernelGGL((k_res_fwd<4>), grid, block, 0, s, a); break;
+    case 8: hipLaunchKernelGGL((k_res_fwd<8>), grid, block, 0, s, a); break;
+    case 12: hipLaunchKernelGGL((k_res_fwd<12>), grid, block, 0, s, a); break;
+    case 16: hipLaunchKernelGGL((k_res_fwd<16>), grid, block, 0, s, a); break;
+  }
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// backward data path
+// -----------------------------------------------------------------------------------------------------------------
+namespace {
+// pointwise backward of RMSNorm -> (scale+1, shift) -> SiLU at one position; returns dU in d[], accumulates dg / dsc / dsh
+template <int C, bool SS>
+__device__ __forceinline__ void norm_act_bwd(const float* u, float* d, const float* __restrict__ g, const float* __restrict__ ss,
+                                             float* dg, float* dsc, float* dsh) {
+  const float sqC = sqrtf((float)C);
+  float ssq = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) ssq = fmaf(u[c], u[c], ssq);
+  const float nrm = sqrtf(ssq), inv = 1.0f / fmaxf(nrm, RMS_EPS);
+  float uh[C];
+  float dot = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    uh[c] = u[c] * inv;
+    const float z = uh[c] * g[c] * sqC;
+    const float sc = SS ? ss[c] + 1.0f : 1.0f, sh = SS ? ss[C + c] : 0.f;
+    const float w = fmaf(z, sc, sh);
+    const float dw = d[c] * silu_grad_f(w);
+    if (SS) { dsh[c] += dw; dsc[c] = fmaf(dw, z, dsc[c]); }
+    const float dz = dw * sc;
+    dg[c] = fmaf(dz, uh[c] * sqC, dg[c]);
+    d[c] = dz * g[c] * sqC;
+    dot = fmaf(d[c], uh[c], dot);
+  }
+  const bool clamped = nrm < RMS_EPS;
+#pragma unroll
+  for (int c = 0; c < C; ++c) d[c] = clamped ? d[c] * inv : inv * (d[c] - uh[c] * dot);
+}
+}  // namespace
+
+template <int C>
+__global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
+  __shared__ float sh[C][256 + 2];
+  __shared__ float red[4][4 * C];
+  const int b = blockIdx.y;
+  const int per_sample = a.rows_per_sample * a.n;
+  const int it = blockIdx.x * 256 + threadIdx.x;
+  const bool live = it < per_sample;
+  const int row = b * a.rows_per_sample + (live ? it / a.n : 0), p = live ? it % a.n : 0;
+  const int cin = a.cinA + a.cinB;
+  const int64_t obase = ((int64_t)row * C) * a.n + p;
+  const bool hasL = live && p > 0, hasR = live && p + 1 < a.n;  // dead threads must not read the (unwritten) halo slots
+  float dg2[C], dg1[C], dsc[C], dsh[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) dg2[c] = dg1[c] = dsc[c] = dsh[c] = 0.f;
+
+  // ---- block2: dU2 = norm/act backward of d out
+  float dout[C], d[C], u[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    dout[c] = live ? a.dout[obase + (int64_t)c * a.n] : 0.f;
+    u[c] = live ? a.u2[obase + (int64_t)c * a.n] : 1.f;
+    d[c] = dout[c];
+  }
+  norm_act_bwd<C, false>(u, d, a.g2, nullptr, dg2, nullptr, nullptr);
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) a.du2[obase + (int64_t)c * a.n] = d[c];
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) sh[c][threadIdx.x + 1] = live ? d[c] : 0.f;
+  __syncthreads();
+  // ---- d a1[ci][p] = sum_co sum_k W2[co][ci][k] dU2[co][p + 1 - k]
+  float da1[C];
+#pragma unroll
+  for (int ci = 0; ci < C; ++ci) da1[ci] = 0.f;
+#pragma unroll 1
+  for (int co = 0; co < C; ++co) {
+    const float dr = hasR ? sh[co][threadIdx.x + 2] : 0.f, dc = sh[co][threadIdx.x + 1], dl = hasL ? sh[co][threadIdx.x] : 0.f;
+    const float* w = a.w2 + (int64_t)co * C * 3;
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci) da1[ci] = fmaf(w[ci * 3 + 0], dr, fmaf(w[ci * 3 + 1], dc, fmaf(w[ci * 3 + 2], dl, da1[ci])));
+  }
+  __syncthreads();
+  // ---- block1: dU1
+#pragma unroll
+  for (int c = 0; c < C; ++c) u[c] = live ? a.u1[obase + (int64_t)c * a.n] : 1.f;
+  norm_act_bwd<C, true>(u, da1, a.g1, a.ss + (int64_t)b * a.ss_stride, dg1, dsc, dsh);
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) a.du1[obase + (int64_t)c * a.n] = da1[c];
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) sh[c][threadIdx.x + 1] = live ? da1[c] : 0.f;
+  __syncthreads();
+  // ---- d x[ci][p] = sum_co sum_k W1[co][ci][k] dU1[co][p + 1 - k]  (+ residual branch), accumulated into dA / dB
+  if (live && (a.dA || a.dB)) {
+    if (a.wr) {
+      for (int ci = 0; ci < cin; ++ci) {
+        float* dst;
+        if (ci < a.cinA) { if (!a.dA) continue; dst = a.dA + ((int64_t)row * a.cinA + ci) * a.n + p; }
+        else { if (!a.dB) continue; dst = a.dB + ((int64_t)row * a.cinB + (ci - a.cinA)) * a.n + p; }
+        float v = 0.f;
+#pragma unroll 4
+        for (int co = 0; co < C; ++co) {
+          const float* w = a.w1 + ((int64_t)co * cin + ci) * 3;
+          const float dr = hasR ? sh[co][threadIdx.x + 2] : 0.f, dc = sh[co][threadIdx.x + 1], dl = hasL ? sh[co][threadIdx.x] : 0.f;
+          v = fmaf(w[0], dr, fmaf(w[1], dc, fmaf(w[2], dl, v)));
+          v = fmaf(a.wr[(int64_t)co * cin + ci], a.dout[obase + (int64_t)co * a.n], v);
+        }
+        *dst += v;
+      }
+    } else if (a.dA) {  // identity residual: cin == C, single input
+      float dx[C];
+#pragma unroll
+      for (int ci = 0; ci < C; ++ci) dx[ci] = dout[ci];
+#pragma unroll 1
+      for (int co = 0; co < C; ++co) {
+        const float dr = hasR ? sh[co][threadIdx.x + 2] : 0.f, dc = sh[co][threadIdx.x + 1], dl = hasL ? sh[co][threadIdx.x] : 0.f;
+        const float* w = a.w1 + (int64_t)co * C * 3;
+#pragma unroll
+        for (int ci = 0; ci < C; ++ci) dx[ci] = fmaf(w[ci * 3 + 0], dr, fmaf(w[ci * 3 + 1], dc, fmaf(w[ci * 3 + 2], dl, dx[ci])));
+      }
+#pragma unroll
+      for (int ci = 0; ci < C; ++ci) a.dA[obase + (int64_t)ci * a.n] += dx[ci];
+    }
+  }
+  // ---- reductions: dg2, dg1 (atomic), per-sample d(scale), d(shift) (atomic)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float s0 = wave_sum(dg2[c]), s1 = wave_sum(dg1[c]), s2 = wave_sum(dsc[c]), s3 = wave_sum(dsh[c]);
+    if (lane == 0) { red[wv][c] = s0; red[wv][C + c] = s1; red[wv][2 * C + c] = s2; red[wv][3 * C + c] = s3; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) {
+    const float v = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    if (i < C) atomicAdd(a.dg2 + i, v);
+    else if (i < 2 * C) atomicAdd(a.dg1 + (i - C), v);
+    else atomicAdd(a.dss + (int64_t)b * a.ss_stride + (i - 2 * C), v);  // [dscale(C) | dshift(C)]
+  }
+}
+
+int launch_res_bwd(const ResBwd& a, hipStream_t s) {
+  DQ_REQUIRE(res_fusable(a.n, a.C), "res_bwd: row length must divide 256 and C be 4/8/12/16");
+  DQ_REQUIRE(a.rows % a.rows_per_sample == 0, "res_bwd: rows must be a multiple of rows_per_sample");
+  DQ_REQUIRE(a.wr || (a.cinA == a.C && a.cinB == 0), "res_bwd: identity residual needs C input channels");
+  const int B = a.rows / a.rows_per_sample;
+  dim3 grid(cdiv((int64_t)a.rows_per_sample * a.n, 256), B), block(256);
+  switch (a.C) {
+    case 4: hipLaunchKernelGGL((k_res_bwd<4>), grid, block, 0, s, a); break;
+    case 8: hipLaunchKernelGGL((k_res_bwd<8>), grid, block, 0, s, a); break;
+    case 12: hipLaunchKernelGGL((k_res_bwd<12>), grid, block, 0, s, a); break;
+    case 16: hipLaunchKernelGGL((k_res_bwd<16>), grid, block, 0, s, a); break;
+  }
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace dq

