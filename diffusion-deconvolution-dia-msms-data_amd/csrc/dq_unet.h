@@ -45,6 +45,12 @@ struct dq_plan {
   // every pointer baked into its kernel arguments is unchanged
   hipGraphExec_t step_exec = nullptr;
   hipGraph_t step_graph = nullptr;
+  // side stream for the weight-gradient kernels of the backward (forked / joined with events from this ring)
+  static constexpr int NUM_EVENTS = 256;
+  hipStream_t side_stream = nullptr;
+  hipEvent_t events[NUM_EVENTS] = {};
+  unsigned ev_next = 0;
+  bool side_used = false;
   hipStream_t cap_stream = nullptr;  // capture-only stream (the caller's may be the uncapturable legacy default stream)
   const void* g_params = nullptr; const void* g_rope = nullptr; const void* g_ws = nullptr;
   int g_B = 0, g_RT = 0, g_norm = -1;

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace dq {
@@ -77,6 +78,11 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
 
 namespace {
 
+bool side_stream_enabled() {
+  static const bool on = [] { const char* e = std::getenv("DQ_NO_SIDE_STREAM"); return !(e && e[0] == '1'); }();
+  return on;
+}
+
 struct Ctx {
   const Plan& p;
   const Arena& ar;
@@ -87,11 +93,17 @@ struct Ctx {
   int B, RT;
   hipStream_t s;
   bool save = true;  // keep what the backward needs (pre-norm conv outputs, LinearAttention pre-norm output)
+  dq_plan* owner = nullptr;  // side stream + events for the weight-gradient kernels (null => everything on s)
   float* w(int64_t off) const { return W + off; }
   float* g(int64_t off) const { return G + off; }
   const float* prm(int64_t off) const { return P + off; }
   float* dprm(int64_t off) const { return dP + off; }
 };
+
+// The weight-gradient kernels depend only on tensors that are final when they are issued (dU, forward activations) and
+// nothing on the data-gradient chain depends on them: they run on a side stream, forked by an event, joined at the end.
+int wgrad_async(const Ctx& c, const ConvWgrad& w);
+int join_side(const Ctx& c);
 
 #define DQ_TRY(expr)            \
   do {                          \
@@ -153,14 +165,14 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
     w2.scratch = c.w(c.ar.wg); w2.scratch_floats = c.ar.wg_floats;
     w2.du = c.g(b.u2); w2.inA = c.w(b.a1); w2.cinA = r.cout; w2.cout = r.cout; w2.K = 3; w2.mode = CONV_S1;
     w2.rows = rows; w2.n_in = n; w2.n_out = n; w2.dw = c.dprm(r.c2.w); w2.dbias = c.dprm(r.c2.b);
-    DQ_TRY(launch_conv_wgrad(w2, c.s));
+    DQ_TRY(wgrad_async(c, w2));
     ConvWgrad w1 = w2;
     w1.du = c.g(b.u1); w1.inA = inA; w1.inB = inB; w1.cinA = cinA; w1.cinB = cinB; w1.dw = c.dprm(r.c1.w); w1.dbias = c.dprm(r.c1.b);
-    DQ_TRY(launch_conv_wgrad(w1, c.s));
+    DQ_TRY(wgrad_async(c, w1));
     if (r.res.cout) {
       ConvWgrad wr = w1;
       wr.du = dout; wr.K = 1; wr.dw = c.dprm(r.res.w); wr.dbias = c.dprm(r.res.b);
-      DQ_TRY(launch_conv_wgrad(wr, c.s));
+      DQ_TRY(wgrad_async(c, wr));
     }
     return 0;
   }
@@ -173,7 +185,7 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
   wg.scratch = c.w(c.ar.wg); wg.scratch_floats = c.ar.wg_floats;
   wg.du = c.g(b.u2); wg.inA = c.w(b.a1); wg.cinA = r.cout; wg.cout = r.cout; wg.K = 3; wg.mode = CONV_S1;
   wg.rows = rows; wg.n_in = n; wg.n_out = n; wg.dw = c.dprm(r.c2.w); wg.dbias = c.dprm(r.c2.b);
-  DQ_TRY(launch_conv_wgrad(wg, c.s));
+  DQ_TRY(wgrad_async(c, wg));
   ConvBwdData bd;
   bd.du = c.g(b.u2); bd.w = c.prm(r.c2.w); bd.cout = r.cout; bd.K = 3; bd.mode = CONV_S1; bd.rows = rows; bd.n_in = n; bd.n_out = n;
   bd.dinA = c.g(b.a1); bd.cinA = r.cout; bd.accumulate = 0;
@@ -188,7 +200,7 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
   w1.scratch = c.w(c.ar.wg); w1.scratch_floats = c.ar.wg_floats;
   w1.du = c.g(b.u1); w1.inA = inA; w1.inB = inB; w1.cinA = cinA; w1.cinB = cinB; w1.cout = r.cout; w1.K = 3; w1.mode = CONV_S1;
   w1.rows = rows; w1.n_in = n; w1.n_out = n; w1.dw = c.dprm(r.c1.w); w1.dbias = c.dprm(r.c1.b);
-  DQ_TRY(launch_conv_wgrad(w1, c.s));
+  DQ_TRY(wgrad_async(c, w1));
   if (dA || dB) {
     ConvBwdData d1;
     d1.du = c.g(b.u1); d1.w = c.prm(r.c1.w); d1.cout = r.cout; d1.K = 3; d1.mode = CONV_S1; d1.rows = rows; d1.n_in = n; d1.n_out = n;
@@ -202,7 +214,7 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
   wr.scratch = c.w(c.ar.wg); wr.scratch_floats = c.ar.wg_floats;
     wr.du = dout; wr.inA = inA; wr.inB = inB; wr.cinA = cinA; wr.cinB = cinB; wr.cout = r.cout; wr.K = 1; wr.mode = CONV_S1;
     wr.rows = rows; wr.n_in = n; wr.n_out = n; wr.dw = c.dprm(r.res.w); wr.dbias = c.dprm(r.res.b);
-    DQ_TRY(launch_conv_wgrad(wr, c.s));
+    DQ_TRY(wgrad_async(c, wr));
     if (dA || dB) {
       ConvBwdData dr;
       dr.du = dout; dr.w = c.prm(r.res.w); dr.cout = r.cout; dr.K = 1; dr.mode = CONV_S1; dr.rows = rows; dr.n_in = n; dr.n_out = n;
@@ -247,7 +259,7 @@ int conv_plain_bwd(const Ctx& c, const ConvP& cp, int mode, const float* in, con
   wg.scratch = c.w(c.ar.wg); wg.scratch_floats = c.ar.wg_floats;
   wg.du = dout; wg.inA = in; wg.cinA = cp.cin; wg.cout = cp.cout; wg.K = cp.k; wg.mode = mode; wg.rows = rows; wg.n_in = n_in;
   wg.n_out = n_out; wg.dw = c.dprm(cp.w); wg.dbias = cp.b >= 0 ? c.dprm(cp.b) : nullptr;
-  DQ_TRY(launch_conv_wgrad(wg, c.s));
+  DQ_TRY(wgrad_async(c, wg));
   if (din) {
     ConvBwdData bd;
     bd.du = dout; bd.w = c.prm(cp.w); bd.cout = cp.cout; bd.K = cp.k; bd.mode = mode; bd.rows = rows; bd.n_in = n_in; bd.n_out = n_out;
@@ -410,6 +422,30 @@ int unet_backward(const Ctx& c, const float* rope, const float* init_cond, float
   }
   // time embedding: all scale/shift heads + the MLP
   DQ_TRY(launch_time_embed_bwd(p, dt, c.P, c.dP, c.w(a.tbuf), c.g(a.ss), B, c.s));
+  return join_side(c);
+}
+
+int wgrad_async(const Ctx& c, const ConvWgrad& w) {
+  dq_plan* pl = c.owner;
+  if (!pl) return launch_conv_wgrad(w, c.s);
+  if (!pl->side_stream) {
+    DQ_HIP_OK(hipStreamCreateWithFlags(&pl->side_stream, hipStreamNonBlocking));
+    for (auto& e : pl->events) DQ_HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  hipEvent_t ev = pl->events[pl->ev_next++ % dq_plan::NUM_EVENTS];
+  DQ_HIP_OK(hipEventRecord(ev, c.s));
+  DQ_HIP_OK(hipStreamWaitEvent(pl->side_stream, ev, 0));
+  pl->side_used = true;
+  return launch_conv_wgrad(w, pl->side_stream);
+}
+
+int join_side(const Ctx& c) {
+  dq_plan* pl = c.owner;
+  if (!pl || !pl->side_used) return 0;
+  hipEvent_t ev = pl->events[pl->ev_next++ % dq_plan::NUM_EVENTS];
+  DQ_HIP_OK(hipEventRecord(ev, pl->side_stream));
+  DQ_HIP_OK(hipStreamWaitEvent(c.s, ev, 0));
+  pl->side_used = false;
   return 0;
 }
 
@@ -461,6 +497,10 @@ void dq_plan_destroy(dq_plan* plan) {
   if (plan->step_exec) (void)hipGraphExecDestroy(plan->step_exec);
   if (plan->step_graph) (void)hipGraphDestroy(plan->step_graph);
   if (plan->cap_stream) (void)hipStreamDestroy(plan->cap_stream);
+  if (plan->side_stream) {
+    (void)hipStreamDestroy(plan->side_stream);
+    for (auto& e : plan->events) if (e) (void)hipEventDestroy(e);
+  }
   delete plan;
 }
 
@@ -514,6 +554,7 @@ int dq_unet_bwd(dq_plan* plan, const float* params, const float* rope_freqs, con
   DQ_REQUIRE(workspace_bytes >= 2 * (int64_t)sizeof(float) * plan->arena.floats, "dq_unet_bwd: workspace too small (training=1)");
   float* W = (float*)workspace;
   Ctx c{plan->plan, plan->arena, params, W, W + plan->arena.floats, grads, B, RT, (hipStream_t)stream};
+  c.owner = side_stream_enabled() ? plan : nullptr;
   return unet_backward(c, rope_freqs, init_cond, cond_mul, cond_add, plan->dev, grad_out, grad_x);
 }
 
@@ -543,6 +584,7 @@ int dq_train_step(dq_plan* plan, const float* params, const float* rope_freqs, c
   hipStream_t s = (hipStream_t)stream;
   float* W = (float*)workspace;
   Ctx c{plan->plan, a, params, W, W + a.floats, grads, B, RT, s};
+  c.owner = side_stream_enabled() ? plan : nullptr;
   const int64_t per = (int64_t)RT * plan->plan.mz;
   const float cm = auto_normalize ? 2.f : 1.f, ca = auto_normalize ? -1.f : 0.f;
   DQ_TRY(launch_q_sample(alpha_bars_dev, x0, t, noise, c.w(a.xa), B, per, auto_normalize, s));               // model.py:349-352
