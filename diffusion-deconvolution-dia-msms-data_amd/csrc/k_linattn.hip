@@ -44,6 +44,19 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
     const int r = i & 15, c = (i >> 4) % C, hh = (i / (16 * C)) & 1, hd = i / (32 * C);
     wo_lds[i] = a.w_out[c * 128 + hd * 32 + rowmap(r, hh)];
   }
+  // MFMA weight operands, laid out [q|k|v][head][j][half][col] so that a wave reads 2 x 32 consecutive floats; channels beyond C
+  // are zero.  The q and k rows carry log2(e): both softmaxes then use exp2 (v_exp_f32) directly, which changes nothing
+  // mathematically (softmax(x) = 2^(x*log2e - max) / sum).
+  constexpr int WQ = 3 * 4 * NJ * 2 * 32;
+  __shared__ float wqkv_lds[N > 1 ? WQ : 1];
+  if (N > 1) {
+    for (int i = threadIdx.x; i < WQ; i += blockDim.x) {
+      const int cc = i & 31, hh = (i >> 5) & 1, j = (i >> 6) % NJ, hd = (i / (64 * NJ)) & 3, m = i / (256 * NJ);
+      const int c = rowmap(j, hh);
+      const float w = c < C ? a.w_qkv[(m * 128 + hd * 32 + cc) * C + c] : 0.f;
+      wqkv_lds[i] = m < 2 ? w * 1.4426950408889634f : w;
+    }
+  }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
@@ -89,11 +102,15 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
     float wq[NJ], wk[NJ], wv[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int c = rowmap(j, half);
-      const bool ok = c < C;
-      wq[j] = ok ? a.w_qkv[(hd * 32 + col) * C + c] : 0.f;
-      wk[j] = ok ? a.w_qkv[(128 + hd * 32 + col) * C + c] : 0.f;
-      wv[j] = ok ? a.w_qkv[(256 + hd * 32 + col) * C + c] : 0.f;
+      if (N > 1) {
+        wq[j] = wqkv_lds[(((0 * 4 + hd) * NJ + j) * 2 + half) * 32 + col];
+        wk[j] = wqkv_lds[(((1 * 4 + hd) * NJ + j) * 2 + half) * 32 + col];
+        wv[j] = wqkv_lds[(((2 * 4 + hd) * NJ + j) * 2 + half) * 32 + col];
+      } else {
+        const int c = rowmap(j, half);
+        wq[j] = wk[j] = 0.f;
+        wv[j] = c < C ? a.w_qkv[(256 + hd * 32 + col) * C + c] : 0.f;
+      }
     }
 
     f32x16 out[NB];
@@ -130,7 +147,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
         for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
           for (int r = s0; r < s0 + SEG; ++r) {
-            const float e = __expf(kT[blk][r] - m);
+            const float e = __builtin_amdgcn_exp2f(kT[blk][r] - m);  // k rows are pre-scaled by log2(e)
             kT[blk][r] = e;
             ssum += e;
           }
@@ -162,7 +179,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
         float ssum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          q[r] = __expf(q[r] - m);
+          q[r] = __builtin_amdgcn_exp2f(q[r] - m);  // q rows are pre-scaled by log2(e)
           ssum += q[r];
         }
         ssum += swap32(ssum);
