@@ -106,7 +106,10 @@ def roofline_linattn(device):
     fl_f = la_flops_fwd(C, n) * rows
     ach_f, ach_b = fl_f / t_f / 1e12, 2 * fl_f / t_b / 1e12
     return {"bound": "mfma", "kernel": "k_linattn_bwd<4,64>", "achieved": round(ach_b, 3), "peak": F32_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach_b / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(ach_b / F32_MFMA_PEAK_TFLOPS, 4),
+            # HBM-side bytes per launch from the PMC passes of this shape (profiles/r01_pmc_linattn.md: 2 x FETCH_SIZE +
+            # WRITE_SIZE, FETCH_SIZE calibrated on k_q_sample); PMC cannot be collected inside this process
+            "traffic": 181.9e6,
             "launch_us": round(t_b * 1e6, 2), "flops_per_launch": 2 * fl_f,
             "fwd_kernel": {"kernel": "k_linattn_fwd<4,64>", "achieved": round(ach_f, 3), "frac": round(ach_f / F32_MFMA_PEAK_TFLOPS, 4),
                            "launch_us": round(t_f * 1e6, 2), "flops_per_launch": fl_f}}
