@@ -89,7 +89,7 @@ def roofline_linattn(device):
     bo, g1, g2 = torch.zeros(C, device=device), torch.ones(C, device=device), torch.ones(C, device=device)
     y, ypre, dx = torch.empty_like(x), torch.empty_like(x), torch.zeros_like(x)
     dw, dwo, dbo, dg1, dg2 = (torch.zeros_like(t) for t in (w, wo, bo, g1, g2))
-    scratch = torch.empty(2 * x.numel() + 1024 * 512 * C, device=device)
+    scratch = torch.empty(2 * x.numel() + 2048 * 512 * C, device=device)
     L = N.lib()
 
     def fwd():
@@ -182,7 +182,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    dist_on = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)  # under torchrun, also with one rank
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -200,7 +201,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -216,7 +217,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], device=device, dtype=torch.float64)
-    if world > 1:
+    if dist_on:
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
     dt = float(tt)
     train_wps = world * TRAIN_BATCH * args.steps / dt
@@ -239,7 +240,7 @@ def main():
         barrier()
         ds = time.perf_counter() - t0
         ts = torch.tensor([ds], device=device, dtype=torch.float64)
-        if world > 1:
+        if dist_on:
             torch.distributed.all_reduce(ts, op=torch.distributed.ReduceOp.MAX)
         sample = {"metric": "MS2 windows/s (50-step DDIM sample)", "value": round(world * B / float(ts), 2), "batch_per_gpu": B,
                   "steps": SAMPLE_STEPS, "seconds": round(float(ts), 4)}
@@ -262,7 +263,7 @@ def main():
             "sample": sample, "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

@@ -137,7 +137,7 @@ struct LinAttnBwd {
 int launch_linattn_fwd_long(const LinAttn& a, hipStream_t s);
 int launch_linattn_bwd_long(const float* x, const float* dyp, float* dxh, const float* w_qkv, const float* w_out, const float* g_pre,
                             float* part, int C, int rows, int n, int* waves_out, hipStream_t s);
-constexpr int LA_MAX_WAVES = 1024;  // the backward grid is one resident round: <= 1024 waves, one partial slot each
+constexpr int LA_MAX_WAVES = 2048;  // the backward grid is one resident round: <= 1024 waves, one partial slot each
 int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s);
 
 // ---- k_attn.hip : softmax attention over RT of the bottleneck (q,k,v,o in (B, 128, RT) conv layout)

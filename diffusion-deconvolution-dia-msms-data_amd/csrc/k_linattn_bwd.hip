@@ -19,6 +19,7 @@
 #include "dq_common.h"
 #include "dq_kernels.h"
 #include "dq_mfma.h"
+#include <cstdlib>
 
 namespace dq {
 
@@ -441,7 +442,8 @@ int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s) {
   DQ_REQUIRE(a.part && a.part_floats >= (int64_t)LA_MAX_WAVES * 512 * C, "linattn_bwd: partial-sum scratch missing or too small");
   k.part = a.part;
   int rc;
-  if (n > 64) {
+  static const bool long_all = [] { const char* e = std::getenv("DQ_LA_BWD_LONG"); return e && e[0] == '1'; }();
+  if (n > 64 || (long_all && n >= 32 && C <= 8)) {
     int waves = 0;
     rc = launch_linattn_bwd_long(a.f.x, a.dyp, a.dxh, a.f.w_qkv, a.f.w_out, a.f.g_pre, a.part, C, rows, n, &waves, s);
     if (rc) return rc;

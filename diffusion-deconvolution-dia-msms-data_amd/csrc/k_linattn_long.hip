@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd_long(LinAttn a) {
 
 // ---------------------------------------------------------------------------------------------------------------
 template <int C, int N>
-__global__ void __launch_bounds__(256) k_linattn_bwd_long(LinAttnBwdLongK a) {
+__global__ void __launch_bounds__(256, 2) k_linattn_bwd_long(LinAttnBwdLongK a) {  // <= 256 registers: two waves per SIMD
   constexpr int NB = N / 32;
   constexpr int NJ = C <= 8 ? 4 : 8;
   __shared__ float wp_lds[3 * 4 * 2 * C * 16];
@@ -408,7 +408,8 @@ int launch_linattn_fwd_long(const LinAttn& a, hipStream_t s) {
 
 int launch_linattn_bwd_long(const float* x, const float* dyp, float* dxh, const float* w_qkv, const float* w_out, const float* g_pre,
                             float* part, int C, int rows, int n, int* waves_out, hipStream_t s) {
-  LinAttnBwdLongK k{x, dyp, dxh, w_qkv, w_out, g_pre, part, rows, std::max(1, cdiv(rows, 1024))};
+  // two waves per SIMD are resident (<= 256 registers): 2048 waves = one resident round, and <= LA_MAX_WAVES partial slots
+  LinAttnBwdLongK k{x, dyp, dxh, w_qkv, w_out, g_pre, part, rows, std::max(1, cdiv(rows, 2048))};
   const int waves = cdiv(rows, k.units_per_wave);
   *waves_out = waves;
   dim3 grid(cdiv(waves, 4)), block(256);
@@ -419,6 +420,7 @@ int launch_linattn_bwd_long(const float* x, const float* dyp, float* dxh, const 
     return 0;                                                                      \
   }
   DQ_LBL(4, 128) DQ_LBL(4, 256) DQ_LBL(8, 128) DQ_LBL(8, 256) DQ_LBL(12, 128) DQ_LBL(16, 128)
+  DQ_LBL(4, 64) DQ_LBL(4, 32) DQ_LBL(8, 32) DQ_LBL(8, 64)
 #undef DQ_LBL
   set_error("linattn_bwd: (C, n) = (" + std::to_string(C) + ", " + std::to_string(n) + ") is not built");
   return 2;

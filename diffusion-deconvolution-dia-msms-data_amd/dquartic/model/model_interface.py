@@ -304,8 +304,8 @@ class ModelInterface(object):
                 noise = self.normalize(noise)  # reference quirk: a passed noise is mapped 2n-1 (model.py:346)
             loss = self.train_step_fused(x_0, ms2_cond, ms1_cond, t=t, noise=noise, zero_grads=True)
             world = _world()
-            if world > 1:
-                torch.distributed.all_reduce(self.model.flat_grads())  # one flat RCCL all-reduce (sum)
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                torch.distributed.all_reduce(self.model.flat_grads())  # one flat RCCL all-reduce (sum) of 515 KB
             self.optimizer.grad_scale = 1.0 / world
             self.optimizer.step()
             self.last_grad_norm = self.optimizer.last_grad_norm

@@ -52,7 +52,7 @@ def test_linattn_bwd_vs_autograd(N, C, n, rows):
                              N.stream_ptr()), "dq_linattn_fwd")
     dx = torch.zeros_like(xd)
     dw, dwo, dbo, dg1, dg2 = (torch.zeros_like(t) for t in (w, wo, bo, g1, g2))
-    scratch = torch.empty(2 * xd.numel() + 1024 * 512 * C, device="cuda")
+    scratch = torch.empty(2 * xd.numel() + 2048 * 512 * C, device="cuda")
     N.check(L.dq_linattn_bwd(N.ptr(xd), N.ptr(ypre), N.ptr(gyd), N.ptr(dx), N.ptr(w), N.ptr(wo), N.ptr(bo), N.ptr(g1), N.ptr(g2),
                              N.ptr(dw), N.ptr(dwo), N.ptr(dbo), N.ptr(dg1), N.ptr(dg2), N.ptr(scratch), C, rows, n, N.stream_ptr()),
             "dq_linattn_bwd")

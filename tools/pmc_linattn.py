@@ -12,7 +12,7 @@ w = (torch.randn(384, C, generator=g) * .4).cuda(); wo = (torch.randn(C, 128, ge
 bo, g1, g2 = torch.zeros(C).cuda(), torch.ones(C).cuda(), torch.ones(C).cuda()
 y, ypre, dx = torch.empty_like(x), torch.empty_like(x), torch.zeros_like(x)
 dw, dwo, dbo, dg1, dg2 = (torch.zeros_like(t) for t in (w, wo, bo, g1, g2))
-scratch = torch.empty(2 * x.numel() + 1024 * 512 * C, device="cuda")
+scratch = torch.empty(2 * x.numel() + 2048 * 512 * C, device="cuda")
 L = N.lib()
 for _ in range(5):
     N.check(L.dq_linattn_fwd(N.ptr(x), N.ptr(y), N.ptr(ypre), N.ptr(w), N.ptr(wo), N.ptr(bo), N.ptr(g1), N.ptr(g2), C, rows, n, N.stream_ptr()), "f")
