@@ -429,7 +429,12 @@ int wgrad_async(const Ctx& c, const ConvWgrad& w) {
   dq_plan* pl = c.owner;
   if (!pl) return launch_conv_wgrad(w, c.s);
   if (!pl->side_stream) {
-    DQ_HIP_OK(hipStreamCreateWithFlags(&pl->side_stream, hipStreamNonBlocking));
+    // Own priority class => own hardware queue.  Normal-priority streams share a small round-robin pool of HSA queues,
+    // and once RCCL has taken its streams from that pool a plain stream can land on the caller's queue, which serialises
+    // the weight-gradient kernels behind the main chain (measured: 15.7 vs 13.0 ms/step under torch.distributed.run).
+    int prio_least = 0, prio_greatest = 0;
+    DQ_HIP_OK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    DQ_HIP_OK(hipStreamCreateWithPriority(&pl->side_stream, hipStreamNonBlocking, prio_greatest));
     for (auto& e : pl->events) DQ_HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   hipEvent_t ev = pl->events[pl->ev_next++ % dq_plan::NUM_EVENTS];
