@@ -12,12 +12,15 @@ constexpr int MSE_MAX_BLOCKS = 1024;  // size of the partial-sum scratch used by
 int launch_q_sample(const float* alpha_bars, const float* x0, const int64_t* t, const float* noise, float* x_t, int B,
                     int64_t per_sample, int normalize, hipStream_t s);
 int launch_ddim_step(const float* x_t, const float* eps, float* x_prev, const float* coef_dev, int64_t n, const int* step_ptr,
-                     hipStream_t s);  // x_prev may alias x_t (element-wise); step_ptr (nullable): row index into coef_dev
+                     hipStream_t s, int pred_x0 = 0, float* eps_out = nullptr);
+// x_prev may alias x_t (element-wise); step_ptr (nullable): row index into coef_dev; pred_x0: ``eps`` is the network's x0
+// prediction and the derived eps goes to eps_out (nullable)
 int launch_inc_step(int* p, hipStream_t s);
 int launch_sample_finish(const float* x, const float* ms2_cond, float* out_x, float* out_noise, int64_t n, int normalize,
                          hipStream_t s);
 int launch_mse_fwd_bwd(const float* eps, const float* noise, float* loss_out, float* grad_out, float* partials, int64_t n,
-                       hipStream_t s);
+                       hipStream_t s, const float* lw = nullptr, const int64_t* t = nullptr, int64_t per_sample = 0, float tm = 1.f,
+                       float ta = 0.f);  // lw: per-timestep loss weights (x0 objective); target' = target*tm + ta
 int launch_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, float* partials, float gscale, float max_norm,
                       double lr, double b1, double b2, double eps, double wd, int step, float* gnorm_out, hipStream_t s);
 

@@ -53,5 +53,5 @@ struct dq_plan {
   bool side_used = false;
   hipStream_t cap_stream = nullptr;  // capture-only stream (the caller's may be the uncapturable legacy default stream)
   const void* g_params = nullptr; const void* g_rope = nullptr; const void* g_ws = nullptr;
-  int g_B = 0, g_RT = 0, g_norm = -1;
+  int g_B = 0, g_RT = 0, g_norm = -1, g_pred = -1;
 };

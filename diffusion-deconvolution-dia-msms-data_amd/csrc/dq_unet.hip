@@ -482,7 +482,7 @@ using namespace dq;
 extern "C" {
 
 const char* dq_last_error(void) { return g_err.c_str(); }
-int dq_abi_version(void) { return 1; }
+int dq_abi_version(void) { return 2; }
 
 dq_plan* dq_plan_create(int dim, int n_mults, const int* dim_mults, int mz, int num_timesteps) {
   dq_plan* h = new dq_plan();
@@ -539,6 +539,12 @@ int dq_ddim_step(const float* x_t, const float* eps, float* x_prev, const float*
   return launch_ddim_step(x_t, eps, x_prev, coef_dev, n, nullptr, (hipStream_t)stream);
 }
 
+int dq_ddim_step_x0(const float* x_t, const float* x0_pred, float* x_prev, float* eps_out, const float* coef_dev, int64_t n,
+                    void* stream) {
+  DQ_REQUIRE(x_t && x0_pred && x_prev && coef_dev, "dq_ddim_step_x0: null argument");
+  return launch_ddim_step(x_t, x0_pred, x_prev, coef_dev, n, nullptr, (hipStream_t)stream, 1, eps_out);
+}
+
 int dq_unet_fwd(dq_plan* plan, const float* params, const float* rope_freqs, const float* x, const int64_t* t, int t_scalar,
                 const float* init_cond, const float* attn_cond, float cond_mul, float cond_add, float* out, int save_for_bwd,
                 void* workspace, int64_t workspace_bytes, int B, int RT, void* stream) {
@@ -569,6 +575,15 @@ int dq_mse_loss_fwd_bwd(const float* eps, const float* noise, float* loss_out, f
   return launch_mse_fwd_bwd(eps, noise, loss_out, grad_out, scratch, n, (hipStream_t)stream);
 }
 
+int dq_mse_loss_weighted_fwd_bwd(const float* pred, const float* target, float target_mul, float target_add,
+                                 const float* loss_weight_dev, const int64_t* t, float* loss_out, float* grad_out, float* scratch,
+                                 int B, int64_t per_sample, void* stream) {
+  DQ_REQUIRE(pred && target && loss_weight_dev && t && loss_out && scratch, "dq_mse_loss_weighted_fwd_bwd: null argument");
+  DQ_REQUIRE(B > 0 && per_sample > 0, "dq_mse_loss_weighted_fwd_bwd: B and per_sample must be positive");
+  return launch_mse_fwd_bwd(pred, target, loss_out, grad_out, scratch, (int64_t)B * per_sample, (hipStream_t)stream, loss_weight_dev,
+                            t, per_sample, target_mul, target_add);
+}
+
 int dq_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float* scratch,
                        float grad_scale, float max_norm, double lr, double beta1, double beta2, double eps, double weight_decay,
                        int step, float* gnorm_out, void* stream) {
@@ -579,9 +594,12 @@ int dq_adamw_clip_step(float* params, const float* grads, float* exp_avg, float*
 
 int dq_train_step(dq_plan* plan, const float* params, const float* rope_freqs, const float* alpha_bars_dev, const float* x0,
                   const float* ms2_cond, const float* ms1_cond, const int64_t* t, const float* noise, int auto_normalize,
-                  float* grads, float* loss_out, void* workspace, int64_t workspace_bytes, int B, int RT, void* stream) {
+                  int pred_type, const float* loss_weight_dev, float* grads, float* loss_out, void* workspace,
+                  int64_t workspace_bytes, int B, int RT, void* stream) {
   DQ_REQUIRE(plan && params && alpha_bars_dev && x0 && ms2_cond && ms1_cond && t && noise && grads && loss_out && workspace,
              "dq_train_step: null argument");
+  DQ_REQUIRE(pred_type == DQ_PRED_EPS || pred_type == DQ_PRED_X0, "dq_train_step: Unknown pred_type");
+  DQ_REQUIRE(pred_type == DQ_PRED_EPS || loss_weight_dev, "dq_train_step: pred_type x0 needs the loss-weight (SNR) table");
   DQ_REQUIRE(B > 0 && RT > 0, "dq_train_step: B and RT must be positive");
   DQ_TRY(ensure_arena(plan, B, RT));
   const Arena& a = plan->arena;
@@ -595,17 +613,22 @@ int dq_train_step(dq_plan* plan, const float* params, const float* rope_freqs, c
   DQ_TRY(launch_q_sample(alpha_bars_dev, x0, t, noise, c.w(a.xa), B, per, auto_normalize, s));               // model.py:349-352
   DQ_TRY(unet_forward(c, rope_freqs, c.w(a.xa), t, 0, ms2_cond, ms1_cond, cm, ca, plan->dev, c.w(a.eps)));   // model.py:359
   // the gradient twin is zeroed inside unet_backward, so the loss gradient goes to a forward-arena buffer (xb)
-  DQ_TRY(launch_mse_fwd_bwd(c.w(a.eps), noise, loss_out, c.w(a.xb), c.w(a.partials), B * per, s));           // model.py:361
+  if (pred_type == DQ_PRED_X0)  // model.py:372-376, 404: target = normalised x0, per-sample weight loss_weight[t_b]
+    DQ_TRY(launch_mse_fwd_bwd(c.w(a.eps), x0, loss_out, c.w(a.xb), c.w(a.partials), B * per, s, loss_weight_dev, t, per, cm, ca));
+  else
+    DQ_TRY(launch_mse_fwd_bwd(c.w(a.eps), noise, loss_out, c.w(a.xb), c.w(a.partials), B * per, s));         // model.py:361
   DQ_TRY(unet_backward(c, rope_freqs, ms2_cond, cm, ca, plan->dev, c.w(a.xb), nullptr));
   return 0;
 }
 
 int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, const float* alpha_bars_host, const float* x_T,
-                   const float* ms2_cond, const float* ms1_cond, int auto_normalize, const int32_t* timesteps_host,
-                   int num_steps, float* out_x, float* out_noise, float* traj_x, float* traj_eps, int use_graph, void* workspace,
-                   int64_t workspace_bytes, int B, int RT, void* stream) {
+                   const float* ms2_cond, const float* ms1_cond, int auto_normalize, int pred_type,
+                   const int32_t* timesteps_host, int num_steps, float* out_x, float* out_noise, float* traj_x, float* traj_eps,
+                   int use_graph, void* workspace, int64_t workspace_bytes, int B, int RT, void* stream) {
   DQ_REQUIRE(plan && params && alpha_bars_host && x_T && ms2_cond && ms1_cond && timesteps_host && out_x && out_noise && workspace,
              "dq_ddim_sample: null argument");
+  DQ_REQUIRE(pred_type == DQ_PRED_EPS || pred_type == DQ_PRED_X0, "dq_ddim_sample: Unknown pred_type");
+  const int px0 = pred_type == DQ_PRED_X0;
   DQ_REQUIRE(B > 0 && RT > 0 && num_steps >= 1 && num_steps <= 1024, "dq_ddim_sample: need B, RT > 0 and 1 <= num_steps <= 1024");
   DQ_TRY(ensure_arena(plan, B, RT));
   const Arena& a = plan->arena;
@@ -652,7 +675,7 @@ int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, 
     DQ_HIP_OK(hipMemcpyAsync(c.w(a.c1_stage), ms1_cond, sizeof(float) * (int64_t)B * RT, hipMemcpyDeviceToDevice, s));
     DQ_HIP_OK(hipStreamSynchronize(s));  // ts is caller memory; also keeps the capture below free of pending copies
     const bool valid = plan->step_exec && plan->g_params == params && plan->g_rope == rope_freqs && plan->g_ws == workspace &&
-                       plan->g_B == B && plan->g_RT == RT && plan->g_norm == auto_normalize;
+                       plan->g_B == B && plan->g_RT == RT && plan->g_norm == auto_normalize && plan->g_pred == pred_type;
     if (!valid) {
       if (plan->step_exec) { (void)hipGraphExecDestroy(plan->step_exec); plan->step_exec = nullptr; }
       if (plan->step_graph) { (void)hipGraphDestroy(plan->step_graph); plan->step_graph = nullptr; }
@@ -664,7 +687,7 @@ int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, 
       cc.save = false;
       DQ_HIP_OK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
       int rc = unet_forward(cc, rope_freqs, xa, nullptr, 0, c.w(a.c2_stage), c.w(a.c1_stage), cm, ca, plan->dev, c.w(a.eps), ts_tab, step);
-      if (!rc) rc = launch_ddim_step(xa, c.w(a.eps), xa, c.w(a.coef), n, step, cs);  // in place: element-wise
+      if (!rc) rc = launch_ddim_step(xa, c.w(a.eps), xa, c.w(a.coef), n, step, cs, px0, nullptr);  // in place: element-wise
       if (!rc) rc = launch_inc_step(step, cs);
       hipGraph_t g = nullptr;
       const hipError_t ce = hipStreamEndCapture(cs, &g);
@@ -672,17 +695,19 @@ int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, 
       DQ_HIP_OK(ce);
       plan->step_graph = g;
       DQ_HIP_OK(hipGraphInstantiate(&plan->step_exec, g, nullptr, nullptr, 0));
-      plan->g_params = params; plan->g_rope = rope_freqs; plan->g_ws = workspace; plan->g_B = B; plan->g_RT = RT; plan->g_norm = auto_normalize;
+      plan->g_params = params; plan->g_rope = rope_freqs; plan->g_ws = workspace; plan->g_B = B; plan->g_RT = RT; plan->g_norm = auto_normalize; plan->g_pred = pred_type;
     }
     for (int i = 0; i < num_steps; ++i) DQ_HIP_OK(hipGraphLaunch(plan->step_exec, s));
     DQ_TRY(launch_sample_finish(xa, ms2_cond, out_x, out_noise, n, auto_normalize, s));
     return 0;
   }
   for (int i = 0; i < num_steps; ++i) {
-    float* eps = traj_eps ? traj_eps + (int64_t)i * n : c.w(a.eps);
-    DQ_TRY(unet_forward(c, rope_freqs, xa, nullptr, ts[i], ms2_cond, ms1_cond, cm, ca, plan->dev, eps));  // model.py:271
+    // eps objective: the network output IS the trajectory's eps; x0 objective: it goes to the arena, the derived eps to the trajectory
+    float* eps = (traj_eps && !px0) ? traj_eps + (int64_t)i * n : c.w(a.eps);
+    DQ_TRY(unet_forward(c, rope_freqs, xa, nullptr, ts[i], ms2_cond, ms1_cond, cm, ca, plan->dev, eps));  // model.py:271 / :276
     float* xn = traj_x ? traj_x + (int64_t)i * n : xb;
-    DQ_TRY(launch_ddim_step(xa, eps, xn, c.w(a.coef) + 4 * i, n, nullptr, s));                             // model.py:273-289
+    DQ_TRY(launch_ddim_step(xa, eps, xn, c.w(a.coef) + 4 * i, n, nullptr, s, px0,
+                            (traj_eps && px0) ? traj_eps + (int64_t)i * n : nullptr));                    // model.py:273-289
     if (traj_x) {
       DQ_HIP_OK(hipMemcpyAsync(xa, xn, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
     } else {

@@ -42,22 +42,30 @@ int launch_q_sample(const float* alpha_bars, const float* x0, const int64_t* t, 
 
 // ---- K9: x0 = (x_t - sb*eps)/sa ; x_prev = sap*x0 + sbp*eps (t>0) else x0 : 12 B / element
 // ``coef`` is a device table of 4 floats per step [sa, sb, sap, sbp]; sap < 0 marks the t == 0 step.
+// PRED_X0 (model.py:274-278): ``eps`` holds the network's x0 prediction, eps = (x_t - sa*x0)/sb is derived (and written to
+// eps_out when given: p_sample returns it).
+template <bool PRED_X0>
 __global__ void __launch_bounds__(256) k_ddim_step(const float* __restrict__ x_t, const float* __restrict__ eps,
-                                                   float* __restrict__ x_prev, const float* __restrict__ coef, int64_t n4,
-                                                   const int* __restrict__ step_ptr) {
+                                                   float* __restrict__ x_prev, float* __restrict__ eps_out,
+                                                   const float* __restrict__ coef, int64_t n4, const int* __restrict__ step_ptr) {
   if (step_ptr) coef += 4 * step_ptr[0];  // graph replay: this step's row of the coefficient table
   const float sa = coef[0], sb = coef[1], sap = coef[2], sbp = coef[3];
   const bool last = sap < 0.f;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const float4 x = reinterpret_cast<const float4*>(x_t)[i];
     const float4 e = reinterpret_cast<const float4*>(eps)[i];
-    float4 o;
-    float x0;
-    x0 = (x.x - sb * e.x) / sa; o.x = last ? x0 : sap * x0 + sbp * e.x;
-    x0 = (x.y - sb * e.y) / sa; o.y = last ? x0 : sap * x0 + sbp * e.y;
-    x0 = (x.z - sb * e.z) / sa; o.z = last ? x0 : sap * x0 + sbp * e.z;
-    x0 = (x.w - sb * e.w) / sa; o.w = last ? x0 : sap * x0 + sbp * e.w;
-    reinterpret_cast<float4*>(x_prev)[i] = o;
+    const float xv[4] = {x.x, x.y, x.z, x.w}, ev[4] = {e.x, e.y, e.z, e.w};
+    float ov[4], dv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x0, ep;
+      if (PRED_X0) { x0 = ev[j]; ep = (xv[j] - sa * x0) / sb; }
+      else         { ep = ev[j]; x0 = (xv[j] - sb * ep) / sa; }
+      ov[j] = last ? x0 : sap * x0 + sbp * ep;
+      dv[j] = ep;
+    }
+    reinterpret_cast<float4*>(x_prev)[i] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    if (PRED_X0 && eps_out) reinterpret_cast<float4*>(eps_out)[i] = make_float4(dv[0], dv[1], dv[2], dv[3]);
   }
 }
 
@@ -70,11 +78,12 @@ int launch_inc_step(int* p, hipStream_t s) {
 }
 
 int launch_ddim_step(const float* x_t, const float* eps, float* x_prev, const float* coef_dev, int64_t n, const int* step_ptr,
-                     hipStream_t s) {
+                     hipStream_t s, int pred_x0, float* eps_out) {
   DQ_REQUIRE(n % 4 == 0, "ddim_step: element count must be a multiple of 4");
   if (n == 0) return 0;
   const int grid = (int)std::min<int64_t>(cdiv(n / 4, 256), 2048);
-  hipLaunchKernelGGL(k_ddim_step, dim3(grid), dim3(256), 0, s, x_t, eps, x_prev, coef_dev, n / 4, step_ptr);
+  if (pred_x0) hipLaunchKernelGGL(k_ddim_step<true>, dim3(grid), dim3(256), 0, s, x_t, eps, x_prev, eps_out, coef_dev, n / 4, step_ptr);
+  else hipLaunchKernelGGL(k_ddim_step<false>, dim3(grid), dim3(256), 0, s, x_t, eps, x_prev, eps_out, coef_dev, n / 4, step_ptr);
   DQ_LAUNCH_CHECK();
   return 0;
 }
@@ -113,19 +122,28 @@ int launch_sample_finish(const float* x, const float* ms2_cond, float* out_x, fl
 
 // ---- K10: loss = mean((eps-noise)^2) ; grad = 2*(eps-noise)*gscale : 12 B / element
 // partial sums go to ``partials`` (one per block, fixed order => deterministic); k_loss_final sums them.
+// Weighted form (pred_type "x0", model.py:372-376, 404): target' = target*tm + ta (the normalised x0), every sample's
+// squared error and gradient are multiplied by lw[t[b]] (the SNR table); lw == nullptr => weight 1.
 __global__ void __launch_bounds__(256) k_mse_fwd_bwd(const float* __restrict__ eps, const float* __restrict__ noise,
                                                      float* __restrict__ grad, float* __restrict__ partials, int64_t n4,
-                                                     float gscale) {
+                                                     float gscale, const float* __restrict__ lw, const int64_t* __restrict__ t,
+                                                     int64_t per4, float tm, float ta) {
   float acc = 0.f;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const float4 e = reinterpret_cast<const float4*>(eps)[i];
-    const float4 z = reinterpret_cast<const float4*>(noise)[i];
+    float4 z = reinterpret_cast<const float4*>(noise)[i];
+    float w = 1.f;
+    if (lw) {
+      w = lw[t[i / per4]];
+      z.x = z.x * tm + ta; z.y = z.y * tm + ta; z.z = z.z * tm + ta; z.w = z.w * tm + ta;
+    }
     float4 d;
     d.x = e.x - z.x; d.y = e.y - z.y; d.z = e.z - z.z; d.w = e.w - z.w;
-    acc += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+    acc += w * (d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w);
     if (grad) {
+      const float gs = gscale * w;
       float4 g;
-      g.x = d.x * gscale; g.y = d.y * gscale; g.z = d.z * gscale; g.w = d.w * gscale;
+      g.x = d.x * gs; g.y = d.y * gs; g.z = d.z * gs; g.w = d.w * gs;
       reinterpret_cast<float4*>(grad)[i] = g;
     }
   }
@@ -155,10 +173,13 @@ int launch_axpy(float* dst, const float* src, int64_t n, hipStream_t s) {
 }
 
 int launch_mse_fwd_bwd(const float* eps, const float* noise, float* loss_out, float* grad_out, float* partials, int64_t n,
-                       hipStream_t s) {
+                       hipStream_t s, const float* lw, const int64_t* t, int64_t per_sample, float tm, float ta) {
   DQ_REQUIRE(n % 4 == 0 && n > 0, "mse: element count must be a positive multiple of 4");
+  DQ_REQUIRE(!lw || (t && per_sample > 0 && per_sample % 4 == 0 && n % per_sample == 0),
+             "mse: the weighted form needs t and a per-sample element count that is a multiple of 4");
   const int grid = (int)std::min<int64_t>(cdiv(n / 4, 256), MSE_MAX_BLOCKS);
-  hipLaunchKernelGGL(k_mse_fwd_bwd, dim3(grid), dim3(256), 0, s, eps, noise, grad_out, partials, n / 4, 2.0f / (float)n);
+  hipLaunchKernelGGL(k_mse_fwd_bwd, dim3(grid), dim3(256), 0, s, eps, noise, grad_out, partials, n / 4, 2.0f / (float)n, lw, t,
+                     lw ? per_sample / 4 : (int64_t)1, tm, ta);
   DQ_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, s, partials, grid, 1.0f / (float)n, loss_out);
   DQ_LAUNCH_CHECK();

@@ -8,6 +8,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DQ_HIP_LIB", os.path.join(os.path.dirname(_HERE), "libdq_hip.so"))
 
 _lib = None
+ABI_VERSION = 2  # DQ_ABI_VERSION of include/dq_hip.h this table was written against
+PRED_TYPES = {"eps": 0, "x0": 1}  # DQ_PRED_EPS / DQ_PRED_X0
 
 # name -> (restype, argtypes); this table is checked against include/dq_hip.h by tests/test_abi.py
 PROTOTYPES = {
@@ -21,16 +23,19 @@ PROTOTYPES = {
     "dq_unet_workspace_bytes": (c_int64, [c_void_p, c_int, c_int, c_int]),
     "dq_q_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "dq_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dq_ddim_step_x0": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "dq_unet_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_float,
                             c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "dq_unet_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_int64, c_int, c_int, c_void_p]),
     "dq_mse_loss_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dq_mse_loss_weighted_fwd_bwd": (c_int, [c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_int, c_int64, c_void_p]),
     "dq_adamw_clip_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_double,
                                    c_double, c_double, c_double, c_double, c_int, c_void_p, c_void_p]),
     "dq_train_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                              c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
-    "dq_ddim_sample": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_float), c_void_p, c_void_p, c_void_p, c_int,
+                              c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "dq_ddim_sample": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_float), c_void_p, c_void_p, c_void_p, c_int, c_int,
                                POINTER(c_int32), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int,
                                c_void_p]),
     "dq_debug_tensor_offset": (c_int64, [c_void_p, c_char_p]),
@@ -52,6 +57,8 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        if L.dq_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {L.dq_abi_version()}, this package binds version {ABI_VERSION}: rebuild it")
         _lib = L
     return _lib
 

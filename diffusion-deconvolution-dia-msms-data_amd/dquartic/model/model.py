@@ -8,7 +8,8 @@ gradient buffer).  Any other ``nn.Module`` is driven with plain tensor ops exact
 stays usable as a generic harness -- but that is the caller's network, not this package's hot path.
 
 Documented deviations: batches are supported and ``train_step`` returns a 0-dim loss (the mean over
-samples of the reference's B = 1 loss); ``ms1_loss_weight > 0`` and ``pred_type="x0"`` are "next" rows.
+samples of the reference's B = 1 loss); both ``pred_type`` values are built, ``ms1_loss_weight > 0`` is not (the
+reference's branch raises TypeError).
 """
 import ctypes
 import math
@@ -76,7 +77,7 @@ class DDIMDiffusionModel(ModelInterface):
         alphas = get_alphas(betas).to(torch.float32)
         alpha_bars = get_alpha_bars(alphas).to(torch.float32)
         self.betas, self.alphas, self.alpha_bars = betas.to(device), alphas.to(device), alpha_bars.to(device)
-        snr = self.alpha_bars / (1 - self.alpha_bars)
+        snr = (alpha_bars / (1 - alpha_bars)).to(device)  # model.py:205
         if pred_type == "eps":
             self.loss_weight = torch.ones_like(snr)
         elif pred_type == "x0":
@@ -132,26 +133,29 @@ class DDIMDiffusionModel(ModelInterface):
         t_tensor = torch.full((batch_size,), int(t), device=x_t.device, dtype=torch.long)
         ab = self.alpha_bars[t]
         sa, sb = torch.sqrt(ab), torch.sqrt(1.0 - ab)
-        if self.pred_type == "eps":
-            eps_pred = self.model(x_t, t_tensor, init_cond, attn_cond)
-            x0_pred = None
-        elif self.pred_type == "x0":
-            x0_pred = self.model(x_t, t_tensor, init_cond, attn_cond)
-            eps_pred = (x_t - sa * x0_pred) / sb
-        else:
+        if self.pred_type not in N.PRED_TYPES:
             raise ValueError(f"Unknown pred_type: {self.pred_type}")
-        if x_t.is_cuda and self.pred_type == "eps":
+        out = self.model(x_t, t_tensor, init_cond, attn_cond)  # eps_pred or x0_pred (model.py:271 / :276)
+        if x_t.is_cuda:
             if t > 0:
                 abp = self.alpha_bars[t - 1]
                 coef = torch.stack([sa, sb, torch.sqrt(abp), torch.sqrt(1.0 - abp)]).to(x_t.device, torch.float32)
             else:
                 coef = torch.stack([sa, sb, -torch.ones_like(sa), torch.zeros_like(sa)]).to(x_t.device, torch.float32)
-            xt, ep = x_t.detach().float().contiguous(), eps_pred.detach().float().contiguous()
+            xt, o = x_t.detach().float().contiguous(), out.detach().float().contiguous()
             x_prev = torch.empty_like(xt)
-            N.check(N.lib().dq_ddim_step(N.ptr(xt), N.ptr(ep), N.ptr(x_prev), N.ptr(coef), xt.numel(), N.stream_ptr()), "dq_ddim_step")
+            if self.pred_type == "eps":
+                N.check(N.lib().dq_ddim_step(N.ptr(xt), N.ptr(o), N.ptr(x_prev), N.ptr(coef), xt.numel(), N.stream_ptr()), "dq_ddim_step")
+                return x_prev, out
+            eps_pred = torch.empty_like(xt)
+            N.check(N.lib().dq_ddim_step_x0(N.ptr(xt), N.ptr(o), N.ptr(x_prev), N.ptr(eps_pred), N.ptr(coef), xt.numel(),
+                                            N.stream_ptr()), "dq_ddim_step_x0")
             return x_prev, eps_pred
-        if x0_pred is None:
-            x0_pred = (x_t - sb * eps_pred) / sa
+        # host tensors (only reachable with a non-native network): the reference's arithmetic as is
+        if self.pred_type == "eps":
+            eps_pred, x0_pred = out, (x_t - sb * out) / sa
+        else:
+            x0_pred, eps_pred = out, (x_t - sa * out) / sb
         if t > 0:
             abp = self.alpha_bars[t - 1]
             x_prev = torch.sqrt(abp) * x0_pred + torch.sqrt(1.0 - abp) * eps_pred
@@ -161,7 +165,7 @@ class DDIMDiffusionModel(ModelInterface):
 
     def sample(self, x_t, ms2_cond=None, ms1_cond=None, num_steps=1000, return_trajectory=False):
         """model.py:293-324: returns (denoised, mixture - denoised).  Native loop when the network is UNet1d."""
-        if self.native and x_t.is_cuda and self.pred_type == "eps" and ms2_cond is not None and ms1_cond is not None:
+        if self.native and x_t.is_cuda and ms2_cond is not None and ms1_cond is not None:
             return self._sample_native(x_t, ms2_cond, ms1_cond, num_steps, return_trajectory)
         ms2n = self.normalize(ms2_cond) if ms2_cond is not None else None
         ms1n = self.normalize(ms1_cond) if ms1_cond is not None else None
@@ -188,7 +192,8 @@ class DDIMDiffusionModel(ModelInterface):
         traj_x = torch.empty((num_steps, B, RT, MZ), device=x_T.device) if return_trajectory else None
         traj_e = torch.empty((num_steps, B, RT, MZ), device=x_T.device) if return_trajectory else None
         N.check(N.lib().dq_ddim_sample(net._plan, N.ptr(flat), N.ptr(net.rope_freqs()), self._alpha_bars_host(), N.ptr(x_T), N.ptr(c2),
-                                       N.ptr(c1), 1 if self.auto_normalize else 0, ts_c, num_steps, N.ptr(out_x), N.ptr(out_n),
+                                       N.ptr(c1), 1 if self.auto_normalize else 0, N.PRED_TYPES[self.pred_type], ts_c, num_steps,
+                                       N.ptr(out_x), N.ptr(out_n),
                                        N.ptr(traj_x), N.ptr(traj_e), 1 if (self.use_graph and not return_trajectory) else 0, N.ptr(ws),
                                        ws.numel(), B, RT, N.stream_ptr()), "dq_ddim_sample")
         if return_trajectory:
@@ -197,13 +202,14 @@ class DDIMDiffusionModel(ModelInterface):
 
     # ------------------------------------------------------------------ training objective
     def train_step(self, x_0, ms2_cond=None, ms1_cond=None, noise=None, ms1_loss_weight=0.0, t=None):
-        """model.py:326-406 (eps objective).  Draw order as in the reference: ``randint`` then ``randn_like``.
-        A passed ``noise`` is mapped 2*noise-1 like the reference does (model.py:346).  Returns a 0-dim loss that carries
-        autograd history through the native network (generic path; the fused path is ``train_step_fused``)."""
+        """model.py:326-406 (both pred types, ms1_loss_weight = 0).  Draw order as in the reference: ``randint`` then
+        ``randn_like``.  A passed ``noise`` is mapped 2*noise-1 like the reference does (model.py:346).  Returns a 0-dim loss
+        (mean over samples of loss_weight[t_b] * MSE_b) that carries autograd history through the native network (generic
+        path; the fused path is ``train_step_fused``)."""
         if ms1_loss_weight and ms1_loss_weight > 0.0:
             raise NotImplementedError("ms1_loss_weight > 0 is not built (the reference's branch raises TypeError; SURVEY 8f)")
-        if self.pred_type != "eps":
-            raise NotImplementedError('pred_type="x0" training is not built (SURVEY 8f)')
+        if self.pred_type not in N.PRED_TYPES:
+            raise ValueError(f"Unknown pred_type: {self.pred_type}")
         batch_size = x_0.size(0)
         if t is None:
             t = torch.randint(0, self.num_timesteps, (batch_size,), device=x_0.device).long()
@@ -212,9 +218,11 @@ class DDIMDiffusionModel(ModelInterface):
         ms2n = self.normalize(ms2_cond) if ms2_cond is not None else None
         ms1n = self.normalize(ms1_cond) if ms1_cond is not None else None
         x_t = self.q_sample(x_0, t, noise=noise)
-        eps_pred = self.model(x_t, t, ms2n, ms1n)
-        loss = F.mse_loss(eps_pred, noise)
-        return loss * 1.0  # loss_weight is all-ones for the eps objective (model.py:208-209, 404)
+        out = self.model(x_t, t, ms2n, ms1n)
+        if self.pred_type == "eps":
+            return F.mse_loss(out, noise) * 1.0  # loss_weight is all-ones for the eps objective (model.py:208-209, 404)
+        per_sample = ((out - x_0) ** 2).flatten(1).mean(dim=1)  # model.py:376 at B = 1, per sample here
+        return (per_sample * self.loss_weight.to(per_sample.device)[t]).mean()  # model.py:404
 
     def train_step_fused(self, x_0, ms2_cond, ms1_cond, t=None, noise=None, zero_grads=True):
         """One native call: normalise, q_sample, U-Net forward, MSE, backward into ``model.flat_grads()`` (+=).
@@ -238,7 +246,8 @@ class DDIMDiffusionModel(ModelInterface):
         ws = net.workspace(B, RT, True)
         loss = torch.empty((), dtype=torch.float32, device=x_0.device)
         ab = self.alpha_bars.to(x_0.device)
+        lw = self.loss_weight.to(device=x_0.device, dtype=torch.float32).contiguous()
         N.check(N.lib().dq_train_step(net._plan, N.ptr(flat), N.ptr(net.rope_freqs()), N.ptr(ab), N.ptr(x_0), N.ptr(c2), N.ptr(c1),
-                                      N.ptr(t), N.ptr(noise), 1 if self.auto_normalize else 0, N.ptr(grads), N.ptr(loss), N.ptr(ws),
-                                      ws.numel(), B, RT, N.stream_ptr()), "dq_train_step")
+                                      N.ptr(t), N.ptr(noise), 1 if self.auto_normalize else 0, N.PRED_TYPES[self.pred_type], N.ptr(lw),
+                                      N.ptr(grads), N.ptr(loss), N.ptr(ws), ws.numel(), B, RT, N.stream_ptr()), "dq_train_step")
         return loss

@@ -30,8 +30,13 @@ typedef struct dq_plan dq_plan;
 
 /* Text of the last error on this thread ("" if none). */
 const char* dq_last_error(void);
-/* ABI version of this header (bumped on any signature change). */
+/* ABI version of this header (bumped on any signature change).  2: pred_type arguments, dq_ddim_step_x0,
+ * dq_mse_loss_weighted_fwd_bwd. */
 int dq_abi_version(void);
+#define DQ_ABI_VERSION 2
+
+/* DDIMDiffusionModel.pred_type (model.py:205-213, 269-280, 354-389); any other value is rejected ("Unknown pred_type"). */
+enum { DQ_PRED_EPS = 0, DQ_PRED_X0 = 1 };
 
 /* ---- network description -------------------------------------------------------------------------------------
  * Replaces UNet1d.__init__ (unet1d.py:918-1084) for simple=True, conditional=True, channels=1,
@@ -57,6 +62,10 @@ int dq_q_sample(const float* alpha_bars_dev, const float* x0, const int64_t* t, 
  * coef_dev: 4 device floats [sqrt(ab_t), sqrt(1-ab_t), sqrt(ab_{t-1}), sqrt(1-ab_{t-1})]; coef_dev[2] < 0 means t == 0
  * (x_prev = x0_pred). */
 int dq_ddim_step(const float* x_t, const float* eps, float* x_prev, const float* coef_dev, int64_t n, void* stream);
+/* pred_type "x0" (model.py:274-278): the network output is x0_pred; eps = (x_t - sqrt(ab_t)*x0_pred)/sqrt(1-ab_t) is derived
+ * and written to eps_out (nullable); x_prev as above. */
+int dq_ddim_step_x0(const float* x_t, const float* x0_pred, float* x_prev, float* eps_out, const float* coef_dev, int64_t n,
+                    void* stream);
 
 /* ---- K1-K8: UNet1d.forward (unet1d.py:1086-1166) ---------------------------------------------------------------
  * params: flat parameter buffer; rope_freqs: the 8 non-trainable RoPE frequencies (device).
@@ -78,6 +87,11 @@ int dq_unet_bwd(dq_plan* plan, const float* params, const float* rope_freqs, con
  * scratch: >= 1024 device floats. */
 int dq_mse_loss_fwd_bwd(const float* eps, const float* noise, float* loss_out, float* grad_out, float* scratch, int64_t n,
                         void* stream);
+/* pred_type "x0" (model.py:372-376, 404): loss = mean over samples b of loss_weight_dev[t_b] * MSE_b(pred, target*target_mul +
+ * target_add); loss_weight_dev: the T-entry table DDIMDiffusionModel.loss_weight (SNR, model.py:205-210); grad_out nullable. */
+int dq_mse_loss_weighted_fwd_bwd(const float* pred, const float* target, float target_mul, float target_add,
+                                 const float* loss_weight_dev, const int64_t* t, float* loss_out, float* grad_out, float* scratch,
+                                 int B, int64_t per_sample, void* stream);
 
 /* ---- K11: clip_grad_norm_(max_norm) + AdamW step (model_interface.py:1121-1122, torch defaults) ----------------
  * grads are first multiplied by grad_scale (1/world_size after a summing all-reduce), the global L2 norm of the
@@ -88,25 +102,28 @@ int dq_adamw_clip_step(float* params, const float* grads, float* exp_avg, float*
                        float grad_scale, float max_norm, double lr, double beta1, double beta2, double eps, double weight_decay,
                        int step, float* gnorm_out, void* stream);
 
-/* ---- DDIMDiffusionModel.train_step (model.py:326-406, eps objective) fused with its backward ------------------
+/* ---- DDIMDiffusionModel.train_step (model.py:326-406, ms1_loss_weight = 0) fused with its backward --------------
  * normalise x0/conds, q_sample, network forward, MSE loss, backward into grads (+=).  t (B) int64 and noise (B,RT,MZ) are
- * drawn by the caller (the reference draws randint then randn_like, model.py:344-346).  loss_out: 1 device float =
- * mean over the batch of the per-sample MSE. */
+ * drawn by the caller (the reference draws randint then randn_like, model.py:344-346).  pred_type DQ_PRED_EPS: target =
+ * noise, loss_weight_dev ignored (may be NULL); DQ_PRED_X0: target = normalised x0, every sample weighted by
+ * loss_weight_dev[t_b] (model.py:209-210, 404).  loss_out: 1 device float = mean over the batch of the per-sample loss. */
 int dq_train_step(dq_plan* plan, const float* params, const float* rope_freqs, const float* alpha_bars_dev, const float* x0,
                   const float* ms2_cond, const float* ms1_cond, const int64_t* t, const float* noise, int auto_normalize,
-                  float* grads, float* loss_out, void* workspace, int64_t workspace_bytes, int B, int RT, void* stream);
+                  int pred_type, const float* loss_weight_dev, float* grads, float* loss_out, void* workspace,
+                  int64_t workspace_bytes, int B, int RT, void* stream);
 
 /* ---- DDIMDiffusionModel.sample (model.py:293-324) --------------------------------------------------------------
  * Runs the whole strided loop natively over timesteps_host[num_steps] (host ints; the caller forms them as
  * trunc(linspace(T-1, 0, num_steps)), model.py:313): each step = network forward + K9 (landing on alpha_bars[t-1],
  * model.py:284), then the epilogue (model.py:319-322).  alpha_bars_host: T host floats.  x_T (B,RT,MZ) is not modified.  out_x = denoised in [0,1]; out_noise = mixture -
  * denoised.  traj_x / traj_eps (nullable): (num_steps,B,RT,MZ) per-step x_{t-1} and eps.  use_graph != 0 (and no trajectory
- * requested): one step is captured into a hipGraph (cached in the plan while params/workspace/B/RT stay the same) and
+ * requested; traj_eps always holds eps_pred, derived from the x0 prediction under DQ_PRED_X0): one step is captured
+ * into a hipGraph (cached in the plan while params/workspace/B/RT stay the same) and
  * replayed num_steps times; the conditions are staged inside the workspace, the step index lives on the device. */
 int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, const float* alpha_bars_host, const float* x_T,
-                   const float* ms2_cond, const float* ms1_cond, int auto_normalize, const int32_t* timesteps_host,
-                   int num_steps, float* out_x, float* out_noise, float* traj_x, float* traj_eps, int use_graph, void* workspace,
-                   int64_t workspace_bytes, int B, int RT, void* stream);
+                   const float* ms2_cond, const float* ms1_cond, int auto_normalize, int pred_type,
+                   const int32_t* timesteps_host, int num_steps, float* out_x, float* out_noise, float* traj_x, float* traj_eps,
+                   int use_graph, void* workspace, int64_t workspace_bytes, int B, int RT, void* stream);
 
 /* ---- building blocks exported for the per-block parity tests (tests/test_blocks_gpu.py) ------------------------
  * Residual(PreNorm(LinearAttention)) (unet1d.py:446-496, 1017) on (rows, C, n). */

@@ -137,6 +137,17 @@ def ddim_update(alpha_bars: torch.Tensor, x_t: torch.Tensor, eps: torch.Tensor, 
     return x0
 
 
+def ddim_update_x0(alpha_bars: torch.Tensor, x_t: torch.Tensor, x0_pred: torch.Tensor, t: int):
+    """model.py:274-289, pred_type='x0': the network output is x0; eps is derived from it.  Returns (x_prev, eps)."""
+    ab = alpha_bars[t]
+    sa, sb = torch.sqrt(ab), torch.sqrt(1.0 - ab)
+    eps = (x_t - sa * x0_pred) / sb
+    if t > 0:
+        abp = alpha_bars[t - 1]
+        return torch.sqrt(abp) * x0_pred + torch.sqrt(1.0 - abp) * eps, eps
+    return x0_pred, eps
+
+
 # --------------------------------------------------------------------------------------
 # network blocks (unet1d.py)
 # --------------------------------------------------------------------------------------
@@ -337,9 +348,18 @@ class Diffusion:
     kind: str = "cosine"
     use_rope: bool = True
     sched: Dict[str, torch.Tensor] = field(default_factory=dict)
+    pred_type: str = "eps"
 
     def __post_init__(self):
+        if self.pred_type not in ("eps", "x0"):
+            raise ValueError(f"Unknown pred_type: {self.pred_type}")  # model.py:213
         self.sched = make_schedule(self.T, self.kind)
+
+    @property
+    def loss_weight(self):
+        """model.py:205-211: ones for 'eps', SNR = ab / (1 - ab) for 'x0'."""
+        ab = self.alpha_bars
+        return torch.ones_like(ab) if self.pred_type == "eps" else ab / (1 - ab)
 
     @property
     def alpha_bars(self):
@@ -349,10 +369,12 @@ class Diffusion:
         return unet_forward(self.params, self.cfg, x_t, t, ms2_cond, ms1_cond, self.use_rope)
 
     def p_sample(self, x_t, t: int, ms2_cond, ms1_cond):
-        """model.py:244-291 (pred_type='eps').  Conditions are already normalised."""
+        """model.py:244-291.  Conditions are already normalised.  Returns (x_prev, eps_pred) for both pred types."""
         tt = torch.full((x_t.shape[0],), t, dtype=torch.long)
-        eps = self.net(x_t, tt, ms2_cond, ms1_cond)
-        return ddim_update(self.alpha_bars, x_t, eps, t), eps
+        out = self.net(x_t, tt, ms2_cond, ms1_cond)
+        if self.pred_type == "x0":
+            return ddim_update_x0(self.alpha_bars, x_t, out, t)
+        return ddim_update(self.alpha_bars, x_t, out, t), out
 
     def sample(self, x_T, ms2_cond, ms1_cond, num_steps: int, trace: Optional[list] = None):
         """model.py:293-324: returns (denoised in [0,1], mixture - denoised)."""
@@ -366,12 +388,16 @@ class Diffusion:
         return x, unnormalize(c2) - x
 
     def train_loss(self, x0, ms2_cond, ms1_cond, t, noise):
-        """model.py:344-361, 404 with explicit (t, noise): scalar mean-over-batch MSE (eps objective,
-        loss_weight == 1).  At B = 1 this equals the reference's (1,)-shaped loss."""
+        """model.py:344-361, 372-376, 404 with explicit (t, noise): mean over the batch of
+        loss_weight[t_b] * MSE_b (target = noise for 'eps', normalised x0 for 'x0'; ms1_loss_weight = 0).
+        At B = 1 this equals the reference's (1,)-shaped loss.  Returns (loss, network output)."""
         x0n, c2, c1 = normalize(x0), normalize(ms2_cond), normalize(ms1_cond)
         x_t = q_sample(self.alpha_bars, x0n, t, noise)
-        eps = self.net(x_t, t, c2, c1)
-        return F.mse_loss(eps, noise), eps
+        out = self.net(x_t, t, c2, c1)
+        if self.pred_type == "eps":
+            return F.mse_loss(out, noise), out
+        per = ((out - x0n) ** 2).flatten(1).mean(dim=1)
+        return (per * self.loss_weight[t]).mean(), out
 
 
 # --------------------------------------------------------------------------------------

@@ -275,6 +275,57 @@ def main():
             losses.append(torch.nn.functional.mse_loss(tnet(xti, tb[i:i + 1], ci, mi), nb[i:i + 1]))
     td.update({"batch/noise": nb, "batch/loss_mean": torch.stack(losses).mean()})
 
+    # ---------------------------------------------------------------- 4b. pred_type="x0" (model.py:209-210, 274-278, 372-376)
+    # own generator: must not disturb the draws of the sections below
+    g2 = torch.Generator().manual_seed(77)
+    dmx = ref_model.DDIMDiffusionModel(model_class=tnet, num_timesteps=1000, beta_schedule_type="cosine",
+                                       pred_type="x0", auto_normalize=True, ms1_loss_weight=0.0, device="cpu")
+    xd = {k: v for k, v in td.items() if k.startswith("w/")}
+    xd.update({"x0": x0, "ms2_cond": ms2c, "ms1_cond": ms1, "loss_weight": dmx.loss_weight})
+    xtx = torch.randn(1, RT, MZ, generator=g2)
+    xd["p/x_t"] = xtx
+    tnet.eval()
+    with torch.no_grad():
+        for tv in (999, 500, 1, 0):
+            xp, ep = dmx.p_sample(xtx, tv, dmx.normalize(ms2c), dmx.normalize(ms1))
+            xd[f"p/{tv}/x_prev"], xd[f"p/{tv}/eps"] = xp, ep
+        xx = xtx.clone()
+        traj_x, traj_e = [], []
+        for tv in torch.linspace(999, 0, 5, dtype=torch.long):
+            xx, ee = dmx.p_sample(xx, tv.item(), dmx.normalize(ms2c), dmx.normalize(ms1))
+            traj_x.append(xx.clone()), traj_e.append(ee.clone())
+        s, pn = dmx.sample(xtx.clone(), ms2c, ms1, num_steps=5)
+        xd["s5/traj_x"], xd["s5/traj_eps"], xd["s5/sample"], xd["s5/pred_noise"] = torch.stack(traj_x), torch.stack(traj_e), s, pn
+    tnet.train()
+    tnet.zero_grad()
+    torch.manual_seed(3)  # train_step draws (t, noise) itself: randint first, then randn_like (model.py:344-346)
+    lossx = dmx.train_step(x0, ms2c, ms1)
+    torch.manual_seed(3)
+    tx = torch.randint(0, 1000, (1,)).long()
+    nx = torch.randn_like(x0)
+    lossx.sum().backward()
+    xd.update({"train/t": tx, "train/noise": nx, "train/loss": lossx.detach()})
+    xd.update({"train/grad/" + k: p_.grad.detach().clone() for k, p_ in tnet.named_parameters() if p_.grad is not None})
+    tnet.zero_grad()
+    # B > 1: per-sample loop of the B = 1 reference train_step with pinned (t, noise): mean of the (1,)-shaped losses
+    nbx = torch.randn(Bn, RT, MZ, generator=g2)
+    tbx = torch.tensor([30, 640, 999])
+    lx = []
+    with torch.no_grad():
+        for i in range(Bn):
+            xi, ci, mi = dmx.normalize(xb[i:i + 1]), dmx.normalize(cb[i:i + 1]), dmx.normalize(mb[i:i + 1])
+            xti = dmx.q_sample(xi, tbx[i:i + 1], nbx[i:i + 1])
+            li = torch.nn.functional.mse_loss(tnet(xti, tbx[i:i + 1], ci, mi), xi) * dmx.loss_weight[tbx[i]]
+            lx.append(li)
+    xd.update({"batch/x": xb, "batch/init_cond": cb, "batch/attn_cond": mb, "batch/t": tbx, "batch/noise": nbx,
+               "batch/loss_mean": torch.stack(lx).mean(), "batch/losses": torch.stack(lx)})
+    np.savez_compressed(os.path.join(OUT, "tiny_x0.npz"), **npd(xd))
+    # oracle cross-check
+    _po = {k[2:]: v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v)) for k, v in xd.items() if k.startswith("w/")}
+    _od = O.Diffusion(_po, O.UNetConfig(dim=4, dim_mults=(1, 2), downsample_dim=8), pred_type="x0")
+    _l, _ = _od.train_loss(x0, ms2c, ms1, tx, nx)
+    assert abs(float(_l) - float(lossx)) <= 1e-5 * abs(float(lossx)), (float(_l), float(lossx))
+
     # _train_one_batch: params after 1 and 3 steps at lr=1e-5, losses, pre-clip grad norm
     dm._set_optimizer(1e-5)
     tnet.train()

@@ -190,3 +190,48 @@ def test_harness_contract(golden):
         s, pn = d.sample(T(g["pred/x_T"]), T(g["pred/ms2_cond"]), T(g["pred/ms1_cond"]), 5)
     close(s[0], g["pred/sample0"], rtol=3e-4)
     close(pn[0], g["pred/pred_noise0"], rtol=3e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# pred_type = "x0" (model.py:209-210, 274-278, 372-376): SURVEY 8(f) row 2
+# ---------------------------------------------------------------------------------------------------------------
+def _tiny_x0(golden):
+    g = golden("tiny_x0.npz")
+    return g, O.Diffusion(sub(g, "w/"), O.UNetConfig(dim_mults=(1, 2), downsample_dim=8), pred_type="x0")
+
+
+def test_x0_loss_weight_and_p_sample(golden):
+    g, d = _tiny_x0(golden)
+    assert np.array_equal(d.loss_weight.numpy(), g["loss_weight"])  # SNR table, bit-exact
+    c2, c1 = O.normalize(T(g["ms2_cond"])), O.normalize(T(g["ms1_cond"]))
+    with torch.no_grad():
+        for tv in (999, 500, 1, 0):
+            xp, ep = d.p_sample(T(g["p/x_t"]), tv, c2, c1)
+            close(ep, g[f"p/{tv}/eps"], rtol=1e-4)
+            close(xp, g[f"p/{tv}/x_prev"], rtol=1e-4)
+        tr = []
+        s, pn = d.sample(T(g["p/x_t"]), T(g["ms2_cond"]), T(g["ms1_cond"]), 5, trace=tr)
+    close(torch.stack([e for _, _, e in tr]), g["s5/traj_eps"], rtol=3e-4)
+    close(torch.stack([x for _, x, _ in tr]), g["s5/traj_x"], rtol=3e-4)
+    close(s, g["s5/sample"], rtol=3e-4)
+    close(pn, g["s5/pred_noise"], rtol=3e-4)
+
+
+def test_x0_train_loss_grads_and_batch(golden):
+    g, d = _tiny_x0(golden)
+    keys = O.trainable_keys(d.params)
+    for k in keys:
+        d.params[k].requires_grad_(True)
+    loss, _ = d.train_loss(T(g["x0"]), T(g["ms2_cond"]), T(g["ms1_cond"]), T(g["train/t"]), T(g["train/noise"]))
+    close(loss.reshape(1), g["train/loss"], rtol=1e-5)
+    loss.backward()
+    gmax = max(float(np.abs(g["train/grad/" + k]).max()) for k in keys)
+    for k in keys:
+        ref = T(g["train/grad/" + k])
+        err = float((d.params[k].grad - ref).abs().max())
+        assert err <= 2e-4 * max(float(ref.abs().max()), 1e-4 * gmax), (k, err)
+    with torch.no_grad():
+        lb, _ = d.train_loss(T(g["batch/x"]), T(g["batch/init_cond"]), T(g["batch/attn_cond"]), T(g["batch/t"]), T(g["batch/noise"]))
+    close(lb, g["batch/loss_mean"], rtol=1e-5)
+    with pytest.raises(ValueError):
+        O.Diffusion(d.params, d.cfg, pred_type="v")
