@@ -115,6 +115,35 @@ def roofline_linattn(device):
                            "launch_us": round(t_f * 1e6, 2), "flops_per_launch": fl_f}}
 
 
+def batch_formation(device):
+    """forming one training batch (gather + per-pair min-max + mixture, dq_pair_batch) from a dataset that is
+    resident in HBM; HBM-bound.  Algorithmic bytes per pair = read 2 windows + write ms2_1, ms2_2, ms2_cond (5 x RT*MZ*4 B)
+    + MS1 (read 2, write 2 rows).  4,096 resident windows (420 MB) so the gathers do not all hit the Infinity Cache."""
+    from dquartic import _native as N
+
+    n, B = 4096, TRAIN_BATCH
+    g = torch.Generator(device="cpu").manual_seed(0)
+    ms2 = torch.rand(n, RT, MZ, device=device)
+    ms1 = torch.rand(n, RT, device=device)
+    idx = torch.randint(0, n, (64, 2 * B), generator=g).to(device)
+    new = lambda *s: torch.empty(s, device=device)
+    a, b, c, m1, m2 = new(B, RT, MZ), new(B, RT, MZ), new(B, RT, MZ), new(B, RT), new(B, RT)
+    L = N.lib()
+    sc = torch.empty(L.dq_pair_batch_scratch_bytes(B) // 4, device=device)
+    k = [0]
+
+    def form():
+        k[0] = (k[0] + 1) % 64
+        N.check(L.dq_pair_batch(N.ptr(ms2), N.ptr(ms1), n, N.ptr(idx[k[0]]), B, RT, MZ, RT, 0.5, 0.5, N.ptr(a), N.ptr(m1), N.ptr(b),
+                                N.ptr(m2), N.ptr(c), N.ptr(sc), sc.numel() * 4, N.stream_ptr()), "dq_pair_batch")
+
+    t = time_kernel(form, iters=50)
+    nbytes = B * (5 * RT * MZ * 4 + 4 * RT * 4)
+    return {"kernel": "k_pair_minmax + k_pair_mix (dq_pair_batch)", "pairs_per_s": round(B / t, 1), "call_us": round(t * 1e6, 2),
+            "bound": "hbm", "achieved": round(nbytes / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / t / 8e12, 4),
+            "bytes_per_call": nbytes}
+
+
 def cpu_baseline(net):
     """The oracle (CPU restatement of the reference, kind 'port') on this box's host cores: per-sample (B = 1) train steps
     -- the only batch size the reference runs at -- incl. clip + AdamW, on a bounded sample of the same workload."""
@@ -247,6 +276,7 @@ def main():
 
     log("roofline leg")
     roof = roofline_linattn(device) if rank == 0 else None
+    form = batch_formation(device) if rank == 0 else None
     log("cpu baseline leg")
     cpu = cpu_baseline(net) if (rank == 0 and world == 1 and not args.no_cpu) else None
 
@@ -260,7 +290,7 @@ def main():
                                    "windows 400 RT x 64 m/z, batch 32 per GPU, fp32", "global_batch": world * TRAIN_BATCH,
                        "window": [RT, MZ], "parallelism": f"dp{world}"},
             "last_loss": round(last_loss, 6),
-            "sample": sample, "roofline": roof, "cpu_baseline": cpu,
+            "sample": sample, "roofline": roof, "cpu_baseline": cpu, "batch_formation": form,
         }
         print(json.dumps(out))
     if dist_on:

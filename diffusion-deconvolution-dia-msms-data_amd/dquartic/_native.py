@@ -38,6 +38,9 @@ PROTOTYPES = {
     "dq_ddim_sample": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_float), c_void_p, c_void_p, c_void_p, c_int, c_int,
                                POINTER(c_int32), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int,
                                c_void_p]),
+    "dq_pair_batch_scratch_bytes": (c_int64, [c_int]),
+    "dq_pair_batch": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int64, c_float, c_float, c_void_p,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "dq_debug_tensor_offset": (c_int64, [c_void_p, c_char_p]),
     "dq_linattn_fwd": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p]),
     "dq_linattn_bwd": (c_int, [c_void_p] * 15 + [c_int, c_int, c_int, c_void_p]),

@@ -40,7 +40,10 @@ def cli():
 @click.option("--checkpoint-path", default=None, help="Where to save the best model (overrides the config)")
 @click.option("--use-wandb", default=None, cls=PythonLiteralOption, help="Use wandb for logging (overrides the config)")
 @click.option("--threads", default=None, help="Data-loading worker processes (overrides the config)")
-def train(config_path, parquet_directory, ms2_data_path, ms1_data_path, batch_size, checkpoint_path, use_wandb, threads):
+@click.option("--resident-dataset", is_flag=True, default=False,
+              help="Keep the whole dataset in HBM and form batches on the GPU (dq_pair_batch) instead of a DataLoader")
+def train(config_path, parquet_directory, ms2_data_path, ms1_data_path, batch_size, checkpoint_path, use_wandb, threads,
+          resident_dataset):
     """Train a DDIM model on DIA-MS windows."""
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -72,8 +75,13 @@ def train(config_path, parquet_directory, ms2_data_path, ms1_data_path, batch_si
         dataset = DIAMSDataset(config["data"]["parquet_directory"], config["data"]["ms2_data_path"], config["data"]["ms1_data_path"],
                                normalize=config["data"]["normalize"])
     per_rank = max(1, int(m["batch_size"]) // world)
-    loader = DataLoader(dataset, batch_size=per_rank, shuffle=True, num_workers=int(config["threads"]), drop_last=len(dataset) > per_rank)
     device = torch.device("cuda", local)
+    if resident_dataset and not syn:
+        from .utils.data_loader import ResidentPairLoader
+
+        loader = ResidentPairLoader(dataset, per_rank, device=device, drop_last=len(dataset) // world > per_rank, rank=rank, world_size=world)
+    else:
+        loader = DataLoader(dataset, batch_size=per_rank, shuffle=True, num_workers=int(config["threads"]), drop_last=len(dataset) > per_rank)
     if m["use_model"] != "UNet1d":
         raise click.ClickException(f"use_model={m['use_model']!r}: only UNet1d is built (CustomTransformer is unreachable through "
                                    "DDIMDiffusionModel in the reference, SURVEY F3)")

@@ -286,10 +286,15 @@ class ModelInterface(object):
     def _train_one_epoch(self, epoch, dataloader, mixture_weights=(0.5, 0.5)):
         self.model.train()
         batch_loss = []
-        for batch_idx, (ms2_1, ms1_1, ms2_2, ms1_2) in enumerate(dataloader):
+        for batch_idx, batch in enumerate(dataloader):
+            ms2_1, ms1_1, ms2_2, ms1_2 = batch
             x_0, ms1_cond = ms2_1.to(self.device), ms1_1.to(self.device)
-            # simulated mixed spectra from the target window and the other window (reference :1073-1075)
-            ms2_cond = (ms2_1 * mixture_weights[0]).to(self.device) + (ms2_2 * mixture_weights[1]).to(self.device)
+            # simulated mixed spectra from the target window and the other window (reference :1073-1075); a resident loader
+            # (utils/data_loader.py:ResidentPairLoader) has already formed it on the GPU in the kernel that normalised the pair
+            if getattr(batch, "ms2_cond", None) is not None and batch.mixture_weights == tuple(float(w) for w in mixture_weights):
+                ms2_cond = batch.ms2_cond
+            else:
+                ms2_cond = (ms2_1 * mixture_weights[0]).to(self.device) + (ms2_2 * mixture_weights[1]).to(self.device)
             loss = self._train_one_batch(x_0, ms2_cond=ms2_cond, ms1_cond=ms1_cond, noise=None, ms1_loss_weight=self.ms1_loss_weight)
             batch_loss.append(loss)
             self.callback_handler.batch_callback(batch_idx, loss)

@@ -93,3 +93,93 @@ class DIAMSDataset(Dataset):
         else:
             raise ValueError("Invalid normalization method. Valid options are: None, 'minmax'.")
         return tuple(torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for v in (ms2_1, ms1_1, ms2_2, ms1_2))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# HBM-resident batch formation: not in the reference -- at ~2,500 windows/s per GPU the per-item numpy
+# min-max + collate + H2D copy of a DataLoader becomes the bottleneck, so the whole dataset lives in HBM (288 GB hold
+# ~2.8 M windows of 400 x 64) and a batch is formed by one native call (csrc/k_pairs.hip: dq_pair_batch).
+# ----------------------------------------------------------------------------------------------------------------------
+class PairBatch(tuple):
+    """``(ms2_1, ms1_1, ms2_2, ms1_2)`` -- what a ``DataLoader(DIAMSDataset)`` batch unpacks to -- already on the device,
+    plus ``ms2_cond`` = the mixture for ``mixture_weights`` (formed in the same kernel)."""
+
+    def __new__(cls, items, ms2_cond, mixture_weights):
+        self = super().__new__(cls, items)
+        self.ms2_cond = ms2_cond
+        self.mixture_weights = tuple(float(w) for w in mixture_weights)
+        return self
+
+
+class ResidentPairLoader:
+    """Drop-in for ``DataLoader(DIAMSDataset(...), batch_size=B)`` that keeps the windows in HBM.
+
+    Pairs are drawn on the host by ``dataset._draw_pair`` -- the reference's rule (data_loader.py:118-131: two
+    ``random.randint`` per attempt, distinct windows, unused this epoch) consuming the same ``random`` stream as iterating
+    the reference dataset in one process; the gather, the per-pair min-max (:70-79) and the mixture
+    (model_interface.py:1073-1075) run in ``dq_pair_batch``.  One epoch = ``len(dataset) // world_size`` pairs, like a
+    (distributed) sampler over a dataset whose ``__getitem__`` ignores its index.  Arithmetic is fp32: float64 source
+    arrays are converted once at upload (the reference normalises in the source dtype and casts afterwards)."""
+
+    def __init__(self, dataset, batch_size, device="cuda", mixture_weights=(0.5, 0.5), drop_last=False, rank=0, world_size=1):
+        from .. import _native as N
+
+        if getattr(dataset, "normalize", None) != "minmax":
+            raise ValueError("Invalid normalization method. Valid options are: None, 'minmax'.")  # data_loader.py:81
+        if getattr(dataset, "data_type", "npy") == "npy":
+            ms2, ms1 = np.asarray(dataset.ms2_data), np.asarray(dataset.ms1_data)
+            self._same = None
+        else:  # parquet backend: materialise every slice once
+            rows = [dataset._get_parquet_data(e) for e in dataset.meta]
+            ms1, ms2 = np.stack([r[0] for r in rows]), np.stack([r[1] for r in rows])
+            meta = dataset.meta
+            self._same = lambda a, b: meta[a][2] == meta[b][2] and meta[a][3] == meta[b][3]
+        if ms2.ndim != 3 or len(ms1) != len(ms2):
+            raise ValueError(f"expected ms2 (N, RT, MZ) and ms1 (N, ...), got {ms2.shape} and {ms1.shape}")
+        self._N = N
+        self.dataset, self.batch_size, self.device = dataset, int(batch_size), torch.device(device)
+        self.mixture_weights = tuple(float(w) for w in mixture_weights)
+        self.drop_last, self.rank, self.world_size = bool(drop_last), int(rank), int(world_size)
+        N.lib()  # fail loudly now if the native library is missing
+        import warnings
+
+        with warnings.catch_warnings():  # read-only mmap views are only read (uploaded) here
+            warnings.filterwarnings("ignore", message="The given NumPy array is not writable")
+            self.ms2 = torch.from_numpy(np.ascontiguousarray(ms2, dtype=np.float32)).to(self.device)
+            self.ms1 = torch.from_numpy(np.ascontiguousarray(ms1, dtype=np.float32)).to(self.device)
+        self.n, self.RT, self.MZ = self.ms2.shape
+        self.ms1_shape = tuple(self.ms1.shape[1:])
+        self.ms1_per = int(np.prod(self.ms1_shape)) if self.ms1_shape else 1
+        self._scratch = torch.empty(max(1, N.lib().dq_pair_batch_scratch_bytes(self.batch_size) // 4), dtype=torch.float32, device=self.device)
+
+    def _items(self):
+        return max(1, len(self.dataset) // self.world_size)
+
+    def __len__(self):
+        n = self._items()
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def form(self, idx1, idx2):
+        """One native call for explicit index lists -> PairBatch (also the parity-test entry)."""
+        N = self._N
+        B = len(idx1)
+        if B != len(idx2) or B == 0 or B > self.batch_size:
+            raise ValueError(f"need 1..{self.batch_size} index pairs, got {len(idx1)} and {len(idx2)}")
+        idx = torch.tensor(list(idx1) + list(idx2), dtype=torch.int64).to(self.device, non_blocking=True)
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=self.device)
+        a, b, c = new(B, self.RT, self.MZ), new(B, self.RT, self.MZ), new(B, self.RT, self.MZ)
+        m1, m2 = new(B, *self.ms1_shape), new(B, *self.ms1_shape)
+        N.check(N.lib().dq_pair_batch(N.ptr(self.ms2), N.ptr(self.ms1), self.n, N.ptr(idx), B, self.RT, self.MZ, self.ms1_per,
+                                      self.mixture_weights[0], self.mixture_weights[1], N.ptr(a), N.ptr(m1), N.ptr(b), N.ptr(m2), N.ptr(c),
+                                      N.ptr(self._scratch), self._scratch.numel() * 4, N.stream_ptr()), "dq_pair_batch")
+        return PairBatch((a, m1, b, m2), c, self.mixture_weights)
+
+    def __iter__(self):
+        left = self._items()
+        while left > 0:
+            B = min(self.batch_size, left)
+            if B < self.batch_size and self.drop_last:
+                return
+            pairs = [self.dataset._draw_pair(self.n, self._same) for _ in range(B)]
+            left -= B
+            yield self.form([p[0] for p in pairs], [p[1] for p in pairs])

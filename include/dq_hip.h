@@ -31,7 +31,7 @@ typedef struct dq_plan dq_plan;
 /* Text of the last error on this thread ("" if none). */
 const char* dq_last_error(void);
 /* ABI version of this header (bumped on any signature change).  2: pred_type arguments, dq_ddim_step_x0,
- * dq_mse_loss_weighted_fwd_bwd. */
+ * dq_mse_loss_weighted_fwd_bwd, dq_pair_batch. */
 int dq_abi_version(void);
 #define DQ_ABI_VERSION 2
 
@@ -124,6 +124,20 @@ int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, 
                    const float* ms2_cond, const float* ms1_cond, int auto_normalize, int pred_type,
                    const int32_t* timesteps_host, int num_steps, float* out_x, float* out_noise, float* traj_x, float* traj_eps,
                    int use_graph, void* workspace, int64_t workspace_bytes, int B, int RT, void* stream);
+
+/* ---- batch formation from an HBM-resident dataset (the step right before the hot path) ------------
+ * Replaces, for B (window 1, window 2) pairs, DIAMSDataset.__getitem__'s min-max normalisation (utils/data_loader.py:70-79:
+ * MS2 min/max over both windows, MS1 min/max over window 1 only, (x - min) / (max - min), no epsilon: a constant pair gives
+ * NaN like the reference) and the mixture ms2_cond = w1*ms2_1 + w2*ms2_2 of _train_one_epoch (model_interface.py:1073-1075).
+ * Bit-identical to the reference's numpy/torch arithmetic on float32 data without NaNs.
+ * ms2_data (n_windows, RT, MZ), ms1_data (n_windows, ms1_per_window) fp32 on the device; idx_dev: 2*B device int64
+ * [idx1 (B) | idx2 (B)] -- a pair with an index outside [0, n_windows) is never dereferenced, its outputs are NaN.
+ * Outputs (device): ms2_1, ms2_2, ms2_cond (B, RT, MZ); ms1_1, ms1_2 (B, ms1_per_window); ms2_2 / ms1_2 / ms2_cond nullable.
+ * scratch: dq_pair_batch_scratch_bytes(B) bytes.  Asynchronous on stream, no host synchronisation. */
+int64_t dq_pair_batch_scratch_bytes(int B);
+int dq_pair_batch(const float* ms2_data, const float* ms1_data, int64_t n_windows, const int64_t* idx_dev, int B, int RT, int MZ,
+                  int64_t ms1_per_window, float w1, float w2, float* ms2_1, float* ms1_1, float* ms2_2, float* ms1_2,
+                  float* ms2_cond, void* scratch, int64_t scratch_bytes, void* stream);
 
 /* ---- building blocks exported for the per-block parity tests (tests/test_blocks_gpu.py) ------------------------
  * Residual(PreNorm(LinearAttention)) (unet1d.py:446-496, 1017) on (rows, C, n). */

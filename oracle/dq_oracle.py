@@ -401,6 +401,31 @@ class Diffusion:
 
 
 # --------------------------------------------------------------------------------------
+# batch formation: the step before the hot path
+# --------------------------------------------------------------------------------------
+def pair_batch(ms2_data, ms1_data, idx1, idx2, mixture_weights=(0.5, 0.5)):
+    """DIAMSDataset.__getitem__ (data_loader.py:70-79, normalize='minmax') for explicit index pairs + the mixture of
+    ModelInterface._train_one_epoch (model_interface.py:1073-1075).  numpy in the data's dtype, cast to float32 at the end
+    like the reference (:83-88); the mixture is formed on the float32 tensors.  Returns float32 arrays
+    (ms2_1, ms1_1, ms2_2, ms1_2, ms2_cond), each stacked over the pairs."""
+    import numpy as np
+
+    outs = [[], [], [], [], []]
+    for i, j in zip(idx1, idx2):
+        a, m1, b, m2 = ms2_data[i], ms1_data[i], ms2_data[j], ms1_data[j]
+        lo, hi = np.min([a.min(), b.min()]), np.max([a.max(), b.max()])   # MS2: over both windows
+        lo1, hi1 = np.min([m1.min()]), np.max([m1.max()])                 # MS1: window 1 only, applied to both
+        with np.errstate(invalid="ignore", divide="ignore"):
+            a, b = (a - lo) / (hi - lo), (b - lo) / (hi - lo)
+            m1, m2 = (m1 - lo1) / (hi1 - lo1), (m2 - lo1) / (hi1 - lo1)
+        a, m1, b, m2 = (np.asarray(v).astype(np.float32) for v in (a, m1, b, m2))
+        c = (torch.from_numpy(a) * mixture_weights[0] + torch.from_numpy(b) * mixture_weights[1]).numpy()
+        for o, v in zip(outs, (a, m1, b, m2, c)):
+            o.append(v)
+    return tuple(np.stack(o) for o in outs)
+
+
+# --------------------------------------------------------------------------------------
 # optimiser step (model_interface.py:1011, 1112-1123)
 # --------------------------------------------------------------------------------------
 def clip_coef(grads: Sequence[torch.Tensor], max_norm: float = 10.0) -> Tuple[float, float]:
