@@ -2,10 +2,13 @@
 // reference's backward is autograd over those ops).  Same wave-per-row, all-in-registers MFMA scheme as the forward
 // (k_linattn.hip); derivation and lane-level check: oracle/wave_emu.py::la_bwd_unit.
 //
-// The backward is split in three launches (host: launch_linattn_bwd):
-//   (1) k_block_bwd (k_conv.hip) : post-norm backward on the saved pre-norm output  -> dYpre, d g_out, d b_out
-//   (2) k_linattn_bwd (here)     : everything between xh = rmsnorm(x)*g_pre and Ypre -> dXh (R,C,n), dWqkv, dWo
-//   (3) k_block_bwd              : pre-norm backward, accumulated into dx together with the residual
+// One launch does the whole block (rows of up to 64 positions; longer rows: k_linattn_long.hip + two k_block_bwd):
+//   (1) post-norm backward, recomputed per head from the saved pre-norm output (per position, over channels: in-lane
+//       + one swap with lane^32)                                                   -> dYpre ; d g_out, d b_out (head 0 only)
+//   (2) everything between xh = rmsnorm(x)*g_pre and Ypre                         -> dXh (accumulated over heads), dWqkv, dWo
+//   (3) in the last head's pass: residual + pre-norm backward on the completed dXh -> dx += dy + d/dx ; d g_pre
+// All parameter gradients go to this wave's partial slot (plain stores) and are summed by k_linattn_dw_reduce in a fixed
+// order: no atomics, bitwise repeatable.
 //
 // (2): the HEAD loop is the outer loop of a wave and its rows the inner one, so the four per-head weight-gradient
 // tiles (dWq, dWk, dWv, dWo as 32x32 f32 MFMA accumulators, rows = channel) stay in registers across the wave's rows and
@@ -41,12 +44,21 @@ __device__ __forceinline__ f32x16 tr32(f32x16 a, float* tile, int col, int half)
 }
 
 struct LinAttnBwdK {
-  const float* x; const float* dyp; float* dxh;  // (rows, C, n)
-  const float* w_qkv; const float* w_out; const float* g_pre;
-  float* dw_qkv; float* dw_out;
-  float* part;  // per-wave partial dW slots: [wave][512*C]
+  const float* x; const float* ypre; const float* dy;  // (rows, C, n): block input, saved pre-norm output, d loss / d y
+  float* dx;                                            // += d loss / d x (incl. the residual)
+  float* dxh;                                           // scratch (rows, C, n): dXh accumulated over heads 0..2
+  const float* w_qkv; const float* w_out; const float* g_pre; const float* g_out;
+  float* part;  // per-wave partial slots: [wave][LA_SLOT(C)] = dWqkv (384C) | dWo (128C) | d g_out | d b_out | d g_pre
   int rows; int units_per_wave;
 };
+constexpr int la_slot(int C) { return 515 * C; }
+
+// sum over the 32 lanes that share (lane >> 5)
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
 
 template <int C, int N>
 __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
@@ -55,6 +67,7 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
   constexpr int NJ = C <= 8 ? 4 : 8;
   constexpr int SEG = N >= 32 ? 16 : (N >= 8 ? N / 2 : N);
   constexpr bool PARTNER = N >= 8;
+  constexpr bool PREFETCH = C <= 8;
   static_assert(NB <= 2, "rows longer than 64 are not built");
 
   __shared__ float wp_lds[3 * 4 * 2 * C * 16];  // [q|k|v][head][half][c][r] = Wqkv[m*128 + head*32 + rmap(r,half)][c]
@@ -89,32 +102,78 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
       wo[j] = ok ? a.w_out[c * 128 + hd * 32 + col] : 0.f;
     }
     f32x16 gq = {0}, gk = {0}, gv = {0}, go = {0};  // weight-gradient tiles of this head: rows c, cols d / e
+    float nacc0[NJ], nacc1[NJ];  // norm-gain / bias gradient partials: head 0: (d g_out, d b_out); head 3: (d g_pre, -)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) nacc0[j] = nacc1[j] = 0.f;
+
+    // raw operands of one unit (row block): loaded one unit AHEAD when the registers allow it (C <= 8), so that the global
+    // latency hides behind the previous unit's MFMAs -- with one wave per SIMD nothing else would cover it
+    float px[NB][NJ], pu[NB][NJ], pd[NB][NJ];
+    auto load_unit = [&](int u) {
+      const int row = u * RW + rl;
+      const bool row_ok = row < a.rows;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int pos = N >= 32 ? b * 32 + col : col % N;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int c = rmap(j, half);
+          const bool ok = row_ok && c < C;
+          const int64_t off = ((int64_t)row * C + c) * N + pos;
+          px[b][j] = ok ? a.x[off] : 0.f;
+          pu[b][j] = ok ? a.ypre[off] : 0.f;
+          pd[b][j] = ok ? a.dy[off] : 0.f;
+        }
+      }
+    };
+    if (PREFETCH) load_unit(u0);
 
 #pragma unroll 1
     for (int u = u0; u < u1; ++u) {
       const int row = u * RW + rl;
       const bool row_ok = row < a.rows;
-      // ---- load x, dYpre; pre-norm recompute
+      // ---- x, ypre, dy; pre-norm recompute; post-norm backward (same arithmetic as k_block_bwd) -> DY = dYpre
       float Xh[NB][NJ], DY[NB][NJ];
+      float cx[NB][NJ], cu[NB][NJ], cd[NB][NJ];
+      if (!PREFETCH) load_unit(u);
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { cx[b][j] = px[b][j]; cu[b][j] = pu[b][j]; cd[b][j] = pd[b][j]; }
+      if (PREFETCH && u + 1 < u1) load_unit(u + 1);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        const int pos = N >= 32 ? b * 32 + col : col % N;
-        float xv[NJ];
-        float ssq = 0.f;
+        float xv[NJ], uv[NJ], dv_[NJ];
+        float ssq = 0.f, usq = 0.f;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const int c = rmap(j, half);
-          const bool ok = row_ok && c < C;
-          xv[j] = ok ? a.x[((int64_t)row * C + c) * N + pos] : 0.f;
-          DY[b][j] = ok ? a.dyp[((int64_t)row * C + c) * N + pos] : 0.f;
+          xv[j] = cx[b][j]; uv[j] = cu[b][j]; dv_[j] = cd[b][j];
           ssq = fmaf(xv[j], xv[j], ssq);
+          usq = fmaf(uv[j], uv[j], usq);
         }
         ssq += swp32(ssq);
+        usq += swp32(usq);
         const float inv = sqC / fmaxf(sqrtf(ssq), RMS_EPS);
+        const float unrm = sqrtf(usq);
+        const float uinv = 1.0f / fmaxf(unrm, RMS_EPS);
+        float dot = 0.f;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const int c = rmap(j, half);
           Xh[b][j] = xv[j] * inv * (c < C ? a.g_pre[c] : 0.f);
+          const float uh = uv[j] * uinv;
+          if (hd == 0) nacc0[j] = fmaf(dv_[j], uh * sqC, nacc0[j]);  // d g_out
+          const float gd = dv_[j] * (c < C ? a.g_out[c] : 0.f) * sqC;
+          uv[j] = uh;
+          dv_[j] = gd;
+          dot = fmaf(gd, uh, dot);
+        }
+        dot += swp32(dot);
+        const bool clamped = unrm < RMS_EPS;  // F.normalize clamps the norm: below eps the map is linear
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          DY[b][j] = clamped ? dv_[j] * uinv : uinv * (dv_[j] - uv[j] * dot);
+          if (hd == 0) nacc1[j] += DY[b][j];  // d b_out (bias of to_out)
         }
       }
       float part[NB][C];  // d xh partial sums of this lane-half (this head)
@@ -347,7 +406,7 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const int pos = N >= 32 ? b * 32 + col : col % N;
-        float full[C];
+        float full[C], tot[NJ];
 #pragma unroll
         for (int c = 0; c < C; ++c) full[c] = part[b][c] + swp32(part[b][c]);
 #pragma unroll
@@ -357,10 +416,49 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
           if (c0 < C) lo = full[c0 < C ? c0 : 0];
           if (c1 < C) hi = full[c1 < C ? c1 : 0];
           const int c = c0 + 4 * half;
+          const float val = half ? hi : lo;
+          lo = 0.f;  // from here on: this lane's total dXh of channel c (heads 0..3), only formed in the last head's pass
           if (row_ok && c < C) {
             float* dst = a.dxh + ((int64_t)row * C + c) * N + pos;
-            const float val = half ? hi : lo;
-            *dst = hd == 0 ? val : *dst + val;  // head 0 initialises, heads 1..3 accumulate (same lane, same address)
+            if (hd < 3) *dst = hd == 0 ? val : *dst + val;  // head 0 initialises, heads 1, 2 accumulate (same lane, same address)
+            else lo = *dst + val;
+          }
+          tot[j] = lo;
+        }
+        if (hd == 3) {
+          // ---- residual + pre-norm backward on the completed dXh (own channels c = rmap(j, half)); dx += dy + d/dx
+          float xv[NJ];
+          float ssq = 0.f;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int c = rmap(j, half);
+            xv[j] = (row_ok && c < C) ? a.x[((int64_t)row * C + c) * N + pos] : 0.f;
+            ssq = fmaf(xv[j], xv[j], ssq);
+          }
+          ssq += swp32(ssq);
+          const float nrm = sqrtf(ssq);
+          const float inv = 1.0f / fmaxf(nrm, RMS_EPS);
+          float dot = 0.f;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int c = rmap(j, half);
+            const float uh = xv[j] * inv;
+            nacc0[j] = fmaf(tot[j], uh * sqC, nacc0[j]);  // d g_pre
+            const float gd = tot[j] * (c < C ? a.g_pre[c] : 0.f) * sqC;
+            xv[j] = uh;
+            tot[j] = gd;
+            dot = fmaf(gd, uh, dot);
+          }
+          dot += swp32(dot);
+          const bool clamped = nrm < RMS_EPS;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int c = rmap(j, half);
+            if (row_ok && c < C) {
+              const int64_t off = ((int64_t)row * C + c) * N + pos;
+              const float du = clamped ? tot[j] * inv : inv * (tot[j] - xv[j] * dot);
+              a.dx[off] = (a.dx[off] + a.dy[off]) + du;
+            }
           }
         }
       }
@@ -369,7 +467,7 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
     // ---- flush this head's weight gradients to this wave's partial slot (plain stores; float atomics at this access
     // shape -- one dword per lane, lanes C floats apart -- run ~17x below the store rate and made the flush the
     // kernel's critical path).  Register r holds channel rmap(r, half), lane column = d / e.
-    float* slot = a.part + (int64_t)wave_id * (512 * C);
+    float* slot = a.part + (int64_t)wave_id * la_slot(C);
 #pragma unroll
     for (int r = 0; r < NJ; ++r) {
       const int c = rmap(r, half);
@@ -380,27 +478,43 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
         slot[384 * C + c * 128 + hd * 32 + col] = go[r];
       }
     }
+    if (hd == 0 || hd == 3) {  // norm gains / bias: sum over the 32 positions-lanes of this half, one lane stores
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c = rmap(j, half);
+        const float s0 = half_sum(nacc0[j]), s1 = half_sum(nacc1[j]);
+        if (col == 0 && c < C) {
+          if (hd == 0) { slot[512 * C + c] = s0; slot[513 * C + c] = s1; }
+          else slot[514 * C + c] = s0;
+        }
+      }
+    }
   }
 }
 
-// dW[e] += sum over the wave slots, one wave per element, fixed order (deterministic)
-__global__ void __launch_bounds__(256) k_linattn_dw_reduce(const float* __restrict__ part, int nslots, int C,
-                                                           float* __restrict__ dw_qkv, float* __restrict__ dw_out) {
+// grad[e] += sum over the wave slots, one wave per element, fixed order (deterministic).  Slot layout: dWqkv (384C) | dWo (128C)
+// [| d g_out (C) | d b_out (C) | d g_pre (C) when nelem == 515C]
+__global__ void __launch_bounds__(256) k_linattn_dw_reduce(const float* __restrict__ part, int nslots, int C, int nelem,
+                                                           float* __restrict__ dw_qkv, float* __restrict__ dw_out,
+                                                           float* __restrict__ dg_out, float* __restrict__ db_out,
+                                                           float* __restrict__ dg_pre) {
   const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const int nelem = 512 * C;
   if (e >= nelem) return;
   float s = 0.f;
   for (int b = lane; b < nslots; b += 64) s += part[(int64_t)b * nelem + e];
   s = wave_sum(s);
   if (lane == 0) {
     if (e < 384 * C) dw_qkv[e] += s;
-    else dw_out[e - 384 * C] += s;
+    else if (e < 512 * C) dw_out[e - 384 * C] += s;
+    else if (e < 513 * C) dg_out[e - 512 * C] += s;
+    else if (e < 514 * C) db_out[e - 513 * C] += s;
+    else dg_pre[e - 514 * C] += s;
   }
 }
 
 template <int C>
-static int linattn_bwd_n(const LinAttnBwdK& k, int n, hipStream_t s) {
+static int linattn_bwd_n(const LinAttnBwdK& k, int n, const LinAttnBwd& g, hipStream_t s) {
 #define DQ_LB(NN)                                                                                  \
   case NN: {                                                                                       \
     constexpr int RW = NN >= 32 ? 1 : 32 / NN;                                                     \
@@ -410,7 +524,8 @@ static int linattn_bwd_n(const LinAttnBwdK& k, int n, hipStream_t s) {
     kk.units_per_wave = std::max(1, cdiv(units, 1024));                                            \
     const int waves = cdiv(units, kk.units_per_wave);                                              \
     hipLaunchKernelGGL((k_linattn_bwd<C, NN>), dim3(cdiv(waves, 4)), dim3(256), 0, s, kk);         \
-    hipLaunchKernelGGL(k_linattn_dw_reduce, dim3(cdiv(512 * C, 4)), dim3(256), 0, s, kk.part, waves, C, kk.dw_qkv, kk.dw_out); \
+    hipLaunchKernelGGL(k_linattn_dw_reduce, dim3(cdiv(la_slot(C), 4)), dim3(256), 0, s, kk.part, waves, C, la_slot(C), g.dw_qkv, \
+                       g.dw_out, g.dg_out, g.db_out, g.dg_pre);                                    \
     break;                                                                                         \
   }
   switch (n) {
@@ -424,46 +539,44 @@ static int linattn_bwd_n(const LinAttnBwdK& k, int n, hipStream_t s) {
   return 0;
 }
 
-// a.f.y is unused; needs: a.ypre (saved pre-norm output), scratch dyp and dxh (rows, C, n)
+// a.f.y is unused; needs: a.ypre (saved pre-norm output), the (rows, C, n) scratch dxh (and dyp for rows longer than 64) and
+// the partial-slot scratch
 int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s) {
   DQ_REQUIRE(a.f.x && a.dy && a.dx && a.ypre && a.dyp && a.dxh && a.dw_qkv && a.dw_out && a.db_out && a.dg_pre && a.dg_out,
              "linattn_bwd: missing operand");
   if (a.f.rows == 0) return 0;
   const int C = a.f.C, rows = a.f.rows, n = a.f.n;
-  // (1) post-norm backward: dyp = d loss / d ypre, d g_out, d b_out
-  BlockBwd b2;
-  b2.u = a.ypre; b2.dy = a.dy; b2.du = a.dyp; b2.C = C; b2.rows = rows; b2.n = n; b2.rows_per_sample = rows;
-  b2.g = a.f.g_out; b2.dg = a.dg_out; b2.dbias = a.db_out;
-  if (int rc = launch_block_bwd(b2, s)) return rc;
-  // (2) attention core
-  LinAttnBwdK k;
-  k.x = a.f.x; k.dyp = a.dyp; k.dxh = a.dxh; k.w_qkv = a.f.w_qkv; k.w_out = a.f.w_out; k.g_pre = a.f.g_pre;
-  k.dw_qkv = a.dw_qkv; k.dw_out = a.dw_out; k.rows = rows; k.units_per_wave = 1;
   DQ_REQUIRE(a.part && a.part_floats >= (int64_t)LA_MAX_WAVES * 512 * C, "linattn_bwd: partial-sum scratch missing or too small");
-  k.part = a.part;
-  int rc;
+  static_assert((int64_t)LA_MAX_WAVES * 512 >= 1024 * (int64_t)la_slot(1), "slot scratch: 1024 waves x 515*C floats must fit");
   static const bool long_all = [] { const char* e = std::getenv("DQ_LA_BWD_LONG"); return e && e[0] == '1'; }();
   if (n > 64 || (long_all && n >= 32 && C <= 8)) {
+    // rows of 128 / 256 positions: the sweep kernel between two pointwise norm-backward launches
+    BlockBwd b2;  // (1) post-norm backward: dyp = d loss / d ypre, d g_out, d b_out
+    b2.u = a.ypre; b2.dy = a.dy; b2.du = a.dyp; b2.C = C; b2.rows = rows; b2.n = n; b2.rows_per_sample = rows;
+    b2.g = a.f.g_out; b2.dg = a.dg_out; b2.dbias = a.db_out;
+    if (int rc = launch_block_bwd(b2, s)) return rc;
     int waves = 0;
-    rc = launch_linattn_bwd_long(a.f.x, a.dyp, a.dxh, a.f.w_qkv, a.f.w_out, a.f.g_pre, a.part, C, rows, n, &waves, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_linattn_dw_reduce, dim3(cdiv(512 * C, 4)), dim3(256), 0, s, a.part, waves, C, a.dw_qkv, a.dw_out);
+    if (int rc = launch_linattn_bwd_long(a.f.x, a.dyp, a.dxh, a.f.w_qkv, a.f.w_out, a.f.g_pre, a.part, C, rows, n, &waves, s)) return rc;
+    hipLaunchKernelGGL(k_linattn_dw_reduce, dim3(cdiv(512 * C, 4)), dim3(256), 0, s, a.part, waves, C, 512 * C, a.dw_qkv, a.dw_out,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr);
     DQ_LAUNCH_CHECK();
-  } else
+    // (3) residual + pre-norm backward, accumulated into dx
+    if (int r2 = launch_axpy(a.dx, a.dy, (int64_t)rows * C * n, s)) return r2;
+    BlockBwd b1;
+    b1.u = a.f.x; b1.dy = a.dxh; b1.du = a.dx; b1.C = C; b1.rows = rows; b1.n = n; b1.rows_per_sample = rows;
+    b1.g = a.f.g_pre; b1.dg = a.dg_pre; b1.accumulate = 1;
+    return launch_block_bwd(b1, s);
+  }
+  LinAttnBwdK k;
+  k.x = a.f.x; k.ypre = a.ypre; k.dy = a.dy; k.dx = a.dx; k.dxh = a.dxh; k.w_qkv = a.f.w_qkv; k.w_out = a.f.w_out;
+  k.g_pre = a.f.g_pre; k.g_out = a.f.g_out; k.part = a.part; k.rows = rows; k.units_per_wave = 1;
   switch (C) {
-    case 4: rc = linattn_bwd_n<4>(k, n, s); break;
-    case 8: rc = linattn_bwd_n<8>(k, n, s); break;
-    case 12: rc = linattn_bwd_n<12>(k, n, s); break;
-    case 16: rc = linattn_bwd_n<16>(k, n, s); break;
+    case 4: return linattn_bwd_n<4>(k, n, a, s);
+    case 8: return linattn_bwd_n<8>(k, n, a, s);
+    case 12: return linattn_bwd_n<12>(k, n, a, s);
+    case 16: return linattn_bwd_n<16>(k, n, a, s);
     default: set_error("linattn_bwd: unsupported channel count " + std::to_string(C)); return 2;
   }
-  if (rc) return rc;
-  // (3) residual + pre-norm backward, accumulated into dx
-  if (int r2 = launch_axpy(a.dx, a.dy, (int64_t)rows * C * n, s)) return r2;
-  BlockBwd b1;
-  b1.u = a.f.x; b1.dy = a.dxh; b1.du = a.dx; b1.C = C; b1.rows = rows; b1.n = n; b1.rows_per_sample = rows;
-  b1.g = a.f.g_pre; b1.dg = a.dg_pre; b1.accumulate = 1;
-  return launch_block_bwd(b1, s);
 }
 
 }  // namespace dq
