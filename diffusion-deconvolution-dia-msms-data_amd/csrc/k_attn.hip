@@ -4,17 +4,25 @@
 // softmax(q k^T * 32^-0.5) v).  RoPE comes from the third-party rotary_embedding_torch (unet1d.py:529, 560-561):
 // default 'lang' mode, adjacent-pair rotation of the first 16 of the 32 head channels -- restated, parity unpinned.
 //
-// q, k, v, o live in conv layout (B, heads*32, RT), RT contiguous.  One thread owns one query row (forward, dQ) or one
-// key row (dK, dV): its 32-wide vectors and accumulators stay in registers, the other side is streamed through LDS
-// 64 rows at a time and read with wave-uniform (broadcast) ds_read_b128, 4 rows per read.  Flash-style online softmax;
-// the score matrix never exists in memory.  3.4 % of the network FLOPs at 64x400 -- kept simple on purpose.
+// q, k, v, o live in conv layout (B, heads*32, RT), RT contiguous.  Flash-style: the RT x RT score matrix never exists in
+// memory.  One WAVE owns a block of 32 queries (forward, dQ) or 32 keys (dK, dV) of one (sample, head) and sweeps the other
+// side in blocks of 32; every product is a 32x32 tile on v_mfma_f32_32x32x2_f32 (exact fp32), with the orientations chosen
+// so that (a) every operand tile is loaded straight from global memory in one of two register layouts -- "rows = channel,
+// col = position" (16 coalesced row loads) or "rows = position, col = channel" (4 x 16-B loads per lane) -- and (b) each
+// accumulator is directly the next product's operand (sum_r mfma(X.r, Y.r) = X^T Y, dq_mfma.h).  The softmax runs over the
+// 16 registers of a lane + its partner lane^32.  No LDS, no barriers; several waves per SIMD hide the load latency.
+//   forward   (queries on lanes):  S^T = K^T.. xty(Kt, Qt) ; online softmax over rows ; O^T = xty(Vx, P^T)
+//   dQ kernel (queries on lanes):  S^T, dP^T = xty(Vt, dOt), dS^T = P^T o (dP^T - delta) ; dQ = xty(Kx, dS^T)
+//   dK/dV     (keys on lanes):     S = xty(Qt, Kt), dP = xty(dOt, Vt) ; dV = xty(dOx, P) ; dK = xty(Qx, dS)
+// 3.4 % of the network FLOPs at 64x400.
 #include "dq_common.h"
 #include "dq_kernels.h"
+#include "dq_mfma.h"
 
 namespace dq {
 
 constexpr float ATT_SCALE = 0.17677669529663687f;  // 32^-0.5
-constexpr int TJ = 64;                              // rows per LDS tile
+constexpr float LOG2E = 1.4426950408889634f;
 
 // ---- RoPE, in place.  sign = +1 forward, -1 backward (transpose of the rotation).
 __global__ void __launch_bounds__(256) k_rope(float* __restrict__ t, const float* __restrict__ freqs, int64_t batch_stride, int RT,
@@ -44,72 +52,98 @@ int launch_rope(float* qk, const float* freqs, int B, int64_t batch_stride, int 
   return 0;
 }
 
-// ---- forward: thread = query row
+// ---- operand tiles (32 channels of one head x 32 positions starting at p0; zero beyond RT)
+// rows = channel (registers: rmap(r, half)), col = position (lane & 31): 16 row loads, each coalesced over the lanes
+__device__ __forceinline__ f32x16 tile_ch_rows(const float* __restrict__ src, int RT, int p0, int col, int half, float mul) {
+  f32x16 t;
+  const int p = p0 + col;
+  const bool ok = p < RT;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) t[r] = ok ? src[(int64_t)rmap(r, half) * RT + p] * mul : 0.f;
+  return t;
+}
+// rows = position (registers: p0 + rmap(r, half)), col = channel (lane & 31): 4 x 16-B loads per lane when RT % 4 == 0
+__device__ __forceinline__ f32x16 tile_pos_rows(const float* __restrict__ src, int RT, int p0, int col, int half, float mul) {
+  f32x16 t;
+  const float* row = src + (int64_t)col * RT;
+  if ((RT & 3) == 0 && p0 + 32 <= RT) {
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const float4 v = *reinterpret_cast<const float4*>(row + p0 + 8 * q4 + 4 * half);
+      t[4 * q4 + 0] = v.x * mul; t[4 * q4 + 1] = v.y * mul; t[4 * q4 + 2] = v.z * mul; t[4 * q4 + 3] = v.w * mul;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int p = p0 + rmap(r, half);
+      t[r] = p < RT ? row[p] * mul : 0.f;
+    }
+  }
+  return t;
+}
+// per-position scalars by register row: v[p0 + rmap(r, half)], ``fill`` beyond RT
+__device__ __forceinline__ f32x16 rows_scalar(const float* __restrict__ v, int RT, int p0, int half, float fill) {
+  f32x16 t;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int p = p0 + rmap(r, half);
+    t[r] = p < RT ? v[p] : fill;
+  }
+  return t;
+}
+
+// ---- forward: wave = 32 queries of one (sample, head)
 __global__ void __launch_bounds__(64) k_attn_fwd(const float* __restrict__ q, int64_t q_bs, const float* __restrict__ k, int64_t k_bs,
                                                  const float* __restrict__ v, int64_t v_bs, float* __restrict__ o,
                                                  float* __restrict__ lse, int RT) {
-  __shared__ __attribute__((aligned(16))) float k_lds[32][TJ];
-  __shared__ __attribute__((aligned(16))) float v_lds[32][TJ];
-  const int lane = threadIdx.x, bh = blockIdx.y, b = bh >> 2, h = bh & 3;
-  const int i = blockIdx.x * 64 + lane;
-  const bool valid = i < RT;
+  const int lane = threadIdx.x, col = lane & 31, half = lane >> 5;
+  const int bh = blockIdx.y, b = bh >> 2, h = bh & 3;
+  const int i0 = blockIdx.x * 32, i = i0 + col;
   const float* qb = q + b * q_bs + (int64_t)h * 32 * RT;
   const float* kb = k + b * k_bs + (int64_t)h * 32 * RT;
   const float* vb = v + b * v_bs + (int64_t)h * 32 * RT;
-  float qr[32], oa[32];
-#pragma unroll
-  for (int c = 0; c < 32; ++c) {
-    qr[c] = valid ? qb[(int64_t)c * RT + i] * ATT_SCALE : 0.f;
-    oa[c] = 0.f;
-  }
+  const f32x16 Qt = tile_ch_rows(qb, RT, i0, col, half, ATT_SCALE);  // rows d, col i
+  f32x16 Oa = {0};                                                   // rows e, col i
   float m = -INFINITY, l = 0.f;
-  for (int j0 = 0; j0 < RT; j0 += TJ) {
-    __syncthreads();
-    {
-      const int j = j0 + lane;
+  for (int j0 = 0; j0 < RT; j0 += 32) {
+    const f32x16 Kt = tile_ch_rows(kb, RT, j0, col, half, 1.f);   // rows d, col j
+    const f32x16 Vx = tile_pos_rows(vb, RT, j0, col, half, 1.f);  // rows j, col e
+    f32x16 St = xty(Kt, Qt, f32x16{0});                           // rows j, col i
+    float mx = -INFINITY;
 #pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        k_lds[c][lane] = j < RT ? kb[(int64_t)c * RT + j] : 0.f;
-        v_lds[c][lane] = j < RT ? vb[(int64_t)c * RT + j] : 0.f;
-      }
+    for (int r = 0; r < 16; ++r) {
+      if (j0 + rmap(r, half) >= RT) St[r] = -INFINITY;
+      mx = fmaxf(mx, St[r]);
     }
-    __syncthreads();
-    const int jmax = min(TJ, RT - j0);
-    for (int jj = 0; jj < jmax; jj += 4) {
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    mx = fmaxf(mx, swap_half(mx));
+    const float mn = fmaxf(m, mx);  // finite: every block holds at least one valid key
+    const float al = __builtin_amdgcn_exp2f((m - mn) * LOG2E);
+    float ls = 0.f;
 #pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        const float4 kk = *reinterpret_cast<const float4*>(&k_lds[c][jj]);
-        s0 = fmaf(qr[c], kk.x, s0); s1 = fmaf(qr[c], kk.y, s1); s2 = fmaf(qr[c], kk.z, s2); s3 = fmaf(qr[c], kk.w, s3);
-      }
-      if (jj + 1 >= jmax) s1 = -INFINITY;
-      if (jj + 2 >= jmax) s2 = -INFINITY;
-      if (jj + 3 >= jmax) s3 = -INFINITY;
-      const float mn = fmaxf(fmaxf(m, s0), fmaxf(fmaxf(s1, s2), s3));
-      const float al = expf(m - mn);
-      const float p0 = expf(s0 - mn), p1 = expf(s1 - mn), p2 = expf(s2 - mn), p3 = expf(s3 - mn);
-      l = fmaf(l, al, (p0 + p1) + (p2 + p3));
-      m = mn;
-#pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        const float4 vv = *reinterpret_cast<const float4*>(&v_lds[c][jj]);
-        oa[c] = fmaf(oa[c], al, fmaf(p0, vv.x, fmaf(p1, vv.y, fmaf(p2, vv.z, p3 * vv.w))));
-      }
+    for (int r = 0; r < 16; ++r) {
+      St[r] = __builtin_amdgcn_exp2f((St[r] - mn) * LOG2E);
+      ls += St[r];
     }
+    ls += swap_half(ls);
+    l = fmaf(l, al, ls);
+    m = mn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Oa[r] *= al;
+    Oa = xty(Vx, St, Oa);  // rows e, col i
   }
-  if (valid) {
+  if (i < RT) {
     const float rl = 1.0f / l;
     float* ob = o + (int64_t)b * 128 * RT + (int64_t)h * 32 * RT;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) ob[(int64_t)c * RT + i] = oa[c] * rl;
-    if (lse) lse[(int64_t)bh * RT + i] = m + logf(l);
+    for (int r = 0; r < 16; ++r) ob[(int64_t)rmap(r, half) * RT + i] = Oa[r] * rl;
+    if (lse && half == 0) lse[(int64_t)bh * RT + i] = m + __logf(l);
   }
 }
 
 int launch_attn_fwd(const float* q, int64_t q_bs, const float* k, int64_t k_bs, const float* v, int64_t v_bs, float* o, float* lse,
                     int B, int RT, hipStream_t s) {
   if (B == 0 || RT == 0) return 0;
-  hipLaunchKernelGGL(k_attn_fwd, dim3(cdiv(RT, 64), B * 4), dim3(64), 0, s, q, q_bs, k, k_bs, v, v_bs, o, lse, RT);
+  hipLaunchKernelGGL(k_attn_fwd, dim3(cdiv(RT, 32), B * 4), dim3(64), 0, s, q, q_bs, k, k_bs, v, v_bs, o, lse, RT);
   DQ_LAUNCH_CHECK();
   return 0;
 }
@@ -120,62 +154,43 @@ __global__ void __launch_bounds__(64) k_attn_bwd_q(const float* __restrict__ q, 
                                                    const float* __restrict__ o, const float* __restrict__ d_o,
                                                    const float* __restrict__ lse, float* __restrict__ delta,
                                                    float* __restrict__ dq, int64_t dq_bs, int RT) {
-  __shared__ __attribute__((aligned(16))) float k_lds[32][TJ];
-  __shared__ __attribute__((aligned(16))) float v_lds[32][TJ];
-  const int lane = threadIdx.x, bh = blockIdx.y, b = bh >> 2, h = bh & 3;
-  const int i = blockIdx.x * 64 + lane;
-  const bool valid = i < RT;
+  const int lane = threadIdx.x, col = lane & 31, half = lane >> 5;
+  const int bh = blockIdx.y, b = bh >> 2, h = bh & 3;
+  const int i0 = blockIdx.x * 32, i = i0 + col;
   const float* qb = q + b * q_bs + (int64_t)h * 32 * RT;
   const float* kb = k + b * k_bs + (int64_t)h * 32 * RT;
   const float* vb = v + b * v_bs + (int64_t)h * 32 * RT;
   const float* ob = o + (int64_t)b * 128 * RT + (int64_t)h * 32 * RT;
   const float* dob = d_o + (int64_t)b * 128 * RT + (int64_t)h * 32 * RT;
-  float qr[32], dor[32], dqa[32];
+  const f32x16 Qt = tile_ch_rows(qb, RT, i0, col, half, ATT_SCALE);  // rows d, col i
+  const f32x16 dOt = tile_ch_rows(dob, RT, i0, col, half, 1.f);      // rows e, col i
   float dl = 0.f;
+  {
+    const f32x16 Ot = tile_ch_rows(ob, RT, i0, col, half, 1.f);
 #pragma unroll
-  for (int c = 0; c < 32; ++c) {
-    qr[c] = valid ? qb[(int64_t)c * RT + i] * ATT_SCALE : 0.f;
-    dor[c] = valid ? dob[(int64_t)c * RT + i] : 0.f;
-    dl = fmaf(dor[c], valid ? ob[(int64_t)c * RT + i] : 0.f, dl);
-    dqa[c] = 0.f;
+    for (int r = 0; r < 16; ++r) dl = fmaf(dOt[r], Ot[r], dl);
+    dl += swap_half(dl);
   }
-  const float ls = valid ? lse[(int64_t)bh * RT + i] : INFINITY;
-  for (int j0 = 0; j0 < RT; j0 += TJ) {
-    __syncthreads();
-    {
-      const int j = j0 + lane;
+  const float ls = i < RT ? lse[(int64_t)bh * RT + i] : INFINITY;
+  f32x16 dQa = {0};  // rows d, col i
+  for (int j0 = 0; j0 < RT; j0 += 32) {
+    const f32x16 Kt = tile_ch_rows(kb, RT, j0, col, half, 1.f);   // rows d, col j
+    const f32x16 Vt = tile_ch_rows(vb, RT, j0, col, half, 1.f);   // rows e, col j
+    const f32x16 Kx = tile_pos_rows(kb, RT, j0, col, half, 1.f);  // rows j, col d
+    f32x16 St = xty(Kt, Qt, f32x16{0});                           // rows j, col i
+    const f32x16 dPt = xty(Vt, dOt, f32x16{0});                   // rows j, col i
 #pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        k_lds[c][lane] = j < RT ? kb[(int64_t)c * RT + j] : 0.f;
-        v_lds[c][lane] = j < RT ? vb[(int64_t)c * RT + j] : 0.f;
-      }
+    for (int r = 0; r < 16; ++r) {
+      const float p = (j0 + rmap(r, half) < RT) ? __builtin_amdgcn_exp2f((St[r] - ls) * LOG2E) : 0.f;
+      St[r] = p * (dPt[r] - dl);  // dS^T
     }
-    __syncthreads();
-    const int jmax = min(TJ, RT - j0);
-    for (int jj = 0; jj < jmax; jj += 4) {
-      float s[4] = {0.f, 0.f, 0.f, 0.f}, dp[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        const float4 kk = *reinterpret_cast<const float4*>(&k_lds[c][jj]);
-        const float4 vv = *reinterpret_cast<const float4*>(&v_lds[c][jj]);
-        s[0] = fmaf(qr[c], kk.x, s[0]); s[1] = fmaf(qr[c], kk.y, s[1]); s[2] = fmaf(qr[c], kk.z, s[2]); s[3] = fmaf(qr[c], kk.w, s[3]);
-        dp[0] = fmaf(dor[c], vv.x, dp[0]); dp[1] = fmaf(dor[c], vv.y, dp[1]); dp[2] = fmaf(dor[c], vv.z, dp[2]); dp[3] = fmaf(dor[c], vv.w, dp[3]);
-      }
-      float ds[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) ds[u] = (jj + u < jmax) ? expf(s[u] - ls) * (dp[u] - dl) : 0.f;
-#pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        const float4 kk = *reinterpret_cast<const float4*>(&k_lds[c][jj]);
-        dqa[c] = fmaf(ds[0], kk.x, fmaf(ds[1], kk.y, fmaf(ds[2], kk.z, fmaf(ds[3], kk.w, dqa[c]))));
-      }
-    }
+    dQa = xty(Kx, St, dQa);
   }
-  if (valid) {
+  if (i < RT) {
     float* dqb = dq + b * dq_bs + (int64_t)h * 32 * RT;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) dqb[(int64_t)c * RT + i] = dqa[c] * ATT_SCALE;
-    delta[(int64_t)bh * RT + i] = dl;
+    for (int r = 0; r < 16; ++r) dqb[(int64_t)rmap(r, half) * RT + i] = dQa[r] * ATT_SCALE;
+    if (half == 0) delta[(int64_t)bh * RT + i] = dl;
   }
 }
 
@@ -185,69 +200,40 @@ __global__ void __launch_bounds__(64) k_attn_bwd_kv(const float* __restrict__ q,
                                                     const float* __restrict__ d_o, const float* __restrict__ lse,
                                                     const float* __restrict__ delta, float* __restrict__ dk, int64_t dk_bs,
                                                     float* __restrict__ dv, int64_t dv_bs, int RT) {
-  __shared__ __attribute__((aligned(16))) float q_lds[32][TJ];
-  __shared__ __attribute__((aligned(16))) float do_lds[32][TJ];
-  __shared__ __attribute__((aligned(16))) float ls_lds[TJ];
-  __shared__ __attribute__((aligned(16))) float dl_lds[TJ];
-  const int lane = threadIdx.x, bh = blockIdx.y, b = bh >> 2, h = bh & 3;
-  const int j = blockIdx.x * 64 + lane;
-  const bool valid = j < RT;
+  const int lane = threadIdx.x, col = lane & 31, half = lane >> 5;
+  const int bh = blockIdx.y, b = bh >> 2, h = bh & 3;
+  const int j0 = blockIdx.x * 32, j = j0 + col;
   const float* qb = q + b * q_bs + (int64_t)h * 32 * RT;
   const float* kb = k + b * k_bs + (int64_t)h * 32 * RT;
   const float* vb = v + b * v_bs + (int64_t)h * 32 * RT;
   const float* dob = d_o + (int64_t)b * 128 * RT + (int64_t)h * 32 * RT;
-  float kr[32], vr[32], dka[32], dva[32];
+  const f32x16 Kt = tile_ch_rows(kb, RT, j0, col, half, 1.f);  // rows d, col j
+  const f32x16 Vt = tile_ch_rows(vb, RT, j0, col, half, 1.f);  // rows e, col j
+  f32x16 dKa = {0}, dVa = {0};                                 // rows d / e, col j
+  for (int i0 = 0; i0 < RT; i0 += 32) {
+    const f32x16 Qt = tile_ch_rows(qb, RT, i0, col, half, ATT_SCALE);   // rows d, col i
+    const f32x16 dOt = tile_ch_rows(dob, RT, i0, col, half, 1.f);       // rows e, col i
+    const f32x16 Qx = tile_pos_rows(qb, RT, i0, col, half, ATT_SCALE);  // rows i, col d
+    const f32x16 dOx = tile_pos_rows(dob, RT, i0, col, half, 1.f);      // rows i, col e
+    const f32x16 lsr = rows_scalar(lse + (int64_t)bh * RT, RT, i0, half, INFINITY);  // exp(s - inf) = 0 masks the tail
+    const f32x16 dlr = rows_scalar(delta + (int64_t)bh * RT, RT, i0, half, 0.f);
+    f32x16 S = xty(Qt, Kt, f32x16{0});              // rows i, col j
+    f32x16 dP = xty(dOt, Vt, f32x16{0});            // rows i, col j
 #pragma unroll
-  for (int c = 0; c < 32; ++c) {
-    kr[c] = valid ? kb[(int64_t)c * RT + j] : 0.f;
-    vr[c] = valid ? vb[(int64_t)c * RT + j] : 0.f;
-    dka[c] = 0.f;
-    dva[c] = 0.f;
-  }
-  for (int i0 = 0; i0 < RT; i0 += TJ) {
-    __syncthreads();
-    {
-      const int i = i0 + lane;
-      const bool ok = i < RT;
-#pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        q_lds[c][lane] = ok ? qb[(int64_t)c * RT + i] * ATT_SCALE : 0.f;
-        do_lds[c][lane] = ok ? dob[(int64_t)c * RT + i] : 0.f;
-      }
-      ls_lds[lane] = ok ? lse[(int64_t)bh * RT + i] : INFINITY;  // exp(s - inf) = 0 masks the tail
-      dl_lds[lane] = ok ? delta[(int64_t)bh * RT + i] : 0.f;
+    for (int r = 0; r < 16; ++r) {
+      S[r] = __builtin_amdgcn_exp2f((S[r] - lsr[r]) * LOG2E);  // P
+      dP[r] = S[r] * (dP[r] - dlr[r]);                          // dS
     }
-    __syncthreads();
-    for (int ii = 0; ii < TJ; ii += 4) {
-      float s[4] = {0.f, 0.f, 0.f, 0.f}, dp[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        const float4 qq = *reinterpret_cast<const float4*>(&q_lds[c][ii]);
-        const float4 dd = *reinterpret_cast<const float4*>(&do_lds[c][ii]);
-        s[0] = fmaf(kr[c], qq.x, s[0]); s[1] = fmaf(kr[c], qq.y, s[1]); s[2] = fmaf(kr[c], qq.z, s[2]); s[3] = fmaf(kr[c], qq.w, s[3]);
-        dp[0] = fmaf(vr[c], dd.x, dp[0]); dp[1] = fmaf(vr[c], dd.y, dp[1]); dp[2] = fmaf(vr[c], dd.z, dp[2]); dp[3] = fmaf(vr[c], dd.w, dp[3]);
-      }
-      const float4 l4 = *reinterpret_cast<const float4*>(&ls_lds[ii]);
-      const float4 d4 = *reinterpret_cast<const float4*>(&dl_lds[ii]);
-      float p[4], ds[4];
-      p[0] = expf(s[0] - l4.x); p[1] = expf(s[1] - l4.y); p[2] = expf(s[2] - l4.z); p[3] = expf(s[3] - l4.w);
-      ds[0] = p[0] * (dp[0] - d4.x); ds[1] = p[1] * (dp[1] - d4.y); ds[2] = p[2] * (dp[2] - d4.z); ds[3] = p[3] * (dp[3] - d4.w);
-#pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        const float4 qq = *reinterpret_cast<const float4*>(&q_lds[c][ii]);
-        const float4 dd = *reinterpret_cast<const float4*>(&do_lds[c][ii]);
-        dva[c] = fmaf(p[0], dd.x, fmaf(p[1], dd.y, fmaf(p[2], dd.z, fmaf(p[3], dd.w, dva[c]))));
-        dka[c] = fmaf(ds[0], qq.x, fmaf(ds[1], qq.y, fmaf(ds[2], qq.z, fmaf(ds[3], qq.w, dka[c]))));
-      }
-    }
+    dVa = xty(dOx, S, dVa);
+    dKa = xty(Qx, dP, dKa);
   }
-  if (valid) {
+  if (j < RT) {
     float* dkb = dk + b * dk_bs + (int64_t)h * 32 * RT;
     float* dvb = dv + b * dv_bs + (int64_t)h * 32 * RT;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {
-      dkb[(int64_t)c * RT + j] = dka[c];  // q_lds already carries the 32^-0.5
-      dvb[(int64_t)c * RT + j] = dva[c];
+    for (int r = 0; r < 16; ++r) {
+      dkb[(int64_t)rmap(r, half) * RT + j] = dKa[r];  // Qx already carries the 32^-0.5
+      dvb[(int64_t)rmap(r, half) * RT + j] = dVa[r];
     }
   }
 }
@@ -256,7 +242,7 @@ int launch_attn_bwd(const float* q, int64_t q_bs, const float* k, int64_t k_bs, 
                     const float* d_o, const float* lse, float* delta, float* dq, int64_t dq_bs, float* dk, int64_t dk_bs, float* dv,
                     int64_t dv_bs, int B, int RT, hipStream_t s) {
   if (B == 0 || RT == 0) return 0;
-  dim3 grid(cdiv(RT, 64), B * 4), block(64);
+  dim3 grid(cdiv(RT, 32), B * 4), block(64);
   hipLaunchKernelGGL(k_attn_bwd_q, grid, block, 0, s, q, q_bs, k, k_bs, v, v_bs, o, d_o, lse, delta, dq, dq_bs, RT);
   DQ_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_attn_bwd_kv, grid, block, 0, s, q, q_bs, k, k_bs, v, v_bs, d_o, lse, delta, dk, dk_bs, dv, dv_bs, RT);

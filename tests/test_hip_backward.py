@@ -214,3 +214,40 @@ def test_large_window_config_forward_and_grads_vs_oracle():
         xt = O.q_sample(O.make_schedule()["alpha_bars"], O.normalize(x0), t, nz)
         y = net(xt.cuda(), t.cuda(), O.normalize(c2).cuda(), O.normalize(c1).cuda())
     assert rel_err(y, eps_o) < 5e-5
+
+
+@pytest.mark.parametrize("RT", [70, 96])
+def test_default_net_grads_multiblock_attention(RT):
+    """RT > 32: the bottleneck attention sweeps several 32-position blocks (RT = 70: ragged tail + unaligned rows, scalar
+    operand loads; RT = 96: whole blocks, 16-byte operand loads).  Loss, eps and all parameter gradients vs the oracle's autograd."""
+    from oracle import dq_oracle as O
+    from dquartic.model.model import DDIMDiffusionModel
+    from dquartic.model.unet1d import UNet1d
+
+    torch.manual_seed(9)
+    net = UNet1d(dim=4, channels=1, dim_mults=(1, 2, 2, 3, 3, 4, 4), conditional=True, init_cond_channels=1,
+                 attn_cond_channels=1, downsample_dim=64, simple=True)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    po = {k: v.detach().clone().cpu() for k, v in net.state_dict().items()}
+    dm = DDIMDiffusionModel(model_class=net.cuda(), device="cuda")
+    od = O.Diffusion(po, O.UNetConfig(downsample_dim=64))
+    B, MZ = 2, 64
+    gen = torch.Generator().manual_seed(RT)
+    x0, c2, c1 = torch.rand(B, RT, MZ, generator=gen), torch.rand(B, RT, MZ, generator=gen), torch.rand(B, RT, generator=gen)
+    t, nz = torch.tensor([40, 700]), torch.randn(B, RT, MZ, generator=gen)
+    keys = O.trainable_keys(po)
+    for k in keys:
+        po[k].requires_grad_(True)
+    lo, eps_o = od.train_loss(x0, c2, c1, t, nz)
+    lo.backward()
+    net.train()
+    loss = dm.train_step_fused(x0.cuda(), c2.cuda(), c1.cuda(), t=t.cuda(), noise=nz.cuda())
+    assert abs(float(loss) - float(lo)) < 2e-5 * abs(float(lo))
+    gmax = max(float(po[k].grad.abs().max()) for k in keys)
+    named = dict(net.named_parameters())
+    for k in keys:
+        ref = po[k].grad
+        err = float((named[k].grad.cpu() - ref).abs().max())
+        assert err <= 1e-3 * max(float(ref.abs().max()), 1e-4 * gmax), (k, err)
