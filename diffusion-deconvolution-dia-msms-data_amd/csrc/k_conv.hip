@@ -370,6 +370,40 @@ int launch_conv_bwd_data(const ConvBwdData& a, hipStream_t s) {
 //      lives in registers, is reduced over the block (wave shuffles + LDS) and written to partials[x][element];
 //  (2) k_wgrad_reduce sums the <= 64 partials of every element in order and adds them to dW / dbias.
 // -------------------------------------------------------------------------------------------------
+// block-level reduction of the per-thread (COB x CIB x K) sub-block + bias sums -> this block's partial slot
+template <int COB, int CIB, int K>
+__device__ __forceinline__ void wgrad_block_reduce(float (&acc)[COB][CIB][K], float (&accb)[COB], const ConvWgrad& a, int co0, int ci0,
+                                                   int cin, int nelem_w) {
+  constexpr int NACC = COB * CIB * K + COB;
+  __shared__ float red[4][NACC];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < COB; ++i) {
+#pragma unroll
+    for (int j = 0; j < CIB; ++j)
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float v = wave_sum(acc[i][j][k]);
+        if (lane == 0) red[wv][(i * CIB + j) * K + k] = v;
+      }
+    const float vb = wave_sum(accb[i]);
+    if (lane == 0) red[wv][COB * CIB * K + i] = vb;
+  }
+  __syncthreads();
+  float* part = a.scratch + (int64_t)blockIdx.x * (nelem_w + a.cout);
+  for (int e = threadIdx.x; e < NACC; e += blockDim.x) {
+    const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    if (e < COB * CIB * K) {
+      const int i = e / (CIB * K), j = (e / K) % CIB, k = e % K;
+      const int co = co0 + i, ci = ci0 + j;
+      if (co < a.cout && ci < cin) part[((int64_t)co * cin + ci) * K + k] = v;
+    } else if (ci0 == 0) {
+      const int co = co0 + (e - COB * CIB * K);
+      if (co < a.cout) part[nelem_w + co] = v;
+    }
+  }
+}
+
 template <int COB, int CIB, int K, int MODE>
 __global__ void __launch_bounds__(256) k_conv_wgrad(ConvWgrad a, int n_cib, int nelem_w) {
   const int cin = a.cinA + a.cinB;
@@ -410,34 +444,64 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(ConvWgrad a, int n_cib, int 
 #pragma unroll
     for (int i = 0; i < COB; ++i) accb[i] += d[i];
   }
-  constexpr int NACC = COB * CIB * K + COB;
-  __shared__ float red[4][NACC];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  wgrad_block_reduce<COB, CIB, K>(acc, accb, a, co0, ci0, cin, nelem_w);
+}
+
+// stride-1 'same' convs with n % 4 == 0 (K = 1 or 3): a thread takes 4 consecutive positions per step -- 16-byte loads of
+// du and x (+ the two halo values), a quarter of the memory instructions and index arithmetic of the scalar form
+template <int COB, int CIB, int K>
+__global__ void __launch_bounds__(256) k_conv_wgrad_v4(ConvWgrad a, int n_cib, int nelem_w) {
+  static_assert(K == 1 || K == 3, "vectorised weight gradient: K = 1 or 3");
+  constexpr int H = (K - 1) / 2;
+  const int cin = a.cinA + a.cinB;
+  const int co0 = (blockIdx.y / n_cib) * COB, ci0 = (blockIdx.y % n_cib) * CIB;
+  const int n = a.n_out, n4 = n >> 2;
+  const int total4 = a.rows * n4;
+  float acc[COB][CIB][K];
+  float accb[COB];
 #pragma unroll
   for (int i = 0; i < COB; ++i) {
+    accb[i] = 0.f;
 #pragma unroll
     for (int j = 0; j < CIB; ++j)
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const float v = wave_sum(acc[i][j][k]);
-        if (lane == 0) red[wv][(i * CIB + j) * K + k] = v;
-      }
-    const float vb = wave_sum(accb[i]);
-    if (lane == 0) red[wv][COB * CIB * K + i] = vb;
+      for (int k = 0; k < K; ++k) acc[i][j][k] = 0.f;
   }
-  __syncthreads();
-  float* part = a.scratch + (int64_t)blockIdx.x * (nelem_w + a.cout);
-  for (int e = threadIdx.x; e < NACC; e += blockDim.x) {
-    const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-    if (e < COB * CIB * K) {
-      const int i = e / (CIB * K), j = (e / K) % CIB, k = e % K;
-      const int co = co0 + i, ci = ci0 + j;
-      if (co < a.cout && ci < cin) part[((int64_t)co * cin + ci) * K + k] = v;
-    } else if (ci0 == 0) {
-      const int co = co0 + (e - COB * CIB * K);
-      if (co < a.cout) part[nelem_w + co] = v;
+  for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < total4; it += gridDim.x * blockDim.x) {
+    const int row = it / n4, p = (it - row * n4) << 2;
+    float d[COB][4];
+    const float* dub = a.du + ((int64_t)row * a.cout + co0) * n + p;
+#pragma unroll
+    for (int i = 0; i < COB; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (co0 + i < a.cout) v = *reinterpret_cast<const float4*>(dub + (int64_t)i * n);
+      d[i][0] = v.x; d[i][1] = v.y; d[i][2] = v.z; d[i][3] = v.w;
+      accb[i] += (v.x + v.y) + (v.z + v.w);
+    }
+#pragma unroll
+    for (int j = 0; j < CIB; ++j) {
+      const int ci = ci0 + j;
+      if (ci >= cin) continue;
+      const float* src = (ci < a.cinA) ? a.inA + ((int64_t)row * a.cinA + ci) * n : a.inB + ((int64_t)row * a.cinB + (ci - a.cinA)) * n;
+      const float4 xm = *reinterpret_cast<const float4*>(src + p);
+      float win[4 + 2 * H];
+      win[H + 0] = xm.x; win[H + 1] = xm.y; win[H + 2] = xm.z; win[H + 3] = xm.w;
+      if (H) {
+        win[0] = p > 0 ? src[p - 1] : 0.f;
+        win[4 + H] = p + 4 < n ? src[p + 4] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int i = 0; i < COB; ++i) {
+          float t = acc[i][j][k];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) t = fmaf(d[i][q], win[q + k], t);
+          acc[i][j][k] = t;
+        }
     }
   }
+  wgrad_block_reduce<COB, CIB, K>(acc, accb, a, co0, ci0, cin, nelem_w);
 }
 
 // one wave per element: lane l sums partials l, l+64, ... in order, then a fixed butterfly => deterministic
@@ -466,9 +530,18 @@ int launch_conv_wgrad(const ConvWgrad& a, hipStream_t s) {
   const int n_cob = cdiv(a.cout, COB), n_cib = cdiv(cin, CIB);
   const int nelem_w = a.cout * cin * a.K;
   // <= WGRAD_MAX_PARTS partial blocks per element; ~4 items per thread, ~2048 blocks in flight where the problem allows it
-  const int gx = std::max(1, std::min({cdiv(total, 256 * 4), WGRAD_MAX_PARTS, std::max(1, 2048 / (n_cob * n_cib))}));
+  const bool vec4 = a.mode == CONV_S1 && (a.K == 1 || a.K == 3) && a.n_out % 4 == 0 && a.n_in == a.n_out;
+  const int gx = std::max(1, std::min({cdiv(total, 256 * (vec4 ? 8 : 4)), WGRAD_MAX_PARTS, std::max(1, 2048 / (n_cob * n_cib))}));
   DQ_REQUIRE((int64_t)gx * (nelem_w + a.cout) <= a.scratch_floats, "conv_wgrad: scratch too small");
   dim3 grid(gx, n_cob * n_cib), block(256);
+  if (vec4) {
+    if (a.K == 1) hipLaunchKernelGGL((k_conv_wgrad_v4<COB, CIB, 1>), grid, block, 0, s, a, n_cib, nelem_w);
+    else hipLaunchKernelGGL((k_conv_wgrad_v4<COB, CIB, 3>), grid, block, 0, s, a, n_cib, nelem_w);
+    DQ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(nelem_w + a.cout, 4)), dim3(256), 0, s, a.scratch, gx, nelem_w, a.cout, a.dw, a.dbias);
+    DQ_LAUNCH_CHECK();
+    return 0;
+  }
 #define DQ_WG(KK, MM)                                                                                  \
   if (a.K == KK && a.mode == MM) {                                                                      \
     hipLaunchKernelGGL((k_conv_wgrad<COB, CIB, KK, MM>), grid, block, 0, s, a, n_cib, nelem_w);         \
