@@ -492,19 +492,32 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
   }
 }
 
-// grad[e] += sum over the wave slots, one wave per element, fixed order (deterministic).  Slot layout: dWqkv (384C) | dWo (128C)
-// [| d g_out (C) | d b_out (C) | d g_pre (C) when nelem == 515C]
+// grad[e] += sum over the wave slots in a fixed order (deterministic).  A block owns 16 consecutive elements x 16 slot
+// groups: thread (e, g) sums slots g, g+16, g+32, ... (64-byte segments per group: every fetched sector is fully used, unlike
+// a lane-per-slot gather), the 16 group sums meet in LDS.
+// Slot layout: dWqkv (384C) | dWo (128C) [| d g_out (C) | d b_out (C) | d g_pre (C) when nelem == 515C]
 __global__ void __launch_bounds__(256) k_linattn_dw_reduce(const float* __restrict__ part, int nslots, int C, int nelem,
                                                            float* __restrict__ dw_qkv, float* __restrict__ dw_out,
                                                            float* __restrict__ dg_out, float* __restrict__ db_out,
                                                            float* __restrict__ dg_pre) {
-  const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (e >= nelem) return;
-  float s = 0.f;
-  for (int b = lane; b < nslots; b += 64) s += part[(int64_t)b * nelem + e];
-  s = wave_sum(s);
-  if (lane == 0) {
+  __shared__ float red[16][17];
+  const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + el;
+  float s0 = 0.f, s1 = 0.f;
+  if (e < nelem) {
+    int b = g;
+    for (; b + 16 < nslots; b += 32) {
+      s0 += part[(int64_t)b * nelem + e];
+      s1 += part[(int64_t)(b + 16) * nelem + e];
+    }
+    if (b < nslots) s0 += part[(int64_t)b * nelem + e];
+  }
+  red[g][el] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && e < nelem) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][el];
     if (e < 384 * C) dw_qkv[e] += s;
     else if (e < 512 * C) dw_out[e - 384 * C] += s;
     else if (e < 513 * C) dg_out[e - 512 * C] += s;
@@ -524,7 +537,7 @@ static int linattn_bwd_n(const LinAttnBwdK& k, int n, const LinAttnBwd& g, hipSt
     kk.units_per_wave = std::max(1, cdiv(units, 1024));                                            \
     const int waves = cdiv(units, kk.units_per_wave);                                              \
     hipLaunchKernelGGL((k_linattn_bwd<C, NN>), dim3(cdiv(waves, 4)), dim3(256), 0, s, kk);         \
-    hipLaunchKernelGGL(k_linattn_dw_reduce, dim3(cdiv(la_slot(C), 4)), dim3(256), 0, s, kk.part, waves, C, la_slot(C), g.dw_qkv, \
+    hipLaunchKernelGGL(k_linattn_dw_reduce, dim3(cdiv(la_slot(C), 16)), dim3(256), 0, s, kk.part, waves, C, la_slot(C), g.dw_qkv, \
                        g.dw_out, g.dg_out, g.db_out, g.dg_pre);                                    \
     break;                                                                                         \
   }
@@ -557,7 +570,7 @@ int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s) {
     if (int rc = launch_block_bwd(b2, s)) return rc;
     int waves = 0;
     if (int rc = launch_linattn_bwd_long(a.f.x, a.dyp, a.dxh, a.f.w_qkv, a.f.w_out, a.f.g_pre, a.part, C, rows, n, &waves, s)) return rc;
-    hipLaunchKernelGGL(k_linattn_dw_reduce, dim3(cdiv(512 * C, 4)), dim3(256), 0, s, a.part, waves, C, 512 * C, a.dw_qkv, a.dw_out,
+    hipLaunchKernelGGL(k_linattn_dw_reduce, dim3(cdiv(512 * C, 16)), dim3(256), 0, s, a.part, waves, C, 512 * C, a.dw_qkv, a.dw_out,
                        (float*)nullptr, (float*)nullptr, (float*)nullptr);
     DQ_LAUNCH_CHECK();
     // (3) residual + pre-norm backward, accumulated into dx
