@@ -53,6 +53,13 @@ struct LinAttnBwdK {
 };
 constexpr int la_slot(int C) { return 515 * C; }
 
+// v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 outer products.  Block = lane >> 2; a lane supplies A_blk[i = lane & 3] and
+// B_blk[j = lane & 3]; register i of lane (blk, j) receives A_blk[i] * B_blk[j] (mapping measured: tools/probe/mfma4x4.hip).
+// With C <= 16 channels the weight-gradient (rows = channel) and dXh (rows = channel) products are exactly this shape: on the
+// 32x32x2 form their 4..16 rows were padded to 32.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
 // sum over the 32 lanes that share (lane >> 5)
 __device__ __forceinline__ float half_sum(float v) {
 #pragma unroll
@@ -68,10 +75,14 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
   constexpr int SEG = N >= 32 ? 16 : (N >= 8 ? N / 2 : N);
   constexpr bool PARTNER = N >= 8;
   constexpr bool PREFETCH = C <= 8;
+  constexpr int CG = C / 4;      // channel groups of 4 (one 4x4x1 MFMA each)
+  constexpr int NP = NB * 32;    // positions (lanes x blocks) of one unit
   static_assert(NB <= 2, "rows longer than 64 are not built");
+  static_assert(C % 4 == 0, "channel count must be a multiple of 4");
 
   __shared__ float wp_lds[3 * 4 * 2 * C * 16];  // [q|k|v][head][half][c][r] = Wqkv[m*128 + head*32 + rmap(r,half)][c]
   __shared__ float tiles[4][32 * 33];
+  __shared__ __attribute__((aligned(16))) float stage[4][2 * C * NP];  // per wave: xh[c][n] | dYpre[c][n] of the current unit
   for (int i = threadIdx.x; i < 3 * 4 * 2 * C * 16; i += blockDim.x) {
     const int r = i & 15, c = (i >> 4) % C, hh = (i / (16 * C)) & 1, hd = (i / (32 * C)) & 3, m = i / (128 * C);
     wp_lds[i] = a.w_qkv[(m * 128 + hd * 32 + rmap(r, hh)) * C + c];
@@ -80,6 +91,8 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
 
   const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wv = threadIdx.x >> 6;
   float* tile = tiles[wv];
+  float* xs = stage[wv];
+  float* dys = xs + C * NP;
   const int wave_id = blockIdx.x * (blockDim.x >> 6) + wv;
   const int n_units = (a.rows + RW - 1) / RW;
   const int u0 = wave_id * a.units_per_wave;
@@ -101,7 +114,11 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
       wvv[j] = ok ? a.w_qkv[(256 + hd * 32 + col) * C + c] : 0.f;
       wo[j] = ok ? a.w_out[c * 128 + hd * 32 + col] : 0.f;
     }
-    f32x16 gq = {0}, gk = {0}, gv = {0}, go = {0};  // weight-gradient tiles of this head: rows c, cols d / e
+    // weight-gradient accumulators of this head, 4x4x1 form: register i of group cg = channel 4*cg + i, lane = (half, d / e);
+    // each lane-half sums its own 16 positions of every 32-block, the halves are added at the flush
+    f32x4 gq[CG], gk[CG], gv[CG], go[CG];
+#pragma unroll
+    for (int g = 0; g < CG; ++g) gq[g] = gk[g] = gv[g] = go[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     float nacc0[NJ], nacc1[NJ];  // norm-gain / bias gradient partials: head 0: (d g_out, d b_out); head 3: (d g_pre, -)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) nacc0[j] = nacc1[j] = 0.f;
@@ -176,32 +193,60 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
           if (hd == 0) nacc1[j] += DY[b][j];  // d b_out (bias of to_out)
         }
       }
-      float part[NB][C];  // d xh partial sums of this lane-half (this head)
+      // stage xh and dYpre as [c][n] for the 4x4x1 A operands (every lane needs 4 channels of OTHER lanes' positions)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int c = 0; c < C; ++c) part[b][c] = 0.f;
+        for (int j = 0; j < NJ; ++j) {
+          const int c = rmap(j, half);
+          if (c < C) {
+            xs[c * NP + b * 32 + col] = Xh[b][j];
+            dys[c * NP + b * 32 + col] = DY[b][j];
+          }
+        }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
 
-      // VALU: part[c] += sum_r W[m][hd][half][c][r] * t[r]
+      f32x4 part[NB][CG];  // d xh partial sums of this lane-half (this head): register i = channel 4*cg + i, lane = position
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int g = 0; g < CG; ++g) part[b][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+      // part[c][n] += sum_r W[m][hd][rmap(r,half)][c] * t[r][n]: B = the tile register (rows d, col n), A = the weight column
+      // W[..][c = 4*cg + (lane & 3)] read from LDS (16 consecutive r = 4 ds_read_b128)
       auto add_dxh = [&](int b, int m, const f32x16& t) {
         const float* wl = wp_lds + ((m * 4 + hd) * 2 + half) * C * 16;
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-          float acc = part[b][c];
+        for (int g = 0; g < CG; ++g) {
+          const float* wr = wl + (g * 4 + (lane & 3)) * 16;
+          f32x4 acc = part[b][g];
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4) {
-            const float4 w4 = *reinterpret_cast<const float4*>(wl + c * 16 + r4 * 4);
-            acc = fmaf(w4.x, t[r4 * 4 + 0], acc); acc = fmaf(w4.y, t[r4 * 4 + 1], acc);
-            acc = fmaf(w4.z, t[r4 * 4 + 2], acc); acc = fmaf(w4.w, t[r4 * 4 + 3], acc);
+            const float4 w4 = *reinterpret_cast<const float4*>(wr + r4 * 4);
+            acc = mfma4(w4.x, t[r4 * 4 + 0], acc); acc = mfma4(w4.y, t[r4 * 4 + 1], acc);
+            acc = mfma4(w4.z, t[r4 * 4 + 2], acc); acc = mfma4(w4.w, t[r4 * 4 + 3], acc);
           }
-          part[b][c] = acc;
+          part[b][g] = acc;
         }
       };
-      auto as_acc = [&](const float* xr) {
-        f32x16 t = {0};
+      // dW[c][d] += sum_n src[c][n] * tt[n][d] over the positions of 32-block b: B = register r of the (rows n, col d) tile,
+      // A = src[c = 4*cg + (lane & 3)][b*32 + rmap(r, half)] from the staged copy (4 ds_read_b128 per group)
+      auto add_dw = [&](f32x4 (&acc)[CG], const float* src, int b, const f32x16& tt) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) t[j] = xr[j];
-        return t;
+        for (int g = 0; g < CG; ++g) {
+          const float* ar = src + (g * 4 + (lane & 3)) * NP + b * 32 + 4 * half;
+          f32x4 t = acc[g];
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(ar + 8 * q4);
+            t = mfma4(a4.x, tt[q4 * 4 + 0], t); t = mfma4(a4.y, tt[q4 * 4 + 1], t);
+            t = mfma4(a4.z, tt[q4 * 4 + 2], t); t = mfma4(a4.w, tt[q4 * 4 + 3], t);
+          }
+          acc[g] = t;
+        }
       };
 
       // ---- K^T (normalised over the positions of each row) and V^T
@@ -301,15 +346,10 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
             outT = mfma32b(q[r], ctx[r], outT);
             dq = mfma32b(ctxT[r], dO[r], dq);
           }
-          const f32x16 dypT = tr32(as_acc(DY[b]), tile, col, half);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) go = mfma32b(dypT[r], outT[r], go);
+          add_dw(go, dys, b, outT);
           const f32x16 dq_raw = q_softmax_bwd(q, dq);
           add_dxh(b, 0, dq_raw);
-          const f32x16 xhT = tr32(as_acc(Xh[b]), tile, col, half);
-          const f32x16 dq_rawT = tr32(dq_raw, tile, col, half);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) gq = mfma32b(xhT[r], dq_rawT[r], gq);
+          add_dw(gq, xs, b, tr32(dq_raw, tile, col, half));
         }
         const f32x16 dctxT = tr32(dctx, tile, col, half);
         float delta = 0.f;
@@ -327,18 +367,14 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
           f32x16 dk_rawT;
 #pragma unroll
           for (int r = 0; r < 16; ++r) dk_rawT[r] = kT[b][r] * (dkT[r] - delta);
-          const f32x16 xhT = tr32(as_acc(Xh[b]), tile, col, half);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) gk = mfma32b(xhT[r], dk_rawT[r], gk);
+          add_dw(gk, xs, b, dk_rawT);
           add_dxh(b, 1, tr32(dk_rawT, tile, col, half));
           const f32x16 Kd = tr32(kT[b], tile, col, half);
           f32x16 dv = {0};
 #pragma unroll
           for (int r = 0; r < 16; ++r) dv = mfma32b(dctx[r], Kd[r], dv);
           add_dxh(b, 2, dv);
-          const f32x16 dvT = tr32(dv, tile, col, half);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) gv = mfma32b(xhT[r], dvT[r], gv);
+          add_dw(gv, xs, b, tr32(dv, tile, col, half));
         }
       } else {
         // ================= 32/N rows per wave, one block: per-row ctx / dctx =================
@@ -375,12 +411,9 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
           dq = mfma32b(kT[0][r], dst[r], dq);     // rows d,  col n
           dkT = mfma32b(dsm[r], qT[r], dkT);      // rows n', col d
         }
-        const f32x16 dypT = tr32(as_acc(DY[0]), tile, col, half);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) go = mfma32b(dypT[r], outT[r], go);
+        add_dw(go, dys, 0, outT);
         const f32x16 dq_raw = q_softmax_bwd(q, dq);
         add_dxh(0, 0, dq_raw);
-        const f32x16 xhT = tr32(as_acc(Xh[0]), tile, col, half);
         const f32x16 dq_rawT = tr32(dq_raw, tile, col, half);
         f32x16 dk_rawT;  // softmax over the positions of each row: a lane's own register segment (+ lane^32)
 #pragma unroll
@@ -392,12 +425,9 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
 #pragma unroll
           for (int r = s0; r < s0 + SEG; ++r) dk_rawT[r] = kT[0][r] * (dkT[r] - dl);
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          gq = mfma32b(xhT[r], dq_rawT[r], gq);
-          gk = mfma32b(xhT[r], dk_rawT[r], gk);
-          gv = mfma32b(xhT[r], dvT[r], gv);
-        }
+        add_dw(gq, xs, 0, dq_rawT);
+        add_dw(gk, xs, 0, dk_rawT);
+        add_dw(gv, xs, 0, dvT);
         add_dxh(0, 1, tr32(dk_rawT, tile, col, half));
         add_dxh(0, 2, dv);
       }
@@ -408,7 +438,7 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
         const int pos = N >= 32 ? b * 32 + col : col % N;
         float full[C], tot[NJ];
 #pragma unroll
-        for (int c = 0; c < C; ++c) full[c] = part[b][c] + swp32(part[b][c]);
+        for (int c = 0; c < C; ++c) full[c] = part[b][c >> 2][c & 3] + swp32(part[b][c >> 2][c & 3]);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const int c0 = rmap(j, 0), c1 = c0 + 4;
@@ -469,15 +499,19 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
     // kernel's critical path).  Register r holds channel rmap(r, half), lane column = d / e.
     float* slot = a.part + (int64_t)wave_id * la_slot(C);
 #pragma unroll
-    for (int r = 0; r < NJ; ++r) {
-      const int c = rmap(r, half);
-      if (c < C) {
-        slot[(hd * 32 + col) * C + c] = gq[r];
-        slot[(128 + hd * 32 + col) * C + c] = gk[r];
-        slot[(256 + hd * 32 + col) * C + c] = gv[r];
-        slot[384 * C + c * 128 + hd * 32 + col] = go[r];
+    for (int g = 0; g < CG; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = 4 * g + i;
+        const float vq = gq[g][i] + swp32(gq[g][i]), vk = gk[g][i] + swp32(gk[g][i]);
+        const float vv = gv[g][i] + swp32(gv[g][i]), vo = go[g][i] + swp32(go[g][i]);
+        if (half == 0) {  // lane = d / e
+          slot[(hd * 32 + col) * C + c] = vq;
+          slot[(128 + hd * 32 + col) * C + c] = vk;
+          slot[(256 + hd * 32 + col) * C + c] = vv;
+          slot[384 * C + c * 128 + hd * 32 + col] = vo;
+        }
       }
-    }
     if (hd == 0 || hd == 3) {  // norm gains / bias: sum over the 32 positions-lanes of this half, one lane stores
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
