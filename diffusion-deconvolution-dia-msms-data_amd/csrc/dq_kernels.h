@@ -101,6 +101,10 @@ struct ResBwd {
   int C = 0, rows = 0, n = 0, rows_per_sample = 1;
 };
 bool res_fusable(int n, int C);
+// k_res_cp.hip: channel-parallel variant for the deep levels (n <= 8, C = 12 / 16); launch_res_fwd / _bwd dispatch to it
+bool res_cp_usable(int n, int C, int cinA, int cinB);
+int launch_res_fwd_cp(const ResFwd& a, hipStream_t s);
+int launch_res_bwd_cp(const ResBwd& a, hipStream_t s);
 int launch_res_fwd(const ResFwd& a, hipStream_t s);
 int launch_res_bwd(const ResBwd& a, hipStream_t s);
 

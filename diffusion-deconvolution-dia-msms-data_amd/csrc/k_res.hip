@@ -110,6 +110,7 @@ int launch_res_fwd(const ResFwd& a, hipStream_t s) {
   DQ_REQUIRE(res_fusable(a.n, a.C), "res_fwd: row length must divide 256 and C be 4/8/12/16");
   DQ_REQUIRE(a.rows % a.rows_per_sample == 0, "res_fwd: rows must be a multiple of rows_per_sample");
   DQ_REQUIRE(a.wr || (a.cinA == a.C && a.cinB == 0), "res_fwd: identity residual needs C input channels");
+  if (res_cp_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_fwd_cp(a, s);
   const int B = a.rows / a.rows_per_sample;
   dim3 grid(cdiv((int64_t)a.rows_per_sample * a.n, 256), B), block(256);
   switch (a.C) {
@@ -263,6 +264,7 @@ int launch_res_bwd(const ResBwd& a, hipStream_t s) {
   DQ_REQUIRE(res_fusable(a.n, a.C), "res_bwd: row length must divide 256 and C be 4/8/12/16");
   DQ_REQUIRE(a.rows % a.rows_per_sample == 0, "res_bwd: rows must be a multiple of rows_per_sample");
   DQ_REQUIRE(a.wr || (a.cinA == a.C && a.cinB == 0), "res_bwd: identity residual needs C input channels");
+  if (res_cp_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_bwd_cp(a, s);
   const int B = a.rows / a.rows_per_sample;
   dim3 grid(cdiv((int64_t)a.rows_per_sample * a.n, 256), B), block(256);
   switch (a.C) {
