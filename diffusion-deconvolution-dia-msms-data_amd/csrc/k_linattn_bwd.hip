@@ -158,6 +158,19 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) { cx[b][j] = px[b][j]; cu[b][j] = pu[b][j]; cd[b][j] = pd[b][j]; }
       if (PREFETCH && u + 1 < u1) load_unit(u + 1);
+      // what the tail of this iteration reads back -- dXh of the earlier heads, and dx in the last head's pass -- is requested
+      // now, so that its latency hides behind the MFMA work instead of stalling the read-modify-write at the end
+      float pdxh[NB][NJ], pdx[NB][NJ];
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int c = rmap(j, half);
+          const int64_t off = ((int64_t)row * C + c) * N + (N >= 32 ? b * 32 + col : col % N);
+          const bool ok = row_ok && c < C;
+          pdxh[b][j] = (PREFETCH && ok && hd > 0) ? a.dxh[off] : 0.f;
+          pdx[b][j] = (PREFETCH && ok && hd == 3) ? a.dx[off] : 0.f;
+        }
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         float xv[NJ], uv[NJ], dv_[NJ];
@@ -451,8 +464,10 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
           lo = 0.f;  // from here on: this lane's total dXh of channel c (heads 0..3), only formed in the last head's pass
           if (row_ok && c < C) {
             float* dst = a.dxh + ((int64_t)row * C + c) * N + pos;
-            if (hd < 3) *dst = hd == 0 ? val : *dst + val;  // head 0 initialises, heads 1, 2 accumulate (same lane, same address)
-            else lo = *dst + val;
+            // head 0 initialises, heads 1, 2 accumulate (same lane, same address); C > 8 has no registers for the prefetch
+            const float prev = PREFETCH ? pdxh[b][j] : (hd > 0 ? *dst : 0.f);
+            if (hd < 3) *dst = prev + val;
+            else lo = prev + val;
           }
           tot[j] = lo;
         }
@@ -463,7 +478,7 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
             const int c = rmap(j, half);
-            xv[j] = (row_ok && c < C) ? a.x[((int64_t)row * C + c) * N + pos] : 0.f;
+            xv[j] = (c < C) ? cx[b][j] : 0.f;  // raw x of this unit (zero for masked rows / channels), still in registers
             ssq = fmaf(xv[j], xv[j], ssq);
           }
           ssq += swp32(ssq);
@@ -488,7 +503,7 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
             if (row_ok && c < C) {
               const int64_t off = ((int64_t)row * C + c) * N + pos;
               const float du = clamped ? tot[j] * inv : inv * (tot[j] - xv[j] * dot);
-              a.dx[off] = (a.dx[off] + a.dy[off]) + du;
+              a.dx[off] = ((PREFETCH ? pdx[b][j] : a.dx[off]) + cd[b][j]) + du;  // cd: raw dy of this unit, still in registers
             }
           }
         }
