@@ -101,6 +101,19 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
   const float sqC = sqrtf((float)C);
   const float scale = 0.17677669529663687f;
   const int rl = N >= 32 ? 0 : col / N;
+  // norm gains of this lane's channels, once per wave (a load inside the row loop cannot be hoisted past the loop's stores
+  // by the compiler and would sit on the critical path of every row)
+  // (the two largest variants have no registers to spare for it -- and crash this compiler's AGPR-copy rewrite when pushed)
+  constexpr bool HOIST_G = !(C >= 12 && N == 64);
+  float gpre[NJ], gout[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = rmap(j, half);
+    gpre[j] = (HOIST_G && c < C) ? a.g_pre[c] : 0.f;
+    gout[j] = (HOIST_G && c < C) ? a.g_out[c] : 0.f;
+  }
+  auto g_pre_of = [&](int j) { return HOIST_G ? gpre[j] : (rmap(j, half) < C ? a.g_pre[rmap(j, half)] : 0.f); };
+  auto g_out_of = [&](int j) { return HOIST_G ? gout[j] : (rmap(j, half) < C ? a.g_out[rmap(j, half)] : 0.f); };
 
 #pragma unroll 1
   for (int hd = 0; hd < 4; ++hd) {
@@ -189,11 +202,10 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
         float dot = 0.f;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const int c = rmap(j, half);
-          Xh[b][j] = xv[j] * inv * (c < C ? a.g_pre[c] : 0.f);
+          Xh[b][j] = xv[j] * inv * g_pre_of(j);
           const float uh = uv[j] * uinv;
           if (hd == 0) nacc0[j] = fmaf(dv_[j], uh * sqC, nacc0[j]);  // d g_out
-          const float gd = dv_[j] * (c < C ? a.g_out[c] : 0.f) * sqC;
+          const float gd = dv_[j] * g_out_of(j) * sqC;
           uv[j] = uh;
           dv_[j] = gd;
           dot = fmaf(gd, uh, dot);
@@ -487,10 +499,9 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
           float dot = 0.f;
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
-            const int c = rmap(j, half);
             const float uh = xv[j] * inv;
             nacc0[j] = fmaf(tot[j], uh * sqC, nacc0[j]);  // d g_pre
-            const float gd = tot[j] * (c < C ? a.g_pre[c] : 0.f) * sqC;
+            const float gd = tot[j] * g_pre_of(j) * sqC;
             xv[j] = uh;
             tot[j] = gd;
             dot = fmaf(gd, uh, dot);
