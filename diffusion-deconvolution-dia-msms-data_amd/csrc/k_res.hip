@@ -173,12 +173,15 @@ __global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
 #pragma unroll
   for (int c = 0; c < C; ++c) dg2[c] = dg1[c] = dsc[c] = dsh[c] = 0.f;
 
-  // ---- block2: dU2 = norm/act backward of d out
-  float dout[C], d[C], u[C];
+  // ---- block2: dU2 = norm/act backward of d out.  Everything this thread will read from global memory (d out, u2, u1 and,
+  // for the identity residual, the old dA) is requested here, so one latency is exposed instead of three
+  float dout[C], d[C], u[C], u1v[C], dold[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     dout[c] = live ? a.dout[obase + (int64_t)c * a.n] : 0.f;
     u[c] = live ? a.u2[obase + (int64_t)c * a.n] : 1.f;
+    u1v[c] = live ? a.u1[obase + (int64_t)c * a.n] : 1.f;
+    dold[c] = (live && !a.wr && a.dA) ? a.dA[obase + (int64_t)c * a.n] : 0.f;
     d[c] = dout[c];
   }
   norm_act_bwd<C, false>(u, d, a.g2, nullptr, dg2, nullptr, nullptr);
@@ -203,7 +206,7 @@ __global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
   __syncthreads();
   // ---- block1: dU1
 #pragma unroll
-  for (int c = 0; c < C; ++c) u[c] = live ? a.u1[obase + (int64_t)c * a.n] : 1.f;
+  for (int c = 0; c < C; ++c) u[c] = u1v[c];
   norm_act_bwd<C, true>(u, da1, a.g1, a.ss + (int64_t)b * a.ss_stride, dg1, dsc, dsh);
   if (live) {
 #pragma unroll
@@ -241,7 +244,7 @@ __global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
         for (int ci = 0; ci < C; ++ci) dx[ci] = fmaf(w[ci * 3 + 0], dr, fmaf(w[ci * 3 + 1], dc, fmaf(w[ci * 3 + 2], dl, dx[ci])));
       }
 #pragma unroll
-      for (int ci = 0; ci < C; ++ci) a.dA[obase + (int64_t)ci * a.n] += dx[ci];
+      for (int ci = 0; ci < C; ++ci) a.dA[obase + (int64_t)ci * a.n] = dold[ci] + dx[ci];
     }
   }
   // ---- reductions: dg2, dg1 (atomic), per-sample d(scale), d(shift) (atomic)
