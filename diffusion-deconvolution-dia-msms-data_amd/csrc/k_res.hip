@@ -14,6 +14,17 @@ namespace dq {
 
 namespace {
 __device__ __forceinline__ float ldg(const float* p) { return *p; }
+// Ordering point of the LDS neighbour exchange.  When the row length divides 64, a wave's 64 consecutive items are whole
+// rows: the +-1 neighbours a lane reads were written by its own wave (reads across a row boundary are masked), so a
+// wave-level fence is enough and the four waves of the block never wait for each other.
+__device__ __forceinline__ void exch_sync(bool wave_local) {
+  if (wave_local) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    __syncthreads();
+  }
+}
 }
 
 template <int C>
@@ -21,6 +32,7 @@ __global__ void __launch_bounds__(256) k_res_fwd(ResFwd a) {
   __shared__ float sh[C][256 + 2];
   const int b = blockIdx.y;
   const int per_sample = a.rows_per_sample * a.n;
+  const bool wave_local = a.n <= 64 && (64 % a.n) == 0;
   const int it = blockIdx.x * 256 + threadIdx.x;
   const bool live = it < per_sample;
   const int row = b * a.rows_per_sample + (live ? it / a.n : 0), p = live ? it % a.n : 0;
@@ -62,7 +74,7 @@ __global__ void __launch_bounds__(256) k_res_fwd(ResFwd a) {
   // ---- neighbours of a1 through LDS (zero outside the row)
 #pragma unroll
   for (int co = 0; co < C; ++co) sh[co][threadIdx.x + 1] = live ? acc[co] : 0.f;
-  __syncthreads();
+  exch_sync(wave_local);
   float o[C];
 #pragma unroll
   for (int co = 0; co < C; ++co) o[co] = a.b2[co];
@@ -163,6 +175,7 @@ __global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
   __shared__ float red[4][4 * C];
   const int b = blockIdx.y;
   const int per_sample = a.rows_per_sample * a.n;
+  const bool wave_local = a.n <= 64 && (64 % a.n) == 0;
   const int it = blockIdx.x * 256 + threadIdx.x;
   const bool live = it < per_sample;
   const int row = b * a.rows_per_sample + (live ? it / a.n : 0), p = live ? it % a.n : 0;
@@ -191,7 +204,7 @@ __global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
   }
 #pragma unroll
   for (int c = 0; c < C; ++c) sh[c][threadIdx.x + 1] = live ? d[c] : 0.f;
-  __syncthreads();
+  exch_sync(wave_local);
   // ---- d a1[ci][p] = sum_co sum_k W2[co][ci][k] dU2[co][p + 1 - k]
   float da1[C];
 #pragma unroll
@@ -203,7 +216,7 @@ __global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
 #pragma unroll
     for (int ci = 0; ci < C; ++ci) da1[ci] = fmaf(w[ci * 3 + 0], dr, fmaf(w[ci * 3 + 1], dc, fmaf(w[ci * 3 + 2], dl, da1[ci])));
   }
-  __syncthreads();
+  exch_sync(wave_local);
   // ---- block1: dU1
 #pragma unroll
   for (int c = 0; c < C; ++c) u[c] = u1v[c];
@@ -214,7 +227,7 @@ __global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
   }
 #pragma unroll
   for (int c = 0; c < C; ++c) sh[c][threadIdx.x + 1] = live ? da1[c] : 0.f;
-  __syncthreads();
+  exch_sync(wave_local);
   // ---- d x[ci][p] = sum_co sum_k W1[co][ci][k] dU1[co][p + 1 - k]  (+ residual branch), accumulated into dA / dB
   if (live && (a.dA || a.dB)) {
     if (a.wr) {
