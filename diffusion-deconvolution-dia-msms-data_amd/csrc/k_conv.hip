@@ -504,17 +504,30 @@ __global__ void __launch_bounds__(256) k_conv_wgrad_v4(ConvWgrad a, int n_cib, i
   wgrad_block_reduce<COB, CIB, K>(acc, accb, a, co0, ci0, cin, nelem_w);
 }
 
-// one wave per element: lane l sums partials l, l+64, ... in order, then a fixed butterfly => deterministic
+// dW[e] += sum over the per-block partials in a fixed order (deterministic).  A block owns 16 consecutive elements x 16
+// partial groups: thread (e, g) sums partials g, g+16, ... (64-byte segments: every fetched sector is fully used), the 16
+// group sums meet in LDS.
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ part, int nblk, int nelem_w, int cout,
                                                       float* __restrict__ dw, float* __restrict__ dbias) {
-  const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
+  __shared__ float red[16][17];
+  const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + el;
   const int nelem = nelem_w + cout;
-  if (e >= nelem) return;
-  float s = 0.f;
-  for (int b = lane; b < nblk; b += 64) s += part[(int64_t)b * nelem + e];
-  s = wave_sum(s);
-  if (lane == 0) {
+  float s0 = 0.f, s1 = 0.f;
+  if (e < nelem) {
+    int b = g;
+    for (; b + 16 < nblk; b += 32) {
+      s0 += part[(int64_t)b * nelem + e];
+      s1 += part[(int64_t)(b + 16) * nelem + e];
+    }
+    if (b < nblk) s0 += part[(int64_t)b * nelem + e];
+  }
+  red[g][el] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && e < nelem) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][el];
     if (e < nelem_w) dw[e] += s;
     else if (dbias) dbias[e - nelem_w] += s;
   }
@@ -538,7 +551,7 @@ int launch_conv_wgrad(const ConvWgrad& a, hipStream_t s) {
     if (a.K == 1) hipLaunchKernelGGL((k_conv_wgrad_v4<COB, CIB, 1>), grid, block, 0, s, a, n_cib, nelem_w);
     else hipLaunchKernelGGL((k_conv_wgrad_v4<COB, CIB, 3>), grid, block, 0, s, a, n_cib, nelem_w);
     DQ_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(nelem_w + a.cout, 4)), dim3(256), 0, s, a.scratch, gx, nelem_w, a.cout, a.dw, a.dbias);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(nelem_w + a.cout, 16)), dim3(256), 0, s, a.scratch, gx, nelem_w, a.cout, a.dw, a.dbias);
     DQ_LAUNCH_CHECK();
     return 0;
   }
@@ -546,7 +559,7 @@ int launch_conv_wgrad(const ConvWgrad& a, hipStream_t s) {
   if (a.K == KK && a.mode == MM) {                                                                      \
     hipLaunchKernelGGL((k_conv_wgrad<COB, CIB, KK, MM>), grid, block, 0, s, a, n_cib, nelem_w);         \
     DQ_LAUNCH_CHECK();                                                                                  \
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(nelem_w + a.cout, 4)), dim3(256), 0, s, a.scratch, gx, nelem_w, a.cout, a.dw, \
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(nelem_w + a.cout, 16)), dim3(256), 0, s, a.scratch, gx, nelem_w, a.cout, a.dw, \
                        a.dbias);                                                                        \
     DQ_LAUNCH_CHECK();                                                                                  \
     return 0;                                                                                           \
