@@ -39,10 +39,17 @@ void set_error(const std::string& msg);
 
 constexpr float RMS_EPS = 1e-12f;  // F.normalize eps (reference unet1d.py:140)
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of the ~10-instruction correctly-rounded division / square root sequences: the
+// pointwise ResnetBlock kernels are VALU-bound at sampling batch sizes, and 1 ulp is far inside the fp32 parity tolerance
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+// sqrt(C) / max(||u||, eps) of RMSNorm / F.normalize
+__device__ __forceinline__ float rms_inv(float ssq, float sqC) { return sqC * fast_rcp(fmaxf(fast_sqrt(ssq), RMS_EPS)); }
+
+__device__ __forceinline__ float silu_f(float x) { return x * fast_rcp(1.0f + __expf(-x)); }
 // d/dx silu(x) = s + x*s*(1-s), s = sigmoid(x)
 __device__ __forceinline__ float silu_grad_f(float x) {
-  float s = 1.0f / (1.0f + __expf(-x));
+  float s = fast_rcp(1.0f + __expf(-x));
   return s * (1.0f + x * (1.0f - s));
 }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

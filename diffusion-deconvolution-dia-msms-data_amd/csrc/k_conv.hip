@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(256) k_conv_fwd(ConvFwd a) {
     float ssq = 0.f;
 #pragma unroll
     for (int co = 0; co < COUT; ++co) ssq = fmaf(acc[co], acc[co], ssq);
-    const float inv = sqrtf((float)COUT) / fmaxf(sqrtf(ssq), RMS_EPS);
+    const float inv = rms_inv(ssq, sqrtf((float)COUT));
 #pragma unroll
     for (int co = 0; co < COUT; ++co) acc[co] = acc[co] * inv * a.g[co];
   }
@@ -183,8 +183,8 @@ __global__ void __launch_bounds__(256) k_block_bwd(BlockBwd a) {
       float ssq = 0.f;
 #pragma unroll
       for (int c = 0; c < C; ++c) ssq = fmaf(u[c], u[c], ssq);
-      const float nrm = sqrtf(ssq);
-      const float inv = 1.0f / fmaxf(nrm, RMS_EPS);
+      const float nrm = fast_sqrt(ssq);
+      const float inv = fast_rcp(fmaxf(nrm, RMS_EPS));
       float dot = 0.f;
 #pragma unroll
       for (int c = 0; c < C; ++c) {
@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(256) k_rmsnorm_fwd(const float* __restrict__ x
   float ssq = 0.f;
 #pragma unroll
   for (int c = 0; c < C; ++c) { v[c] = x[base + (int64_t)c * n]; ssq = fmaf(v[c], v[c], ssq); }
-  const float inv = sqrtf((float)C) / fmaxf(sqrtf(ssq), RMS_EPS);
+  const float inv = rms_inv(ssq, sqrtf((float)C));
 #pragma unroll
   for (int c = 0; c < C; ++c) y[base + (int64_t)c * n] = v[c] * inv * g[c];
 }

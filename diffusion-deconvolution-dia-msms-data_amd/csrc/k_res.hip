@@ -42,14 +42,40 @@ __global__ void __launch_bounds__(256) k_res_fwd(ResFwd a) {
   // ---- conv1 (k3, zero padding) over cat(A, B)
 #pragma unroll
   for (int co = 0; co < C; ++co) acc[co] = a.b1[co];
-  if (live) {
-    for (int ci = 0; ci < cin; ++ci) {
-      const float* src = (ci < a.cinA) ? a.inA + ((int64_t)row * a.cinA + ci) * a.n : a.inB + ((int64_t)row * a.cinB + (ci - a.cinA)) * a.n;
-      const float x0 = p > 0 ? src[p - 1] : 0.f, x1 = src[p], x2 = p + 1 < a.n ? src[p + 1] : 0.f;
+  // cat(A, B) has cinA == C channels from A (launcher-checked) and cinB <= C from B: every load of the thread is issued
+  // up front from compile-time-unrolled loops -- a runtime ci loop serialised one exposed global latency per channel
+  float xa[C][3], xb[C][3];
 #pragma unroll
-      for (int co = 0; co < C; ++co) {
-        const float* w = a.w1 + ((int64_t)co * cin + ci) * 3;
-        acc[co] = fmaf(w[0], x0, fmaf(w[1], x1, fmaf(w[2], x2, acc[co])));
+  for (int ci = 0; ci < C; ++ci) {
+    const float* src = a.inA + ((int64_t)row * C + ci) * a.n;
+    xa[ci][0] = (live && p > 0) ? src[p - 1] : 0.f;
+    xa[ci][1] = live ? src[p] : 0.f;
+    xa[ci][2] = (live && p + 1 < a.n) ? src[p + 1] : 0.f;
+  }
+#pragma unroll
+  for (int ci = 0; ci < C; ++ci) {
+    const bool ok = live && ci < a.cinB;
+    const float* src = a.inB + ((int64_t)row * a.cinB + ci) * a.n;
+    xb[ci][0] = (ok && p > 0) ? src[p - 1] : 0.f;
+    xb[ci][1] = ok ? src[p] : 0.f;
+    xb[ci][2] = (ok && p + 1 < a.n) ? src[p + 1] : 0.f;
+  }
+#pragma unroll
+  for (int ci = 0; ci < C; ++ci)
+#pragma unroll
+    for (int co = 0; co < C; ++co) {
+      const float* w = a.w1 + ((int64_t)co * cin + ci) * 3;
+      acc[co] = fmaf(w[0], xa[ci][0], fmaf(w[1], xa[ci][1], fmaf(w[2], xa[ci][2], acc[co])));
+    }
+  if (a.cinB) {
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci) {
+      if (ci < a.cinB) {
+#pragma unroll
+        for (int co = 0; co < C; ++co) {
+          const float* w = a.w1 + ((int64_t)co * cin + C + ci) * 3;
+          acc[co] = fmaf(w[0], xb[ci][0], fmaf(w[1], xb[ci][1], fmaf(w[2], xb[ci][2], acc[co])));
+        }
       }
     }
   }
@@ -62,7 +88,7 @@ __global__ void __launch_bounds__(256) k_res_fwd(ResFwd a) {
     float ssq = 0.f;
 #pragma unroll
     for (int co = 0; co < C; ++co) ssq = fmaf(acc[co], acc[co], ssq);
-    const float inv = sqC / fmaxf(sqrtf(ssq), RMS_EPS);
+    const float inv = rms_inv(ssq, sqC);
     const float* ss = a.ss + (int64_t)b * a.ss_stride;
 #pragma unroll
     for (int co = 0; co < C; ++co) acc[co] = silu_f(fmaf(acc[co] * inv * a.g1[co], ss[co] + 1.0f, ss[C + co]));
@@ -95,7 +121,7 @@ __global__ void __launch_bounds__(256) k_res_fwd(ResFwd a) {
     float ssq = 0.f;
 #pragma unroll
     for (int co = 0; co < C; ++co) ssq = fmaf(o[co], o[co], ssq);
-    const float inv = sqC / fmaxf(sqrtf(ssq), RMS_EPS);
+    const float inv = rms_inv(ssq, sqC);
 #pragma unroll
     for (int co = 0; co < C; ++co) o[co] = silu_f(o[co] * inv * a.g2[co]);
   }
@@ -103,14 +129,20 @@ __global__ void __launch_bounds__(256) k_res_fwd(ResFwd a) {
   if (a.wr) {
 #pragma unroll
     for (int co = 0; co < C; ++co) o[co] += a.br[co];
-    for (int ci = 0; ci < cin; ++ci) {
-      const float xv = (ci < a.cinA) ? a.inA[((int64_t)row * a.cinA + ci) * a.n + p] : a.inB[((int64_t)row * a.cinB + (ci - a.cinA)) * a.n + p];
 #pragma unroll
-      for (int co = 0; co < C; ++co) o[co] = fmaf(a.wr[(int64_t)co * cin + ci], xv, o[co]);
+    for (int ci = 0; ci < C; ++ci)
+#pragma unroll
+      for (int co = 0; co < C; ++co) o[co] = fmaf(a.wr[(int64_t)co * cin + ci], xa[ci][1], o[co]);
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci) {
+      if (ci < a.cinB) {
+#pragma unroll
+        for (int co = 0; co < C; ++co) o[co] = fmaf(a.wr[(int64_t)co * cin + C + ci], xb[ci][1], o[co]);
+      }
     }
   } else {
 #pragma unroll
-    for (int co = 0; co < C; ++co) o[co] += a.inA[obase + (int64_t)co * a.n];
+    for (int co = 0; co < C; ++co) o[co] += xa[co][1];
   }
 #pragma unroll
   for (int co = 0; co < C; ++co) a.out[obase + (int64_t)co * a.n] = o[co];
@@ -123,6 +155,7 @@ int launch_res_fwd(const ResFwd& a, hipStream_t s) {
   DQ_REQUIRE(a.rows % a.rows_per_sample == 0, "res_fwd: rows must be a multiple of rows_per_sample");
   DQ_REQUIRE(a.wr || (a.cinA == a.C && a.cinB == 0), "res_fwd: identity residual needs C input channels");
   if (res_cp_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_fwd_cp(a, s);
+  DQ_REQUIRE(a.cinA == a.C && a.cinB <= a.C && (a.cinB == 0 || a.inB), "res_fwd: input must be C channels (+ at most C skip channels)");
   const int B = a.rows / a.rows_per_sample;
   dim3 grid(cdiv((int64_t)a.rows_per_sample * a.n, 256), B), block(256);
   switch (a.C) {
@@ -147,7 +180,7 @@ __device__ __forceinline__ void norm_act_bwd(const float* u, float* d, const flo
   float ssq = 0.f;
 #pragma unroll
   for (int c = 0; c < C; ++c) ssq = fmaf(u[c], u[c], ssq);
-  const float nrm = sqrtf(ssq), inv = 1.0f / fmaxf(nrm, RMS_EPS);
+  const float nrm = fast_sqrt(ssq), inv = fast_rcp(fmaxf(nrm, RMS_EPS));
   float uh[C];
   float dot = 0.f;
 #pragma unroll

@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256) k_res_fwd_cp(ResFwd a) {
 #pragma unroll
     for (int p = 0; p < N; ++p) {
       const float ssq = gsum16(acc[p] * acc[p]);
-      const float inv = sqC / fmaxf(sqrtf(ssq), RMS_EPS);
+      const float inv = rms_inv(ssq, sqC);
       acc[p] = act ? silu_f(fmaf(acc[p] * inv * g1, sc, sh)) : 0.f;
     }
   }
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256) k_res_fwd_cp(ResFwd a) {
 #pragma unroll
     for (int p = 0; p < N; ++p) {
       const float ssq = gsum16(o[p] * o[p]);
-      const float inv = sqC / fmaxf(sqrtf(ssq), RMS_EPS);
+      const float inv = rms_inv(ssq, sqC);
       o[p] = silu_f(o[p] * inv * g2);
     }
   }
@@ -185,7 +185,7 @@ __device__ __forceinline__ float norm_act_bwd_cp(float u, float d, float g, floa
                                                  float& dsh) {
   const float sqC = sqrtf((float)C);
   const float ssq = gsum16(u * u);
-  const float nrm = sqrtf(ssq), inv = 1.0f / fmaxf(nrm, RMS_EPS);
+  const float nrm = fast_sqrt(ssq), inv = fast_rcp(fmaxf(nrm, RMS_EPS));
   const float uh = u * inv;
   const float z = uh * g * sqC;
   const float w = SS ? fmaf(z, sc, sh) : z;
