@@ -105,6 +105,9 @@ bool res_fusable(int n, int C);
 bool res_cp_usable(int n, int C, int cinA, int cinB);
 int launch_res_fwd_cp(const ResFwd& a, hipStream_t s);
 int launch_res_bwd_cp(const ResBwd& a, hipStream_t s);
+// k_res_v4.hip: 4-positions-per-thread forward for the wide levels (C = 4 / 8, n >= 8)
+bool res_v4_usable(int n, int C, int cinA, int cinB);
+int launch_res_fwd_v4(const ResFwd& a, hipStream_t s);
 int launch_res_fwd(const ResFwd& a, hipStream_t s);
 int launch_res_bwd(const ResBwd& a, hipStream_t s);
 

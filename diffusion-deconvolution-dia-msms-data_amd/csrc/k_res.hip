@@ -155,6 +155,7 @@ int launch_res_fwd(const ResFwd& a, hipStream_t s) {
   DQ_REQUIRE(a.rows % a.rows_per_sample == 0, "res_fwd: rows must be a multiple of rows_per_sample");
   DQ_REQUIRE(a.wr || (a.cinA == a.C && a.cinB == 0), "res_fwd: identity residual needs C input channels");
   if (res_cp_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_fwd_cp(a, s);
+  if (res_v4_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_fwd_v4(a, s);
   DQ_REQUIRE(a.cinA == a.C && a.cinB <= a.C && (a.cinB == 0 || a.inB), "res_fwd: input must be C channels (+ at most C skip channels)");
   const int B = a.rows / a.rows_per_sample;
   dim3 grid(cdiv((int64_t)a.rows_per_sample * a.n, 256), B), block(256);
