@@ -12,6 +12,7 @@
 // rounding (parity tests: tests/test_hip_forward.py, tests/test_hip_backward.py run every level through these kernels).
 #include "dq_common.h"
 #include "dq_kernels.h"
+#include <algorithm>
 
 namespace dq {
 
@@ -47,7 +48,7 @@ __device__ __forceinline__ void stage_wt(float* dst, const float* __restrict__ w
 }  // namespace
 
 template <int C, int N>
-__global__ void __launch_bounds__(256) k_res_fwd_cp(ResFwd a) {
+__global__ void __launch_bounds__(256) k_res_fwd_cp(ResFwd a, int iters) {  // iters: 16-row groups per block (weights staged once)
   __shared__ __attribute__((aligned(16))) float w1s[CI * 3 * 16];
   __shared__ __attribute__((aligned(16))) float w2s[16 * 3 * 16];
   __shared__ __attribute__((aligned(16))) float wrs[CI * 16];
@@ -55,9 +56,7 @@ __global__ void __launch_bounds__(256) k_res_fwd_cp(ResFwd a) {
   __shared__ __attribute__((aligned(16))) float ys[GR][N + 2][16];
   const int cin = a.cinA + a.cinB, cin4 = (cin + 3) >> 2;
   const int g = threadIdx.x >> 4, co = threadIdx.x & 15;
-  const int b = blockIdx.y, rs = blockIdx.x * GR + g;
-  const bool live = rs < a.rows_per_sample;
-  const int row = b * a.rows_per_sample + (live ? rs : 0);
+  const int b = blockIdx.y;
   const bool act = co < C;
 
   stage_w<3>(w1s, a.w1, C, cin, cin4 * 4);
@@ -65,6 +64,13 @@ __global__ void __launch_bounds__(256) k_res_fwd_cp(ResFwd a) {
   if (a.wr) stage_w<1>(wrs, a.wr, C, cin, cin4 * 4);
   for (int i = threadIdx.x; i < GR * (N + 2) * CI; i += blockDim.x) (&xs[0][0][0])[i] = 0.f;
   for (int i = threadIdx.x; i < GR * (N + 2) * 16; i += blockDim.x) (&ys[0][0][0])[i] = 0.f;
+  // Large batches: a block walks `iters` groups of 16 rows with the weights staged once.  A group's xs / ys slice is only ever
+  // touched by its own 16 lanes; the halo slots and the unused channels are never written again and stay zero.
+#pragma unroll 1
+  for (int itr = 0; itr < iters; ++itr) {
+  const int rs = (blockIdx.x * iters + itr) * GR + g;
+  const bool live = rs < a.rows_per_sample;
+  const int row = b * a.rows_per_sample + (live ? rs : 0);
   __syncthreads();
   if (live) {
 #pragma unroll
@@ -172,6 +178,7 @@ __global__ void __launch_bounds__(256) k_res_fwd_cp(ResFwd a) {
 #pragma unroll
     for (int p = 0; p < N; ++p) a.out[obase + p] = o[p];
   }
+  }  // itr
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -350,9 +357,13 @@ bool res_cp_usable(int n, int C, int cinA, int cinB) {
 
 int launch_res_fwd_cp(const ResFwd& a, hipStream_t s) {
   const int B = a.rows / a.rows_per_sample;
-  dim3 grid(cdiv(a.rows_per_sample, GR), B), block(256);
+  // training batches: one 16-row group per block (parallelism); sampling batches: up to 8 groups per block while >= ~2048
+  // blocks remain, so that the per-block weight staging amortises
+  const int groups = cdiv(a.rows_per_sample, GR);
+  const int iters = std::max(1, std::min({8, groups, (int)((int64_t)groups * B / 2048)}));
+  dim3 grid(cdiv(groups, iters), B), block(256);
 #define DQ_CP(CC, NN) \
-  if (a.C == CC && a.n == NN) { hipLaunchKernelGGL((k_res_fwd_cp<CC, NN>), grid, block, 0, s, a); DQ_LAUNCH_CHECK(); return 0; }
+  if (a.C == CC && a.n == NN) { hipLaunchKernelGGL((k_res_fwd_cp<CC, NN>), grid, block, 0, s, a, iters); DQ_LAUNCH_CHECK(); return 0; }
   DQ_CP(12, 1) DQ_CP(12, 2) DQ_CP(12, 4) DQ_CP(12, 8) DQ_CP(16, 1) DQ_CP(16, 2) DQ_CP(16, 4) DQ_CP(16, 8)
 #undef DQ_CP
   set_error("res_fwd_cp: unsupported (C, n)");
