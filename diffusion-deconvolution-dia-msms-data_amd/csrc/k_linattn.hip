@@ -1,32 +1,40 @@
-// K5: Residual(PreNorm(LinearAttention)) over m/z, forward (and backward, below), 89 % of the network's FLOPs.
+// K5: Residual(PreNorm(LinearAttention)) over m/z, forward; 89 % of the reference network's FLOPs.
 // Reference arithmetic: dquartic/model/unet1d.py:446-496 (LinearAttention), :143-176 (PreNorm), :64-79 (Residual),
 // :113-140 (RMSNorm):
 //   xh = rmsnorm(x)*g_pre ; q,k,v = Wqkv xh  (4 heads x 32) ; q = softmax_d(q) * 32^-0.5 ; k = softmax_n(k)
 //   ctx[d][e] = sum_n k[d][n] v[e][n] ; out[e][n] = sum_d ctx[d][e] q[d][n] ; y = rmsnorm(Wo out + b)*g_out + x
 //
-// gfx950 design: ONE WAVE owns one m/z row (n >= 32) or 32/n rows (n < 32) and keeps the whole block in registers;
-// all four contractions run on the exact-f32 matrix pipe (v_mfma_f32_32x32x2_f32) with operand orientations
-// chosen so that every accumulator is directly the next MFMA's operand (an accumulator X feeds, register by
-// register, a product that sums over X's ROW index) and both softmaxes are reductions over a lane's own
-// registers plus one swap with lane^32:
-//   kT[n][d] = mfma(A = xh, B = Wk)   -> column d on the lane, positions n in the registers  (softmax over n in-lane)
-//   vT[n][e] = mfma(A = xh, B = Wv)
-//   ctx[d][e] = sum_r mfma(A = kT.r, B = vT.r)
-//   q[d][n]  = mfma(A = Wq, B = xh)   -> position on the lane, d in the registers             (softmax over d in-lane)
-//   out[e][n] = sum_r mfma(A = ctx.r, B = q.r)
-// to_out (K = 128, M = C <= 16) is done on the VALU from out's registers with Wo pre-permuted in LDS; no other LDS,
-// no barriers after the weight staging, no HBM traffic besides x in / y out (8*C*n bytes per row).
-// Checked lane-for-lane on the CPU by oracle/wave_emu.py.
+// The value path is LINEAR in xh, and xh has only C <= 16 channels.  Re-associating the three contractions
+//   M[d][c]  = sum_n k[d][n] xh[c][n]                      (32 x C per head, instead of ctx: 32 x 32)
+//   P[c][n]  = sum_d M[d][c] q[d][n]                       (C x n,           instead of out: 32 x n)
+//   y[c'][n] = sum_heads sum_c W2_h[c'][c] P_h[c][n] + b ,  W2_h = Wo_h Wv_h  (C x C per head, formed once per block)
+// gives the same function with 32*C instead of 32*32 multiply-adds per (position, d) in the two big products: 4.75x fewer
+// FLOPs at C = 4, 2.75x at C = 8 (exact algebra; only the fp32 summation order differs from the reference).
+//
+// gfx950 design: ONE WAVE owns one m/z row (n >= 32) or 32/n rows (n < 32) and keeps the block in registers.
+//   kT[n][d] = mfma32(A = xh, B = Wk)  -> column d on the lane, positions n in the registers  (softmax over n in-lane)
+//   q[d][n]  = mfma32(A = Wq, B = xh)  -> position on the lane, d in the registers             (softmax over d in-lane)
+//   M^T[c][d] and P[c][n] have C rows: they run on v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 outer products, no padding of
+//   C to 32): B operand = a register of the 32x32 tile, A operand = xh[c][n] resp. M[d][c] staged as [c][..] in LDS.
+//   Short rows (n < 32): masked S^T[n'][n] = sum_d k[d][n'] q[d][n] as before, then R[c][n] = sum_n' xh[c][n'] S^T[n'][n]
+//   (again C rows, 4x4x1).  Both softmax normalisations are applied to the C-row results (M, P / R), not to the 32-row tiles.
+//   The W2 contraction and the post-norm run on the VALU for this lane's own channels; HBM traffic: x in, y out (+ ypre).
 #include "dq_common.h"
 #include "dq_kernels.h"
 #include "dq_mfma.h"
 
 namespace dq {
 
-
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+// block = lane >> 2; a lane supplies A_blk[i = lane & 3] and B_blk[j = lane & 3]; register i of lane (blk, j) += A_blk[i] * B_blk[j]
+__device__ __forceinline__ f32x4 mfma4f(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ constexpr int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 __device__ __forceinline__ float swap32(float v) { return __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 
 template <int C, int N>
 __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
@@ -35,32 +43,41 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   constexpr int NJ = C <= 8 ? 4 : 8;          // x registers per lane (channel = rowmap(j, half))
   constexpr int SEG = N >= 32 ? 16 : (N >= 8 ? N / 2 : N);  // registers of one row inside a lane
   constexpr bool PARTNER = N >= 8;            // does lane^32 hold positions of the same row?
-  static_assert(NB <= 2, "rows longer than 64 take the two-pass path (not built here)");
+  constexpr int CG = C / 4;                   // channel groups of 4 (one 4x4x1 MFMA chain each)
+  constexpr int NP = NB * 32;                 // staged positions per wave
+  static_assert(NB <= 2, "rows longer than 64 take the two-pass path (k_linattn_long.hip)");
+  static_assert(C % 4 == 0, "channel count must be a multiple of 4");
 
-  __shared__ float wo_lds[4 * 2 * C * 16];  // [head][half][c][r] = Wo[c][head*32 + rowmap(r, half)]
+  __shared__ __attribute__((aligned(16))) float w2_lds[4 * C * C];  // [head][c'][c] = sum_e Wo[c'][head*32+e] Wv[head*32+e][c]
+  __shared__ __attribute__((aligned(16))) float xs_lds[4][C * NP];  // per wave: xh as [c][n]
+  __shared__ __attribute__((aligned(16))) float ms_lds[4][C * 32];  // per wave: M of the current head as [c][d]
   __shared__ float tiles[(N > 1 && N < 32) ? 4 : 1][(N > 1 && N < 32) ? 32 * 33 : 1];  // wave-private transpose tiles (short rows only)
   float* tile = tiles[(N > 1 && N < 32) ? (threadIdx.x >> 6) : 0];
-  for (int i = threadIdx.x; i < 4 * 2 * C * 16; i += blockDim.x) {
-    const int r = i & 15, c = (i >> 4) % C, hh = (i / (16 * C)) & 1, hd = i / (32 * C);
-    wo_lds[i] = a.w_out[c * 128 + hd * 32 + rowmap(r, hh)];
+  for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) {
+    const int c = i % C, cp = (i / C) % C, hd = i / (C * C);
+    float s = 0.f;
+#pragma unroll 8
+    for (int e = 0; e < 32; ++e) s = fmaf(a.w_out[cp * 128 + hd * 32 + e], a.w_qkv[(256 + hd * 32 + e) * C + c], s);
+    w2_lds[i] = s;
   }
-  // MFMA weight operands, laid out [q|k|v][head][j][half][col] so that a wave reads 2 x 32 consecutive floats; channels beyond C
-  // are zero.  The q and k rows carry log2(e): both softmaxes then use exp2 (v_exp_f32) directly, which changes nothing
+  // MFMA weight operands, laid out [q|k][head][j][half][col] so that a wave reads 2 x 32 consecutive floats; channels beyond C
+  // are zero.  The rows carry log2(e): both softmaxes then use exp2 (v_exp_f32) directly, which changes nothing
   // mathematically (softmax(x) = 2^(x*log2e - max) / sum).
-  constexpr int WQ = 3 * 4 * NJ * 2 * 32;
-  __shared__ float wqkv_lds[N > 1 ? WQ : 1];
+  constexpr int WQ = 2 * 4 * NJ * 2 * 32;
+  __shared__ float wqk_lds[N > 1 ? WQ : 1];
   if (N > 1) {
     for (int i = threadIdx.x; i < WQ; i += blockDim.x) {
       const int cc = i & 31, hh = (i >> 5) & 1, j = (i >> 6) % NJ, hd = (i / (64 * NJ)) & 3, m = i / (256 * NJ);
       const int c = rowmap(j, hh);
-      const float w = c < C ? a.w_qkv[(m * 128 + hd * 32 + cc) * C + c] : 0.f;
-      wqkv_lds[i] = m < 2 ? w * 1.4426950408889634f : w;
+      wqk_lds[i] = c < C ? a.w_qkv[(m * 128 + hd * 32 + cc) * C + c] * 1.4426950408889634f : 0.f;
     }
   }
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
-  const int unit = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wv = threadIdx.x >> 6;
+  float* xs = xs_lds[wv];
+  float* ms = ms_lds[wv];
+  const int unit = blockIdx.x * (blockDim.x >> 6) + wv;
   const int row0 = unit * RW;
   if (row0 >= a.rows) return;
   const int rl = N >= 32 ? 0 : col / N;
@@ -69,7 +86,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   const float sqC = sqrtf((float)C);
   const float scale = 0.17677669529663687f;  // 32^-0.5
 
-  // ---- load x, pre-norm
+  // ---- load x, pre-norm; stage xh as [c][n] for the 4x4x1 A operands
   float X[NB][NJ], Xh[NB][NJ];
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk) {
@@ -87,171 +104,190 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
     for (int j = 0; j < NJ; ++j) {
       const int c = rowmap(j, half);
       Xh[blk][j] = X[blk][j] * inv * (c < C ? a.g_pre[c] : 0.f);
+      if (c < C) xs[c * NP + blk * 32 + col] = Xh[blk][j];
     }
   }
+  wave_fence();
 
-  float ypart[NB][C];
+  float yown[NB][NJ];  // (Wo out) of this lane's channels c' = rowmap(j, half)
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
-    for (int c = 0; c < C; ++c) ypart[blk][c] = 0.f;
+    for (int j = 0; j < NJ; ++j) yown[blk][j] = 0.f;
+
+  // yown[blk][j] += f * sum_c W2[hd][c' = rowmap(j, half)][c] * p[c]
+  auto add_w2 = [&](int hd, int blk, const float (&p)[C], float f) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int cp = rowmap(j, half);
+      if (cp < C) {
+        const float* w = w2_lds + (hd * C + cp) * C;
+        float s = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < CG; ++c4) {
+          const float4 w4 = *reinterpret_cast<const float4*>(w + 4 * c4);
+          s = fmaf(w4.x, p[4 * c4 + 0], fmaf(w4.y, p[4 * c4 + 1], fmaf(w4.z, p[4 * c4 + 2], fmaf(w4.w, p[4 * c4 + 3], s))));
+        }
+        yown[blk][j] = fmaf(f, s, yown[blk][j]);
+      }
+    }
+  };
+  // sum_r mfma4(A = src[(4*g + (lane&3)) * pitch + off + rowmap(r, half)], B = t[r]): two interleaved accumulator chains
+  auto chain4 = [&](const float* src, int pitch, int off, int g, const f32x16& t) {
+    const float* ar = src + (g * 4 + (lane & 3)) * pitch + off + 4 * half;
+    f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const float4 a4 = *reinterpret_cast<const float4*>(ar + 8 * q4);
+      t0 = mfma4f(a4.x, t[q4 * 4 + 0], t0); t1 = mfma4f(a4.y, t[q4 * 4 + 1], t1);
+      t0 = mfma4f(a4.z, t[q4 * 4 + 2], t0); t1 = mfma4f(a4.w, t[q4 * 4 + 3], t1);
+    }
+    return t0 + t1;
+  };
 
 #pragma unroll 1
   for (int hd = 0; hd < 4; ++hd) {
+    if (N == 1) {
+      // softmax over a single position is 1 and the q softmax sums to 1: out = 32^-0.5 * v, i.e. y += 32^-0.5 * W2 xh
+      float xf[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) xf[c] = xs[c * NP + col];
+      add_w2(hd, 0, xf, scale);
+      continue;
+    }
     // weight operands of this head: lane (col, half) supplies W[o_base + col][rowmap(j, half)]
-    float wq[NJ], wk[NJ], wv[NJ];
+    float wq[NJ], wk[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      if (N > 1) {
-        wq[j] = wqkv_lds[(((0 * 4 + hd) * NJ + j) * 2 + half) * 32 + col];
-        wk[j] = wqkv_lds[(((1 * 4 + hd) * NJ + j) * 2 + half) * 32 + col];
-        wv[j] = wqkv_lds[(((2 * 4 + hd) * NJ + j) * 2 + half) * 32 + col];
-      } else {
-        const int c = rowmap(j, half);
-        wq[j] = wk[j] = 0.f;
-        wv[j] = c < C ? a.w_qkv[(256 + hd * 32 + col) * C + c] : 0.f;
-      }
+      wq[j] = wqk_lds[(((0 * 4 + hd) * NJ + j) * 2 + half) * 32 + col];
+      wk[j] = wqk_lds[(((1 * 4 + hd) * NJ + j) * 2 + half) * 32 + col];
     }
-
-    f32x16 out[NB];
-    if (N == 1) {
-      // softmax over a single position is 1 and the q softmax sums to 1: out = 32^-0.5 * v
-      f32x16 v = {0};
+    // ---------------- K^T (rows n, col d), softmax over the positions of each row
+    f32x16 kT[NB];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) v = mfma32(wv[j], Xh[0][j], v);  // v[e][row]
-      out[0] = v * scale;
-    } else {
-      // ---------------- K^T and V^T, softmax over the positions of each row
-      f32x16 kT[NB], vT[NB];
+    for (int blk = 0; blk < NB; ++blk) {
+      f32x16 ak = {0};
 #pragma unroll
-      for (int blk = 0; blk < NB; ++blk) {
-        f32x16 ak = {0}, av = {0};
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          ak = mfma32(Xh[blk][j], wk[j], ak);
-          av = mfma32(Xh[blk][j], wv[j], av);
-        }
-        kT[blk] = ak;
-        vT[blk] = av;
-      }
-#pragma unroll
-      for (int s0 = 0; s0 < 16; s0 += SEG) {
-        float m = -INFINITY;
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk)
-#pragma unroll
-          for (int r = s0; r < s0 + SEG; ++r) m = fmaxf(m, kT[blk][r]);
-        if (PARTNER) m = fmaxf(m, swap32(m));
-        float ssum = 0.f;
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk)
-#pragma unroll
-          for (int r = s0; r < s0 + SEG; ++r) {
-            const float e = __builtin_amdgcn_exp2f(kT[blk][r] - m);  // k rows are pre-scaled by log2(e)
-            kT[blk][r] = e;
-            ssum += e;
-          }
-        if (PARTNER) ssum += swap32(ssum);
-        const float rs = 1.0f / ssum;
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk)
-#pragma unroll
-          for (int r = s0; r < s0 + SEG; ++r) kT[blk][r] *= rs;
-      }
-
-      // ---------------- per block: q, softmax over d ; per row: ctx, out
-      f32x16 ctx_row = {0};  // n >= 32: the wave's single row
-      if (N >= 32) {
-#pragma unroll
-        for (int b2 = 0; b2 < NB; ++b2)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) ctx_row = mfma32(kT[b2][r], vT[b2][r], ctx_row);
-      }
-#pragma unroll
-      for (int blk = 0; blk < NB; ++blk) {
-        f32x16 q = {0};
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) q = mfma32(wq[j], Xh[blk][j], q);
-        float m = q[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) m = fmaxf(m, q[r]);
-        m = fmaxf(m, swap32(m));
-        float ssum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          q[r] = __builtin_amdgcn_exp2f(q[r] - m);  // q rows are pre-scaled by log2(e)
-          ssum += q[r];
-        }
-        ssum += swap32(ssum);
-        const float qs = scale / ssum;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) q[r] *= qs;
-
-        f32x16 o = {0};
-        if (N >= 32) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o = mfma32(ctx_row[r], q[r], o);
-        } else {
-          // short rows (32/N rows share this block): "quadratic" form, no per-row loop and no wasted MFMAs:
-          //   S^T[n'][n] = sum_d K[d][n'] q[d][n], kept only for pairs of the same m/z row ; out[e][n] = sum_n' v[e][n'] S^T[n'][n]
-          const f32x16 Kd = transpose_tile(kT[0], tile, col, half);  // rows d, col n'
-          f32x16 st = {0};
-          st = xty(Kd, q, st);
-          st = mask_same_row<N>(st, col, half);
-          o = xty(vT[0], st, o);
-        }
-        out[blk] = o;
-      }
+      for (int j = 0; j < NJ; ++j) ak = mfma32(Xh[blk][j], wk[j], ak);
+      kT[blk] = ak;
     }
-
-    // ---------------- to_out on the VALU: lane holds out[e = rowmap(r, half)][position]
-    const float* wl = wo_lds + (hd * 2 + half) * C * 16;
+    float krs = 1.f;  // n >= 32: 1 / sum_n exp(k[d][n]) of this lane's d, applied to M instead of to the 32 x n tile
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      float w16[16];
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const float4 t = *reinterpret_cast<const float4*>(wl + c * 16 + r4 * 4);
-        w16[r4 * 4 + 0] = t.x; w16[r4 * 4 + 1] = t.y; w16[r4 * 4 + 2] = t.z; w16[r4 * 4 + 3] = t.w;
-      }
+    for (int s0 = 0; s0 < 16; s0 += SEG) {
+      float m = -INFINITY;
 #pragma unroll
       for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ypart[blk][c] = fmaf(w16[r], out[blk][r], ypart[blk][c]);
+        for (int r = s0; r < s0 + SEG; ++r) m = fmaxf(m, kT[blk][r]);
+      if (PARTNER) m = fmaxf(m, swap32(m));
+      float ssum = 0.f;
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int r = s0; r < s0 + SEG; ++r) {
+          const float e = __builtin_amdgcn_exp2f(kT[blk][r] - m);  // k rows are pre-scaled by log2(e)
+          kT[blk][r] = e;
+          ssum += e;
+        }
+      if (PARTNER) ssum += swap32(ssum);
+      const float rs = 1.0f / ssum;
+      if (N >= 32) krs = rs;
+      else {
+#pragma unroll
+        for (int r = s0; r < s0 + SEG; ++r) kT[0][r] *= rs;
+      }
+    }
+    // q (rows d, col n): un-normalised exp; its 32^-0.5 / sum factor goes onto the C-row result
+    auto make_q = [&](int blk, float& qs) {
+      f32x16 q = {0};
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) q = mfma32(wq[j], Xh[blk][j], q);
+      float m = q[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) m = fmaxf(m, q[r]);
+      m = fmaxf(m, swap32(m));
+      float ssum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        q[r] = __builtin_amdgcn_exp2f(q[r] - m);  // q rows are pre-scaled by log2(e)
+        ssum += q[r];
+      }
+      ssum += swap32(ssum);
+      qs = scale / ssum;
+      return q;
+    };
+
+    if (N >= 32) {
+      // ---------------- M^T[c][d] = sum_n xh[c][n] e_k[n][d] (this lane: d = col, its half's positions), then both halves, / sum
+      wave_fence();  // the previous head's reads of ms are done
+#pragma unroll
+      for (int g = 0; g < CG; ++g) {
+        f32x4 mt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) mt += chain4(xs, NP, blk * 32, g, kT[blk]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = (mt[i] + swap32(mt[i])) * krs;
+          if (half == 0) ms[(g * 4 + i) * 32 + col] = v;
+        }
+      }
+      wave_fence();
+      // ---------------- per block: q ; P[c][n] = sum_d M[d][c] e_q[d][n] ; y += W2 P * (32^-0.5 / sum_d e_q)
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk) {
+        float qs;
+        const f32x16 q = make_q(blk, qs);
+        float P[C];
+#pragma unroll
+        for (int g = 0; g < CG; ++g) {
+          const f32x4 pp = chain4(ms, 32, 0, g, q);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) P[g * 4 + i] = pp[i] + swap32(pp[i]);
+        }
+        add_w2(hd, blk, P, qs);
+      }
+    } else {
+      // ---------------- short rows (32/N rows share this block): masked S^T[n'][n] = sum_d k[d][n'] e_q[d][n] for pairs of the
+      // same m/z row, then R[c][n] = sum_n' xh[c][n'] S^T[n'][n]
+      float qs;
+      const f32x16 q = make_q(0, qs);
+      const f32x16 Kd = transpose_tile(kT[0], tile, col, half);  // rows d, col n'
+      f32x16 st = {0};
+      st = xty(Kd, q, st);
+      st = mask_same_row<N>(st, col, half);
+      float R[C];
+#pragma unroll
+      for (int g = 0; g < CG; ++g) {
+        const f32x4 rr = chain4(xs, NP, 0, g, st);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) R[g * 4 + i] = rr[i] + swap32(rr[i]);
+      }
+      add_w2(hd, 0, R, qs);
     }
   }
 
-  // ---- bias, post-norm, residual, store
+  // ---- bias, post-norm, residual, store (this lane's channels c = rowmap(j, half))
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk) {
     const int pos = N >= 32 ? blk * 32 + col : col % N;
-    float yv[C];
+    float yv[NJ];
     float ssq = 0.f;
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      yv[c] = ypart[blk][c] + swap32(ypart[blk][c]) + a.b_out[c];
-      ssq = fmaf(yv[c], yv[c], ssq);
+    for (int j = 0; j < NJ; ++j) {
+      const int c = rowmap(j, half);
+      yv[j] = c < C ? yown[blk][j] + a.b_out[c] : 0.f;
+      ssq = fmaf(yv[j], yv[j], ssq);
     }
+    ssq += swap32(ssq);
     const float inv = sqC / fmaxf(sqrtf(ssq), RMS_EPS);
-    if (a.ypre) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int c0 = rowmap(j, 0), c1 = c0 + 4;
-        float lo = 0.f, hi = 0.f;
-        if (c0 < C) lo = yv[c0 < C ? c0 : 0];
-        if (c1 < C) hi = yv[c1 < C ? c1 : 0];
-        const int c = c0 + 4 * half;
-        if (row_ok && c < C) a.ypre[((int64_t)row * C + c) * N + pos] = half ? hi : lo;
-      }
-    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int c0 = rowmap(j, 0), c1 = c0 + 4;  // this lane's channel is c0 + 4*half
-      float lo = 0.f, hi = 0.f;
-      if (c0 < C) lo = yv[c0 < C ? c0 : 0] * a.g_out[c0 < C ? c0 : 0];
-      if (c1 < C) hi = yv[c1 < C ? c1 : 0] * a.g_out[c1 < C ? c1 : 0];
-      const int c = c0 + 4 * half;
-      if (row_ok && c < C) a.y[((int64_t)row * C + c) * N + pos] = fmaf(half ? hi : lo, inv, X[blk][j]);
+      const int c = rowmap(j, half);
+      if (row_ok && c < C) {
+        const int64_t off = ((int64_t)row * C + c) * N + pos;
+        if (a.ypre) a.ypre[off] = yv[j];
+        a.y[off] = fmaf(yv[j] * a.g_out[c], inv, X[blk][j]);
+      }
     }
   }
 }
