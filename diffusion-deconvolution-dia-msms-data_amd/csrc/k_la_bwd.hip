@@ -1,24 +1,25 @@
 // K5 backward: gradient of Residual(PreNorm(LinearAttention)) (reference forward: dquartic/model/unet1d.py:446-496; the
-// reference's backward is autograd over those ops).  Same wave-per-row, all-in-registers MFMA scheme as the forward
-// (k_linattn.hip); derivation and lane-level check: oracle/wave_emu.py::la_bwd_unit.
+// reference's backward is autograd over those ops).  Same wave-per-row scheme and the same re-associated forward as
+// k_linattn.hip (per head: M[d][c] = sum_n K[d][n] xh[c][n], P[c][n] = sum_d M[d][c] Q[d][n], ypre = sum_h W2_h P_h + b with
+// W2_h = Wo_h Wv_h), differentiated in that form -- no 32x32 context / value tiles exist in either direction.
 //
 // One launch does the whole block (rows of up to 64 positions; longer rows: k_linattn_long.hip + two k_block_bwd):
 //   (1) post-norm backward, recomputed per head from the saved pre-norm output (per position, over channels: in-lane
 //       + one swap with lane^32)                                                   -> dYpre ; d g_out, d b_out (head 0 only)
-//   (2) everything between xh = rmsnorm(x)*g_pre and Ypre                         -> dXh (accumulated over heads), dWqkv, dWo
+//   (2) per head, recomputing the forward in registers:
+//         dP[c][n] = sum_c' W2[c'][c] dYpre[c'][n]                  VALU, C x C per position
+//         dW2[c'][c] += sum_n dYpre[c'][n] P[c][n]                  4x4x1 MFMA, both operands staged [c][n] in LDS
+//         dQ[d][n] = sum_c M[d][c] dP[c][n]   ; dK^T[n][d] = sum_c xh[c][n] dM[d][c]      32x32x2 MFMA with K = C
+//         dM^T[c][d] = sum_n dP[c][n] Q[d][n]                       4x4x1 MFMA (B = Q^T tile)
+//         softmax backward of q (over d, in-lane) and k (over n, in-lane in the K^T orientation)
+//         dXh += Wq^T dq_raw + Wk^T dk_raw + sum_d K[d][n] dM[d][c]                        4x4x1 MFMA
+//         dWq += xh dq_raw^T, dWk += xh dk_raw^T                     4x4x1 MFMA
+//       Short rows (n < 32, 32/n rows per wave): the masked quadratic form S^T[n'][n] = sum_d K[d][n'] Q[d][n],
+//       R[c][n] = sum_n' xh[c][n'] S^T[n'][n] in place of M / P.
 //   (3) in the last head's pass: residual + pre-norm backward on the completed dXh -> dx += dy + d/dx ; d g_pre
+// dWv and dWo follow from dW2 once per (wave, head): dWo_h = dW2_h Wv_h^T, dWv_h = Wo_h^T dW2_h.
 // All parameter gradients go to this wave's partial slot (plain stores) and are summed by k_linattn_dw_reduce in a fixed
-// order: no atomics, bitwise repeatable.
-//
-// (2): the HEAD loop is the outer loop of a wave and its rows the inner one, so the four per-head weight-gradient
-// tiles (dWq, dWk, dWv, dWo as 32x32 f32 MFMA accumulators, rows = channel) stay in registers across the wave's rows and
-// are flushed with one atomic per element per (wave, head).  Per head and 32-position block (recomputing the forward):
-//   kT, vT, q, v, do = Wo^T dYpre, doT           (projections, K = C)
-//   ctx = kT^T vT ; dctx = qT^T doT ; outT = q^T ctx ; dq = ctxT^T do ; dkT = v^T dctxT ; dv = dctx^T K
-//   softmax backward of q (over d, in-lane) and of k (over n, in-lane in the kT orientation), with
-//   sum_n dK K = rowsum(dctx o ctx) so that no cross-lane reduction over positions is ever needed
-//   dW* += XhT^T (.)T ; dXh via VALU from the (rows d/e, col n) tiles with Wqkv pre-permuted in LDS.
-// Orientation changes (q -> qT etc.) go through a wave-private 32x33 LDS tile (16 ds_write + 16 ds_read, conflict-free).
+// order: no atomics, bitwise repeatable.  Orientation changes (q -> q^T etc.) go through a wave-private 32x33 LDS tile.
 #include "dq_common.h"
 #include "dq_kernels.h"
 #include "dq_mfma.h"
@@ -28,15 +29,17 @@ namespace dq {
 
 __device__ __forceinline__ f32x16 mfma32b(float a, float b, f32x16 c) { return mfma_f32(a, b, c); }
 __device__ __forceinline__ float swp32(float v) { return swap_half(v); }
+__device__ __forceinline__ void wfence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 
 // 32x32 transpose of an accumulator tile through a wave-private LDS tile [32][33]
 __device__ __forceinline__ f32x16 tr32(f32x16 a, float* tile, int col, int half) {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  wfence();
 #pragma unroll
   for (int r = 0; r < 16; ++r) tile[rmap(r, half) * 33 + col] = a[r];
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  wfence();
   f32x16 o;
 #pragma unroll
   for (int r = 0; r < 16; ++r) o[r] = tile[col * 33 + rmap(r, half)];
@@ -55,8 +58,6 @@ constexpr int la_slot(int C) { return 515 * C; }
 
 // v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 outer products.  Block = lane >> 2; a lane supplies A_blk[i = lane & 3] and
 // B_blk[j = lane & 3]; register i of lane (blk, j) receives A_blk[i] * B_blk[j] (mapping measured: tools/probe/mfma4x4.hip).
-// With C <= 16 channels the weight-gradient (rows = channel) and dXh (rows = channel) products are exactly this shape: on the
-// 32x32x2 form their 4..16 rows were padded to 32.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 
@@ -75,17 +76,26 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
   constexpr int SEG = N >= 32 ? 16 : (N >= 8 ? N / 2 : N);
   constexpr bool PARTNER = N >= 8;
   constexpr bool PREFETCH = C <= 8;
-  constexpr int CG = C / 4;      // channel groups of 4 (one 4x4x1 MFMA each)
+  constexpr int CG = C / 4;      // channel groups of 4 (one 4x4x1 MFMA chain each)
   constexpr int NP = NB * 32;    // positions (lanes x blocks) of one unit
   static_assert(NB <= 2, "rows longer than 64 are not built");
   static_assert(C % 4 == 0, "channel count must be a multiple of 4");
 
-  __shared__ float wp_lds[3 * 4 * 2 * C * 16];  // [q|k|v][head][half][c][r] = Wqkv[m*128 + head*32 + rmap(r,half)][c]
+  __shared__ __attribute__((aligned(16))) float wp_lds[2 * 4 * 2 * C * 16];  // [q|k][head][half][c][r] = Wqkv[m*128 + head*32 + rmap(r,half)][c]
+  __shared__ __attribute__((aligned(16))) float w2_lds[4 * C * C];           // [head][c'][c] = sum_e Wo[c'][head*32+e] Wv[head*32+e][c]
   __shared__ float tiles[4][32 * 33];
-  __shared__ __attribute__((aligned(16))) float stage[4][2 * C * NP];  // per wave: xh[c][n] | dYpre[c][n] of the current unit
-  for (int i = threadIdx.x; i < 3 * 4 * 2 * C * 16; i += blockDim.x) {
+  // per wave: xh | dYpre | P (normalised) | dP as [c][n] ; M | dM as [c][d] ; dW2 of the head being flushed [c'][c]
+  __shared__ __attribute__((aligned(16))) float stage[4][4 * C * NP + 2 * C * 32 + C * C];
+  for (int i = threadIdx.x; i < 2 * 4 * 2 * C * 16; i += blockDim.x) {
     const int r = i & 15, c = (i >> 4) % C, hh = (i / (16 * C)) & 1, hd = (i / (32 * C)) & 3, m = i / (128 * C);
     wp_lds[i] = a.w_qkv[(m * 128 + hd * 32 + rmap(r, hh)) * C + c];
+  }
+  for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) {
+    const int c = i % C, cp = (i / C) % C, hd = i / (C * C);
+    float s = 0.f;
+#pragma unroll 8
+    for (int e = 0; e < 32; ++e) s = fmaf(a.w_out[cp * 128 + hd * 32 + e], a.w_qkv[(256 + hd * 32 + e) * C + c], s);
+    w2_lds[i] = s;
   }
   __syncthreads();
 
@@ -93,6 +103,11 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
   float* tile = tiles[wv];
   float* xs = stage[wv];
   float* dys = xs + C * NP;
+  float* ps = dys + C * NP;
+  float* dps = ps + C * NP;
+  float* ms = dps + C * NP;
+  float* dms = ms + C * 32;
+  float* w2g = dms + C * 32;
   const int wave_id = blockIdx.x * (blockDim.x >> 6) + wv;
   const int n_units = (a.rows + RW - 1) / RW;
   const int u0 = wave_id * a.units_per_wave;
@@ -100,38 +115,64 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
   const int u1 = min(n_units, u0 + a.units_per_wave);
   const float sqC = sqrtf((float)C);
   const float scale = 0.17677669529663687f;
+  const float LOG2E = 1.4426950408889634f;
   const int rl = N >= 32 ? 0 : col / N;
   // norm gains of this lane's channels, once per wave (a load inside the row loop cannot be hoisted past the loop's stores
   // by the compiler and would sit on the critical path of every row)
-  // (the two largest variants have no registers to spare for it -- and crash this compiler's AGPR-copy rewrite when pushed)
-  constexpr bool HOIST_G = !(C >= 12 && N == 64);
   float gpre[NJ], gout[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int c = rmap(j, half);
-    gpre[j] = (HOIST_G && c < C) ? a.g_pre[c] : 0.f;
-    gout[j] = (HOIST_G && c < C) ? a.g_out[c] : 0.f;
+    gpre[j] = c < C ? a.g_pre[c] : 0.f;
+    gout[j] = c < C ? a.g_out[c] : 0.f;
   }
-  auto g_pre_of = [&](int j) { return HOIST_G ? gpre[j] : (rmap(j, half) < C ? a.g_pre[rmap(j, half)] : 0.f); };
-  auto g_out_of = [&](int j) { return HOIST_G ? gout[j] : (rmap(j, half) < C ? a.g_out[rmap(j, half)] : 0.f); };
+
+  // sum_r mfma4(A = src[(4*g + (lane&3)) * pitch + off + rmap(r, half)], B = t[r]) on two interleaved accumulator chains (a
+  // dependent 4x4x1 MFMA issues every ~14.5 cycles, independent ones every ~8.5)
+  auto chain4 = [&](const float* src, int pitch, int off, int g, const f32x16& t) {
+    const float* ar = src + (g * 4 + (lane & 3)) * pitch + off + 4 * half;
+    f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const float4 a4 = *reinterpret_cast<const float4*>(ar + 8 * q4);
+      t0 = mfma4(a4.x, t[q4 * 4 + 0], t0); t1 = mfma4(a4.y, t[q4 * 4 + 1], t1);
+      t0 = mfma4(a4.z, t[q4 * 4 + 2], t0); t1 = mfma4(a4.w, t[q4 * 4 + 3], t1);
+    }
+    return t0 + t1;
+  };
+  // static-weight variant: A = wp_lds[m][hd][half][c = 4*g + (lane&3)][r] (16 consecutive r)
+  auto chainw = [&](int m, int hd, int g, const f32x16& t) {
+    const float* wr = wp_lds + (((m * 4 + hd) * 2 + half) * C + g * 4 + (lane & 3)) * 16;
+    f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const float4 w4 = *reinterpret_cast<const float4*>(wr + r4 * 4);
+      t0 = mfma4(w4.x, t[r4 * 4 + 0], t0); t1 = mfma4(w4.y, t[r4 * 4 + 1], t1);
+      t0 = mfma4(w4.z, t[r4 * 4 + 2], t0); t1 = mfma4(w4.w, t[r4 * 4 + 3], t1);
+    }
+    return t0 + t1;
+  };
 
 #pragma unroll 1
   for (int hd = 0; hd < 4; ++hd) {
-    float wq[NJ], wk[NJ], wvv[NJ], wo[NJ];
+    float wq[NJ], wk[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int c = rmap(j, half);
       const bool ok = c < C;
-      wq[j] = ok ? a.w_qkv[(hd * 32 + col) * C + c] : 0.f;
-      wk[j] = ok ? a.w_qkv[(128 + hd * 32 + col) * C + c] : 0.f;
-      wvv[j] = ok ? a.w_qkv[(256 + hd * 32 + col) * C + c] : 0.f;
-      wo[j] = ok ? a.w_out[c * 128 + hd * 32 + col] : 0.f;
+      wq[j] = ok ? a.w_qkv[(hd * 32 + col) * C + c] * LOG2E : 0.f;   // log2(e) folded in: the softmaxes use exp2 like the forward
+      wk[j] = ok ? a.w_qkv[(128 + hd * 32 + col) * C + c] * LOG2E : 0.f;
     }
-    // weight-gradient accumulators of this head, 4x4x1 form: register i of group cg = channel 4*cg + i, lane = (half, d / e);
+    // weight-gradient accumulators of this head, 4x4x1 form: register i of group g = channel 4*g + i, lane = (half, d);
     // each lane-half sums its own 16 positions of every 32-block, the halves are added at the flush
-    f32x4 gq[CG], gk[CG], gv[CG], go[CG];
+    f32x4 gq[CG], gk[CG];
+    f32x4 gw2[CG][CG];  // dW2[c' = 4*g1 + i][c = 4*g2 + (lane&3)], partial over the positions of this 4-lane block
 #pragma unroll
-    for (int g = 0; g < CG; ++g) gq[g] = gk[g] = gv[g] = go[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < CG; ++g) {
+      gq[g] = gk[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g2 = 0; g2 < CG; ++g2) gw2[g][g2] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     float nacc0[NJ], nacc1[NJ];  // norm-gain / bias gradient partials: head 0: (d g_out, d b_out); head 3: (d g_pre, -)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) nacc0[j] = nacc1[j] = 0.f;
@@ -202,10 +243,10 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
         float dot = 0.f;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          Xh[b][j] = xv[j] * inv * g_pre_of(j);
+          Xh[b][j] = xv[j] * inv * gpre[j];
           const float uh = uv[j] * uinv;
           if (hd == 0) nacc0[j] = fmaf(dv_[j], uh * sqC, nacc0[j]);  // d g_out
-          const float gd = dv_[j] * g_out_of(j) * sqC;
+          const float gd = dv_[j] * gout[j] * sqC;
           uv[j] = uh;
           dv_[j] = gd;
           dot = fmaf(gd, uh, dot);
@@ -218,9 +259,8 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
           if (hd == 0) nacc1[j] += DY[b][j];  // d b_out (bias of to_out)
         }
       }
-      // stage xh and dYpre as [c][n] for the 4x4x1 A operands (every lane needs 4 channels of OTHER lanes' positions)
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      // stage xh and dYpre as [c][n]: 4x4x1 A operands, and every lane needs ALL channels of dYpre at its position
+      wfence();
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -231,62 +271,68 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
             dys[c * NP + b * 32 + col] = DY[b][j];
           }
         }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      wfence();
 
-      f32x4 part[NB][CG];  // d xh partial sums of this lane-half (this head): register i = channel 4*cg + i, lane = position
+      // dP[c][n] = sum_c' W2[hd][c'][c] dYpre[c'][n] at this lane's position of block b (identical in both lane halves)
+      auto make_dp = [&](int b, float (&dp)[C]) {
+        float dya[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { dya[c] = dys[c * NP + b * 32 + col]; dp[c] = 0.f; }
+#pragma unroll
+        for (int cp = 0; cp < C; ++cp) {
+          const float* w = w2_lds + (hd * C + cp) * C;
+#pragma unroll
+          for (int c4 = 0; c4 < CG; ++c4) {
+            const float4 w4 = *reinterpret_cast<const float4*>(w + 4 * c4);
+            dp[4 * c4 + 0] = fmaf(w4.x, dya[cp], dp[4 * c4 + 0]); dp[4 * c4 + 1] = fmaf(w4.y, dya[cp], dp[4 * c4 + 1]);
+            dp[4 * c4 + 2] = fmaf(w4.z, dya[cp], dp[4 * c4 + 2]); dp[4 * c4 + 3] = fmaf(w4.w, dya[cp], dp[4 * c4 + 3]);
+          }
+        }
+      };
+      // this lane's operand slice of a per-position / per-d channel vector: v[c = rmap(j, half)] (zero beyond C)
+      auto own = [&](const float (&v)[C], int j) {
+        const int c0 = rmap(j, 0);
+        const float lo = c0 < C ? v[c0 < C ? c0 : 0] : 0.f, hi = c0 + 4 < C ? v[c0 + 4 < C ? c0 + 4 : 0] : 0.f;
+        return half ? hi : lo;
+      };
+
+      f32x4 part[NB][CG];  // d xh partial sums of this lane-half (this head): register i = channel 4*g + i, lane = position
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int g = 0; g < CG; ++g) part[b][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-
       // part[c][n] += sum_r W[m][hd][rmap(r,half)][c] * t[r][n]: B = the tile register (rows d, col n), A = the weight column
-      // W[..][c = 4*cg + (lane & 3)] read from LDS (16 consecutive r = 4 ds_read_b128)
       auto add_dxh = [&](int b, int m, const f32x16& t) {
-        const float* wl = wp_lds + ((m * 4 + hd) * 2 + half) * C * 16;
 #pragma unroll
-        for (int g = 0; g < CG; ++g) {
-          const float* wr = wl + (g * 4 + (lane & 3)) * 16;
-          // two interleaved chains: a dependent 4x4x1 MFMA issues every ~14.5 cycles, independent ones every ~8.5
-          f32x4 acc = part[b][g], acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const float4 w4 = *reinterpret_cast<const float4*>(wr + r4 * 4);
-            acc = mfma4(w4.x, t[r4 * 4 + 0], acc); acc2 = mfma4(w4.y, t[r4 * 4 + 1], acc2);
-            acc = mfma4(w4.z, t[r4 * 4 + 2], acc); acc2 = mfma4(w4.w, t[r4 * 4 + 3], acc2);
-          }
-          part[b][g] = acc + acc2;
-        }
+        for (int g = 0; g < CG; ++g) part[b][g] += chainw(m, hd, g, t);
       };
-      // dW[c][d] += sum_n src[c][n] * tt[n][d] over the positions of 32-block b: B = register r of the (rows n, col d) tile,
-      // A = src[c = 4*cg + (lane & 3)][b*32 + rmap(r, half)] from the staged copy (4 ds_read_b128 per group)
-      auto add_dw = [&](f32x4 (&acc)[CG], const float* src, int b, const f32x16& tt) {
+      // dW[c][d] += sum_n xh[c][n] * tt[n][d] over the positions of 32-block b (B = register r of the (rows n, col d) tile)
+      auto add_dw = [&](f32x4 (&acc)[CG], int b, const f32x16& tt) {
 #pragma unroll
-        for (int g = 0; g < CG; ++g) {
-          const float* ar = src + (g * 4 + (lane & 3)) * NP + b * 32 + 4 * half;
-          f32x4 t = acc[g], t2 = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < CG; ++g) acc[g] += chain4(xs, NP, b * 32, g, tt);
+      };
+      // dW2[c'][c] += sum_n dYpre[c'][n] p[c][n] over all staged positions: position n = 16 * s + (lane >> 2)
+      auto add_dw2 = [&]() {
 #pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            const float4 a4 = *reinterpret_cast<const float4*>(ar + 8 * q4);
-            t = mfma4(a4.x, tt[q4 * 4 + 0], t); t2 = mfma4(a4.y, tt[q4 * 4 + 1], t2);
-            t = mfma4(a4.z, tt[q4 * 4 + 2], t); t2 = mfma4(a4.w, tt[q4 * 4 + 3], t2);
+        for (int s = 0; s < NP / 16; ++s) {
+          const int n = 16 * s + (lane >> 2);
+#pragma unroll
+          for (int g1 = 0; g1 < CG; ++g1) {
+            const float av = dys[(4 * g1 + (lane & 3)) * NP + n];
+#pragma unroll
+            for (int g2 = 0; g2 < CG; ++g2) gw2[g1][g2] = mfma4(av, ps[(4 * g2 + (lane & 3)) * NP + n], gw2[g1][g2]);
           }
-          acc[g] = t + t2;
         }
       };
 
-      // ---- K^T (normalised over the positions of each row) and V^T
-      f32x16 kT[NB], vT[NB];
+      // ---- K^T (rows n, col d): exps, then normalised in place (softmax over the positions of each row)
+      f32x16 kT[NB];
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        f32x16 ak = {0}, av = {0};
+        f32x16 ak = {0};
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          ak = mfma32b(Xh[b][j], wk[j], ak);
-          av = mfma32b(Xh[b][j], wvv[j], av);
-        }
+        for (int j = 0; j < NJ; ++j) ak = mfma32b(Xh[b][j], wk[j], ak);
         kT[b] = ak;
-        vT[b] = av;
       }
 #pragma unroll
       for (int s0 = 0; s0 < 16; s0 += SEG) {
@@ -301,7 +347,7 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
         for (int b = 0; b < NB; ++b)
 #pragma unroll
           for (int r = s0; r < s0 + SEG; ++r) {
-            const float e = __expf(kT[b][r] - m);
+            const float e = __builtin_amdgcn_exp2f(kT[b][r] - m);
             kT[b][r] = e;
             ssum += e;
           }
@@ -312,8 +358,7 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
 #pragma unroll
           for (int r = s0; r < s0 + SEG; ++r) kT[b][r] *= rs;
       }
-
-      // q (rows d, col n) with its softmax; returns the tile
+      // q (rows d, col n) with its softmax (normalised, incl. 32^-0.5)
       auto make_q = [&](int b) {
         f32x16 q = {0};
 #pragma unroll
@@ -325,7 +370,7 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
         float ssum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          q[r] = __expf(q[r] - m);
+          q[r] = __builtin_amdgcn_exp2f(q[r] - m);
           ssum += q[r];
         }
         ssum += swp32(ssum);
@@ -346,101 +391,134 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
       };
 
       if (N >= 32) {
-        // ================= one row per wave, NB blocks: phased to keep few tiles live =================
-        f32x16 ctx = {0};
+        // ================= one row per wave: M / P form =================
+        // M[d = col][c] (both lane halves hold the total) and its [c][d] image for the P chains
+        float Mr[C];
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int g = 0; g < CG; ++g) {
+          f32x4 mt = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int r = 0; r < 16; ++r) ctx = mfma32b(kT[b][r], vT[b][r], ctx);
-        const f32x16 ctxT = tr32(ctx, tile, col, half);
-        f32x16 dctx = {0};
+          for (int b = 0; b < NB; ++b) mt += chain4(xs, NP, b * 32, g, kT[b]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            Mr[g * 4 + i] = mt[i] + swp32(mt[i]);
+            if (half == 0) ms[(g * 4 + i) * 32 + col] = Mr[g * 4 + i];
+          }
+        }
+        wfence();
+        f32x16 qT[NB];  // Q^T (rows n, col d), kept for dM
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           const f32x16 q = make_q(b);
-          f32x16 dO = {0}, dOT = {0};
+          float dP[C], P[C];
+          make_dp(b, dP);
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            dO = mfma32b(wo[j], DY[b][j], dO);
-            dOT = mfma32b(DY[b][j], wo[j], dOT);
+          for (int g = 0; g < CG; ++g) {
+            const f32x4 pp = chain4(ms, 32, 0, g, q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) P[g * 4 + i] = pp[i] + swp32(pp[i]);
           }
-          const f32x16 qT = tr32(q, tile, col, half);
+          if (half == 0) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) dctx = mfma32b(qT[r], dOT[r], dctx);
-          f32x16 outT = {0}, dq = {0};
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            outT = mfma32b(q[r], ctx[r], outT);
-            dq = mfma32b(ctxT[r], dO[r], dq);
+            for (int c = 0; c < C; ++c) { ps[c * NP + b * 32 + col] = P[c]; dps[c * NP + b * 32 + col] = dP[c]; }
           }
-          add_dw(go, dys, b, outT);
+          // dQ[d][n] = sum_c M[d][c] dP[c][n] (K = C on the 32x32x2 pipe), softmax backward, Wq paths
+          f32x16 dq = {0};
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) dq = mfma32b(own(Mr, j), own(dP, j), dq);
           const f32x16 dq_raw = q_softmax_bwd(q, dq);
           add_dxh(b, 0, dq_raw);
-          add_dw(gq, xs, b, tr32(dq_raw, tile, col, half));
+          add_dw(gq, b, tr32(dq_raw, tile, col, half));
+          qT[b] = tr32(q, tile, col, half);
         }
-        const f32x16 dctxT = tr32(dctx, tile, col, half);
-        float delta = 0.f;
+        wfence();  // ps / dps complete
+        add_dw2();
+        // dM^T[c][d] = sum_n dP[c][n] Q[d][n] ; both halves ; its [c][d] image for the dXh chain
+        float dMr[C];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) delta = fmaf(dctxT[r], ctxT[r], delta);
-        delta += swp32(delta);
+        for (int g = 0; g < CG; ++g) {
+          f32x4 mt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int b = 0; b < NB; ++b) mt += chain4(dps, NP, b * 32, g, qT[b]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            dMr[g * 4 + i] = mt[i] + swp32(mt[i]);
+            if (half == 0) dms[(g * 4 + i) * 32 + col] = dMr[g * 4 + i];
+          }
+        }
+        wfence();
+        // dK^T[n][d] = sum_c xh[c][n] dM[d][c] ; softmax backward over the positions (lane-local + partner)
+        f32x16 dkT[NB];
+        float dl = 0.f;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-          f32x16 v = {0};
+          f32x16 t = {0};
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) v = mfma32b(wvv[j], Xh[b][j], v);
-          f32x16 dkT = {0};
+          for (int j = 0; j < NJ; ++j) t = mfma32b(Xh[b][j], own(dMr, j), t);
+          dkT[b] = t;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) dkT = mfma32b(v[r], dctxT[r], dkT);
+          for (int r = 0; r < 16; ++r) dl = fmaf(t[r], kT[b][r], dl);
+        }
+        dl += swp32(dl);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
           f32x16 dk_rawT;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) dk_rawT[r] = kT[b][r] * (dkT[r] - delta);
-          add_dw(gk, xs, b, dk_rawT);
+          for (int r = 0; r < 16; ++r) dk_rawT[r] = kT[b][r] * (dkT[b][r] - dl);
+          add_dw(gk, b, dk_rawT);
           add_dxh(b, 1, tr32(dk_rawT, tile, col, half));
-          const f32x16 Kd = tr32(kT[b], tile, col, half);
-          f32x16 dv = {0};
+          const f32x16 Kd = tr32(kT[b], tile, col, half);  // rows d, col n
 #pragma unroll
-          for (int r = 0; r < 16; ++r) dv = mfma32b(dctx[r], Kd[r], dv);
-          add_dxh(b, 2, dv);
-          add_dw(gv, xs, b, tr32(dv, tile, col, half));
+          for (int g = 0; g < CG; ++g) part[b][g] += chain4(dms, 32, 0, g, Kd);  // dXh[c][n] += sum_d K[d][n] dM[d][c]
         }
       } else {
-        // ================= 32/N rows per wave, one block: per-row ctx / dctx =================
+        // ================= 32/N rows per wave, one block: masked quadratic form =================
         const f32x16 q = make_q(0);
         const f32x16 qT = tr32(q, tile, col, half);
-        f32x16 dO = {0}, dOT = {0}, v = {0};
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          dO = mfma32b(wo[j], DY[0][j], dO);
-          dOT = mfma32b(DY[0][j], wo[j], dOT);
-          v = mfma32b(wvv[j], Xh[0][j], v);
-        }
         const f32x16 Kd = tr32(kT[0], tile, col, half);
-        // "quadratic" form (oracle/wave_emu.py::la_bwd_unit_quad): S[n][n'] = sum_d q[d][n] K[d][n'] restricted to pairs of
-        // the same m/z row replaces the per-row ctx tiles -- no loop over the 32/N rows, no 1/RW-utilised MFMAs.
-        f32x16 st = {0}, sm = {0}, dst = {0}, dsm = {0};
+        f32x16 st = {0}, sm = {0};
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          st = mfma32b(Kd[r], q[r], st);     // S^T : rows n', col n
-          sm = mfma32b(q[r], Kd[r], sm);     // S   : rows n,  col n'
-          dst = mfma32b(v[r], dO[r], dst);   // dS^T: rows n', col n
-          dsm = mfma32b(dO[r], v[r], dsm);   // dS  : rows n,  col n'
+          st = mfma32b(Kd[r], q[r], st);  // S^T : rows n', col n
+          sm = mfma32b(q[r], Kd[r], sm);  // S   : rows n,  col n'
         }
         st = mask_same_row<N>(st, col, half);
         sm = mask_same_row<N>(sm, col, half);
+        float dR[C], R[C];
+        make_dp(0, dR);
+#pragma unroll
+        for (int g = 0; g < CG; ++g) {
+          const f32x4 rr = chain4(xs, NP, 0, g, st);  // R[c][n] = sum_n' xh[c][n'] S^T[n'][n]
+#pragma unroll
+          for (int i = 0; i < 4; ++i) R[g * 4 + i] = rr[i] + swp32(rr[i]);
+        }
+        if (half == 0) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) { ps[c * NP + col] = R[c]; dps[c * NP + col] = dR[c]; }
+        }
+        wfence();
+        add_dw2();
+        // dS^T[n'][n] = sum_c xh[c][n'] dR[c][n] and dS = its transpose (K = C products), masked to pairs of the same row
+        f32x16 dst = {0}, dsm = {0};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          dst = mfma32b(Xh[0][j], own(dR, j), dst);
+          dsm = mfma32b(own(dR, j), Xh[0][j], dsm);
+        }
         dst = mask_same_row<N>(dst, col, half);
         dsm = mask_same_row<N>(dsm, col, half);
-        f32x16 outT = {0}, dvT = {0}, dv = {0}, dq = {0}, dkT = {0};
+        // dXh[c][n'] += sum_n S[n][n'] dR[c][n]
+#pragma unroll
+        for (int g = 0; g < CG; ++g) part[0][g] += chain4(dps, NP, 0, g, sm);
+        f32x16 dq = {0}, dkT = {0};
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          outT = mfma32b(st[r], vT[0][r], outT);  // rows n,  col e
-          dvT = mfma32b(sm[r], dOT[r], dvT);      // rows n', col e
-          dv = mfma32b(dOT[r], sm[r], dv);        // rows e,  col n'
-          dq = mfma32b(kT[0][r], dst[r], dq);     // rows d,  col n
-          dkT = mfma32b(dsm[r], qT[r], dkT);      // rows n', col d
+          dq = mfma32b(kT[0][r], dst[r], dq);    // rows d,  col n
+          dkT = mfma32b(dsm[r], qT[r], dkT);     // rows n', col d
         }
-        add_dw(go, dys, 0, outT);
         const f32x16 dq_raw = q_softmax_bwd(q, dq);
         add_dxh(0, 0, dq_raw);
-        const f32x16 dq_rawT = tr32(dq_raw, tile, col, half);
+        add_dw(gq, 0, tr32(dq_raw, tile, col, half));
         f32x16 dk_rawT;  // softmax over the positions of each row: a lane's own register segment (+ lane^32)
 #pragma unroll
         for (int s0 = 0; s0 < 16; s0 += SEG) {
@@ -451,11 +529,8 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
 #pragma unroll
           for (int r = s0; r < s0 + SEG; ++r) dk_rawT[r] = kT[0][r] * (dkT[r] - dl);
         }
-        add_dw(gq, xs, 0, dq_rawT);
-        add_dw(gk, xs, 0, dk_rawT);
-        add_dw(gv, xs, 0, dvT);
+        add_dw(gk, 0, dk_rawT);
         add_dxh(0, 1, tr32(dk_rawT, tile, col, half));
-        add_dxh(0, 2, dv);
       }
 
       // ---- d xh of this head: both halves' partial sums, then each lane keeps its own channels
@@ -467,13 +542,9 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
         for (int c = 0; c < C; ++c) full[c] = part[b][c >> 2][c & 3] + swp32(part[b][c >> 2][c & 3]);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const int c0 = rmap(j, 0), c1 = c0 + 4;
-          float lo = 0.f, hi = 0.f;
-          if (c0 < C) lo = full[c0 < C ? c0 : 0];
-          if (c1 < C) hi = full[c1 < C ? c1 : 0];
-          const int c = c0 + 4 * half;
-          const float val = half ? hi : lo;
-          lo = 0.f;  // from here on: this lane's total dXh of channel c (heads 0..3), only formed in the last head's pass
+          const int c = rmap(j, half);
+          const float val = own(full, j);
+          float lo = 0.f;  // this lane's total dXh of channel c (heads 0..3), only formed in the last head's pass
           if (row_ok && c < C) {
             float* dst = a.dxh + ((int64_t)row * C + c) * N + pos;
             // head 0 initialises, heads 1, 2 accumulate (same lane, same address); C > 8 has no registers for the prefetch
@@ -489,8 +560,7 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
           float ssq = 0.f;
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
-            const int c = rmap(j, half);
-            xv[j] = (c < C) ? cx[b][j] : 0.f;  // raw x of this unit (zero for masked rows / channels), still in registers
+            xv[j] = cx[b][j];  // raw x of this unit (zero for masked rows / channels), still in registers
             ssq = fmaf(xv[j], xv[j], ssq);
           }
           ssq += swp32(ssq);
@@ -501,7 +571,7 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
           for (int j = 0; j < NJ; ++j) {
             const float uh = xv[j] * inv;
             nacc0[j] = fmaf(tot[j], uh * sqC, nacc0[j]);  // d g_pre
-            const float gd = tot[j] * g_pre_of(j) * sqC;
+            const float gd = tot[j] * gpre[j] * sqC;
             xv[j] = uh;
             tot[j] = gd;
             dot = fmaf(gd, uh, dot);
@@ -521,24 +591,56 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
       }
     }
 
-    // ---- flush this head's weight gradients to this wave's partial slot (plain stores; float atomics at this access
-    // shape -- one dword per lane, lanes C floats apart -- run ~17x below the store rate and made the flush the
-    // kernel's critical path).  Register r holds channel rmap(r, half), lane column = d / e.
+    // ---- flush this head's gradients to this wave's partial slot (plain stores; the ordered reduce kernel sums the slots)
     float* slot = a.part + (int64_t)wave_id * la_slot(C);
 #pragma unroll
     for (int g = 0; g < CG; ++g)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int c = 4 * g + i;
+        // (dq_raw / dk_raw are gradients w.r.t. the natural-log logits: the log2(e) folded into the projection operands only
+        // changes how the softmax is evaluated, not the function)
         const float vq = gq[g][i] + swp32(gq[g][i]), vk = gk[g][i] + swp32(gk[g][i]);
-        const float vv = gv[g][i] + swp32(gv[g][i]), vo = go[g][i] + swp32(go[g][i]);
-        if (half == 0) {  // lane = d / e
+        if (half == 0) {  // lane = d
           slot[(hd * 32 + col) * C + c] = vq;
           slot[(128 + hd * 32 + col) * C + c] = vk;
-          slot[(256 + hd * 32 + col) * C + c] = vv;
-          slot[384 * C + c * 128 + hd * 32 + col] = vo;
         }
       }
+    // dW2 of this head: sum the 16 position blocks (lanes with equal lane & 3), publish [c'][c], then
+    // dWv[e][c] = sum_c' Wo[c'][e] dW2[c'][c] and dWo[c'][e] = sum_c dW2[c'][c] Wv[e][c] for this lane's e = col
+    wfence();
+#pragma unroll
+    for (int g1 = 0; g1 < CG; ++g1)
+#pragma unroll
+      for (int g2 = 0; g2 < CG; ++g2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = gw2[g1][g2][i];
+          v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+          if (lane < 4) w2g[(4 * g1 + i) * C + 4 * g2 + lane] = v;
+        }
+    wfence();
+    {
+      float wvr[C], wor[C];  // Wv[hd*32 + col][c], Wo[c'][hd*32 + col]
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        wvr[c] = a.w_qkv[(256 + hd * 32 + col) * C + c];
+        wor[c] = a.w_out[c * 128 + hd * 32 + col];
+      }
+      if (half == 0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          float sv = 0.f, so = 0.f;
+#pragma unroll
+          for (int k = 0; k < C; ++k) {
+            sv = fmaf(wor[k], w2g[k * C + c], sv);   // dWv[e][c]  = sum_c' Wo[c'][e] dW2[c'][c]
+            so = fmaf(w2g[c * C + k], wvr[k], so);   // dWo[c][e]  = sum_k  dW2[c][k]  Wv[e][k]
+          }
+          slot[(256 + hd * 32 + col) * C + c] = sv;
+          slot[384 * C + c * 128 + hd * 32 + col] = so;
+        }
+      }
+    }
     if (hd == 0 || hd == 3) {  // norm gains / bias: sum over the 32 positions-lanes of this half, one lane stores
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
@@ -553,6 +655,7 @@ __global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
   }
 }
 
+#ifndef DQ_LA_BIG_TU
 // grad[e] += sum over the wave slots in a fixed order (deterministic).  A block owns 16 consecutive elements x 16 slot
 // groups: thread (e, g) sums slots g, g+16, g+32, ... (64-byte segments per group: every fetched sector is fully used, unlike
 // a lane-per-slot gather), the 16 group sums meet in LDS.
@@ -586,6 +689,24 @@ __global__ void __launch_bounds__(256) k_linattn_dw_reduce(const float* __restri
     else dg_pre[e - 514 * C] += s;
   }
 }
+#endif  // !DQ_LA_BIG_TU
+
+// The two largest instantiations (C >= 12 with 64-position rows; no BASELINE config uses them) crash this compiler's
+// "AMDGPU Rewrite AGPR-Copy-MFMA" pass under -amdgpu-mfma-vgpr-form=1: they live in a second translation unit of this same
+// file (-DDQ_LA_BIG_TU, built without that option; see the Makefile).
+void launch_linattn_bwd_big(const LinAttnBwdK& kk, int C, int waves, hipStream_t s);
+
+#ifdef DQ_LA_BIG_TU
+void launch_linattn_bwd_big(const LinAttnBwdK& kk, int C, int waves, hipStream_t s) {
+  if (C == 12) hipLaunchKernelGGL((k_linattn_bwd<12, 64>), dim3(cdiv(waves, 4)), dim3(256), 0, s, kk);
+  else hipLaunchKernelGGL((k_linattn_bwd<16, 64>), dim3(cdiv(waves, 4)), dim3(256), 0, s, kk);
+}
+#else
+template <int C, int NN>
+static void launch_one(const LinAttnBwdK& kk, int waves, hipStream_t s) {
+  if constexpr (C >= 12 && NN == 64) launch_linattn_bwd_big(kk, C, waves, s);
+  else hipLaunchKernelGGL((k_linattn_bwd<C, NN>), dim3(cdiv(waves, 4)), dim3(256), 0, s, kk);
+}
 
 template <int C>
 static int linattn_bwd_n(const LinAttnBwdK& k, int n, const LinAttnBwd& g, hipStream_t s) {
@@ -594,10 +715,10 @@ static int linattn_bwd_n(const LinAttnBwdK& k, int n, const LinAttnBwd& g, hipSt
     constexpr int RW = NN >= 32 ? 1 : 32 / NN;                                                     \
     const int units = cdiv(k.rows, RW);                                                            \
     LinAttnBwdK kk = k;                                                                            \
-    /* 466 registers => one wave per SIMD, 1024 resident waves: size the grid to ONE resident round */ \
+    /* > 256 registers => one wave per SIMD, 1024 resident waves: size the grid to ONE resident round */ \
     kk.units_per_wave = std::max(1, cdiv(units, 1024));                                            \
     const int waves = cdiv(units, kk.units_per_wave);                                              \
-    hipLaunchKernelGGL((k_linattn_bwd<C, NN>), dim3(cdiv(waves, 4)), dim3(256), 0, s, kk);         \
+    launch_one<C, NN>(kk, waves, s);                                                               \
     hipLaunchKernelGGL(k_linattn_dw_reduce, dim3(cdiv(la_slot(C), 16)), dim3(256), 0, s, kk.part, waves, C, la_slot(C), g.dw_qkv, \
                        g.dw_out, g.dg_out, g.db_out, g.dg_pre);                                    \
     break;                                                                                         \
@@ -652,5 +773,6 @@ int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s) {
     default: set_error("linattn_bwd: unsupported channel count " + std::to_string(C)); return 2;
   }
 }
+#endif  // DQ_LA_BIG_TU
 
 }  // namespace dq
