@@ -69,13 +69,13 @@ __device__ __forceinline__ float half_sum(float v) {
 }
 
 template <int C, int N>
-__global__ void __launch_bounds__(256) k_linattn_bwd(LinAttnBwdK a) {
+__global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBwdK a) {  // C = 4: <= 256 registers, two waves per SIMD
   constexpr int NB = N >= 32 ? N / 32 : 1;
   constexpr int RW = N >= 32 ? 1 : 32 / N;
   constexpr int NJ = C <= 8 ? 4 : 8;
   constexpr int SEG = N >= 32 ? 16 : (N >= 8 ? N / 2 : N);
   constexpr bool PARTNER = N >= 8;
-  constexpr bool PREFETCH = C <= 8;
+  constexpr bool PREFETCH = C == 8;  // C = 4 runs two waves per SIMD instead (the partner wave hides the latency); C > 8: no registers
   constexpr int CG = C / 4;      // channel groups of 4 (one 4x4x1 MFMA chain each)
   constexpr int NP = NB * 32;    // positions (lanes x blocks) of one unit
   static_assert(NB <= 2, "rows longer than 64 are not built");
@@ -710,13 +710,14 @@ static void launch_one(const LinAttnBwdK& kk, int waves, hipStream_t s) {
 
 template <int C>
 static int linattn_bwd_n(const LinAttnBwdK& k, int n, const LinAttnBwd& g, hipStream_t s) {
+  const int64_t k_part_floats = g.part_floats;  // one resident round: 1 wave per SIMD (2 at C = 4), and a partial slot each
 #define DQ_LB(NN)                                                                                  \
   case NN: {                                                                                       \
     constexpr int RW = NN >= 32 ? 1 : 32 / NN;                                                     \
     const int units = cdiv(k.rows, RW);                                                            \
     LinAttnBwdK kk = k;                                                                            \
-    /* > 256 registers => one wave per SIMD, 1024 resident waves: size the grid to ONE resident round */ \
-    kk.units_per_wave = std::max(1, cdiv(units, 1024));                                            \
+    const int max_waves = std::min((C == 4 ? 2048 : 1024), (int)(k_part_floats / la_slot(C)));      \
+    kk.units_per_wave = std::max(1, cdiv(units, max_waves));                                       \
     const int waves = cdiv(units, kk.units_per_wave);                                              \
     launch_one<C, NN>(kk, waves, s);                                                               \
     hipLaunchKernelGGL(k_linattn_dw_reduce, dim3(cdiv(la_slot(C), 16)), dim3(256), 0, s, kk.part, waves, C, la_slot(C), g.dw_qkv, \
