@@ -25,7 +25,8 @@ struct ResBuf { int64_t u1, a1, u2, out; };
 struct LevelBuf { ResBuf r0, r1; int64_t la, la_pre, la_tmp, rs; };  // la_pre: saved pre-norm LA output; la_tmp: backward scratch (twin only)
 struct Arena {
   int B = 0, RT = 0;
-  int64_t floats = 0;
+  int64_t floats = 0;       // total arena size
+  int64_t zero_floats = 0;  // prefix whose gradient twin must be zeroed before a backward (the accumulated-into tensors)
   int64_t tbuf, ss, cat0, ms1n, ms1_u, ms1_a, ms1f, h0;
   std::vector<LevelBuf> downs, ups;
   int64_t mid_in, xn, qv, kk, o, lse, delta, attn_out, mid_back, eps, partials, loss, coef, xa, xb, wg, wg_floats, la_part, la_part_floats, ts_tab, step, c2_stage, c1_stage;
