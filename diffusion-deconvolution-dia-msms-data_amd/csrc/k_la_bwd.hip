@@ -75,7 +75,9 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
   constexpr int NJ = C <= 8 ? 4 : 8;
   constexpr int SEG = N >= 32 ? 16 : (N >= 8 ? N / 2 : N);
   constexpr bool PARTNER = N >= 8;
-  constexpr bool PREFETCH = C == 8;  // C = 4 runs two waves per SIMD instead (the partner wave hides the latency); C > 8: no registers
+  // C = 4 runs two waves per SIMD instead (the partner wave hides the latency); C = 16 and the 64-position C = 12 variant have
+  // no registers to spare
+  constexpr bool PREFETCH = C == 8 || (C == 12 && N < 64);
   constexpr int CG = C / 4;      // channel groups of 4 (one 4x4x1 MFMA chain each)
   constexpr int NP = NB * 32;    // positions (lanes x blocks) of one unit
   static_assert(NB <= 2, "rows longer than 64 are not built");
@@ -390,7 +392,23 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
         return o;
       };
 
-      if (N >= 32) {
+      if (N == 1) {
+        // ================= rows of ONE position: closed form =================
+        // softmax over a single position is 1 and the q softmax sums to 1: S = 32^-0.5 whatever Wq, Wk are, so
+        // R = 32^-0.5 xh, dWq = dWk = 0, dXh = 32^-0.5 W2^T dYpre and dW2 += dYpre (32^-0.5 xh)^T for every head
+        float dR[C];
+        make_dp(0, dR);
+        if (half == 0) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) ps[c * NP + col] = scale * xs[c * NP + col];
+        }
+#pragma unroll
+        for (int g = 0; g < CG; ++g)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) part[0][g][i] = half == 0 ? scale * dR[g * 4 + i] : 0.f;  // (the halves are added below)
+        wfence();
+        add_dw2();
+      } else if (N >= 32) {
         // ================= one row per wave: M / P form =================
         // M[d = col][c] (both lane halves hold the total) and its [c][d] image for the P chains
         float Mr[C];
