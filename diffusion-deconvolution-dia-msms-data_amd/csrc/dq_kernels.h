@@ -143,7 +143,7 @@ struct LinAttnBwd {
   float* part = nullptr; int64_t part_floats = 0;  // per-wave dW partial slots: >= LA_MAX_WAVES * 512 * C floats
   float* dw_qkv = nullptr; float* dw_out = nullptr; float* db_out = nullptr; float* dg_pre = nullptr; float* dg_out = nullptr;
 };
-// rows of 128 / 256 positions (k_linattn_long.hip)
+// rows of 128 / 256 positions (k_la_long.hip)
 int launch_linattn_fwd_long(const LinAttn& a, hipStream_t s);
 int launch_linattn_bwd_long(const float* x, const float* dyp, float* dxh, const float* w_qkv, const float* w_out, const float* g_pre,
                             float* part, int C, int rows, int n, int* waves_out, hipStream_t s);

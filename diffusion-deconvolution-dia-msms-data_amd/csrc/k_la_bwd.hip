@@ -3,7 +3,7 @@
 // k_linattn.hip (per head: M[d][c] = sum_n K[d][n] xh[c][n], P[c][n] = sum_d M[d][c] Q[d][n], ypre = sum_h W2_h P_h + b with
 // W2_h = Wo_h Wv_h), differentiated in that form -- no 32x32 context / value tiles exist in either direction.
 //
-// One launch does the whole block (rows of up to 64 positions; longer rows: k_linattn_long.hip + two k_block_bwd):
+// One launch does the whole block (rows of up to 64 positions; longer rows: k_la_long.hip + two k_block_bwd):
 //   (1) post-norm backward, recomputed per head from the saved pre-norm output (per position, over channels: in-lane
 //       + one swap with lane^32)                                                   -> dYpre ; d g_out, d b_out (head 0 only)
 //   (2) per head, recomputing the forward in registers:

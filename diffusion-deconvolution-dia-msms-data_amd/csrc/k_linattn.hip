@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   constexpr bool PARTNER = N >= 8;            // does lane^32 hold positions of the same row?
   constexpr int CG = C / 4;                   // channel groups of 4 (one 4x4x1 MFMA chain each)
   constexpr int NP = NB * 32;                 // staged positions per wave
-  static_assert(NB <= 2, "rows longer than 64 take the two-pass path (k_linattn_long.hip)");
+  static_assert(NB <= 2, "rows longer than 64 take the two-pass path (k_la_long.hip)");
   static_assert(C % 4 == 0, "channel count must be a multiple of 4");
 
   __shared__ __attribute__((aligned(16))) float w2_lds[4 * C * C];  // [head][c'][c] = sum_e Wo[c'][head*32+e] Wv[head*32+e][c]
