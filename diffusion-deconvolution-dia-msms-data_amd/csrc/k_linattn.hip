@@ -45,14 +45,17 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   constexpr bool PARTNER = N >= 8;            // does lane^32 hold positions of the same row?
   constexpr int CG = C / 4;                   // channel groups of 4 (one 4x4x1 MFMA chain each)
   constexpr int NP = NB * 32;                 // staged positions per wave
+  constexpr bool SEGM = N == 8 || N == 16;    // short rows whose M is accumulated per row (register segment) instead of S^T
   static_assert(NB <= 2, "rows longer than 64 take the two-pass path (k_la_long.hip)");
   static_assert(C % 4 == 0, "channel count must be a multiple of 4");
 
   __shared__ __attribute__((aligned(16))) float w2_lds[4 * C * C];  // [head][c'][c] = sum_e Wo[c'][head*32+e] Wv[head*32+e][c]
   __shared__ __attribute__((aligned(16))) float xs_lds[4][C * NP];  // per wave: xh as [c][n]
-  __shared__ __attribute__((aligned(16))) float ms_lds[4][C * 32];  // per wave: M of the current head as [c][d]
-  __shared__ float tiles[(N > 1 && N < 32) ? 4 : 1][(N > 1 && N < 32) ? 32 * 33 : 1];  // wave-private transpose tiles (short rows only)
-  float* tile = tiles[(N > 1 && N < 32) ? (threadIdx.x >> 6) : 0];
+  constexpr int MS_ROW = C * 32 + 8;  // row stride of M: + 8 floats so that the rows of a unit start in different LDS banks
+  __shared__ __attribute__((aligned(16))) float ms_lds[4][(SEGM ? RW : 1) * MS_ROW];  // per wave: M of the current head as [row][c][d]
+  constexpr bool QUAD = N > 1 && N < 32 && !SEGM;  // masked quadratic form (rows of 2 / 4 positions)
+  __shared__ float tiles[QUAD ? 4 : 1][QUAD ? 32 * 33 : 1];  // wave-private transpose tiles (quadratic form only)
+  float* tile = tiles[QUAD ? (threadIdx.x >> 6) : 0];
   for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) {
     const int c = i % C, cp = (i / C) % C, hd = i / (C * C);
     float s = 0.f;
@@ -172,6 +175,9 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
       kT[blk] = ak;
     }
     float krs = 1.f;  // n >= 32: 1 / sum_n exp(k[d][n]) of this lane's d, applied to M instead of to the 32 x n tile
+    float krs_seg[16 / SEG];  // n = 8, 16: the same per row (register segment) of the unit
+#pragma unroll
+    for (int s = 0; s < 16 / SEG; ++s) krs_seg[s] = 1.f;
 #pragma unroll
     for (int s0 = 0; s0 < 16; s0 += SEG) {
       float m = -INFINITY;
@@ -192,6 +198,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
       if (PARTNER) ssum += swap32(ssum);
       const float rs = 1.0f / ssum;
       if (N >= 32) krs = rs;
+      else if (SEGM) krs_seg[s0 / SEG] = rs;
       else {
 #pragma unroll
         for (int r = s0; r < s0 + SEG; ++r) kT[0][r] *= rs;
@@ -246,9 +253,44 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
         }
         add_w2(hd, blk, P, qs);
       }
+    } else if (SEGM) {
+      // ---------------- rows of 8 / 16 positions (4 / 2 rows share this block): M per ROW.  Row s of the unit is register
+      // segment s of k^T in both lane halves, so M_s^T[c][d] is the 4x4x1 chain restricted to that segment; a position then
+      // contracts with the M of its own row (a 4-lane block never straddles rows).  No S^T tile, no transpose.
+      wave_fence();  // the previous head's reads of ms are done
+#pragma unroll
+      for (int s = 0; s < 16 / SEG; ++s)
+#pragma unroll
+        for (int g = 0; g < CG; ++g) {
+          const float* ar = xs + (g * 4 + (lane & 3)) * NP + 4 * half;
+          f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q4 = s * SEG / 4; q4 < (s + 1) * SEG / 4; ++q4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(ar + 8 * q4);
+            t0 = mfma4f(a4.x, kT[0][q4 * 4 + 0], t0); t1 = mfma4f(a4.y, kT[0][q4 * 4 + 1], t1);
+            t0 = mfma4f(a4.z, kT[0][q4 * 4 + 2], t0); t1 = mfma4f(a4.w, kT[0][q4 * 4 + 3], t1);
+          }
+          const f32x4 mt = t0 + t1;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float v = (mt[i] + swap32(mt[i])) * krs_seg[s];
+            if (half == 0) ms[s * MS_ROW + (g * 4 + i) * 32 + col] = v;
+          }
+        }
+      wave_fence();
+      float qs;
+      const f32x16 q = make_q(0, qs);
+      float P[C];
+#pragma unroll
+      for (int g = 0; g < CG; ++g) {
+        const f32x4 pp = chain4(ms + rl * MS_ROW, 32, 0, g, q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) P[g * 4 + i] = pp[i] + swap32(pp[i]);
+      }
+      add_w2(hd, 0, P, qs);
     } else {
-      // ---------------- short rows (32/N rows share this block): masked S^T[n'][n] = sum_d k[d][n'] e_q[d][n] for pairs of the
-      // same m/z row, then R[c][n] = sum_n' xh[c][n'] S^T[n'][n]
+      // ---------------- rows of 2 / 4 positions (16 / 8 rows share this block): masked S^T[n'][n] = sum_d k[d][n'] e_q[d][n] for
+      // pairs of the same m/z row, then R[c][n] = sum_n' xh[c][n'] S^T[n'][n]
       float qs;
       const f32x16 q = make_q(0, qs);
       const f32x16 Kd = transpose_tile(kT[0], tile, col, half);  // rows d, col n'
