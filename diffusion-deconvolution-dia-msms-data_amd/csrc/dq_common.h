@@ -58,10 +58,23 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 }
 
 // 64-lane wave reductions (all lanes receive the result)
+// Sum over the 64 lanes, every lane receives it.  Inside a 16-lane row: four DPP adds (quad_perm swaps, then the two row
+// mirrors) -- no LDS; across the four rows: v_readlane of one lane per row.  The __shfl_xor butterfly this replaces is six
+// dependent ds_bpermute round trips per value and was the floor (~12 us) of every kernel that ends in a block reduction of
+// dozens of values (the weight-gradient kernels: 52 per wave).
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  int x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false));  // row_half_mirror
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false));  // row_mirror: every lane = its row's sum
+  x = __float_as_int(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(x, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(x, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(x, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(x, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
