@@ -12,6 +12,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ constexpr int rmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+// value of lane ^ 32 (ds_bpermute).  gfx950's v_permlane32_swap_b32 (tools/probe/permlane32.hip) was tried here: with the
+// two register copies and the select it needs it is four VALU instructions, and the VALU-bound forward kernel got 4 % slower
+// (the LDS pipe that serves ds_bpermute is otherwise idle there); the latency-bound backward did not change.
 __device__ __forceinline__ float swap_half(float v) { return __shfl_xor(v, 32, 64); }
 
 // X^T Y over all 16 registers

@@ -30,7 +30,7 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __
 // block = lane >> 2; a lane supplies A_blk[i = lane & 3] and B_blk[j = lane & 3]; register i of lane (blk, j) += A_blk[i] * B_blk[j]
 __device__ __forceinline__ f32x4 mfma4f(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ constexpr int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
-__device__ __forceinline__ float swap32(float v) { return __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ float swap32(float v) { return swap_half(v); }  // v_permlane32_swap (dq_mfma.h)
 __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();

@@ -21,11 +21,15 @@ constexpr int GR = 16;   // rows (16-lane groups) per 256-thread block
 constexpr int CI = 32;   // staged input channels (cat(A, B): <= 16 + 16)
 
 // sum over the 16 lanes of a group (all lanes receive it)
-__device__ __forceinline__ float gsum16(float v) {
-  v += __shfl_xor(v, 1, 16);
-  v += __shfl_xor(v, 2, 16);
-  v += __shfl_xor(v, 4, 16);
-  v += __shfl_xor(v, 8, 16);
+__device__ __forceinline__ float gsum16(float v) {  // four DPP adds inside the 16-lane row, no LDS
+  int x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false));  // row_half_mirror
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false));  // row_mirror
   return v;
 }
 
