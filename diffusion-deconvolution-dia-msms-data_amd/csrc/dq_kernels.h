@@ -79,6 +79,8 @@ struct ConvWgrad {
 };
 constexpr int WGRAD_MAX_PARTS = 512;
 int launch_conv_wgrad(const ConvWgrad& a, hipStream_t s);
+// up to three stride-1 convs over the same (rows, n) in one launch + one merged reduce (each with its own scratch region)
+int launch_conv_wgrad_multi(const ConvWgrad* w, int count, hipStream_t s);
 
 // ---- k_res.hip : fused ResnetBlock over m/z rows whose length divides 256
 struct ResFwd {

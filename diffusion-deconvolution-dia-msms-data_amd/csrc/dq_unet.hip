@@ -112,6 +112,7 @@ struct Ctx {
 // The weight-gradient kernels depend only on tensors that are final when they are issued (dU, forward activations) and
 // nothing on the data-gradient chain depends on them: they run on a side stream, forked by an event, joined at the end.
 int wgrad_async(const Ctx& c, const ConvWgrad& w);
+int wgrad_async_multi(const Ctx& c, ConvWgrad* w, int count);  // <= 3 stride-1 convs over the same rows: one launch + one reduce
 int join_side(const Ctx& c);
 
 #define DQ_TRY(expr)            \
@@ -170,19 +171,25 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
     k.dg1 = c.dprm(r.g1); k.dg2 = c.dprm(r.g2); k.dss = c.g(c.ar.ss) + r.ss_off;
     k.C = r.cout; k.rows = rows; k.n = n; k.rows_per_sample = rows_per_sample;
     DQ_TRY(launch_res_bwd(k, c.s));
-    ConvWgrad w2;
-    w2.scratch = c.w(c.ar.wg); w2.scratch_floats = c.ar.wg_floats;
+    // the block's three weight gradients (conv2, conv1, res_conv) in ONE launch + one reduce; each gets a third of the scratch
+    ConvWgrad w[3];
+    const int64_t third = c.ar.wg_floats / 3 / 64 * 64;
+    ConvWgrad& w2 = w[0];
+    w2.scratch = c.w(c.ar.wg); w2.scratch_floats = third;
     w2.du = c.g(b.u2); w2.inA = c.w(b.a1); w2.cinA = r.cout; w2.cout = r.cout; w2.K = 3; w2.mode = CONV_S1;
     w2.rows = rows; w2.n_in = n; w2.n_out = n; w2.dw = c.dprm(r.c2.w); w2.dbias = c.dprm(r.c2.b);
-    DQ_TRY(wgrad_async(c, w2));
-    ConvWgrad w1 = w2;
+    w[1] = w2;
+    ConvWgrad& w1 = w[1];
+    w1.scratch = c.w(c.ar.wg) + third;
     w1.du = c.g(b.u1); w1.inA = inA; w1.inB = inB; w1.cinA = cinA; w1.cinB = cinB; w1.dw = c.dprm(r.c1.w); w1.dbias = c.dprm(r.c1.b);
-    DQ_TRY(wgrad_async(c, w1));
+    int count = 2;
     if (r.res.cout) {
-      ConvWgrad wr = w1;
-      wr.du = dout; wr.K = 1; wr.dw = c.dprm(r.res.w); wr.dbias = c.dprm(r.res.b);
-      DQ_TRY(wgrad_async(c, wr));
+      w[2] = w1;
+      w[2].scratch = c.w(c.ar.wg) + 2 * third;
+      w[2].du = dout; w[2].K = 1; w[2].dw = c.dprm(r.res.w); w[2].dbias = c.dprm(r.res.b);
+      count = 3;
     }
+    DQ_TRY(wgrad_async_multi(c, w, count));
     return 0;
   }
   // block2: norm -> silu
@@ -451,6 +458,20 @@ int wgrad_async(const Ctx& c, const ConvWgrad& w) {
   DQ_HIP_OK(hipStreamWaitEvent(pl->side_stream, ev, 0));
   pl->side_used = true;
   return launch_conv_wgrad(w, pl->side_stream);
+}
+
+int wgrad_async_multi(const Ctx& c, ConvWgrad* w, int count) {
+  dq_plan* pl = c.owner;
+  if (!pl) return launch_conv_wgrad_multi(w, count, c.s);
+  if (!pl->side_stream) {  // created by the first wgrad_async of a plan (the head convs come before any ResnetBlock)
+    for (int i = 0; i < count; ++i) DQ_TRY(wgrad_async(c, w[i]));
+    return 0;
+  }
+  hipEvent_t ev = pl->events[pl->ev_next++ % dq_plan::NUM_EVENTS];
+  DQ_HIP_OK(hipEventRecord(ev, c.s));
+  DQ_HIP_OK(hipStreamWaitEvent(pl->side_stream, ev, 0));
+  pl->side_used = true;
+  return launch_conv_wgrad_multi(w, count, pl->side_stream);
 }
 
 int join_side(const Ctx& c) {

@@ -405,9 +405,9 @@ __device__ __forceinline__ void wgrad_block_reduce(float (&acc)[COB][CIB][K], fl
 }
 
 template <int COB, int CIB, int K, int MODE>
-__global__ void __launch_bounds__(256) k_conv_wgrad(ConvWgrad a, int n_cib, int nelem_w) {
+__device__ __forceinline__ void wgrad_body(const ConvWgrad& a, int n_cib, int nelem_w, int gx, int by) {
   const int cin = a.cinA + a.cinB;
-  const int co0 = (blockIdx.y / n_cib) * COB, ci0 = (blockIdx.y % n_cib) * CIB;
+  const int co0 = (by / n_cib) * COB, ci0 = (by % n_cib) * CIB;
   const int total = a.rows * a.n_out;  // < 2^31 (checked on the host)
   float acc[COB][CIB][K];
   float accb[COB];
@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(ConvWgrad a, int n_cib, int 
 #pragma unroll
       for (int k = 0; k < K; ++k) acc[i][j][k] = 0.f;
   }
-  for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < total; it += gridDim.x * blockDim.x) {
+  for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < total; it += gx * blockDim.x) {
     const int row = it / a.n_out, p = it - row * a.n_out;
     float d[COB];
     const float* dub = a.du + ((int64_t)row * a.cout + co0) * a.n_out + p;
@@ -449,12 +449,17 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(ConvWgrad a, int n_cib, int 
 
 // stride-1 'same' convs with n % 4 == 0 (K = 1 or 3): a thread takes 4 consecutive positions per step -- 16-byte loads of
 // du and x (+ the two halo values), a quarter of the memory instructions and index arithmetic of the scalar form
+template <int COB, int CIB, int K, int MODE>
+__global__ void __launch_bounds__(256) k_conv_wgrad(ConvWgrad a, int n_cib, int nelem_w) {
+  wgrad_body<COB, CIB, K, MODE>(a, n_cib, nelem_w, gridDim.x, blockIdx.y);
+}
+
 template <int COB, int CIB, int K>
-__global__ void __launch_bounds__(256) k_conv_wgrad_v4(ConvWgrad a, int n_cib, int nelem_w) {
+__device__ __forceinline__ void wgrad_body_v4(const ConvWgrad& a, int n_cib, int nelem_w, int gx, int by) {
   static_assert(K == 1 || K == 3, "vectorised weight gradient: K = 1 or 3");
   constexpr int H = (K - 1) / 2;
   const int cin = a.cinA + a.cinB;
-  const int co0 = (blockIdx.y / n_cib) * COB, ci0 = (blockIdx.y % n_cib) * CIB;
+  const int co0 = (by / n_cib) * COB, ci0 = (by % n_cib) * CIB;
   const int n = a.n_out, n4 = n >> 2;
   const int total4 = a.rows * n4;
   float acc[COB][CIB][K];
@@ -467,7 +472,7 @@ __global__ void __launch_bounds__(256) k_conv_wgrad_v4(ConvWgrad a, int n_cib, i
 #pragma unroll
       for (int k = 0; k < K; ++k) acc[i][j][k] = 0.f;
   }
-  for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < total4; it += gridDim.x * blockDim.x) {
+  for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < total4; it += gx * blockDim.x) {
     const int row = it / n4, p = (it - row * n4) << 2;
     float d[COB][4];
     const float* dub = a.du + ((int64_t)row * a.cout + co0) * n + p;
@@ -504,6 +509,32 @@ __global__ void __launch_bounds__(256) k_conv_wgrad_v4(ConvWgrad a, int n_cib, i
   wgrad_block_reduce<COB, CIB, K>(acc, accb, a, co0, ci0, cin, nelem_w);
 }
 
+template <int COB, int CIB, int K>
+__global__ void __launch_bounds__(256) k_conv_wgrad_v4(ConvWgrad a, int n_cib, int nelem_w) {
+  wgrad_body_v4<COB, CIB, K>(a, n_cib, nelem_w, gridDim.x, blockIdx.y);
+}
+
+// Up to three stride-1 convs over the SAME (rows, n) in one launch (blockIdx.z picks the conv): the two convs and the
+// residual 1x1 conv of a ResnetBlock.  The weight-gradient launches are short and latency-bound -- ~200 of them per train
+// step on the side stream -- so a ResnetBlock now costs 2 launches (this + the merged reduce) instead of 6.
+struct WgradMulti {
+  ConvWgrad c[3];
+  int n_cib[3], nelem_w[3], gx[3], tiles[3];
+};
+template <bool VEC4>
+__global__ void __launch_bounds__(256) k_conv_wgrad_multi(WgradMulti m) {
+  const int z = blockIdx.z;
+  if ((int)blockIdx.x >= m.gx[z] || (int)blockIdx.y >= m.tiles[z]) return;
+  const ConvWgrad& a = m.c[z];
+  if (VEC4) {
+    if (a.K == 3) wgrad_body_v4<4, 4, 3>(a, m.n_cib[z], m.nelem_w[z], m.gx[z], blockIdx.y);
+    else wgrad_body_v4<4, 4, 1>(a, m.n_cib[z], m.nelem_w[z], m.gx[z], blockIdx.y);
+  } else {
+    if (a.K == 3) wgrad_body<4, 4, 3, CONV_S1>(a, m.n_cib[z], m.nelem_w[z], m.gx[z], blockIdx.y);
+    else wgrad_body<4, 4, 1, CONV_S1>(a, m.n_cib[z], m.nelem_w[z], m.gx[z], blockIdx.y);
+  }
+}
+
 // dW[e] += sum over the per-block partials in a fixed order (deterministic).  A block owns 16 consecutive elements x 16
 // partial groups: thread (e, g) sums partials g, g+16, ... (64-byte segments: every fetched sector is fully used), the 16
 // group sums meet in LDS.
@@ -531,6 +562,69 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
     if (e < nelem_w) dw[e] += s;
     else if (dbias) dbias[e - nelem_w] += s;
   }
+}
+
+__global__ void __launch_bounds__(256) k_wgrad_reduce_multi(WgradMulti m) {
+  const int z = blockIdx.z;
+  const ConvWgrad& a = m.c[z];
+  const int nelem_w = m.nelem_w[z], nelem = nelem_w + a.cout, nblk = m.gx[z];
+  if ((int)blockIdx.x * 16 >= nelem) return;  // uniform per block
+  __shared__ float red[16][17];
+  const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + el;
+  float s0 = 0.f, s1 = 0.f;
+  if (e < nelem) {
+    int b = g;
+    for (; b + 16 < nblk; b += 32) {
+      s0 += a.scratch[(int64_t)b * nelem + e];
+      s1 += a.scratch[(int64_t)(b + 16) * nelem + e];
+    }
+    if (b < nblk) s0 += a.scratch[(int64_t)b * nelem + e];
+  }
+  red[g][el] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && e < nelem) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][el];
+    if (e < nelem_w) a.dw[e] += s;
+    else if (a.dbias) a.dbias[e - nelem_w] += s;
+  }
+}
+
+// count <= 3 stride-1 convs with identical (rows, n_in == n_out); each descriptor carries its own scratch region
+int launch_conv_wgrad_multi(const ConvWgrad* w, int count, hipStream_t s) {
+  DQ_REQUIRE(count >= 1 && count <= 3, "conv_wgrad_multi: 1..3 convs");
+  WgradMulti m;
+  int gx_max = 1, tiles_max = 1, nelem_max = 1;
+  const int64_t total = (int64_t)w[0].rows * w[0].n_out;
+  if (total == 0) return 0;
+  DQ_REQUIRE(total < (1ll << 31), "conv_wgrad: rows*n must be below 2^31");
+  const bool vec4 = w[0].n_out % 4 == 0;
+  for (int i = 0; i < count; ++i) {
+    const ConvWgrad& a = w[i];
+    DQ_REQUIRE(a.du && a.inA && a.dw && a.scratch && a.cout > 0 && a.cinA > 0, "conv_wgrad_multi: missing operand");
+    DQ_REQUIRE(a.mode == CONV_S1 && (a.K == 1 || a.K == 3) && a.n_in == a.n_out && a.rows == w[0].rows && a.n_out == w[0].n_out,
+               "conv_wgrad_multi: stride-1 k1/k3 convs over the same rows");
+    const int cin = a.cinA + a.cinB;
+    const int n_cob = cdiv(a.cout, 4), n_cib = cdiv(cin, 4);
+    m.c[i] = a;
+    m.n_cib[i] = n_cib;
+    m.nelem_w[i] = a.cout * cin * a.K;
+    m.tiles[i] = n_cob * n_cib;
+    m.gx[i] = std::max(1, std::min({cdiv(total, 256 * (vec4 ? 8 : 4)), WGRAD_MAX_PARTS, std::max(1, 2048 / m.tiles[i])}));
+    DQ_REQUIRE((int64_t)m.gx[i] * (m.nelem_w[i] + a.cout) <= a.scratch_floats, "conv_wgrad_multi: scratch too small");
+    gx_max = std::max(gx_max, m.gx[i]); tiles_max = std::max(tiles_max, m.tiles[i]);
+    nelem_max = std::max(nelem_max, m.nelem_w[i] + a.cout);
+  }
+  for (int i = count; i < 3; ++i) { m.c[i] = w[0]; m.n_cib[i] = 1; m.nelem_w[i] = 0; m.gx[i] = 0; m.tiles[i] = 0; }
+  dim3 grid(gx_max, tiles_max, count), block(256);
+  if (vec4) hipLaunchKernelGGL(k_conv_wgrad_multi<true>, grid, block, 0, s, m);
+  else hipLaunchKernelGGL(k_conv_wgrad_multi<false>, grid, block, 0, s, m);
+  DQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_wgrad_reduce_multi, dim3(cdiv(nelem_max, 16), 1, count), dim3(256), 0, s, m);
+  DQ_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_conv_wgrad(const ConvWgrad& a, hipStream_t s) {
