@@ -512,7 +512,7 @@ using namespace dq;
 extern "C" {
 
 const char* dq_last_error(void) { return g_err.c_str(); }
-int dq_abi_version(void) { return 2; }
+int dq_abi_version(void) { return DQ_ABI_VERSION; }
 
 dq_plan* dq_plan_create(int dim, int n_mults, const int* dim_mults, int mz, int num_timesteps) {
   dq_plan* h = new dq_plan();

@@ -1,0 +1,242 @@
+"""CustomTransformer noise predictor -- drop-in for the reference's ``dquartic.model.building_blocks.CustomTransformer``.
+
+Same constructor (reference building_blocks.py:205), same ``forward(x_t, t, x_cond)`` contract (:224-260), same
+``state_dict`` keys, shapes and registration order (reference checkpoints load), same default initialisation under the same
+torch seed.  The arithmetic runs in libdq_hip.so: every dense layer and both attention products are the hand-written fp32
+matrix-core GEMM (csrc/k_gemm.hip), the rest is csrc/k_tfm.hip; this module owns the parameters (views of ONE flat fp32
+buffer) and hands raw device pointers to the C ABI (``dq_tfm_*`` in include/dq_hip.h).  No PyTorch fallback: on a CPU tensor or
+without the library ``forward`` raises.
+
+``DDIMTransformerAdapter`` gives it the 4-argument call ``DDIMDiffusionModel`` makes (reference model.py:271, 359) -- the
+reference itself cannot drive this network through its DDIM class: ``model(x_t, t, ms2_cond, ms1_cond)`` ->
+``transformer(x_t, t, ms1_cond)``.
+"""
+import ctypes
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .. import _native as N
+from .unet1d import _attach
+
+__all__ = ["CustomTransformer", "DDIMTransformerAdapter", "apply_rope_tables", "time_embedding_freqs"]
+
+
+def apply_rope_tables(seqlen: int, hidden_dim: int):
+    """sin / cos of apply_rope's angles (reference building_blocks.py:31-49), same torch expressions, fp32 on the host."""
+    half = hidden_dim // 2
+    freq_seq = torch.arange(half, dtype=torch.float32) / half
+    inv_freq = 10000 ** (-freq_seq)
+    angles = torch.einsum("i,j->ij", torch.arange(seqlen, dtype=torch.float32), inv_freq)
+    return torch.sin(angles).contiguous(), torch.cos(angles).contiguous()
+
+
+def time_embedding_freqs(hidden_dim: int):
+    """TimeEmbedding's frequency vector (reference building_blocks.py:104-106)."""
+    half = hidden_dim // 2
+    return torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1))).contiguous()
+
+
+class CustomTransformer(nn.Module):
+    def __init__(self, input_dim=40000, hidden_dim=128, num_heads=1, num_layers=1):
+        super().__init__()
+        self.input_dim, self.hidden_dim, self.num_heads, self.num_layers = int(input_dim), int(hidden_dim), int(num_heads), int(num_layers)
+        lib = N.lib()
+        self._tfm = lib.dq_tfm_create(self.input_dim, self.hidden_dim, self.num_heads, self.num_layers)
+        if not self._tfm:
+            raise NotImplementedError("CustomTransformer (MI355X build): " + (lib.dq_last_error() or b"?").decode())
+        self._layout = []
+        name = ctypes.create_string_buffer(256)
+        off, nd, shp = ctypes.c_int64(), ctypes.c_int(), (ctypes.c_int64 * 2)()
+        for i in range(lib.dq_tfm_num_params(self._tfm)):
+            N.check(lib.dq_tfm_param_info(self._tfm, i, name, 256, ctypes.byref(off), ctypes.byref(nd), shp), "dq_tfm_param_info")
+            self._layout.append((name.value.decode(), int(off.value), tuple(int(shp[k]) for k in range(nd.value))))
+        self._flat = torch.zeros(lib.dq_tfm_param_floats(self._tfm), dtype=torch.float32)
+        self._flat_grad: Optional[torch.Tensor] = None
+        self._by_name = {}
+        for pname, o, shape in self._layout:
+            p = nn.Parameter(self._flat[o:o + math.prod(shape)].view(shape))
+            self._by_name[pname] = p
+            _attach(self, pname, p)
+        self._reset_parameters()
+        self._ws = {}
+        self._tables = {}
+
+    @torch.no_grad()
+    def _reset_parameters(self):
+        """The reference modules' defaults, consuming the RNG in the reference's construction order: nn.Linear
+        (kaiming_uniform(a=sqrt(5)) weight, U(+-1/sqrt(fan_in)) bias); nn.MultiheadAttention builds out_proj (a Linear) first,
+        then xavier_uniform on in_proj_weight and zero in_proj_bias / out_proj.bias; nn.LayerNorm ones / zeros."""
+        def linear(prefix):
+            w, b = self._by_name[prefix + ".weight"], self._by_name[prefix + ".bias"]
+            nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+            bound = 1.0 / math.sqrt(w.shape[1])
+            nn.init.uniform_(b, -bound, bound)
+
+        for pre in ("input_projection", "output_projection", "conditional_projection", "time_embedding.linear1", "time_embedding.linear2"):
+            linear(pre)
+        for l in range(self.num_layers):
+            pre = f"layers.{l}."
+            linear(pre + "attention.out_proj")
+            nn.init.xavier_uniform_(self._by_name[pre + "attention.in_proj_weight"])
+            self._by_name[pre + "attention.in_proj_bias"].zero_()
+            self._by_name[pre + "attention.out_proj.bias"].zero_()
+            self._by_name[pre + "norm1.weight"].fill_(1.0)
+            self._by_name[pre + "norm1.bias"].zero_()
+            linear(pre + "ff.0")
+            linear(pre + "ff.2")
+            self._by_name[pre + "norm2.weight"].fill_(1.0)
+            self._by_name[pre + "norm2.bias"].zero_()
+
+    # ------------------------------------------------------------------ flat buffers (same scheme as UNet1d)
+    def trainable_named(self):
+        return [(n, self._by_name[n]) for n, _, _ in self._layout]
+
+    def _ensure_flat(self):
+        first = self._by_name[self._layout[0][0]]
+        dev = first.device
+        ok = self._flat.device == dev
+        if ok:
+            base = self._flat.data_ptr()
+            ok = all(self._by_name[n].data_ptr() == base + 4 * o for n, o, _ in self._layout)
+        if not ok:
+            flat = torch.empty(self._flat.numel(), dtype=torch.float32, device=dev)
+            for pname, o, shape in self._layout:
+                p = self._by_name[pname]
+                flat[o:o + p.numel()].copy_(p.detach().reshape(-1).to(torch.float32))
+                p.data = flat[o:o + p.numel()].view(shape)
+            self._flat = flat
+            self._flat_grad = None
+        return self._flat
+
+    @property
+    def flat_params(self) -> torch.Tensor:
+        return self._ensure_flat()
+
+    def flat_grads(self, zero: bool = False) -> torch.Tensor:
+        flat = self._ensure_flat()
+        if self._flat_grad is None or self._flat_grad.device != flat.device:
+            self._flat_grad = torch.zeros_like(flat)
+            zero = False
+        if zero:
+            self._flat_grad.zero_()
+        base = self._flat_grad.data_ptr()
+        for pname, o, shape in self._layout:
+            p = self._by_name[pname]
+            if p.grad is None or p.grad.data_ptr() != base + 4 * o:
+                p.grad = self._flat_grad[o:o + p.numel()].view(shape)
+        return self._flat_grad
+
+    def workspace(self, B, S1, S2, training):
+        dev = self._flat.device
+        key = (B, S1, S2, bool(training), str(dev))
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = N.lib().dq_tfm_workspace_bytes(self._tfm, B, S1, S2, 1 if training else 0)
+            if nbytes <= 0:
+                raise RuntimeError("dq_tfm_workspace_bytes failed")
+            self._ws = {k: v for k, v in self._ws.items() if k[3] != bool(training)}
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._ws[key] = ws
+        return ws
+
+    def tables(self, S, device):
+        key = (S, str(device))
+        t = self._tables.get(key)
+        if t is None:
+            sin, cos = apply_rope_tables(S, self.hidden_dim)
+            t = (sin.to(device), cos.to(device), time_embedding_freqs(self.hidden_dim).to(device))
+            self._tables = {key: t}
+        return t
+
+    def __del__(self):
+        try:
+            if getattr(self, "_tfm", None):
+                N.lib().dq_tfm_destroy(self._tfm)
+                self._tfm = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ forward
+    def _prep(self, x_t, t, x_cond):
+        if not x_t.is_cuda:
+            raise RuntimeError("CustomTransformer (MI355X build): tensors must live on the GPU; there is no CPU fallback")
+        if x_t.dim() != 3 or x_t.shape[-1] != self.input_dim:
+            raise ValueError(f"CustomTransformer: x_t must be (batch, seqlen1, input_dim={self.input_dim})")
+        if x_cond.dim() != 2 or x_cond.shape[0] != x_t.shape[0]:
+            raise ValueError("CustomTransformer: x_cond must be (batch, seqlen2) -- one value per conditional position "
+                             "(reference building_blocks.py:241-242 projects it with Linear(1, hidden))")
+        t = t.reshape(-1).to(device=x_t.device, dtype=torch.int64)
+        if t.numel() != x_t.shape[0]:
+            raise ValueError("CustomTransformer: t must have one entry per sample")
+        f32 = lambda v: v.detach().to(torch.float32).contiguous()
+        return f32(x_t), t.contiguous(), f32(x_cond)
+
+    def forward(self, x_t, t, x_cond):
+        xs, ts, cs = self._prep(x_t, t, x_cond)
+        self._ensure_flat()
+        need_grad = torch.is_grad_enabled() and (x_t.requires_grad or x_cond.requires_grad or any(p.requires_grad for _, p in self.trainable_named()))
+        if need_grad:
+            x_in = x_t.to(torch.float32).contiguous() if x_t.requires_grad else xs
+            c_in = x_cond.to(torch.float32).contiguous() if x_cond.requires_grad else cs
+            return _TfmFn.apply(self, x_in, ts, c_in, *[p for _, p in self.trainable_named()])
+        return self._run_fwd(xs, ts, cs, training=False)
+
+    def _run_fwd(self, xs, ts, cs, training):
+        B, S1, _ = xs.shape
+        S2 = cs.shape[1]
+        ws = self.workspace(B, S1, S2, training)
+        sin, cos, freqs = self.tables(max(S1, S2), xs.device)
+        out = torch.empty_like(xs)
+        N.check(N.lib().dq_tfm_fwd(self._tfm, N.ptr(self._flat), N.ptr(sin), N.ptr(cos), N.ptr(freqs), N.ptr(xs), N.ptr(ts), N.ptr(cs),
+                                   N.ptr(out), 1 if training else 0, N.ptr(ws), ws.numel(), B, S1, S2, N.stream_ptr()), "dq_tfm_fwd")
+        return out
+
+    def _run_bwd(self, xs, cs, gout, grads, want_dx, want_dc):
+        B, S1, _ = xs.shape
+        S2 = cs.shape[1]
+        ws = self.workspace(B, S1, S2, True)
+        sin, cos, _ = self.tables(max(S1, S2), xs.device)
+        gx = torch.empty_like(xs) if want_dx else None
+        gc = torch.empty_like(cs) if want_dc else None
+        N.check(N.lib().dq_tfm_bwd(self._tfm, N.ptr(self._flat), N.ptr(sin), N.ptr(cos), N.ptr(xs), N.ptr(cs), N.ptr(gout), N.ptr(grads),
+                                   N.ptr(gx), N.ptr(gc), N.ptr(ws), ws.numel(), B, S1, S2, N.stream_ptr()), "dq_tfm_bwd")
+        return gx, gc
+
+
+class _TfmFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, xs, ts, cs, *params):
+        ctx.net = net
+        ctx.save_for_backward(xs.detach(), cs.detach())
+        ctx.needs = (xs.requires_grad, cs.requires_grad)
+        return net._run_fwd(xs.detach(), ts, cs.detach(), training=True)
+
+    @staticmethod
+    def backward(ctx, gout):
+        net = ctx.net
+        xs, cs = ctx.saved_tensors
+        gout = gout.contiguous().to(torch.float32)
+        grads = torch.zeros_like(net._flat)
+        gx, gc = net._run_bwd(xs, cs, gout, grads, *ctx.needs)
+        pg = [grads[o:o + math.prod(shape)].view(shape) for _, o, shape in net._layout]
+        return (None, gx, None, gc, *pg)
+
+
+class DDIMTransformerAdapter(nn.Module):
+    """``model(x_t, t, init_cond, attn_cond)`` as DDIMDiffusionModel calls it (reference model.py:271, 276, 359, 374), served
+    by the 3-argument transformer: the MS1 chromatogram ``attn_cond`` (B, RT) is its conditional sequence; the MS2 mixture
+    ``init_cond`` has no input on this network (building_blocks.py:224) and is ignored."""
+
+    def __init__(self, transformer: CustomTransformer):
+        super().__init__()
+        self.transformer = transformer
+
+    def forward(self, x_t, t, init_cond=None, attn_cond=None):
+        if attn_cond is None:
+            raise ValueError("DDIMTransformerAdapter: attn_cond (MS1, (B, RT)) is required")
+        if attn_cond.dim() == 3:
+            attn_cond = attn_cond[..., 0]
+        return self.transformer(x_t, t, attn_cond)

@@ -31,9 +31,9 @@ typedef struct dq_plan dq_plan;
 /* Text of the last error on this thread ("" if none). */
 const char* dq_last_error(void);
 /* ABI version of this header (bumped on any signature change).  2: pred_type arguments, dq_ddim_step_x0,
- * dq_mse_loss_weighted_fwd_bwd, dq_pair_batch. */
+ * dq_mse_loss_weighted_fwd_bwd, dq_pair_batch.  3: dq_tfm_* (CustomTransformer), dq_gemm. */
 int dq_abi_version(void);
-#define DQ_ABI_VERSION 2
+#define DQ_ABI_VERSION 3
 
 /* DDIMDiffusionModel.pred_type (model.py:205-213, 269-280, 354-389); any other value is rejected ("Unknown pred_type"). */
 enum { DQ_PRED_EPS = 0, DQ_PRED_X0 = 1 };
@@ -138,6 +138,38 @@ int64_t dq_pair_batch_scratch_bytes(int B);
 int dq_pair_batch(const float* ms2_data, const float* ms1_data, int64_t n_windows, const int64_t* idx_dev, int B, int RT, int MZ,
                   int64_t ms1_per_window, float w1, float w2, float* ms2_1, float* ms1_1, float* ms2_2, float* ms1_2,
                   float* ms2_cond, void* scratch, int64_t scratch_bytes, void* stream);
+
+/* ---- CustomTransformer (dquartic/model/building_blocks.py:179-260) ----------------------------------
+ * The reference's alternative noise predictor: forward(x_t (B,S1,input_dim), t (B) int64, x_cond (B,S2)) -> (B,S1,input_dim).
+ * The handle fixes the parameter layout: one flat fp32 buffer, tensors under the reference's state_dict keys in its
+ * registration order (dq_tfm_param_info).  Needs input_dim % 4 == 0, hidden_dim % 8 == 0, (hidden_dim / num_heads) % 4 == 0;
+ * NULL otherwise (dq_last_error).  Calls that share a handle must not run concurrently. */
+typedef struct dq_tfm dq_tfm;
+dq_tfm* dq_tfm_create(int input_dim, int hidden_dim, int num_heads, int num_layers);
+void dq_tfm_destroy(dq_tfm* tfm);
+int dq_tfm_num_params(const dq_tfm* tfm);
+int64_t dq_tfm_param_floats(const dq_tfm* tfm);
+/* name_cap bytes of name; shape: 2 entries (a vector has shape[1] = 1). */
+int dq_tfm_param_info(const dq_tfm* tfm, int i, char* name, int name_cap, int64_t* offset, int* ndim, int64_t* shape);
+int64_t dq_tfm_workspace_bytes(const dq_tfm* tfm, int B, int S1, int S2, int training);
+/* Forward (building_blocks.py:224-260).  rope_sin / rope_cos: (max(S1,S2), hidden_dim/2) device tables of apply_rope's angles
+ * (:31-49) and time_freqs: (hidden_dim/2) of TimeEmbedding (:104-106) -- formed by the caller with the reference's own torch
+ * expressions so that they are bit-identical.  save_for_bwd != 0 keeps every layer's activations in the workspace. */
+int dq_tfm_fwd(dq_tfm* tfm, const float* params, const float* rope_sin, const float* rope_cos, const float* time_freqs,
+               const float* x_t, const int64_t* t, const float* x_cond, float* out, int save_for_bwd, void* workspace,
+               int64_t workspace_bytes, int B, int S1, int S2, void* stream);
+/* Backward of the last dq_tfm_fwd(save_for_bwd = 1) on the same workspace: grads (flat, same layout as params) +=;
+ * dx_t (B,S1,input_dim) and dx_cond (B,S2) are plain stores and may be NULL. */
+int dq_tfm_bwd(dq_tfm* tfm, const float* params, const float* rope_sin, const float* rope_cos, const float* x_t,
+               const float* x_cond, const float* dout, float* grads, float* dx_t, float* dx_cond, void* workspace,
+               int64_t workspace_bytes, int B, int S1, int S2, void* stream);
+/* The fp32 matrix-core GEMM underneath (exported for the parity tests and the roofline measurement):
+ * C (M,N; ldc) = A B (+ bias[n]) with A(m,k) = a_kmajor ? A[m*lda+k] : A[k*lda+m] and B(k,n) = b_kmajor ? B[n*ldb+k] :
+ * B[k*ldb+n]; splits = 0 lets the library choose a split-K factor; scratch: dq_gemm_scratch_floats(M,N,K) floats. */
+int64_t dq_gemm_scratch_floats(int M, int N, int K);
+int dq_gemm(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int64_t lda, int64_t ldb,
+            int64_t ldc, int a_kmajor, int b_kmajor, int accumulate, int splits, float* scratch, int64_t scratch_floats,
+            void* stream);
 
 /* ---- building blocks exported for the per-block parity tests (tests/test_blocks_gpu.py) ------------------------
  * Residual(PreNorm(LinearAttention)) (unet1d.py:446-496, 1017) on (rows, C, n). */

@@ -1,0 +1,189 @@
+"""CustomTransformer (reference dquartic/model/building_blocks.py).
+CPU: the oracle restatement against fixtures captured from the reference module itself (oracle/make_golden_tfm.py ->
+tests/golden/tfm_tiny.npz: forward output and autograd gradients), the drop-in module's state_dict layout and default
+initialisation against the same fixtures.  GPU: the fp32 matrix-core GEMM against float64 products over layouts, ragged edges and
+split-K; the HIP forward / backward through the C ABI against the fixtures and against the oracle at larger shapes."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dq_oracle_tfm as OT
+
+TAGS = ("a", "b")
+
+
+def _case(g, tag):
+    cfg = [int(v) for v in g[f"{tag}/config"]]
+    params = {k[len(tag) + 7:]: torch.from_numpy(np.array(g[k])) for k in g if k.startswith(f"{tag}/param/")}
+    grads = {k[len(tag) + 6:]: torch.from_numpy(np.array(g[k])) for k in g if k.startswith(f"{tag}/grad/")}
+    t = lambda n: torch.from_numpy(np.array(g[f"{tag}/{n}"]))
+    return cfg, params, grads, t("x_t"), t("t"), t("x_cond"), t("probe"), t("out")
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_oracle_matches_reference_forward_and_gradients(golden, tag):
+    g = golden("tfm_tiny.npz")
+    cfg, params, grads, x, t, c, probe, out = _case(g, tag)
+    p = {k: v.clone().requires_grad_() for k, v in params.items()}
+    x, c = x.clone().requires_grad_(), c.clone().requires_grad_()
+    y = OT.forward(p, x, t, c, cfg[2])
+    assert _rel(y.detach(), out) < 2e-6
+    assert np.array_equal(g[f"{tag}/out"], g[f"{tag}/out_eval"]) or _rel(torch.from_numpy(g[f"{tag}/out_eval"]), out) < 2e-6
+    (y * probe).sum().backward()
+    for k, v in p.items():
+        assert _rel(v.grad, grads[k]) < 5e-6, k
+    assert _rel(x.grad, grads["x_t"]) < 5e-6 and _rel(c.grad, grads["x_cond"]) < 5e-6
+
+
+def test_rope_and_time_tables_known_answers():
+    sin, cos = OT.rope_tables(4, 8)
+    assert sin.shape == (4, 4) and torch.all(sin[0] == 0) and torch.all(cos[0] == 1)
+    assert abs(float(sin[1, 0]) - np.sin(1.0)) < 1e-7 and abs(float(sin[3, 2]) - np.sin(3 * 10000 ** -0.5)) < 1e-7
+    f = OT.time_freqs(8)
+    assert float(f[0]) == 1.0 and abs(float(f[3]) - 1e-4) < 1e-9
+    x = torch.randn(2, 5, 8)
+    y = OT.apply_rope(x)
+    assert torch.allclose(y.pow(2).sum(-1), x.pow(2).sum(-1), atol=1e-5)  # rotations preserve the pair norms
+    assert torch.equal(y[:, 0], x[:, 0])  # position 0 is not rotated
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_module_layout_and_default_init_match_reference(golden, tag):
+    from dquartic.model.building_blocks import CustomTransformer
+
+    g = golden("tfm_tiny.npz")
+    cfg, params, *_ = _case(g, tag)
+    torch.manual_seed(0 if tag == "a" else 1)  # the seed oracle/make_golden_tfm.py constructed the reference module under
+    net = CustomTransformer(input_dim=cfg[0], hidden_dim=cfg[1], num_heads=cfg[2], num_layers=cfg[3])
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g[f"{tag}/keys"]]
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(params[k].shape), k
+        assert torch.equal(v, params[k]), k  # same initialisers, same RNG consumption order
+    net.load_state_dict({k: v + 1 for k, v in params.items()})
+    assert torch.equal(net.state_dict()["layers.0.norm1.bias"], params["layers.0.norm1.bias"] + 1)
+
+
+def test_unsupported_configurations_fail_loudly():
+    from dquartic.model.building_blocks import CustomTransformer
+
+    with pytest.raises(NotImplementedError, match="input_dim % 4"):
+        CustomTransformer(input_dim=30, hidden_dim=16, num_heads=2, num_layers=1)
+    with pytest.raises(NotImplementedError):
+        CustomTransformer(input_dim=32, hidden_dim=16, num_heads=3, num_layers=1)
+    net = CustomTransformer(input_dim=24, hidden_dim=16, num_heads=2, num_layers=1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(1, 3, 24), torch.zeros(1, dtype=torch.long), torch.zeros(1, 2))
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def _gemm(A, B, M, N, K, a_k, b_k, bias=None, C0=None, splits=0):
+    from dquartic import _native as N_
+
+    lib = N_.lib()
+    C = torch.zeros(M, N, device="cuda") if C0 is None else C0.clone()
+    n_s = max(int(lib.dq_gemm_scratch_floats(M, N, K)), 64 * M * N if splits else 4)
+    scratch = torch.empty(n_s, device="cuda")
+    N_.check(lib.dq_gemm(N_.ptr(A), N_.ptr(B), N_.ptr(C), N_.ptr(bias), M, N, K, A.shape[1], B.shape[1], N, int(a_k), int(b_k),
+                         0 if C0 is None else 1, splits, N_.ptr(scratch), scratch.numel(), N_.stream_ptr()), "dq_gemm")
+    return C
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(5, 16, 24), (34, 1024, 4000), (130, 260, 68), (257, 129, 36), (64, 128, 32), (1, 4, 4), (300, 40, 7)])
+@pytest.mark.parametrize("layout", ["kk", "kn", "mn"])
+def test_gemm_against_float64(M, N, K, layout):
+    torch.manual_seed(M * 7 + N)
+    pad = lambda v: (v + 3) // 4 * 4
+    a_k, b_k = layout[0] == "k", layout[1] == "k"
+    A = torch.randn((M, pad(K)) if a_k else (K, pad(M)), device="cuda")
+    B = torch.randn((N, pad(K)) if b_k else (K, pad(N)), device="cuda")
+    Am = (A[:, :K] if a_k else A[:, :M].t()).double()
+    Bm = (B[:, :K].t() if b_k else B[:, :N]).double()
+    bias = torch.randn(N, device="cuda")
+    ref = Am @ Bm + bias.double()
+    got = _gemm(A, B, M, N, K, a_k, b_k, bias=bias)
+    tol = 2e-6 * float(ref.abs().max()) * max(1.0, K ** 0.5 / 8)
+    assert float((got.double() - ref).abs().max()) < tol
+    # += into an existing C, and a forced split-K: same numbers up to fp32 summation order
+    C0 = torch.randn(M, N, device="cuda")
+    got2 = _gemm(A, B, M, N, K, a_k, b_k, C0=C0, splits=3 if K >= 64 else 0)
+    assert float((got2.double() - (Am @ Bm + C0.double())).abs().max()) < tol
+    assert torch.equal(_gemm(A, B, M, N, K, a_k, b_k, bias=bias), got)  # bitwise repeatable
+
+
+def _module(cfg, params):
+    from dquartic.model.building_blocks import CustomTransformer
+
+    net = CustomTransformer(input_dim=cfg[0], hidden_dim=cfg[1], num_heads=cfg[2], num_layers=cfg[3])
+    net.load_state_dict(params)
+    return net.cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", TAGS)
+def test_hip_forward_backward_match_reference_fixtures(golden, tag):
+    g = golden("tfm_tiny.npz")
+    cfg, params, grads, x, t, c, probe, out = _case(g, tag)
+    net = _module(cfg, params)
+    with torch.no_grad():
+        y = net(x.cuda(), t.cuda(), c.cuda())
+    assert _rel(y.cpu(), out) < 1e-5
+    xg, cg = x.cuda().requires_grad_(), c.cuda().requires_grad_()
+    y = net(xg, t.cuda(), cg)
+    assert _rel(y.detach().cpu(), out) < 1e-5
+    (y * probe.cuda()).sum().backward()
+    for k, p in net.named_parameters():
+        assert _rel(p.grad.cpu(), grads[k]) < 2e-5, k
+    assert _rel(xg.grad.cpu(), grads["x_t"]) < 2e-5 and _rel(cg.grad.cpu(), grads["x_cond"]) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,H,heads,layers,B,S1,S2", [(200, 64, 4, 2, 3, 34, 20), (1000, 128, 1, 1, 2, 70, 9), (64, 256, 8, 3, 5, 17, 34)])
+def test_hip_matches_oracle_at_larger_shapes(D, H, heads, layers, B, S1, S2):
+    from dquartic.model.building_blocks import CustomTransformer
+
+    params = OT.init_params(D, H, layers, seed=D + H)
+    net = CustomTransformer(input_dim=D, hidden_dim=H, num_heads=heads, num_layers=layers)
+    net.load_state_dict(params)
+    net = net.cuda()
+    g = torch.Generator().manual_seed(5)
+    x, c = torch.randn(B, S1, D, generator=g), torch.randn(B, S2, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    probe = torch.randn(B, S1, D, generator=g)
+    p = {k: v.clone().requires_grad_() for k, v in params.items()}
+    xr, cr = x.clone().requires_grad_(), c.clone().requires_grad_()
+    ref = OT.forward(p, xr, t, cr, heads)
+    (ref * probe).sum().backward()
+    xg, cg = x.cuda().requires_grad_(), c.cuda().requires_grad_()
+    y = net(xg, t.cuda(), cg)
+    assert _rel(y.detach().cpu(), ref.detach()) < 2e-5
+    (y * probe.cuda()).sum().backward()
+    worst = max(_rel(q.grad.cpu(), p[k].grad) for k, q in net.named_parameters())
+    assert worst < 1e-4, worst
+    assert _rel(xg.grad.cpu(), xr.grad) < 1e-4 and _rel(cg.grad.cpu(), cr.grad) < 1e-4
+    # inference-mode call (shared layer buffers) gives the training-mode numbers
+    with torch.no_grad():
+        assert torch.equal(net(x.cuda(), t.cuda(), c.cuda()), y.detach())
+
+
+@pytest.mark.gpu
+def test_ddim_adapter_trains_the_transformer():
+    """DDIMDiffusionModel drives the transformer through the 4-argument adapter (generic autograd path)."""
+    from dquartic.model.building_blocks import CustomTransformer, DDIMTransformerAdapter
+    from dquartic.model.model import DDIMDiffusionModel
+
+    torch.manual_seed(0)
+    net = DDIMTransformerAdapter(CustomTransformer(input_dim=64, hidden_dim=32, num_heads=2, num_layers=1)).cuda()
+    dm = DDIMDiffusionModel(model_class=net, num_timesteps=1000, beta_schedule_type="cosine", pred_type="eps", auto_normalize=True,
+                            ms1_loss_weight=0.0, device="cuda")
+    x0, c2, c1 = torch.rand(2, 10, 64, device="cuda"), torch.rand(2, 10, 64, device="cuda"), torch.rand(2, 10, device="cuda")
+    loss = dm.train_step(x0, c2, c1)
+    loss.backward()
+    assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    xs, noise = dm.sample(torch.randn(2, 10, 64, device="cuda"), c2, c1, num_steps=3)
+    assert xs.shape == (2, 10, 64) and torch.isfinite(xs).all()
