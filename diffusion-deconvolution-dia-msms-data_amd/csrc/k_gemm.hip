@@ -163,16 +163,22 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm(GemmK g) {
       const int n = n0 + wn0 + 32 * jn + col;
       if (n >= g.N) continue;
       const float bias = (g.splits == 1 && g.bias) ? g.bias[n] : 0.f;
+      const bool rmw = g.splits == 1 && g.accumulate;
+      // all 16 reads of a += tile are issued before the first store (a load behind a store to a pointer the compiler cannot
+      // tell apart would wait for it: 64 serial round trips per lane)
+      float old[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + 32 * i + rmap(r, half);
+        old[r] = (rmw && m < g.M) ? C[(int64_t)m * ldc + n] : 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm0 + 32 * i + rmap(r, half);
         if (m >= g.M) continue;
         float* dst = C + (int64_t)m * ldc + n;
         if (g.splits > 1) *dst = acc[i][jn][r];
-        else {
-          const float v = g.alpha * acc[i][jn][r] + bias;
-          *dst = g.accumulate ? *dst + v : v;
-        }
+        else *dst = old[r] + (g.alpha * acc[i][jn][r] + bias);
       }
     }
 }
@@ -182,7 +188,15 @@ __global__ void __launch_bounds__(256) k_gemm_split_reduce(GemmK g) {
   const int64_t per = (int64_t)g.M * g.N, total = per * g.batch;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
-    for (int sp = 0; sp < g.splits; ++sp) s += g.partial[(int64_t)sp * total + e];
+    int sp = 0;
+    for (; sp + 8 <= g.splits; sp += 8) {  // eight loads in flight, summed in split order
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = g.partial[(int64_t)(sp + k) * total + e];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; sp < g.splits; ++sp) s += g.partial[(int64_t)sp * total + e];
     const int z = (int)(e / per);
     const int64_t mn = e - (int64_t)z * per;
     const int m = (int)(mn / g.N), n = (int)(mn - (int64_t)m * g.N);

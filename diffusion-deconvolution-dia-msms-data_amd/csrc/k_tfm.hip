@@ -76,7 +76,15 @@ __global__ void __launch_bounds__(256) k_partial_reduce(const float* __restrict_
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += part[(int64_t)b * stride + i];
+  int b = 0;
+  for (; b + 8 <= nb; b += 8) {  // eight loads in flight, summed in index order
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = part[(int64_t)(b + k) * stride + i];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += v[k];
+  }
+  for (; b < nb; ++b) s += part[(int64_t)b * stride + i];
   out[i] += s;
 }
 // row part: dx_cond[row] = sum_h dv[row][h] * w[h]   (one wave per row)
@@ -140,6 +148,72 @@ __global__ void __launch_bounds__(256) k_layernorm_fwd(const float* __restrict__
   for (int h = lane; h < H; h += 64) out[(int64_t)row * H + h] = (yr[h] - mean) * rstd * g[h] + b[h];
   if (lane == 0 && stats) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
+// H <= 64 * VM: the row lives in registers (every load is issued up front; with a few dozen rows per launch the kernel is one
+// dependent chain, and passes through memory would triple it)
+template <int VM>
+__global__ void __launch_bounds__(256) k_layernorm_fwd_reg(const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ g,
+                                                           const float* __restrict__ b, float* __restrict__ y, float* __restrict__ out,
+                                                           float* __restrict__ stats, int rows, int H) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int64_t base = (int64_t)row * H;
+  float v[VM], gg[VM], bb[VM];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VM; ++i) {
+    const int h = lane + 64 * i;
+    const bool ok = h < H;
+    v[i] = ok ? (r ? x[base + h] + r[base + h] : x[base + h]) : 0.f;
+    gg[i] = ok ? g[h] : 0.f;
+    bb[i] = ok ? b[h] : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VM; ++i) {
+    const float d = (lane + 64 * i < H) ? v[i] - mean : 0.f;
+    q = fmaf(d, d, q);
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < VM; ++i) {
+    const int h = lane + 64 * i;
+    if (h < H) {
+      y[base + h] = v[i];
+      out[base + h] = (v[i] - mean) * rstd * gg[i] + bb[i];
+    }
+  }
+  if (lane == 0 && stats) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+template <int VM>
+__global__ void __launch_bounds__(256) k_layernorm_bwd_rows_reg(const float* __restrict__ y, const float* __restrict__ stats,
+                                                                const float* __restrict__ g, const float* __restrict__ dout, float* __restrict__ dy,
+                                                                int rows, int H) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+  const int64_t base = (int64_t)row * H;
+  float dxh[VM], xh[VM];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < VM; ++i) {
+    const int h = lane + 64 * i;
+    const bool ok = h < H;
+    dxh[i] = ok ? dout[base + h] * g[h] : 0.f;
+    xh[i] = ok ? (y[base + h] - mean) * rstd : 0.f;
+    s1 += dxh[i];
+    s2 = fmaf(dxh[i], xh[i], s2);
+  }
+  s1 = wave_sum(s1) / (float)H;
+  s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+  for (int i = 0; i < VM; ++i) {
+    const int h = lane + 64 * i;
+    if (h < H) dy[base + h] = rstd * (dxh[i] - s1 - xh[i] * s2);
+  }
+}
+
 // dy = rstd * (dxh - mean(dxh) - xh * mean(dxh * xh)), dxh = dout * g, xh = (y - mean) * rstd
 __global__ void __launch_bounds__(256) k_layernorm_bwd_rows(const float* __restrict__ y, const float* __restrict__ stats, const float* __restrict__ g,
                                                             const float* __restrict__ dout, float* __restrict__ dy, int rows, int H) {
@@ -271,14 +345,18 @@ int launch_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, hipSt
 int launch_layernorm_fwd(const float* x, const float* r, const float* g, const float* b, float* y, float* out, float* stats, int rows, int H,
                          hipStream_t s) {
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(k_layernorm_fwd, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, r, g, b, y, out, stats, rows, H);
+  if (H <= 256) hipLaunchKernelGGL(k_layernorm_fwd_reg<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, r, g, b, y, out, stats, rows, H);
+  else if (H <= 1024) hipLaunchKernelGGL(k_layernorm_fwd_reg<16>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, r, g, b, y, out, stats, rows, H);
+  else hipLaunchKernelGGL(k_layernorm_fwd, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, r, g, b, y, out, stats, rows, H);
   DQ_LAUNCH_CHECK();
   return 0;
 }
 int launch_layernorm_bwd(const float* y, const float* stats, const float* g, const float* dout, float* dy, float* dg, float* db, float* scratch,
                          int rows, int H, hipStream_t s) {
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(k_layernorm_bwd_rows, dim3(cdiv(rows, 4)), dim3(256), 0, s, y, stats, g, dout, dy, rows, H);
+  if (H <= 256) hipLaunchKernelGGL(k_layernorm_bwd_rows_reg<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, y, stats, g, dout, dy, rows, H);
+  else if (H <= 1024) hipLaunchKernelGGL(k_layernorm_bwd_rows_reg<16>, dim3(cdiv(rows, 4)), dim3(256), 0, s, y, stats, g, dout, dy, rows, H);
+  else hipLaunchKernelGGL(k_layernorm_bwd_rows, dim3(cdiv(rows, 4)), dim3(256), 0, s, y, stats, g, dout, dy, rows, H);
   const int nb = std::min(rows, LN_BWD_BLOCKS);
   hipLaunchKernelGGL(k_layernorm_bwd_cols, dim3(cdiv(H, 256), nb), dim3(256), 0, s, y, stats, dout, scratch, rows, H);
   hipLaunchKernelGGL(k_partial_reduce, dim3(cdiv(H, 256)), dim3(256), 0, s, scratch, nb, (int64_t)2 * H, H, dg);

@@ -234,6 +234,21 @@ class DDIMTransformerAdapter(nn.Module):
         super().__init__()
         self.transformer = transformer
 
+    # the flat-buffer surface FlatAdamW and the data-parallel all-reduce use (model_interface.py)
+    @property
+    def _layout(self):
+        return self.transformer._layout
+
+    @property
+    def flat_params(self):
+        return self.transformer.flat_params
+
+    def flat_grads(self, zero: bool = False):
+        return self.transformer.flat_grads(zero=zero)
+
+    def trainable_named(self):
+        return self.transformer.trainable_named()
+
     def forward(self, x_t, t, init_cond=None, attn_cond=None):
         if attn_cond is None:
             raise ValueError("DDIMTransformerAdapter: attn_cond (MS1, (B, RT)) is required")

@@ -227,9 +227,13 @@ class DDIMDiffusionModel(ModelInterface):
     def train_step_fused(self, x_0, ms2_cond, ms1_cond, t=None, noise=None, zero_grads=True):
         """One native call: normalise, q_sample, U-Net forward, MSE, backward into ``model.flat_grads()`` (+=).
         Returns the loss as a 0-dim device tensor (no host sync)."""
+        from .building_blocks import DDIMTransformerAdapter
+
+        if isinstance(self.model, DDIMTransformerAdapter):
+            return self._train_step_fused_tfm(x_0, ms1_cond, t, noise, zero_grads)
         net: UNet1d = self.model
         if not self.native:
-            raise RuntimeError("train_step_fused needs this package's UNet1d")
+            raise RuntimeError("train_step_fused needs this package's UNet1d or a DDIMTransformerAdapter")
         f32 = lambda v: v.detach().to(torch.float32).contiguous()
         x_0, c2, c1 = f32(x_0), f32(ms2_cond), f32(ms1_cond)
         if c1.dim() == 3:
@@ -250,4 +254,46 @@ class DDIMDiffusionModel(ModelInterface):
         N.check(N.lib().dq_train_step(net._plan, N.ptr(flat), N.ptr(net.rope_freqs()), N.ptr(ab), N.ptr(x_0), N.ptr(c2), N.ptr(c1),
                                       N.ptr(t), N.ptr(noise), 1 if self.auto_normalize else 0, N.PRED_TYPES[self.pred_type], N.ptr(lw),
                                       N.ptr(grads), N.ptr(loss), N.ptr(ws), ws.numel(), B, RT, N.stream_ptr()), "dq_train_step")
+        return loss
+
+    def _train_step_fused_tfm(self, x_0, ms1_cond, t=None, noise=None, zero_grads=True):
+        """train_step for the CustomTransformer behind its adapter: the same sequence as the U-Net's dq_train_step (normalise +
+        q_sample, network forward, MSE and its gradient, network backward into the flat gradient buffer), each stage one native
+        call -- dq_q_sample, dq_tfm_fwd, dq_mse_loss(_weighted)_fwd_bwd, dq_tfm_bwd -- issued back to back on the current stream."""
+        tfm = self.model.transformer
+        f32 = lambda v: v.detach().to(torch.float32).contiguous()
+        x_0, c1 = f32(x_0), f32(ms1_cond)
+        if c1.dim() == 3:
+            c1 = c1[..., 0].contiguous()
+        B = x_0.shape[0]
+        per = x_0[0].numel()
+        dev = x_0.device
+        if t is None:
+            t = torch.randint(0, self.num_timesteps, (B,), device=dev).long()
+        if noise is None:
+            noise = torch.randn_like(x_0)
+        t = t.to(device=dev, dtype=torch.int64).contiguous()
+        noise = f32(noise)
+        norm = 1 if self.auto_normalize else 0
+        lib = N.lib()
+        x_t = torch.empty_like(x_0)
+        N.check(lib.dq_q_sample(N.ptr(self.alpha_bars.to(dev)), N.ptr(x_0), N.ptr(t), N.ptr(noise), N.ptr(x_t), B, per, norm, N.stream_ptr()),
+                "dq_q_sample")
+        c1n = self.normalize(c1).contiguous()  # (B, RT) values: the only torch op of the step
+        tfm._ensure_flat()
+        out = tfm._run_fwd(x_t, t, c1n, training=True)
+        grads = tfm.flat_grads(zero=zero_grads)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        dout = torch.empty_like(out)
+        if getattr(self, "_mse_scratch", None) is None or self._mse_scratch.device != dev:
+            self._mse_scratch = torch.empty(4096, dtype=torch.float32, device=dev)
+        if self.pred_type == "eps":
+            N.check(lib.dq_mse_loss_fwd_bwd(N.ptr(out), N.ptr(noise), N.ptr(loss), N.ptr(dout), N.ptr(self._mse_scratch), out.numel(),
+                                            N.stream_ptr()), "dq_mse_loss_fwd_bwd")
+        else:
+            lw = self.loss_weight.to(device=dev, dtype=torch.float32).contiguous()
+            N.check(lib.dq_mse_loss_weighted_fwd_bwd(N.ptr(out), N.ptr(x_0), 2.0 if norm else 1.0, -1.0 if norm else 0.0, N.ptr(lw), N.ptr(t),
+                                                     N.ptr(loss), N.ptr(dout), N.ptr(self._mse_scratch), B, per, N.stream_ptr()),
+                    "dq_mse_loss_weighted_fwd_bwd")
+        tfm._run_bwd(x_t, c1n, dout, grads, False, False)
         return loss

@@ -260,9 +260,10 @@ class ModelInterface(object):
         self._set_lr(lr)
 
     def _native_net(self) -> bool:
+        from .building_blocks import DDIMTransformerAdapter
         from .unet1d import UNet1d
 
-        return isinstance(self.model, UNet1d)
+        return isinstance(self.model, (UNet1d, DDIMTransformerAdapter))
 
     def _set_optimizer(self, lr):
         """Reference :1011: AdamW(model.parameters(), lr) with torch defaults."""
