@@ -202,6 +202,98 @@ def cpu_baseline(net):
             "sample_windows_per_s": round(1.0 / t_s, 5)}
 
 
+# ---------------------------------------------------------------------------------------------- CustomTransformer leg
+TFM_CFG = dict(input_dim=40000, hidden_dim=1024, num_heads=8, num_layers=8)  # reference dquartic_train_config.json "CustomTransformer"
+TFM_RT = 34  # reference `generate-data-slices --window-size` default: the RT rows of one window
+
+
+def transformer_leg(device, with_cpu):
+    """The reference's other noise predictor at its own configuration (191,126,592 parameters, windows of 34 RT x 40000 m/z): train
+    step (q_sample, forward, MSE, backward, clip 10, AdamW -- all native) at batch 1 (the batch size of the reference's wandb
+    runs: ~18.4 steps/s on unstated hardware) and batch 32, the matrix-core roofline of the dominant kernel (the fp32
+    GEMM, measured alone on the output projection's shape) and the oracle on the host cores."""
+    from dquartic import _native as N
+    from dquartic.model.building_blocks import CustomTransformer, DDIMTransformerAdapter
+    from dquartic.model.model import DDIMDiffusionModel
+
+    torch.manual_seed(0)
+    D, H = TFM_CFG["input_dim"], TFM_CFG["hidden_dim"]
+    net = DDIMTransformerAdapter(CustomTransformer(**TFM_CFG)).to(device)
+    dm = DDIMDiffusionModel(model_class=net, num_timesteps=1000, beta_schedule_type="cosine", pred_type="eps", auto_normalize=True,
+                            ms1_loss_weight=0.0, device=device)
+    dm._set_optimizer(1e-5)
+    out = {"config": {"workload": "CustomTransformer(40000, 1024, 8 heads, 8 layers), windows 34 RT x 40000 m/z, MS1 (34,) as x_cond, fp32",
+                      "params": int(net.transformer.flat_params.numel())}}
+    for B in (1, 32):
+        x0, c2, c1 = torch.rand(B, TFM_RT, D, device=device), torch.rand(B, TFM_RT, D, device=device), torch.rand(B, TFM_RT, device=device)
+        for _ in range(2):
+            dm._train_one_batch(x0, ms2_cond=c2, ms1_cond=c1, sync=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        steps = 10
+        for _ in range(steps):
+            loss = dm._train_one_batch(x0, ms2_cond=c2, ms1_cond=c1, sync=False)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out[f"train_b{B}"] = {"value": round(B / dt, 2), "unit": "MS2 windows/s", "ms_per_step": round(dt * 1e3, 3), "loss": round(float(loss), 5)}
+        del x0, c2, c1
+    # roofline of the GEMM on the output projection's forward shape at batch 32
+    lib = N.lib()
+    M, Nn, K = 32 * TFM_RT, D, H
+    A, Bm, C = torch.randn(M, K, device=device), torch.randn(Nn, K, device=device), torch.empty(M, Nn, device=device)
+    scr = torch.empty(max(int(lib.dq_gemm_scratch_floats(M, Nn, K)), 4), device=device)
+    sec = time_kernel(lambda: N.check(lib.dq_gemm(N.ptr(A), N.ptr(Bm), N.ptr(C), None, M, Nn, K, K, K, Nn, 1, 1, 0, 0, N.ptr(scr), scr.numel(),
+                                                  N.stream_ptr()), "dq_gemm"), iters=10)
+    fl = 2.0 * M * Nn * K
+    out["roofline"] = {"bound": "mfma", "kernel": "k_gemm<A k-major, B k-major, 128x128x32> on (1088 x 1024) x (1024 x 40000)",
+                       "achieved": round(fl / sec / 1e12, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": round(fl / sec / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "us_per_launch": round(sec * 1e6, 1)}
+    del net, dm, A, Bm, C
+    torch.cuda.empty_cache()
+    if with_cpu:
+        out["cpu_baseline"] = transformer_cpu_baseline()
+    return out
+
+
+def transformer_cpu_baseline():
+    """The transformer oracle (kind 'port') on the host cores: B = 1 train steps (forward, MSE, backward, clip, AdamW) at the full
+    configuration; bounded to a few steps (each is ~37 GFLOP of dense work plus a 191 M-parameter optimiser update)."""
+    from oracle import dq_oracle_tfm as OT
+
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("DQ_CPU_BASELINE_THREADS", "16"))))
+    torch.set_num_threads(cores)
+    D, H = TFM_CFG["input_dim"], TFM_CFG["hidden_dim"]
+    params = OT.init_params(D, H, TFM_CFG["num_layers"], seed=0)
+    plist = [p.requires_grad_(True) for p in params.values()]
+    opt = torch.optim.AdamW(plist, lr=1e-5)
+    x0, c1 = torch.rand(1, TFM_RT, D), torch.rand(1, TFM_RT)
+    n, tt, t_begin = 0, 0.0, time.perf_counter()
+    for i in range(12):
+        if i >= 3 and time.perf_counter() - t_begin > 15.0:
+            break
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        t = torch.randint(0, 1000, (1,))
+        nz = torch.randn_like(x0)
+        ab = torch.rand(())  # any alpha_bar: the arithmetic does not depend on its value
+        x_t = torch.sqrt(ab) * (2 * x0 - 1) + torch.sqrt(1 - ab) * nz
+        loss = torch.nn.functional.mse_loss(OT.forward(params, x_t, t, 2 * c1 - 1, TFM_CFG["num_heads"]), nz)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(plist, 10.0)
+        opt.step()
+        dt = time.perf_counter() - t0
+        log(f"transformer cpu baseline step {i}: {dt:.2f} s")
+        if i >= 1:
+            n += 1
+            tt += dt
+    return {"value": round(n / tt, 4), "unit": "MS2 windows/s (train step, B=1)", "cores": cores, "kind": "port",
+            "sample": f"{n} timed B=1 train steps (after 1 warm-up) of the same network / window shape"}
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -213,6 +305,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-sample", action="store_true", help="skip the sampling leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-transformer", action="store_true", help="skip the CustomTransformer leg (rank 0, single-GPU runs only)")
     ap.add_argument("--sample-batch", type=int, default=SAMPLE_BATCH)
     args = ap.parse_args()
 
@@ -287,6 +380,12 @@ def main():
     form = batch_formation(device) if rank == 0 else None
     log("cpu baseline leg")
     cpu = cpu_baseline(net) if (rank == 0 and world == 1 and not args.no_cpu) else None
+    tfm = None
+    if rank == 0 and world == 1 and not args.no_transformer:
+        log("transformer leg")
+        del net, dm
+        torch.cuda.empty_cache()
+        tfm = transformer_leg(device, with_cpu=not args.no_cpu)
 
     if rank == 0:
         out = {
@@ -298,7 +397,7 @@ def main():
                                    "windows 400 RT x 64 m/z, batch 32 per GPU, fp32", "global_batch": world * TRAIN_BATCH,
                        "window": [RT, MZ], "parallelism": f"dp{world}"},
             "last_loss": round(last_loss, 6),
-            "sample": sample, "roofline": roof, "cpu_baseline": cpu, "batch_formation": form,
+            "sample": sample, "roofline": roof, "cpu_baseline": cpu, "batch_formation": form, "transformer": tfm,
         }
         print(json.dumps(out))
     if dist_on:

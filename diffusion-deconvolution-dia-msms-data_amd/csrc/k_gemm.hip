@@ -85,7 +85,15 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm(GemmK g) {
   __shared__ __attribute__((aligned(16))) float bs[2][BN * LDK];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, half = lane >> 5;
   const int wm0 = (wv / WN) * TM * 32, wn0 = (wv % WN) * TN * 32;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware tile order: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2), so id -> (id % 8) * (T / 8)
+  // + id / 8 gives every XCD a contiguous run of tiles (m fastest: neighbours share the B panel, then the A panel) instead of
+  // every 8th one
+  int tile_id = blockIdx.x + gridDim.x * blockIdx.y;
+  {
+    const int T = gridDim.x * gridDim.y, per = T >> 3;
+    if (tile_id < per * 8) tile_id = (tile_id & 7) * per + (tile_id >> 3);
+  }
+  const int m0 = (tile_id % (int)gridDim.x) * BM, n0 = (tile_id / (int)gridDim.x) * BN;
   const int z = blockIdx.z % g.batch, sp = blockIdx.z / g.batch;
   const int zo = z / g.inner, zi = z % g.inner;
   const float* A = g.A + zo * g.sAo + zi * g.sAi;
@@ -207,20 +215,34 @@ __global__ void __launch_bounds__(256) k_gemm_split_reduce(GemmK g) {
 }
 
 struct Shape { int bm, bn, splits, k_per_split; };
+// Tile height and split-K factor by a small cost model of the 256-CU machine: blocks are dealt to the CUs in rounds, a block
+// costs (k-steps x MFMA cycles of its tile + a fixed prologue / epilogue), a split adds the second kernel and its traffic.
+// What it buys over "largest tile, no split": 272 or 288 tiles of 128 x 128 (the transformer's 1088- and 2176-row layers) are
+// two rounds with the second one almost empty; 64-row tiles or a split fill it.  Splits are only considered while
+// tiles x splits <= 1024, which bounds the scratch at 1024 tiles of 128 x 128 floats.
 Shape choose(int M, int N, int K, int batch, int forced_splits) {
-  Shape sh;
-  sh.bm = M <= 32 ? 32 : (M <= 64 ? 64 : 128);
-  sh.bn = 128;
-  const int64_t tiles = (int64_t)cdiv(M, sh.bm) * cdiv(N, sh.bn) * batch;
-  int splits = forced_splits;
-  if (splits <= 0) {
-    splits = 1;
-    if (tiles < 256 && K >= 1024) splits = (int)std::min<int64_t>(std::min<int64_t>(cdiv(768, tiles), K / (4 * BK)), 64);
+  constexpr int CUS = 256;
+  const int kt_all = cdiv(K, BK);
+  Shape best{};
+  double best_cost = 1e30;
+  const int bms[3] = {128, 64, 32};
+  const double tile_cycles[3] = {4096.0, 2400.0, 1500.0};  // per k-step of 32: 64 / 32 / 16 MFMAs per wave, smaller tiles less efficient
+  for (int c = 0; c < 3; ++c) {
+    const int bm = bms[c];
+    if (c < 2 && M <= bms[c + 1]) continue;  // a smaller tile covers all rows: the larger one only adds padding
+    const int64_t tiles = (int64_t)cdiv(M, bm) * cdiv(N, 128) * batch;
+    const int smax = forced_splits > 0 ? forced_splits : (int)std::min<int64_t>(std::min<int64_t>(64, kt_all), std::max<int64_t>(1, 1024 / tiles));
+    for (int sp = forced_splits > 0 ? forced_splits : 1; sp <= smax; ++sp) {
+      const int kps = cdiv(cdiv(K, sp), BK) * BK;
+      const int real = cdiv(K, kps);
+      if (real != sp && forced_splits <= 0) continue;  // same partition as a smaller factor
+      const double rounds = (double)cdiv(tiles * real, CUS);
+      double cost = rounds * ((kps / BK) * tile_cycles[c] + 2500.0);
+      if (real > 1) cost += 12000.0 + (double)real * M * N * batch * 4.0 / 1250.0;
+      if (cost < best_cost) { best_cost = cost; best.bm = bm; best.bn = 128; best.splits = real; best.k_per_split = kps; }
+    }
   }
-  splits = std::max(1, std::min(splits, cdiv(K, BK)));
-  sh.k_per_split = cdiv(cdiv(K, splits), BK) * BK;
-  sh.splits = cdiv(K, sh.k_per_split);
-  return sh;
+  return best;
 }
 
 template <bool A_K, bool B_K>
