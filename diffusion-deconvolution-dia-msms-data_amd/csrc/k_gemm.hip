@@ -14,6 +14,7 @@
 #include "dq_mfma.h"
 #include "dq_tfm.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace dq {
 
@@ -38,6 +39,16 @@ struct TileIO {
   static_assert(R * 8 % NT == 0, "tile does not divide over the block");
   float4 v[U];
   __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int r0, int rmax, int k0, int kend, int tid) {
+    if (r0 + R <= rmax && k0 + BK <= kend) {  // interior tile (block-uniform): straight vector loads, no per-unit branches
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        const int u = tid + NT * i;
+        const float* p = KMAJOR ? base + (int64_t)(r0 + (u >> 3)) * ld + k0 + 4 * (u & 7)
+                                : base + (int64_t)(k0 + u / (R / 4)) * ld + r0 + 4 * (u % (R / 4));
+        v[i] = *reinterpret_cast<const float4*>(p);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < U; ++i) {
       const int u = tid + NT * i;
@@ -225,11 +236,13 @@ Shape choose(int M, int N, int K, int batch, int forced_splits) {
   const int kt_all = cdiv(K, BK);
   Shape best{};
   double best_cost = 1e30;
-  const int bms[3] = {128, 64, 32};
-  const double tile_cycles[3] = {4096.0, 2400.0, 1500.0};  // per k-step of 32: 64 / 32 / 16 MFMAs per wave, smaller tiles less efficient
-  for (int c = 0; c < 3; ++c) {
+  static const int force_bm = [] { const char* e = std::getenv("DQ_GEMM_BM"); return e ? std::atoi(e) : 0; }();
+  const int bms[4] = {256, 128, 64, 32};
+  const double tile_cycles[4] = {7000.0, 4096.0, 2400.0, 1500.0};  // per k-step of 32: 128 / 64 / 32 / 16 MFMAs per wave
+  for (int c = 0; c < 4; ++c) {
+    if (force_bm ? bms[c] != force_bm : c == 0) continue;
     const int bm = bms[c];
-    if (c < 2 && M <= bms[c + 1]) continue;  // a smaller tile covers all rows: the larger one only adds padding
+    if (!force_bm && c < 3 && M <= bms[c + 1]) continue;  // a smaller tile covers all rows: the larger one only adds padding
     const int64_t tiles = (int64_t)cdiv(M, bm) * cdiv(N, 128) * batch;
     const int smax = forced_splits > 0 ? forced_splits : (int)std::min<int64_t>(std::min<int64_t>(64, kt_all), std::max<int64_t>(1, 1024 / tiles));
     for (int sp = forced_splits > 0 ? forced_splits : 1; sp <= smax; ++sp) {
@@ -250,6 +263,7 @@ int launch_layout(const GemmK& k, const Shape& sh, hipStream_t s) {
   const dim3 grid(cdiv(k.M, sh.bm), cdiv(k.N, sh.bn), k.batch * k.splits);
   if (sh.bm == 32) hipLaunchKernelGGL((k_gemm<A_K, B_K, 1, 1, 1, 4>), grid, dim3(256), 0, s, k);
   else if (sh.bm == 64) hipLaunchKernelGGL((k_gemm<A_K, B_K, 1, 2, 2, 2>), grid, dim3(256), 0, s, k);
+  else if (sh.bm == 256) hipLaunchKernelGGL((k_gemm<A_K, B_K, 4, 2, 2, 2>), grid, dim3(256), 0, s, k);
   else hipLaunchKernelGGL((k_gemm<A_K, B_K, 2, 2, 2, 2>), grid, dim3(256), 0, s, k);
   DQ_LAUNCH_CHECK();
   return 0;
