@@ -626,6 +626,10 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
       }
     // dW2 of this head: sum the 16 position blocks (lanes with equal lane & 3), publish [c'][c], then
     // dWv[e][c] = sum_c' Wo[c'][e] dW2[c'][c] and dWo[c'][e] = sum_c dW2[c'][c] Wv[e][c] for this lane's e = col
+    // Inside a row of 16 lanes: two DPP rotations (by 4 and by 8 lanes) leave every lane with the sum of its (lane & 3) class;
+    // across the four rows: through the wave-private tile (4 x 16 C^2 / 4 floats <= 1024).  The four-step ds_bpermute butterfly
+    // this replaces was 4 C^2 dependent LDS round trips per head: 8 us of a 25 us head at 16 channels (tools/probe/la_bwd_time.hip).
+    constexpr int NV4 = CG * CG * 16;  // floats one row contributes: [value vi = (g1 * CG + g2) * 4 + i][j = lane & 3]
     wfence();
 #pragma unroll
     for (int g1 = 0; g1 < CG; ++g1)
@@ -634,9 +638,20 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float v = gw2[g1][g2][i];
-          v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-          if (lane < 4) w2g[(4 * g1 + i) * C + 4 * g2 + lane] = v;
+          v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, false));  // row_ror:4
+          v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));  // row_ror:8
+          if ((lane & 15) < 4) tile[(lane >> 4) * NV4 + ((g1 * CG + g2) * 4 + i) * 4 + (lane & 3)] = v;
         }
+    wfence();
+#pragma unroll
+    for (int t = 0; t < (NV4 + 63) / 64; ++t) {
+      const int e = lane + 64 * t;
+      if (e < NV4) {
+        const float v = (tile[e] + tile[NV4 + e]) + (tile[2 * NV4 + e] + tile[3 * NV4 + e]);
+        const int vi = e >> 2, j = e & 3, i = vi & 3, g2 = (vi >> 2) % CG, g1 = (vi >> 2) / CG;
+        w2g[(4 * g1 + i) * C + 4 * g2 + j] = v;
+      }
+    }
     wfence();
     {
       float wvr[C], wor[C];  // Wv[hd*32 + col][c], Wo[c'][hd*32 + col]
