@@ -53,7 +53,15 @@ struct LinAttnBwdK {
   const float* w_qkv; const float* w_out; const float* g_pre; const float* g_out;
   float* part;  // per-wave partial slots: [wave][LA_SLOT(C)] = dWqkv (384C) | dWo (128C) | d g_out | d b_out | d g_pre
   int rows; int units_per_wave;
+#ifdef DQ_LA_PROBE
+  unsigned long long* probe;  // tools/probe/la_bwd_time.hip: [wave][16] shader-clock stamps
+#endif
 };
+#ifdef DQ_LA_PROBE
+#define DQ_STAMP(i) do { if (a.probe && (threadIdx.x & 63) == 0) a.probe[(int64_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (i)] = clock64(); } while (0)
+#else
+#define DQ_STAMP(i) do {} while (0)
+#endif
 constexpr int la_slot(int C) { return 515 * C; }
 
 // v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 outer products.  Block = lane >> 2; a lane supplies A_blk[i = lane & 3] and
@@ -88,6 +96,7 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
   __shared__ float tiles[4][32 * 33];
   // per wave: xh | dYpre | P (normalised) | dP as [c][n] ; M | dM as [c][d] ; dW2 of the head being flushed [c'][c]
   __shared__ __attribute__((aligned(16))) float stage[4][4 * C * NP + 2 * C * 32 + C * C];
+  DQ_STAMP(0);
   for (int i = threadIdx.x; i < 2 * 4 * 2 * C * 16; i += blockDim.x) {
     const int r = i & 15, c = (i >> 4) % C, hh = (i / (16 * C)) & 1, hd = (i / (32 * C)) & 3, m = i / (128 * C);
     wp_lds[i] = a.w_qkv[(m * 128 + hd * 32 + rmap(r, hh)) * C + c];
@@ -100,6 +109,7 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
     w2_lds[i] = s;
   }
   __syncthreads();
+  DQ_STAMP(1);
 
   const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wv = threadIdx.x >> 6;
   float* tile = tiles[wv];
@@ -609,6 +619,7 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
       }
     }
 
+    DQ_STAMP(2 + 2 * hd);
     // ---- flush this head's gradients to this wave's partial slot (plain stores; the ordered reduce kernel sums the slots)
     float* slot = a.part + (int64_t)wave_id * la_slot(C);
 #pragma unroll
@@ -624,6 +635,7 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
           slot[(128 + hd * 32 + col) * C + c] = vk;
         }
       }
+    if (hd == 1) DQ_STAMP(10);
     // dW2 of this head: sum the 16 position blocks (lanes with equal lane & 3), publish [c'][c], then
     // dWv[e][c] = sum_c' Wo[c'][e] dW2[c'][c] and dWo[c'][e] = sum_c dW2[c'][c] Wv[e][c] for this lane's e = col
     // Inside a row of 16 lanes: two DPP rotations (by 4 and by 8 lanes) leave every lane with the sum of its (lane & 3) class;
@@ -653,6 +665,7 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
       }
     }
     wfence();
+    if (hd == 1) DQ_STAMP(11);
     {
       float wvr[C], wor[C];  // Wv[hd*32 + col][c], Wo[c'][hd*32 + col]
 #pragma unroll
@@ -674,6 +687,7 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
         }
       }
     }
+    if (hd == 1) DQ_STAMP(12);
     if (hd == 0 || hd == 3) {  // norm gains / bias: sum over the 32 positions-lanes of this half, one lane stores
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
@@ -685,6 +699,7 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
         }
       }
     }
+    DQ_STAMP(3 + 2 * hd);
   }
 }
 

@@ -82,13 +82,19 @@ def train(config_path, parquet_directory, ms2_data_path, ms1_data_path, batch_si
         loader = ResidentPairLoader(dataset, per_rank, device=device, drop_last=len(dataset) // world > per_rank, rank=rank, world_size=world)
     else:
         loader = DataLoader(dataset, batch_size=per_rank, shuffle=True, num_workers=int(config["threads"]), drop_last=len(dataset) > per_rank)
-    if m["use_model"] != "UNet1d":
-        raise click.ClickException(f"use_model={m['use_model']!r}: only UNet1d is built (CustomTransformer is unreachable through "
-                                   "DDIMDiffusionModel in the reference, SURVEY F3)")
-    u = m["UNet1d"]
-    net = UNet1d(dim=u["dim"], channels=u["channels"], dim_mults=tuple(u["dim_mults"]), conditional=u["conditional"],
-                 init_cond_channels=u["init_cond_channels"], attn_cond_channels=u["attn_cond_channels"],
-                 tfer_dim_mult=u["tfer_dim_mult"], downsample_dim=u["downsample_dim"], simple=u["simple"]).to(device)
+    if m["use_model"] == "UNet1d":
+        u = m["UNet1d"]
+        net = UNet1d(dim=u["dim"], channels=u["channels"], dim_mults=tuple(u["dim_mults"]), conditional=u["conditional"],
+                     init_cond_channels=u["init_cond_channels"], attn_cond_channels=u["attn_cond_channels"],
+                     tfer_dim_mult=u["tfer_dim_mult"], downsample_dim=u["downsample_dim"], simple=u["simple"]).to(device)
+    elif m["use_model"] == "CustomTransformer":  # reference cli.py:102-109; served through the 4-argument adapter
+        from .model.building_blocks import CustomTransformer, DDIMTransformerAdapter
+
+        c = m["CustomTransformer"]
+        net = DDIMTransformerAdapter(CustomTransformer(input_dim=c["input_dim"], hidden_dim=c["hidden_dim"], num_heads=c["num_heads"],
+                                                       num_layers=c["num_layers"])).to(device)
+    else:
+        raise click.ClickException(f"Invalid model class: {m['use_model']}")  # reference cli.py:111 (ValueError there)
     dm = DDIMDiffusionModel(model_class=net, num_timesteps=m["num_timesteps"], beta_schedule_type=m["beta_schedule_type"],
                             pred_type=m["pred_type"], auto_normalize=m["auto_normalize"], ms1_loss_weight=m["ms1_loss_weight"],
                             device=device)

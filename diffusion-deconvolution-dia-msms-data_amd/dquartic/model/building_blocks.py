@@ -234,6 +234,13 @@ class DDIMTransformerAdapter(nn.Module):
         super().__init__()
         self.transformer = transformer
 
+    # checkpoints carry the transformer's own keys (no "transformer." prefix): interchangeable with the reference module's
+    def state_dict(self, *args, **kwargs):
+        return self.transformer.state_dict(*args, **kwargs)
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        return self.transformer.load_state_dict(state_dict, *args, **kwargs)
+
     # the flat-buffer surface FlatAdamW and the data-parallel all-reduce use (model_interface.py)
     @property
     def _layout(self):

@@ -171,6 +171,67 @@ def test_hip_matches_oracle_at_larger_shapes(D, H, heads, layers, B, S1, S2):
         assert torch.equal(net(x.cuda(), t.cuda(), c.cuda()), y.detach())
 
 
+def test_adapter_state_dict_is_the_transformers():
+    from dquartic.model.building_blocks import CustomTransformer, DDIMTransformerAdapter
+
+    net = DDIMTransformerAdapter(CustomTransformer(input_dim=24, hidden_dim=16, num_heads=2, num_layers=1))
+    sd = net.state_dict()
+    assert list(sd)[0] == "input_projection.weight" and not any(k.startswith("transformer.") for k in sd)
+    net.load_state_dict({k: torch.full_like(v, 0.5) for k, v in sd.items()})
+    assert float(net.transformer.flat_params.min()) == 0.5 == float(net.flat_params.max())
+    assert [n for n, _ in net.trainable_named()] == list(sd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pred_type", ["eps", "x0"])
+def test_native_train_step_matches_oracle(pred_type):
+    """_train_one_batch on the adapter = q_sample + forward + (weighted) MSE + backward + clip + AdamW, all native: loss, the
+    pre-clip gradient norm and the updated parameters against the oracle driven by torch autograd / torch.optim.AdamW."""
+    from dquartic.model.building_blocks import CustomTransformer, DDIMTransformerAdapter
+    from dquartic.model.model import DDIMDiffusionModel
+    from dquartic.model.model_interface import FlatAdamW
+
+    D, H, heads, layers, B, RT = 48, 32, 4, 2, 3, 6
+    params = OT.init_params(D, H, layers, seed=3)
+    tf = CustomTransformer(input_dim=D, hidden_dim=H, num_heads=heads, num_layers=layers)
+    tf.load_state_dict(params)
+    net = DDIMTransformerAdapter(tf).cuda()
+    dm = DDIMDiffusionModel(model_class=net, num_timesteps=1000, beta_schedule_type="cosine", pred_type=pred_type, auto_normalize=True,
+                            ms1_loss_weight=0.0, device="cuda")
+    dm._set_optimizer(1e-3)
+    assert isinstance(dm.optimizer, FlatAdamW)
+    g = torch.Generator().manual_seed(11)
+    x0, c2, c1 = torch.rand(B, RT, D, generator=g), torch.rand(B, RT, D, generator=g), torch.rand(B, RT, generator=g)
+    t = torch.tensor([999, 400, 3])
+    noise = torch.randn(B, RT, D, generator=g)
+    loss = dm.train_step_fused(x0.cuda(), c2.cuda(), c1.cuda(), t=t.cuda(), noise=noise.cuda())
+    dm.optimizer.grad_scale = 1.0
+    dm.optimizer.step()
+    # oracle
+    p = {k: v.clone().requires_grad_() for k, v in params.items()}
+    ab = dm.alpha_bars.cpu()[t][:, None, None]
+    xn = 2 * x0 - 1
+    x_t = torch.sqrt(ab) * xn + torch.sqrt(1 - ab) * noise
+    out = OT.forward(p, x_t, t, 2 * c1 - 1, heads)
+    if pred_type == "eps":
+        ref = torch.nn.functional.mse_loss(out, noise)
+    else:
+        ref = (((out - xn) ** 2).flatten(1).mean(1) * dm.loss_weight.cpu()[t]).mean()
+    opt = torch.optim.AdamW(list(p.values()), lr=1e-3)
+    ref.backward()
+    gn = torch.nn.utils.clip_grad_norm_(list(p.values()), 10.0)
+    opt.step()
+    assert abs(float(loss) - float(ref)) < 2e-5 * max(1.0, abs(float(ref)))
+    assert abs(float(dm.optimizer.last_grad_norm) - float(gn)) < 1e-4 * float(gn)
+    for k, v in net.state_dict().items():
+        d = (v.cpu() - p[k].detach()).abs()
+        if k.endswith("attention.in_proj_bias"):
+            # the key bias shifts every score of a row equally: its gradient is zero up to rounding, and Adam's g / (|g| + eps)
+            # turns that rounding noise (1e-9 on both sides) into updates of the order of lr -- not comparable
+            d[H:2 * H] = 0
+        assert float(d.max()) < 2e-5, k
+
+
 @pytest.mark.gpu
 def test_ddim_adapter_trains_the_transformer():
     """DDIMDiffusionModel drives the transformer through the 4-argument adapter (generic autograd path)."""
