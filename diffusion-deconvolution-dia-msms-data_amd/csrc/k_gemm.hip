@@ -30,6 +30,7 @@ struct GemmK {
   int64_t sAo, sAi, sBo, sBi, sCo, sCi;
   const float* bias; float alpha; int accumulate;
   int splits, k_per_split; float* partial;
+  int tile_base, mt;  // first tile of this launch; m-tiles of the whole product (tile id = m-tile + mt * n-tile)
 };
 
 // one (R rows/cols x 32 k) operand tile: global -> registers (float4 units), registers -> LDS
@@ -99,13 +100,15 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm(GemmK g) {
   // XCD-aware tile order: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2), so id -> (id % 8) * (T / 8)
   // + id / 8 gives every XCD a contiguous run of tiles (m fastest: neighbours share the B panel, then the A panel) instead of
   // every 8th one
-  int tile_id = blockIdx.x + gridDim.x * blockIdx.y;
+  // A launch covers the tiles [tile_base, tile_base + gridDim.x) of the (mt x nt) tile grid.
+  int tile_local = blockIdx.x;
   {
-    const int T = gridDim.x * gridDim.y, per = T >> 3;
-    if (tile_id < per * 8) tile_id = (tile_id & 7) * per + (tile_id >> 3);
+    const int T = gridDim.x, per = T >> 3;
+    if (tile_local < per * 8) tile_local = (tile_local & 7) * per + (tile_local >> 3);
   }
-  const int m0 = (tile_id % (int)gridDim.x) * BM, n0 = (tile_id / (int)gridDim.x) * BN;
-  const int z = blockIdx.z % g.batch, sp = blockIdx.z / g.batch;
+  const int tile_id = g.tile_base + tile_local;
+  const int m0 = (tile_id % g.mt) * BM, n0 = (tile_id / g.mt) * BN;
+  const int z = blockIdx.y % g.batch, sp = blockIdx.y / g.batch;
   const int zo = z / g.inner, zi = z % g.inner;
   const float* A = g.A + zo * g.sAo + zi * g.sAi;
   const float* B = g.B + zo * g.sBo + zi * g.sBi;
@@ -173,16 +176,26 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm(GemmK g) {
   }
 
   // register r of lane (col, half) holds C[row = rmap(r, half)][col] of its 32x32 tile
-  float* C = g.splits > 1 ? g.partial + ((int64_t)sp * g.batch + z) * g.M * g.N : g.C + zo * g.sCo + zi * g.sCi;
-  const int64_t ldc = g.splits > 1 ? g.N : g.ldc;
+  if (g.splits > 1) {  // partial tile of this split, tile-local layout [split][z][tile of the launch][BM][BN]
+    float* P = g.partial + (((int64_t)sp * g.batch + z) * gridDim.x + tile_local) * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) P[(wm0 + 32 * i + rmap(r, half)) * BN + wn0 + 32 * jn + col] = acc[i][jn][r];
+    return;
+  }
+  float* C = g.C + zo * g.sCo + zi * g.sCi;
+  const int64_t ldc = g.ldc;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
       const int n = n0 + wn0 + 32 * jn + col;
       if (n >= g.N) continue;
-      const float bias = (g.splits == 1 && g.bias) ? g.bias[n] : 0.f;
-      const bool rmw = g.splits == 1 && g.accumulate;
+      const float bias = g.bias ? g.bias[n] : 0.f;
+      const bool rmw = g.accumulate != 0;
       // all 16 reads of a += tile are issued before the first store (a load behind a store to a pointer the compiler cannot
       // tell apart would wait for it: 64 serial round trips per lane)
       float old[16];
@@ -195,46 +208,52 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm(GemmK g) {
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm0 + 32 * i + rmap(r, half);
         if (m >= g.M) continue;
-        float* dst = C + (int64_t)m * ldc + n;
-        if (g.splits > 1) *dst = acc[i][jn][r];
-        else *dst = old[r] + (g.alpha * acc[i][jn][r] + bias);
+        C[(int64_t)m * ldc + n] = old[r] + (g.alpha * acc[i][jn][r] + bias);
       }
     }
 }
 
-// C = alpha * (sum over the splits, in order) + bias (+ C)
-__global__ void __launch_bounds__(256) k_gemm_split_reduce(GemmK g) {
-  const int64_t per = (int64_t)g.M * g.N, total = per * g.batch;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+// C tile = alpha * (sum over the splits, in order) + bias (+ C); one block per (tile of the launch, z)
+__global__ void __launch_bounds__(256) k_gemm_split_reduce(GemmK g, int ntiles, int bm) {
+  const int t = blockIdx.x % ntiles, z = blockIdx.x / ntiles;
+  const int tile_id = g.tile_base + t;
+  const int m0 = (tile_id % g.mt) * bm, n0 = (tile_id / g.mt) * 128;
+  const int64_t tile_floats = (int64_t)bm * 128, split_stride = (int64_t)g.batch * ntiles * tile_floats;
+  const float* P = g.partial + ((int64_t)z * ntiles + t) * tile_floats;
+  float* C = g.C + (z / g.inner) * g.sCo + (z % g.inner) * g.sCi;
+  {
+    const int e = blockIdx.y * 256 + threadIdx.x;  // one element per thread: (tiles x bm / 2) blocks keep the machine busy
+    const int m = m0 + (e >> 7), n = n0 + (e & 127);
+    if (m >= g.M || n >= g.N) return;
     float s = 0.f;
     int sp = 0;
     for (; sp + 8 <= g.splits; sp += 8) {  // eight loads in flight, summed in split order
       float v[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = g.partial[(int64_t)(sp + k) * total + e];
+      for (int k = 0; k < 8; ++k) v[k] = P[(int64_t)(sp + k) * split_stride + e];
 #pragma unroll
       for (int k = 0; k < 8; ++k) s += v[k];
     }
-    for (; sp < g.splits; ++sp) s += g.partial[(int64_t)sp * total + e];
-    const int z = (int)(e / per);
-    const int64_t mn = e - (int64_t)z * per;
-    const int m = (int)(mn / g.N), n = (int)(mn - (int64_t)m * g.N);
-    float* dst = g.C + (z / g.inner) * g.sCo + (z % g.inner) * g.sCi + (int64_t)m * g.ldc + n;
+    for (; sp < g.splits; ++sp) s += P[(int64_t)sp * split_stride + e];
+    float* dst = C + (int64_t)m * g.ldc + n;
     const float v = g.alpha * s + (g.bias ? g.bias[n] : 0.f);
     *dst = g.accumulate ? *dst + v : v;
   }
 }
 
-struct Shape { int bm, bn, splits, k_per_split; };
-// Tile height and split-K factor by a small cost model of the 256-CU machine: blocks are dealt to the CUs in rounds, a block
-// costs (k-steps x MFMA cycles of its tile + a fixed prologue / epilogue), a split adds the second kernel and its traffic.
-// What it buys over "largest tile, no split": 272 or 288 tiles of 128 x 128 (the transformer's 1088- and 2176-row layers) are
-// two rounds with the second one almost empty; 64-row tiles or a split fill it.  Splits are only considered while
-// tiles x splits <= 1024, which bounds the scratch at 1024 tiles of 128 x 128 floats.
+// A product is run as up to two launches over disjoint tile ranges: the whole rounds of 256 tiles (one per CU) unsplit, and the
+// remaining tiles -- or all of them when there are fewer than 256 -- with the reduction split so that they, too, cover the machine.
+struct Part { int tile_base = 0, ntiles = 0, splits = 1, k_per_split = 0; };
+struct Shape { int bm = 128; Part full, rest; };
+constexpr int MAX_SPLIT_TILES = 1024;  // tiles x splits of a split launch: bounds the scratch at 1024 x 128 x 128 floats
+// Tile height and the split of the remainder by a small cost model of the 256-CU machine: blocks are dealt to the CUs in rounds,
+// a block costs (k-steps x MFMA cycles of its tile + a fixed prologue / epilogue), a split adds the second kernel and its
+// traffic.  What it buys over "largest tile, no split": 272 or 288 tiles of 128 x 128 (the transformer's 2176- and 1088-row
+// layers) would be two rounds with the second one almost empty.
 Shape choose(int M, int N, int K, int batch, int forced_splits) {
   constexpr int CUS = 256;
   const int kt_all = cdiv(K, BK);
-  Shape best{};
+  Shape best;
   double best_cost = 1e30;
   static const int force_bm = [] { const char* e = std::getenv("DQ_GEMM_BM"); return e ? std::atoi(e) : 0; }();
   const int bms[4] = {256, 128, 64, 32};
@@ -243,36 +262,60 @@ Shape choose(int M, int N, int K, int batch, int forced_splits) {
     if (force_bm ? bms[c] != force_bm : c == 0) continue;
     const int bm = bms[c];
     if (!force_bm && c < 3 && M <= bms[c + 1]) continue;  // a smaller tile covers all rows: the larger one only adds padding
-    const int64_t tiles = (int64_t)cdiv(M, bm) * cdiv(N, 128) * batch;
-    const int smax = forced_splits > 0 ? forced_splits : (int)std::min<int64_t>(std::min<int64_t>(64, kt_all), std::max<int64_t>(1, 1024 / tiles));
-    for (int sp = forced_splits > 0 ? forced_splits : 1; sp <= smax; ++sp) {
+    const int tiles = cdiv(M, bm) * cdiv(N, 128);
+    auto block = [&](int kps) { return (kps / BK) * tile_cycles[c] + 2500.0; };
+    Shape sh;
+    sh.bm = bm;
+    double cost;
+    if (forced_splits > 0 || batch > 1) {  // one launch over everything (batched products have short reductions)
+      const int sp = forced_splits > 0 ? std::min(forced_splits, kt_all) : 1;
       const int kps = cdiv(cdiv(K, sp), BK) * BK;
-      const int real = cdiv(K, kps);
-      if (real != sp && forced_splits <= 0) continue;  // same partition as a smaller factor
-      const double rounds = (double)cdiv(tiles * real, CUS);
-      double cost = rounds * ((kps / BK) * tile_cycles[c] + 2500.0);
-      if (real > 1) cost += 12000.0 + (double)real * M * N * batch * 4.0 / 1250.0;
-      if (cost < best_cost) { best_cost = cost; best.bm = bm; best.bn = 128; best.splits = real; best.k_per_split = kps; }
+      sh.rest.ntiles = tiles; sh.rest.k_per_split = kps; sh.rest.splits = cdiv(K, kps);
+      cost = (double)cdiv((int64_t)tiles * batch * sh.rest.splits, CUS) * block(kps);
+    } else {
+      const int full = tiles / CUS * CUS, rem = tiles - full;
+      sh.full.ntiles = full; sh.full.k_per_split = kt_all * BK;
+      cost = (full / CUS) * block(kt_all * BK);
+      if (rem) {
+        double best_rem = 1e30;
+        const int smax = std::max(1, std::min(std::min(64, kt_all), MAX_SPLIT_TILES / rem));
+        for (int sp = 1; sp <= smax; ++sp) {
+          const int kps = cdiv(cdiv(K, sp), BK) * BK, real = cdiv(K, kps);
+          if (real != sp) continue;  // same partition as a smaller factor
+          double cr = (double)cdiv(rem * real, CUS) * block(kps) + (full ? 2000.0 : 0.0);
+          if (real > 1) cr += 12000.0 + (double)real * rem * bm * 128 * 4.0 / 1250.0;
+          if (cr < best_rem) { best_rem = cr; sh.rest.tile_base = full; sh.rest.ntiles = rem; sh.rest.splits = real; sh.rest.k_per_split = kps; }
+        }
+        cost += best_rem;
+      }
     }
+    if (cost < best_cost) { best_cost = cost; best = sh; }
   }
   return best;
 }
 
 template <bool A_K, bool B_K>
-int launch_layout(const GemmK& k, const Shape& sh, hipStream_t s) {
-  const dim3 grid(cdiv(k.M, sh.bm), cdiv(k.N, sh.bn), k.batch * k.splits);
-  if (sh.bm == 32) hipLaunchKernelGGL((k_gemm<A_K, B_K, 1, 1, 1, 4>), grid, dim3(256), 0, s, k);
-  else if (sh.bm == 64) hipLaunchKernelGGL((k_gemm<A_K, B_K, 1, 2, 2, 2>), grid, dim3(256), 0, s, k);
-  else if (sh.bm == 256) hipLaunchKernelGGL((k_gemm<A_K, B_K, 4, 2, 2, 2>), grid, dim3(256), 0, s, k);
+int launch_part(GemmK k, const Part& p, int bm, hipStream_t s) {
+  if (p.ntiles == 0) return 0;
+  k.tile_base = p.tile_base; k.splits = p.splits; k.k_per_split = p.k_per_split;
+  const dim3 grid(p.ntiles, k.batch * p.splits);
+  if (bm == 32) hipLaunchKernelGGL((k_gemm<A_K, B_K, 1, 1, 1, 4>), grid, dim3(256), 0, s, k);
+  else if (bm == 64) hipLaunchKernelGGL((k_gemm<A_K, B_K, 1, 2, 2, 2>), grid, dim3(256), 0, s, k);
+  else if (bm == 256) hipLaunchKernelGGL((k_gemm<A_K, B_K, 4, 2, 2, 2>), grid, dim3(256), 0, s, k);
   else hipLaunchKernelGGL((k_gemm<A_K, B_K, 2, 2, 2, 2>), grid, dim3(256), 0, s, k);
   DQ_LAUNCH_CHECK();
+  if (p.splits > 1) {
+    hipLaunchKernelGGL(k_gemm_split_reduce, dim3(p.ntiles * k.batch, bm / 2), dim3(256), 0, s, k, p.ntiles, bm);
+    DQ_LAUNCH_CHECK();
+  }
   return 0;
 }
+int64_t part_scratch(const Part& p, int bm, int batch) { return p.splits > 1 ? (int64_t)p.splits * batch * p.ntiles * bm * 128 : 0; }
 }  // namespace
 
 int64_t gemm_partial_floats(int M, int N, int K, int batch) {
   const Shape sh = choose(M, N, K, batch, 0);
-  return sh.splits > 1 ? (int64_t)sh.splits * batch * M * N : 0;
+  return std::max(part_scratch(sh.full, sh.bm, batch), part_scratch(sh.rest, sh.bm, batch));
 }
 
 int launch_gemm(const Gemm& g, hipStream_t s) {
@@ -287,20 +330,17 @@ int launch_gemm(const Gemm& g, hipStream_t s) {
   k.A = g.A; k.B = g.B; k.C = g.C; k.M = g.M; k.N = g.N; k.K = g.K; k.lda = g.lda; k.ldb = g.ldb; k.ldc = g.ldc;
   k.batch = g.batch; k.inner = g.inner; k.sAo = g.sAo; k.sAi = g.sAi; k.sBo = g.sBo; k.sBi = g.sBi; k.sCo = g.sCo; k.sCi = g.sCi;
   k.bias = g.bias; k.alpha = g.alpha; k.accumulate = g.accumulate;
-  k.splits = sh.splits; k.k_per_split = sh.k_per_split; k.partial = g.partial;
-  if (sh.splits > 1)
-    DQ_REQUIRE(g.partial && g.partial_floats >= (int64_t)sh.splits * g.batch * g.M * g.N, "gemm: split-K scratch missing or too small");
-  DQ_REQUIRE((int64_t)k.batch * k.splits <= 65535, "gemm: batch x splits exceeds the grid");
-  int rc;
-  if (g.a_kmajor && g.b_kmajor) rc = launch_layout<true, true>(k, sh, s);
-  else if (g.a_kmajor && !g.b_kmajor) rc = launch_layout<true, false>(k, sh, s);
-  else if (!g.a_kmajor && !g.b_kmajor) rc = launch_layout<false, false>(k, sh, s);
-  else { set_error("gemm: the (A transposed, B k-major) layout is not built"); return 2; }
-  if (rc) return rc;
-  if (sh.splits > 1) {
-    const int64_t total = (int64_t)g.M * g.N * g.batch;
-    hipLaunchKernelGGL(k_gemm_split_reduce, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0, s, k);
-    DQ_LAUNCH_CHECK();
+  k.splits = 1; k.k_per_split = 0; k.partial = g.partial; k.tile_base = 0; k.mt = cdiv(g.M, sh.bm);
+  const int64_t need = std::max(part_scratch(sh.full, sh.bm, g.batch), part_scratch(sh.rest, sh.bm, g.batch));
+  if (need > 0) DQ_REQUIRE(g.partial && g.partial_floats >= need, "gemm: split-K scratch missing or too small");
+  DQ_REQUIRE((int64_t)k.batch * std::max(sh.full.splits, sh.rest.splits) <= 65535, "gemm: batch x splits exceeds the grid");
+  for (const Part* p : {&sh.full, &sh.rest}) {
+    int rc;
+    if (g.a_kmajor && g.b_kmajor) rc = launch_part<true, true>(k, *p, sh.bm, s);
+    else if (g.a_kmajor && !g.b_kmajor) rc = launch_part<true, false>(k, *p, sh.bm, s);
+    else if (!g.a_kmajor && !g.b_kmajor) rc = launch_part<false, false>(k, *p, sh.bm, s);
+    else { set_error("gemm: the (A transposed, B k-major) layout is not built"); return 2; }
+    if (rc) return rc;
   }
   return 0;
 }

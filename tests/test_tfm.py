@@ -86,7 +86,7 @@ def _gemm(A, B, M, N, K, a_k, b_k, bias=None, C0=None, splits=0):
 
     lib = N_.lib()
     C = torch.zeros(M, N, device="cuda") if C0 is None else C0.clone()
-    n_s = max(int(lib.dq_gemm_scratch_floats(M, N, K)), 64 * M * N if splits else 4)
+    n_s = max(int(lib.dq_gemm_scratch_floats(M, N, K)), splits * (M + 256) * (N + 128) if splits else 4)  # forced split: tile-padded
     scratch = torch.empty(n_s, device="cuda")
     N_.check(lib.dq_gemm(N_.ptr(A), N_.ptr(B), N_.ptr(C), N_.ptr(bias), M, N, K, A.shape[1], B.shape[1], N, int(a_k), int(b_k),
                          0 if C0 is None else 1, splits, N_.ptr(scratch), scratch.numel(), N_.stream_ptr()), "dq_gemm")
