@@ -2,9 +2,10 @@
 // layers of the reference's CustomTransformer (building_blocks.py: nn.Linear at :86-88, 141-145, 211-213; nn.MultiheadAttention's
 // projections and its two batched products at :136-138) and for their gradients.  See dq_tfm.h for the operand conventions.
 //
-// Tiling: a block of 4 waves owns a (BM x BN) tile of C and walks the reduction in steps of BK = 32.  Each wave keeps
-// TM x TN accumulator tiles of 32x32 (16 registers each).  Global -> registers -> LDS with the next step's global loads in
-// flight during this step's MFMAs (two LDS buffers, one barrier per step).  The reduction order inside a step is free, so a
+// Tiling: a block owns a (BM x 128) tile of C -- 128 rows on 8 waves, 64 / 32 rows on 4 -- and walks the reduction in steps of
+// BK = 32.  Each wave keeps TM x TN accumulator tiles of 32x32 (16 registers each).  Global -> registers -> LDS with the next
+// step's global loads in flight during this step's MFMAs (two LDS buffers, one barrier per step).  A product runs as the whole
+// rounds of 256 tiles unsplit plus the remaining tiles with a split reduction (choose(), below).  The reduction order inside a step is free, so a
 // lane half h takes the four consecutive k = 8j + 4h .. + 3: for an operand whose rows are contiguous along k, the LDS tile
 // keeps the global layout ([row][k], row stride 36 floats -> conflict-free 16-byte reads) and one ds_read_b128 feeds four MFMAs;
 // an operand stored the other way round is kept as [k][col] and read one value per MFMA (conflict-free across the lanes).
@@ -255,13 +256,12 @@ Shape choose(int M, int N, int K, int batch, int forced_splits) {
   const int kt_all = cdiv(K, BK);
   Shape best;
   double best_cost = 1e30;
-  static const int force_bm = [] { const char* e = std::getenv("DQ_GEMM_BM"); return e ? std::atoi(e) : 0; }();
-  const int bms[4] = {256, 128, 64, 32};
-  const double tile_cycles[4] = {7000.0, 4096.0, 2400.0, 1500.0};  // per k-step of 32: 128 / 64 / 32 / 16 MFMAs per wave
-  for (int c = 0; c < 4; ++c) {
-    if (force_bm ? bms[c] != force_bm : c == 0) continue;
+  // (256 x 128 tiles were measured too, on 4 and on 8 waves: never faster than 128 x 128 on this machine, not built)
+  const int bms[3] = {128, 64, 32};
+  const double tile_cycles[3] = {4096.0, 2400.0, 1500.0};  // per k-step of 32: 64 / 32 / 16 MFMAs per SIMD, smaller tiles less efficient
+  for (int c = 0; c < 3; ++c) {
     const int bm = bms[c];
-    if (!force_bm && c < 3 && M <= bms[c + 1]) continue;  // a smaller tile covers all rows: the larger one only adds padding
+    if (c < 2 && M <= bms[c + 1]) continue;  // a smaller tile covers all rows: the larger one only adds padding
     const int tiles = cdiv(M, bm) * cdiv(N, 128);
     auto block = [&](int kps) { return (kps / BK) * tile_cycles[c] + 2500.0; };
     Shape sh;
@@ -301,8 +301,9 @@ int launch_part(GemmK k, const Part& p, int bm, hipStream_t s) {
   const dim3 grid(p.ntiles, k.batch * p.splits);
   if (bm == 32) hipLaunchKernelGGL((k_gemm<A_K, B_K, 1, 1, 1, 4>), grid, dim3(256), 0, s, k);
   else if (bm == 64) hipLaunchKernelGGL((k_gemm<A_K, B_K, 1, 2, 2, 2>), grid, dim3(256), 0, s, k);
-  else if (bm == 256) hipLaunchKernelGGL((k_gemm<A_K, B_K, 4, 2, 2, 2>), grid, dim3(256), 0, s, k);
-  else hipLaunchKernelGGL((k_gemm<A_K, B_K, 2, 2, 2, 2>), grid, dim3(256), 0, s, k);
+  // 128 x 128 on EIGHT waves (32 x 64 each): two waves per SIMD from one block cover each other's LDS / barrier waits, which a
+  // lone 4-wave block per CU (a round of 256 tiles) cannot -- 3-6 % over the 4-wave form on every shape measured
+  else hipLaunchKernelGGL((k_gemm<A_K, B_K, 1, 2, 4, 2>), grid, dim3(512), 0, s, k);
   DQ_LAUNCH_CHECK();
   if (p.splits > 1) {
     hipLaunchKernelGGL(k_gemm_split_reduce, dim3(p.ntiles * k.batch, bm / 2), dim3(256), 0, s, k, p.ntiles, bm);
