@@ -189,11 +189,30 @@ int launch_mse_fwd_bwd(const float* eps, const float* noise, float* loss_out, fl
 // ---- K11: global L2 norm (two-stage, deterministic) + clip + AdamW, flat buffers.
 // norm pass: 4 B / param ; update pass: 28 B / param (read p,g,m,v ; write p,m,v).
 __global__ void __launch_bounds__(256) k_sumsq(const float* __restrict__ g, int64_t n, float gscale, float* __restrict__ partials) {
-  float acc = 0.f;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float v = g[i] * gscale;
-    acc += v * v;
+  // 16-byte loads, four independent accumulators, two loads in flight: the 764 MB gradient of the transformer (191 M parameters)
+  // is a bandwidth job; the scalar one-accumulator loop ran it at 2.3 TB/s
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const int64_t n4 = (((uintptr_t)g & 15) == 0) ? n / 4 : 0;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i + stride < n4; i += 2 * stride) {
+    const float4 u = g4[i], w = g4[i + stride];
+    a0 = fmaf(u.x * gscale, u.x * gscale, a0); a1 = fmaf(u.y * gscale, u.y * gscale, a1);
+    a2 = fmaf(u.z * gscale, u.z * gscale, a2); a3 = fmaf(u.w * gscale, u.w * gscale, a3);
+    a0 = fmaf(w.x * gscale, w.x * gscale, a0); a1 = fmaf(w.y * gscale, w.y * gscale, a1);
+    a2 = fmaf(w.z * gscale, w.z * gscale, a2); a3 = fmaf(w.w * gscale, w.w * gscale, a3);
   }
+  for (; i < n4; i += stride) {
+    const float4 u = g4[i];
+    a0 = fmaf(u.x * gscale, u.x * gscale, a0); a1 = fmaf(u.y * gscale, u.y * gscale, a1);
+    a2 = fmaf(u.z * gscale, u.z * gscale, a2); a3 = fmaf(u.w * gscale, u.w * gscale, a3);
+  }
+  for (int64_t j = n4 * 4 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n; j += stride) {
+    const float v = g[j] * gscale;
+    a0 = fmaf(v, v, a0);
+  }
+  float acc = (a0 + a1) + (a2 + a3);
   __shared__ float red[4];
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
