@@ -247,7 +247,9 @@ def transformer_leg(device, with_cpu):
     fl = 2.0 * M * Nn * K
     out["roofline"] = {"bound": "mfma", "kernel": "k_gemm<A k-major, B k-major, 128x128x32> on (1088 x 1024) x (1024 x 40000)",
                        "achieved": round(fl / sec / 1e12, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                       "frac": round(fl / sec / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "us_per_launch": round(sec * 1e6, 1)}
+                       "frac": round(fl / sec / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                       "traffic": 704.1e6,  # HBM bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_gemm.md
+                       "flops_per_launch": fl, "us_per_launch": round(sec * 1e6, 1)}
     del net, dm, A, Bm, C
     torch.cuda.empty_cache()
     if with_cpu:
