@@ -20,7 +20,11 @@
 namespace dq {
 
 namespace {
-constexpr int BK = 32;
+#ifndef DQ_GEMM_BK
+#define DQ_GEMM_BK 32
+#endif
+constexpr int BK = DQ_GEMM_BK;  // reduction step (floats); Q4 = float4 units per tile row
+constexpr int Q4 = BK / 4;
 constexpr int LDK = BK + 4;
 
 struct GemmK {
@@ -37,15 +41,15 @@ struct GemmK {
 // one (R rows/cols x 32 k) operand tile: global -> registers (float4 units), registers -> LDS
 template <bool KMAJOR, int R, int NT>
 struct TileIO {
-  static constexpr int U = R * 8 / NT;  // float4 units per thread
-  static_assert(R * 8 % NT == 0, "tile does not divide over the block");
+  static constexpr int U = R * Q4 / NT;  // float4 units per thread
+  static_assert(R * Q4 % NT == 0, "tile does not divide over the block");
   float4 v[U];
   __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int r0, int rmax, int k0, int kend, int tid) {
     if (r0 + R <= rmax && k0 + BK <= kend) {  // interior tile (block-uniform): straight vector loads, no per-unit branches
 #pragma unroll
       for (int i = 0; i < U; ++i) {
         const int u = tid + NT * i;
-        const float* p = KMAJOR ? base + (int64_t)(r0 + (u >> 3)) * ld + k0 + 4 * (u & 7)
+        const float* p = KMAJOR ? base + (int64_t)(r0 + (u / Q4)) * ld + k0 + 4 * (u % Q4)
                                 : base + (int64_t)(k0 + u / (R / 4)) * ld + r0 + 4 * (u % (R / 4));
         v[i] = *reinterpret_cast<const float4*>(p);
       }
@@ -56,7 +60,7 @@ struct TileIO {
       const int u = tid + NT * i;
       float4 x = {0.f, 0.f, 0.f, 0.f};
       if (KMAJOR) {
-        const int row = r0 + (u >> 3), k = k0 + 4 * (u & 7);
+        const int row = r0 + (u / Q4), k = k0 + 4 * (u % Q4);
         if (row < rmax) {
           const float* p = base + (int64_t)row * ld + k;
           if (k + 3 < kend) x = *reinterpret_cast<const float4*>(p);
@@ -85,7 +89,7 @@ struct TileIO {
 #pragma unroll
     for (int i = 0; i < U; ++i) {
       const int u = tid + NT * i;
-      if (KMAJOR) *reinterpret_cast<float4*>(lds + (u >> 3) * LDK + 4 * (u & 7)) = v[i];
+      if (KMAJOR) *reinterpret_cast<float4*>(lds + (u / Q4) * LDK + 4 * (u % Q4)) = v[i];
       else *reinterpret_cast<float4*>(lds + (u / (R / 4)) * (R + 4) + 4 * (u % (R / 4))) = v[i];
     }
   }
@@ -94,8 +98,9 @@ struct TileIO {
 template <bool A_K, bool B_K, int TM, int TN, int WM, int WN>
 __global__ void __launch_bounds__(WM * WN * 64) k_gemm(GemmK g) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
-  __shared__ __attribute__((aligned(16))) float as[2][BM * LDK];
-  __shared__ __attribute__((aligned(16))) float bs[2][BN * LDK];
+  // either layout fits: [rows][BK + 4] or [BK][rows + 4].  (BK = 64 was measured: one block per CU instead of two, slower.)
+  __shared__ __attribute__((aligned(16))) float as[2][BM * LDK > BK * (BM + 4) ? BM * LDK : BK * (BM + 4)];
+  __shared__ __attribute__((aligned(16))) float bs[2][BN * LDK > BK * (BN + 4) ? BN * LDK : BK * (BN + 4)];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, half = lane >> 5;
   const int wm0 = (wv / WN) * TM * 32, wn0 = (wv % WN) * TN * 32;
   // XCD-aware tile order: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2), so id -> (id % 8) * (T / 8)
@@ -140,7 +145,7 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm(GemmK g) {
     const float* al = as[kt & 1];
     const float* bl = bs[kt & 1];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < BK / 8; ++j) {
       float av[TM][4], bv[TN][4];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
