@@ -143,6 +143,10 @@ struct LinAttnBwd {
   const float* ypre = nullptr;                     // saved by the forward
   float* dyp = nullptr; float* dxh = nullptr;      // scratch (rows, C, n) each
   float* part = nullptr; int64_t part_floats = 0;  // per-wave dW partial slots: >= LA_MAX_WAVES * 512 * C floats
+  // defer_reduce: rows of <= 64 positions leave their slots unreduced and report the slot count in *waves_out (0 when the
+  // launch reduced them itself: the long-row path); the caller sums them later with launch_linattn_dw_reduce_multi, and then
+  // part_floats only needs la_part_reserve(C)
+  int defer_reduce = 0; int* waves_out = nullptr;
   float* dw_qkv = nullptr; float* dw_out = nullptr; float* db_out = nullptr; float* dg_pre = nullptr; float* dg_out = nullptr;
 };
 // rows of 128 / 256 positions (k_la_long.hip)
@@ -151,6 +155,11 @@ int launch_linattn_bwd_long(const float* x, const float* dyp, float* dxh, const 
                             float* part, int C, int rows, int n, int* waves_out, hipStream_t s);
 constexpr int LA_MAX_WAVES = 2048;  // the backward grid is one resident round: <= 1024 waves, one partial slot each
 int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s);
+// the deferred slot reductions of up to LA_REDUCE_MAX LinearAttention backwards in ONE launch (grad += ordered slot sums)
+struct LaReduceItem { const float* part; int nslots, C; float* dw_qkv; float* dw_out; float* dg_out; float* db_out; float* dg_pre; };
+constexpr int LA_REDUCE_MAX = 16;
+int64_t la_part_reserve(int C);  // floats of slot scratch one deferred launch with C channels can use
+int launch_linattn_dw_reduce_multi(const LaReduceItem* items, int count, hipStream_t s);
 
 // ---- k_attn.hip : softmax attention over RT of the bottleneck (q,k,v,o in (B, 128, RT) conv layout)
 int launch_rope(float* qk, const float* freqs, int B, int64_t batch_stride, int RT, float sign, hipStream_t s);

@@ -737,6 +737,39 @@ __global__ void __launch_bounds__(256) k_linattn_dw_reduce(const float* __restri
     else dg_pre[e - 514 * C] += s;
   }
 }
+// the same reduction for several LinearAttention layers at once: block -> (item, 16-element group) through a prefix table
+struct LaReduceMulti { LaReduceItem it[LA_REDUCE_MAX]; int first_block[LA_REDUCE_MAX + 1]; int count; };
+__global__ void __launch_bounds__(256) k_linattn_dw_reduce_multi(LaReduceMulti m) {
+  int i = 0;
+  while (i + 1 < m.count && (int)blockIdx.x >= m.first_block[i + 1]) ++i;
+  const LaReduceItem& it = m.it[i];
+  const int C = it.C, nelem = la_slot(C), nslots = it.nslots;
+  const float* __restrict__ part = it.part;
+  __shared__ float red[16][17];
+  const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int e = ((int)blockIdx.x - m.first_block[i]) * 16 + el;
+  float s0 = 0.f, s1 = 0.f;
+  if (e < nelem) {
+    int b = g;
+    for (; b + 16 < nslots; b += 32) {
+      s0 += part[(int64_t)b * nelem + e];
+      s1 += part[(int64_t)(b + 16) * nelem + e];
+    }
+    if (b < nslots) s0 += part[(int64_t)b * nelem + e];
+  }
+  red[g][el] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && e < nelem) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][el];
+    if (e < 384 * C) it.dw_qkv[e] += s;
+    else if (e < 512 * C) it.dw_out[e - 384 * C] += s;
+    else if (e < 513 * C) it.dg_out[e - 512 * C] += s;
+    else if (e < 514 * C) it.db_out[e - 513 * C] += s;
+    else it.dg_pre[e - 514 * C] += s;
+  }
+}
 #endif  // !DQ_LA_BIG_TU
 
 // The two largest instantiations (C >= 12 with 64-position rows; no BASELINE config uses them) crash this compiler's
@@ -768,8 +801,10 @@ static int linattn_bwd_n(const LinAttnBwdK& k, int n, const LinAttnBwd& g, hipSt
     kk.units_per_wave = std::max(1, cdiv(units, max_waves));                                       \
     const int waves = cdiv(units, kk.units_per_wave);                                              \
     launch_one<C, NN>(kk, waves, s);                                                               \
-    hipLaunchKernelGGL(k_linattn_dw_reduce, dim3(cdiv(la_slot(C), 16)), dim3(256), 0, s, kk.part, waves, C, la_slot(C), g.dw_qkv, \
-                       g.dw_out, g.dg_out, g.db_out, g.dg_pre);                                    \
+    if (g.defer_reduce) *g.waves_out = waves;                                                      \
+    else                                                                                           \
+      hipLaunchKernelGGL(k_linattn_dw_reduce, dim3(cdiv(la_slot(C), 16)), dim3(256), 0, s, kk.part, waves, C, la_slot(C), g.dw_qkv, \
+                         g.dw_out, g.dg_out, g.db_out, g.dg_pre);                                  \
     break;                                                                                         \
   }
   switch (n) {
@@ -783,6 +818,24 @@ static int linattn_bwd_n(const LinAttnBwdK& k, int n, const LinAttnBwd& g, hipSt
   return 0;
 }
 
+int64_t la_part_reserve(int C) { return (int64_t)(C == 4 ? 2048 : 1024) * la_slot(C); }
+int launch_linattn_dw_reduce_multi(const LaReduceItem* items, int count, hipStream_t s) {
+  if (count == 0) return 0;
+  DQ_REQUIRE(count <= LA_REDUCE_MAX, "linattn dw reduce: too many deferred layers");
+  LaReduceMulti m;
+  m.count = count;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    m.it[i] = items[i];
+    m.first_block[i] = blocks;
+    blocks += cdiv(la_slot(items[i].C), 16);
+  }
+  m.first_block[count] = blocks;
+  hipLaunchKernelGGL(k_linattn_dw_reduce_multi, dim3(blocks), dim3(256), 0, s, m);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
 // a.f.y is unused; needs: a.ypre (saved pre-norm output), the (rows, C, n) scratch dxh (and dyp for rows longer than 64) and
 // the partial-slot scratch
 int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s) {
@@ -790,7 +843,10 @@ int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s) {
              "linattn_bwd: missing operand");
   if (a.f.rows == 0) return 0;
   const int C = a.f.C, rows = a.f.rows, n = a.f.n;
-  DQ_REQUIRE(a.part && a.part_floats >= (int64_t)LA_MAX_WAVES * 512 * C, "linattn_bwd: partial-sum scratch missing or too small");
+  const bool deferred = a.defer_reduce && a.waves_out && n <= 64;
+  if (a.waves_out) *a.waves_out = 0;
+  DQ_REQUIRE(a.part && a.part_floats >= (deferred ? la_part_reserve(C) : (int64_t)LA_MAX_WAVES * 512 * C),
+             "linattn_bwd: partial-sum scratch missing or too small");
   static_assert((int64_t)LA_MAX_WAVES * 512 >= 1024 * (int64_t)la_slot(1), "slot scratch: 1024 waves x 515*C floats must fit");
   static const bool long_all = [] { const char* e = std::getenv("DQ_LA_BWD_LONG"); return e && e[0] == '1'; }();
   if (n > 64 || (long_all && n >= 32 && C <= 8)) {
