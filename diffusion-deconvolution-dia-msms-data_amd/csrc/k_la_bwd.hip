@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
   for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) {
     const int c = i % C, cp = (i / C) % C, hd = i / (C * C);
     float s = 0.f;
-#pragma unroll 8
+#pragma unroll
     for (int e = 0; e < 32; ++e) s = fmaf(a.w_out[cp * 128 + hd * 32 + e], a.w_qkv[(256 + hd * 32 + e) * C + c], s);
     w2_lds[i] = s;
   }
@@ -641,6 +641,12 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
     // Inside a row of 16 lanes: two DPP rotations (by 4 and by 8 lanes) leave every lane with the sum of its (lane & 3) class;
     // across the four rows: through the wave-private tile (4 x 16 C^2 / 4 floats <= 1024).  The four-step ds_bpermute butterfly
     // this replaces was 4 C^2 dependent LDS round trips per head: 8 us of a 25 us head at 16 channels (tools/probe/la_bwd_time.hip).
+    float wvr[C], wor[C];  // Wv[hd*32 + col][c], Wo[c'][hd*32 + col]: requested here, used after the reduction below
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      wvr[c] = a.w_qkv[(256 + hd * 32 + col) * C + c];
+      wor[c] = a.w_out[c * 128 + hd * 32 + col];
+    }
     constexpr int NV4 = CG * CG * 16;  // floats one row contributes: [value vi = (g1 * CG + g2) * 4 + i][j = lane & 3]
     wfence();
 #pragma unroll
@@ -667,12 +673,6 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
     wfence();
     if (hd == 1) DQ_STAMP(11);
     {
-      float wvr[C], wor[C];  // Wv[hd*32 + col][c], Wo[c'][hd*32 + col]
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        wvr[c] = a.w_qkv[(256 + hd * 32 + col) * C + c];
-        wor[c] = a.w_out[c * 128 + hd * 32 + col];
-      }
       if (half == 0) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {

@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) {
     const int c = i % C, cp = (i / C) % C, hd = i / (C * C);
     float s = 0.f;
-#pragma unroll 8
+#pragma unroll
     for (int e = 0; e < 32; ++e) s = fmaf(a.w_out[cp * 128 + hd * 32 + e], a.w_qkv[(256 + hd * 32 + e) * C + c], s);
     w2_lds[i] = s;
   }
