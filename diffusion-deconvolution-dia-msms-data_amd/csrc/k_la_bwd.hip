@@ -70,10 +70,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 
 // sum over the 32 lanes that share (lane >> 5)
+// (four DPP adds give every lane its 16-lane row sum, the two rows of a half meet through v_readlane: no LDS round trips)
 __device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  int x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false));  // row_half_mirror
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false));  // row_mirror
+  x = __float_as_int(v);
+  const float lo = __int_as_float(__builtin_amdgcn_readlane(x, 0)) + __int_as_float(__builtin_amdgcn_readlane(x, 16));
+  const float hi = __int_as_float(__builtin_amdgcn_readlane(x, 32)) + __int_as_float(__builtin_amdgcn_readlane(x, 48));
+  return (threadIdx.x & 32) ? hi : lo;
 }
 
 template <int C, int N>
@@ -94,8 +104,8 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
   __shared__ __attribute__((aligned(16))) float wp_lds[2 * 4 * 2 * C * 16];  // [q|k][head][half][c][r] = Wqkv[m*128 + head*32 + rmap(r,half)][c]
   __shared__ __attribute__((aligned(16))) float w2_lds[4 * C * C];           // [head][c'][c] = sum_e Wo[c'][head*32+e] Wv[head*32+e][c]
   __shared__ float tiles[4][32 * 33];
-  // per wave: xh | dYpre | P (normalised) | dP as [c][n] ; M | dM as [c][d] ; dW2 of the head being flushed [c'][c]
-  __shared__ __attribute__((aligned(16))) float stage[4][4 * C * NP + 2 * C * 32 + C * C];
+  // per wave: xh | dYpre | P (normalised) | dP as [c][n] ; M | dM as [c][d] ; dW2 of the head being flushed [c'][c] and [c][c']
+  __shared__ __attribute__((aligned(16))) float stage[4][4 * C * NP + 2 * C * 32 + 2 * C * C];
   DQ_STAMP(0);
   for (int i = threadIdx.x; i < 2 * 4 * 2 * C * 16; i += blockDim.x) {
     const int r = i & 15, c = (i >> 4) % C, hh = (i / (16 * C)) & 1, hd = (i / (32 * C)) & 3, m = i / (128 * C);
@@ -668,23 +678,28 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
         const float v = (tile[e] + tile[NV4 + e]) + (tile[2 * NV4 + e] + tile[3 * NV4 + e]);
         const int vi = e >> 2, j = e & 3, i = vi & 3, g2 = (vi >> 2) % CG, g1 = (vi >> 2) / CG;
         w2g[(4 * g1 + i) * C + 4 * g2 + j] = v;
+        w2g[C * C + (4 * g2 + j) * C + 4 * g1 + i] = v;  // transposed copy: both halves below read along their reduction index
       }
     }
     wfence();
     if (hd == 1) DQ_STAMP(11);
     {
-      if (half == 0) {
+      // lane half 0: dWv[e][c] = sum_c' Wo[c'][e] dW2[c'][c] (reads the transposed copy along c'); half 1: dWo[c][e] =
+      // sum_k dW2[c][k] Wv[e][k] -- one instruction stream, C^2 FMAs per lane instead of 2 C^2 on half of the lanes
+      const float* mx = half ? w2g : w2g + C * C;
+      float av[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-          float sv = 0.f, so = 0.f;
+      for (int k = 0; k < C; ++k) av[k] = half ? wvr[k] : wor[k];
 #pragma unroll
-          for (int k = 0; k < C; ++k) {
-            sv = fmaf(wor[k], w2g[k * C + c], sv);   // dWv[e][c]  = sum_c' Wo[c'][e] dW2[c'][c]
-            so = fmaf(w2g[c * C + k], wvr[k], so);   // dWo[c][e]  = sum_k  dW2[c][k]  Wv[e][k]
-          }
-          slot[(256 + hd * 32 + col) * C + c] = sv;
-          slot[384 * C + c * 128 + hd * 32 + col] = so;
+      for (int c = 0; c < C; ++c) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int k4 = 0; k4 < C; k4 += 4) {
+          const float4 m4 = *reinterpret_cast<const float4*>(mx + c * C + k4);
+          sacc = fmaf(av[k4], m4.x, sacc); sacc = fmaf(av[k4 + 1], m4.y, sacc);
+          sacc = fmaf(av[k4 + 2], m4.z, sacc); sacc = fmaf(av[k4 + 3], m4.w, sacc);
         }
+        slot[half ? 384 * C + c * 128 + hd * 32 + col : (256 + hd * 32 + col) * C + c] = sacc;
       }
     }
     if (hd == 1) DQ_STAMP(12);
