@@ -2,6 +2,7 @@
 // C ABI (include/dq_hip.h).  Follows UNet1d.forward (dquartic/model/unet1d.py:1086-1166) op by op; the comments
 // name the reference lines each stage replaces.
 #include "dq_common.h"
+#include "dq_tfm.h"
 #include "dq_kernels.h"
 #include "dq_unet.h"
 #include "../../include/dq_hip.h"
@@ -82,6 +83,7 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
   for (const LevelP& l : p.ups) a.la_part_floats += la_part_reserve(l.la.C);
   a.la_part_floats = std::max<int64_t>(a.la_part_floats, (int64_t)LA_MAX_WAVES * 512 * 16);
   a.la_part = take_nz(a.la_part_floats);
+  a.wtmp = take_nz(2 * HID * 64);  // 16-byte aligned copy of a projection weight for the GEMM route of the wide 1x1 convs
   a.ts_tab = take_nz(1024); a.step = take_nz(64);  // graph replay: timestep table (int32) and the device-side step counter
   a.c2_stage = take_nz(R * p.mz); a.c1_stage = take_nz(R);  // conditions staged at fixed addresses for the captured step
   a.zero_floats = off;
@@ -290,7 +292,32 @@ int la_bwd(const Ctx& c, const LAP& l, const LevelBuf& b, const float* x, const 
   return 0;
 }
 
+// A bias-free 1x1 conv with many channels on one side (the bottleneck attention's q|v, k and output projections: 16 <-> 256 / 128
+// channels over (B, C, RT)) is a per-sample matrix product Y_b (cout x n) = W (cout x cin) X_b (cin x n): it goes to the fp32
+// matrix-core GEMM (k_gemm.hip), batched over the samples.  The per-thread channel loop of the generic conv kernels is a serial
+// chain of 128-256 dependent FMAs there (47 us forward, 108 us data gradient at batch 32; ~10 us as a GEMM).
+bool conv_is_gemm(const Ctx& c, const ConvP& cp, int mode, int n_in, int n_out) {
+  return cp.k == 1 && mode == CONV_S1 && cp.b < 0 && n_in == n_out && n_in % 4 == 0 && cp.cin % 4 == 0 && (cp.cout >= 64 || cp.cin >= 64) &&
+         (int64_t)cp.cout * cp.cin <= 2 * HID * 64;
+}
+// the GEMM reads its operands with 16-byte loads; a weight slice of the flat parameter buffer that does not start on a 16-byte
+// boundary is copied (<= 32 KB, device to device, same stream) to an aligned slot of the arena first
+int gemm_weight(const Ctx& c, const ConvP& cp, const float** w) {
+  *w = c.prm(cp.w);
+  if (((uintptr_t)*w & 15) == 0) return 0;
+  DQ_TRY(launch_copy(c.w(c.ar.wtmp), *w, (int64_t)cp.cout * cp.cin, c.s));
+  *w = c.w(c.ar.wtmp);
+  return 0;
+}
+
 int conv_plain_fwd(const Ctx& c, const ConvP& cp, int mode, const float* in, float* out, int rows, int n_in, int n_out) {
+  if (conv_is_gemm(c, cp, mode, n_in, n_out)) {
+    Gemm g;
+    DQ_TRY(gemm_weight(c, cp, &g.A));
+    g.lda = cp.cin; g.B = in; g.b_kmajor = 0; g.ldb = n_in; g.C = out; g.ldc = n_in;
+    g.M = cp.cout; g.N = n_in; g.K = cp.cin; g.batch = rows; g.sBo = (int64_t)cp.cin * n_in; g.sCo = (int64_t)cp.cout * n_in;
+    return launch_gemm(g, c.s);
+  }
   ConvFwd f;
   f.inA = in; f.cinA = cp.cin; f.w = c.prm(cp.w); f.bias = cp.b >= 0 ? c.prm(cp.b) : nullptr;
   f.cout = cp.cout; f.K = cp.k; f.mode = mode; f.rows = rows; f.n_in = n_in; f.n_out = n_out; f.y_out = out;
@@ -304,6 +331,14 @@ int conv_plain_bwd(const Ctx& c, const ConvP& cp, int mode, const float* in, con
   wg.du = dout; wg.inA = in; wg.cinA = cp.cin; wg.cout = cp.cout; wg.K = cp.k; wg.mode = mode; wg.rows = rows; wg.n_in = n_in;
   wg.n_out = n_out; wg.dw = c.dprm(cp.w); wg.dbias = cp.b >= 0 ? c.dprm(cp.b) : nullptr;
   DQ_TRY(wgrad_async(c, wg));
+  if (din && conv_is_gemm(c, cp, mode, n_in, n_out)) {  // dX_b (cin x n) (+)= W^T (cin x cout) dY_b (cout x n)
+    Gemm g;
+    DQ_TRY(gemm_weight(c, cp, &g.A));
+    g.a_kmajor = 0; g.lda = cp.cin; g.B = dout; g.b_kmajor = 0; g.ldb = n_in; g.C = din; g.ldc = n_in;
+    g.M = cp.cin; g.N = n_in; g.K = cp.cout; g.batch = rows; g.sBo = (int64_t)cp.cout * n_in; g.sCo = (int64_t)cp.cin * n_in;
+    g.accumulate = accumulate;
+    return launch_gemm(g, c.s);
+  }
   if (din) {
     ConvBwdData bd;
     bd.du = dout; bd.w = c.prm(cp.w); bd.cout = cp.cout; bd.K = cp.k; bd.mode = mode; bd.rows = rows; bd.n_in = n_in; bd.n_out = n_out;

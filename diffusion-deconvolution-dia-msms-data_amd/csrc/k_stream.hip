@@ -165,6 +165,17 @@ __global__ void __launch_bounds__(256) k_axpy(float* __restrict__ dst, const flo
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] += src[i];
 }
 
+__global__ void __launch_bounds__(256) k_copy(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// plain kernel copy: a hipMemcpyAsync in the middle of the step costs far more than its 3 us blit (queue barriers around it)
+int launch_copy(float* dst, const float* src, int64_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_copy, dim3((int)std::min<int64_t>(cdiv(n, 256), 4096)), dim3(256), 0, s, dst, src, n);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_axpy(float* dst, const float* src, int64_t n, hipStream_t s) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_axpy, dim3((int)std::min<int64_t>(cdiv(n, 256), 4096)), dim3(256), 0, s, dst, src, n);
