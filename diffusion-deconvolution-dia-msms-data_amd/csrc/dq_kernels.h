@@ -25,6 +25,7 @@ int launch_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, f
                       double lr, double b1, double b2, double eps, double wd, int step, float* gnorm_out, hipStream_t s);
 
 int launch_axpy(float* dst, const float* src, int64_t n, hipStream_t s);  // dst += src
+int launch_zero(float* dst, int64_t n, hipStream_t s);  // dst = 0 (a kernel, not a memset node)
 int launch_copy(float* dst, const float* src, int64_t n, hipStream_t s);  // dst = src (a kernel, not a memcpy node)
 
 // ---- k_conv.hip

@@ -5,6 +5,7 @@
 #include "../../include/dq_hip.h"
 #include "dq_common.h"
 #include "dq_tfm.h"
+#include "dq_kernels.h"
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -282,7 +283,7 @@ int dq_tfm_bwd(dq_tfm* p, const float* params, const float* rope_sin, const floa
   const float* P = params;
   float* G = grads;
   const AttnDims ad{B, S1, Sk, H, p->heads, H / p->heads, up4(Sk)};
-  DQ_HIP_OK(hipMemsetAsync(w.dcp, 0, (size_t)R2 * H * sizeof(float), s));
+  if (int rc = launch_zero(w.dcp, (int64_t)R2 * H, s)) return rc;
   // output projection
   float* dx = w.dxa;
   float* other = w.dxb;

@@ -430,7 +430,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
   const Plan& p = c.p;
   const Arena& a = c.ar;
   const int B = c.B, RT = c.RT, R = B * RT, L = p.levels;
-  DQ_HIP_OK(hipMemsetAsync(c.G, 0, sizeof(float) * a.zero_floats, c.s));  // only the accumulated-into region of the twin
+  DQ_TRY(launch_zero(c.G, a.zero_floats, c.s));  // only the accumulated-into region of the twin (offsets are multiples of 64 floats)
   // head
   DQ_TRY(conv_plain_bwd(c, p.final_conv, CONV_S1, c.w(a.fin.out), grad_out, c.g(a.fin.out), R, p.mz, p.mz, 0));
   const LevelBuf& lastup = a.ups[L - 1];

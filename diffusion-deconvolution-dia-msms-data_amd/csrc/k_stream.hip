@@ -168,6 +168,18 @@ __global__ void __launch_bounds__(256) k_axpy(float* __restrict__ dst, const flo
 __global__ void __launch_bounds__(256) k_copy(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
+__global__ void __launch_bounds__(256) k_zero(float4* __restrict__ dst, int64_t n4) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) dst[i] = float4{0.f, 0.f, 0.f, 0.f};
+}
+// dst[0..n) = 0 as a kernel (n a multiple of 4, dst 16-byte aligned): no memset node in the middle of the step
+int launch_zero(float* dst, int64_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  DQ_REQUIRE(n % 4 == 0 && ((uintptr_t)dst & 15) == 0, "zero: needs a 16-byte aligned buffer of a multiple of 4 floats");
+  hipLaunchKernelGGL(k_zero, dim3((int)std::min<int64_t>(cdiv(n / 4, 256), 8192)), dim3(256), 0, s, reinterpret_cast<float4*>(dst), n / 4);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
 // plain kernel copy: a hipMemcpyAsync in the middle of the step costs far more than its 3 us blit (queue barriers around it)
 int launch_copy(float* dst, const float* src, int64_t n, hipStream_t s) {
   if (n == 0) return 0;
