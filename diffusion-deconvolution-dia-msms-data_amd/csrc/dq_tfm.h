@@ -23,6 +23,7 @@ struct Gemm {
   int batch = 1, inner = 1;
   int64_t sAo = 0, sAi = 0, sBo = 0, sBi = 0, sCo = 0, sCi = 0;
   const float* bias = nullptr;  // (N): added to every row
+  const float* bias_m = nullptr;  // (M): added to every column (a conv bias: rows are output channels); unsplit launches only
   float alpha = 1.f;
   int accumulate = 0;           // C += instead of C =
   // split-K: the reduction is cut into `splits` ranges whose partial products go to `partial` ([split][z][M][N] floats) and

@@ -395,11 +395,22 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     }
     const int64_t qvbs = (int64_t)2 * HID * RT, kbs = (int64_t)HID * RT;
     DQ_TRY(launch_attn_fwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.w(a.lse), B, RT, c.s));
-    ConvFwd f;
-    f.inA = c.w(a.o); f.cinA = HID; f.w = c.prm(p.ao_w); f.bias = c.prm(p.ao_b); f.cout = p.mid_c; f.K = 1;
-    f.rows = B; f.n_in = RT; f.n_out = RT; f.y_out = c.w(a.attn_out);
-    f.resA = c.w(a.mid1.out); f.rcinA = p.mid_c;
-    DQ_TRY(launch_conv_fwd(f, c.s));
+    const ConvP ao = proj(p.ao_w, p.mid_c, HID);
+    if (conv_is_gemm(c, ao, CONV_S1, RT, RT)) {
+      // to_out (1x1 conv, 128 -> mid_c channels, with bias) + the residual: attn_out = x ; attn_out += W o + b as a GEMM per sample
+      DQ_TRY(launch_copy(c.w(a.attn_out), c.w(a.mid1.out), (int64_t)B * p.mid_c * RT, c.s));
+      Gemm g;
+      DQ_TRY(gemm_weight(c, ao, &g.A));
+      g.lda = HID; g.B = c.w(a.o); g.b_kmajor = 0; g.ldb = RT; g.C = c.w(a.attn_out); g.ldc = RT; g.M = p.mid_c; g.N = RT; g.K = HID;
+      g.batch = B; g.sBo = (int64_t)HID * RT; g.sCo = (int64_t)p.mid_c * RT; g.bias_m = c.prm(p.ao_b); g.accumulate = 1;
+      DQ_TRY(launch_gemm(g, c.s));
+    } else {
+      ConvFwd f;
+      f.inA = c.w(a.o); f.cinA = HID; f.w = c.prm(p.ao_w); f.bias = c.prm(p.ao_b); f.cout = p.mid_c; f.K = 1;
+      f.rows = B; f.n_in = RT; f.n_out = RT; f.y_out = c.w(a.attn_out);
+      f.resA = c.w(a.mid1.out); f.rcinA = p.mid_c;
+      DQ_TRY(launch_conv_fwd(f, c.s));
+    }
   }
   DQ_TRY(res_fwd(c, p.mid2, a.mid2, c.w(a.attn_out), p.mid_c, nullptr, 0, B, RT, 1));
   DQ_TRY(launch_fold(c.w(a.mid2.out), c.w(a.mid_back), B, RT, p.mid_c, 0, 0, c.s));

@@ -33,7 +33,7 @@ struct GemmK {
   int64_t lda, ldb, ldc;
   int batch, inner;
   int64_t sAo, sAi, sBo, sBi, sCo, sCi;
-  const float* bias; float alpha; int accumulate;
+  const float* bias; const float* bias_m; float alpha; int accumulate;
   int splits, k_per_split; float* partial;
   int tile_base, mt;  // first tile of this launch; m-tiles of the whole product (tile id = m-tile + mt * n-tile)
 };
@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm(GemmK g) {
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm0 + 32 * i + rmap(r, half);
         if (m >= g.M) continue;
-        C[(int64_t)m * ldc + n] = old[r] + (g.alpha * acc[i][jn][r] + bias);
+        C[(int64_t)m * ldc + n] = old[r] + (g.alpha * acc[i][jn][r] + bias + (g.bias_m ? g.bias_m[m] : 0.f));
       }
     }
 }
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256) k_gemm_split_reduce(GemmK g, int ntiles, 
     }
     for (; sp < g.splits; ++sp) s += P[(int64_t)sp * split_stride + e];
     float* dst = C + (int64_t)m * g.ldc + n;
-    const float v = g.alpha * s + (g.bias ? g.bias[n] : 0.f);
+    const float v = g.alpha * s + (g.bias ? g.bias[n] : 0.f) + (g.bias_m ? g.bias_m[m] : 0.f);
     *dst = g.accumulate ? *dst + v : v;
   }
 }
@@ -335,7 +335,7 @@ int launch_gemm(const Gemm& g, hipStream_t s) {
   GemmK k;
   k.A = g.A; k.B = g.B; k.C = g.C; k.M = g.M; k.N = g.N; k.K = g.K; k.lda = g.lda; k.ldb = g.ldb; k.ldc = g.ldc;
   k.batch = g.batch; k.inner = g.inner; k.sAo = g.sAo; k.sAi = g.sAi; k.sBo = g.sBo; k.sBi = g.sBi; k.sCo = g.sCo; k.sCi = g.sCi;
-  k.bias = g.bias; k.alpha = g.alpha; k.accumulate = g.accumulate;
+  k.bias = g.bias; k.bias_m = g.bias_m; k.alpha = g.alpha; k.accumulate = g.accumulate;
   k.splits = 1; k.k_per_split = 0; k.partial = g.partial; k.tile_base = 0; k.mt = cdiv(g.M, sh.bm);
   const int64_t need = std::max(part_scratch(sh.full, sh.bm, g.batch), part_scratch(sh.rest, sh.bm, g.batch));
   if (need > 0) DQ_REQUIRE(g.partial && g.partial_floats >= need, "gemm: split-K scratch missing or too small");
