@@ -210,13 +210,23 @@ __global__ void __launch_bounds__(64) k_attn_bwd_kv(const float* __restrict__ q,
   const f32x16 Kt = tile_ch_rows(kb, RT, j0, col, half, 1.f);  // rows d, col j
   const f32x16 Vt = tile_ch_rows(vb, RT, j0, col, half, 1.f);  // rows e, col j
   f32x16 dKa = {0}, dVa = {0};                                 // rows d / e, col j
+  // The (rows i, col d) orientations of Q and dO come from the (rows d, col i) tiles through a wave-private LDS transpose: read
+  // from memory in that orientation every lane of a load touches its own cache line (stride RT), 32 loads per tile and query
+  // block.  The next query block's tiles are requested before this block's MFMAs.
+  __shared__ float ttile[32 * 33];
+  f32x16 Qn = tile_ch_rows(qb, RT, 0, col, half, ATT_SCALE), dOn = tile_ch_rows(dob, RT, 0, col, half, 1.f);
+  f32x16 lsn = rows_scalar(lse + (int64_t)bh * RT, RT, 0, half, INFINITY), dln = rows_scalar(delta + (int64_t)bh * RT, RT, 0, half, 0.f);
   for (int i0 = 0; i0 < RT; i0 += 32) {
-    const f32x16 Qt = tile_ch_rows(qb, RT, i0, col, half, ATT_SCALE);   // rows d, col i
-    const f32x16 dOt = tile_ch_rows(dob, RT, i0, col, half, 1.f);       // rows e, col i
-    const f32x16 Qx = tile_pos_rows(qb, RT, i0, col, half, ATT_SCALE);  // rows i, col d
-    const f32x16 dOx = tile_pos_rows(dob, RT, i0, col, half, 1.f);      // rows i, col e
-    const f32x16 lsr = rows_scalar(lse + (int64_t)bh * RT, RT, i0, half, INFINITY);  // exp(s - inf) = 0 masks the tail
-    const f32x16 dlr = rows_scalar(delta + (int64_t)bh * RT, RT, i0, half, 0.f);
+    const f32x16 Qt = Qn, dOt = dOn;      // rows d / e, col i
+    const f32x16 lsr = lsn, dlr = dln;    // lse: exp(s - inf) = 0 masks the tail
+    if (i0 + 32 < RT) {
+      Qn = tile_ch_rows(qb, RT, i0 + 32, col, half, ATT_SCALE);
+      dOn = tile_ch_rows(dob, RT, i0 + 32, col, half, 1.f);
+      lsn = rows_scalar(lse + (int64_t)bh * RT, RT, i0 + 32, half, INFINITY);
+      dln = rows_scalar(delta + (int64_t)bh * RT, RT, i0 + 32, half, 0.f);
+    }
+    const f32x16 Qx = transpose_tile(Qt, ttile, col, half);    // rows i, col d
+    const f32x16 dOx = transpose_tile(dOt, ttile, col, half);  // rows i, col e
     f32x16 S = xty(Qt, Kt, f32x16{0});              // rows i, col j
     f32x16 dP = xty(dOt, Vt, f32x16{0});            // rows i, col j
 #pragma unroll
