@@ -265,19 +265,42 @@ __global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
   // ---- d x[ci][p] = sum_co sum_k W1[co][ci][k] dU1[co][p + 1 - k]  (+ residual branch), accumulated into dA / dB
   if (live && (a.dA || a.dB)) {
     if (a.wr) {
-      for (int ci = 0; ci < cin; ++ci) {
-        float* dst;
-        if (ci < a.cinA) { if (!a.dA) continue; dst = a.dA + ((int64_t)row * a.cinA + ci) * a.n + p; }
-        else { if (!a.dB) continue; dst = a.dB + ((int64_t)row * a.cinB + (ci - a.cinA)) * a.n + p; }
-        float v = 0.f;
-#pragma unroll 4
-        for (int co = 0; co < C; ++co) {
-          const float* w = a.w1 + ((int64_t)co * cin + ci) * 3;
-          const float dr = hasR ? sh[co][threadIdx.x + 2] : 0.f, dc = sh[co][threadIdx.x + 1], dl = hasL ? sh[co][threadIdx.x] : 0.f;
-          v = fmaf(w[0], dr, fmaf(w[1], dc, fmaf(w[2], dl, v)));
-          v = fmaf(a.wr[(int64_t)co * cin + ci], a.dout[obase + (int64_t)co * a.n], v);
+      // All input channels of this position at once (cin <= 2 C: a block input is at most the concatenation of two C-channel
+      // tensors): the taps of dU1 are read from LDS once per output channel instead of once per (ci, co), d out comes from the
+      // registers, and the old values of dA / dB are requested together before the first store -- the former per-channel
+      // `*dst += v` was cin serial round trips (a load behind a store the compiler cannot tell apart waits for it).
+      // Same per-channel summation order as before.
+      constexpr int CM = 2 * C;
+      float v[CM];
+#pragma unroll
+      for (int ci = 0; ci < CM; ++ci) v[ci] = 0.f;
+#pragma unroll
+      for (int co = 0; co < C; ++co) {
+        const float dr = hasR ? sh[co][threadIdx.x + 2] : 0.f, dc = sh[co][threadIdx.x + 1], dl = hasL ? sh[co][threadIdx.x] : 0.f;
+        const float dco = dout[co];
+#pragma unroll
+        for (int ci = 0; ci < CM; ++ci) {
+          if (ci < cin) {
+            const float* w = a.w1 + ((int64_t)co * cin + ci) * 3;
+            v[ci] = fmaf(w[0], dr, fmaf(w[1], dc, fmaf(w[2], dl, v[ci])));
+            v[ci] = fmaf(a.wr[(int64_t)co * cin + ci], dco, v[ci]);
+          }
         }
-        *dst += v;
+      }
+      float oldv[CM];
+#pragma unroll
+      for (int ci = 0; ci < CM; ++ci) {
+        float* dst = nullptr;
+        if (ci < a.cinA) { if (a.dA) dst = a.dA + ((int64_t)row * a.cinA + ci) * a.n + p; }
+        else if (ci < cin) { if (a.dB) dst = a.dB + ((int64_t)row * a.cinB + (ci - a.cinA)) * a.n + p; }
+        oldv[ci] = dst ? *dst : 0.f;
+      }
+#pragma unroll
+      for (int ci = 0; ci < CM; ++ci) {
+        float* dst = nullptr;
+        if (ci < a.cinA) { if (a.dA) dst = a.dA + ((int64_t)row * a.cinA + ci) * a.n + p; }
+        else if (ci < cin) { if (a.dB) dst = a.dB + ((int64_t)row * a.cinB + (ci - a.cinA)) * a.n + p; }
+        if (dst) *dst = oldv[ci] + v[ci];
       }
     } else if (a.dA) {  // identity residual: cin == C, single input
       float dx[C];
@@ -314,6 +337,7 @@ int launch_res_bwd(const ResBwd& a, hipStream_t s) {
   DQ_REQUIRE(res_fusable(a.n, a.C), "res_bwd: row length must divide 256 and C be 4/8/12/16");
   DQ_REQUIRE(a.rows % a.rows_per_sample == 0, "res_bwd: rows must be a multiple of rows_per_sample");
   DQ_REQUIRE(a.wr || (a.cinA == a.C && a.cinB == 0), "res_bwd: identity residual needs C input channels");
+  DQ_REQUIRE(a.cinA + a.cinB <= 2 * a.C, "res_bwd: a block input wider than two C-channel tensors is not built");
   if (res_cp_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_bwd_cp(a, s);
   const int B = a.rows / a.rows_per_sample;
   dim3 grid(cdiv((int64_t)a.rows_per_sample * a.n, 256), B), block(256);
