@@ -21,7 +21,7 @@ int launch_time_embed_bwd(const Plan& p, const DevTables& dt, const float* param
 
 // Activation arena: offsets (in floats) of every tensor the forward produces for a given (B, RT).  The backward's
 // gradient of a tensor lives at the same offset in a second arena of the same size ("twin").
-struct ResBuf { int64_t u1, a1, u2, out; };
+struct ResBuf { int64_t u1, a1, u2, out; int64_t gpart = 0, gpart_floats = 0; };  // gpart: per-block norm-gain sums of the backward
 struct LevelBuf { ResBuf r0, r1; int64_t la, la_pre, la_tmp, rs; };  // la_pre: saved pre-norm LA output; la_tmp: backward scratch (twin only)
 struct Arena {
   int B = 0, RT = 0;

@@ -35,6 +35,9 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
   auto res = [&](int64_t rows, int c, int n) {
     ResBuf r;
     r.u1 = take_nz(rows * c * n); r.a1 = take_nz(rows * c * n); r.u2 = take_nz(rows * c * n); r.out = take(rows * c * n);
+    // one slot per ResnetBlock (the ordered reduce runs on the side stream and may lag behind the next block's backward)
+    r.gpart_floats = (int64_t)B * ((rows / B * n + 255) / 256) * 2 * c;
+    r.gpart = take_nz(r.gpart_floats);
     return r;
   };
   a.tbuf = take((int64_t)B * TBUF_FLOATS);
@@ -179,6 +182,8 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
     k.du1 = c.g(b.u1); k.du2 = c.g(b.u2); k.dA = dA; k.dB = dB; k.cinA = cinA; k.cinB = cinB;
     k.dg1 = c.dprm(r.g1); k.dg2 = c.dprm(r.g2); k.dss = c.g(c.ar.ss) + r.ss_off;
     k.C = r.cout; k.rows = rows; k.n = n; k.rows_per_sample = rows_per_sample;
+    int gblocks = 0;
+    k.gpart = c.w(b.gpart); k.gpart_floats = b.gpart_floats; k.gblocks = &gblocks;
     DQ_TRY(launch_res_bwd(k, c.s));
     // the block's three weight gradients (conv2, conv1, res_conv) in ONE launch + one reduce; each gets a third of the scratch
     ConvWgrad w[3];
@@ -199,6 +204,12 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
       count = 3;
     }
     DQ_TRY(wgrad_async_multi(c, w, count));
+    // the ordered sum of the per-block norm-gain partials: behind the weight gradients on the side stream (which has waited for
+    // the event recorded after k_res_bwd), or on the main stream without one
+    if (gblocks > 0) {
+      hipStream_t rs = (c.owner && c.owner->side_stream) ? c.owner->side_stream : c.s;
+      DQ_TRY(launch_res_gain_reduce(c.w(b.gpart), gblocks, r.cout, c.dprm(r.g2), c.dprm(r.g1), rs));
+    }
     return 0;
   }
   // block2: norm -> silu

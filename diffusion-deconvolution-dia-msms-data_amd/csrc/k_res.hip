@@ -327,10 +327,38 @@ __global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
   __syncthreads();
   for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) {
     const float v = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
-    if (i < C) atomicAdd(a.dg2 + i, v);
-    else if (i < 2 * C) atomicAdd(a.dg1 + (i - C), v);
-    else atomicAdd(a.dss + (int64_t)b * a.ss_stride + (i - 2 * C), v);  // [dscale(C) | dshift(C)]
+    if (i < 2 * C) {
+      if (a.gpart) a.gpart[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * C) + i] = v;  // [dg2 | dg1] of this block
+      else if (i < C) atomicAdd(a.dg2 + i, v);
+      else atomicAdd(a.dg1 + (i - C), v);
+    } else atomicAdd(a.dss + (int64_t)b * a.ss_stride + (i - 2 * C), v);  // [dscale(C) | dshift(C)]: contended per sample only
   }
+}
+
+// dg2[c] += sum_blocks gpart[block][c] ; dg1[c] += sum_blocks gpart[block][C + c] : 256 threads = (256 / 2C groups) x 2C outputs,
+// every group sums a strided share in block order, the groups meet in LDS in group order (fixed order: repeatable)
+__global__ void __launch_bounds__(256) k_res_gain_reduce(const float* __restrict__ gpart, int blocks, int C2, float* __restrict__ dg2,
+                                                         float* __restrict__ dg1) {
+  __shared__ float red[256];
+  const int i = threadIdx.x % C2, g = threadIdx.x / C2, G = 256 / C2;
+  float s = 0.f;
+  if (g < G)
+    for (int j = g; j < blocks; j += G) s += gpart[(int64_t)j * C2 + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < C2) {
+    float t = 0.f;
+    for (int k = 0; k < G; ++k) t += red[k * C2 + threadIdx.x];
+    const int C = C2 / 2;
+    if (threadIdx.x < C) dg2[threadIdx.x] += t;
+    else dg1[threadIdx.x - C] += t;
+  }
+}
+int launch_res_gain_reduce(const float* gpart, int blocks, int C, float* dg2, float* dg1, hipStream_t s) {
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL(k_res_gain_reduce, dim3(1), dim3(256), 0, s, gpart, blocks, 2 * C, dg2, dg1);
+  DQ_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_res_bwd(const ResBwd& a, hipStream_t s) {
@@ -338,14 +366,18 @@ int launch_res_bwd(const ResBwd& a, hipStream_t s) {
   DQ_REQUIRE(a.rows % a.rows_per_sample == 0, "res_bwd: rows must be a multiple of rows_per_sample");
   DQ_REQUIRE(a.wr || (a.cinA == a.C && a.cinB == 0), "res_bwd: identity residual needs C input channels");
   DQ_REQUIRE(a.cinA + a.cinB <= 2 * a.C, "res_bwd: a block input wider than two C-channel tensors is not built");
-  if (res_cp_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_bwd_cp(a, s);
+  if (a.gblocks) *a.gblocks = 0;
+  if (res_cp_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_bwd_cp(a, s);  // (keeps its atomics: few blocks there)
   const int B = a.rows / a.rows_per_sample;
   dim3 grid(cdiv((int64_t)a.rows_per_sample * a.n, 256), B), block(256);
+  ResBwd k = a;
+  if (k.gpart && k.gblocks && k.gpart_floats >= (int64_t)grid.x * grid.y * 2 * a.C) *k.gblocks = (int)(grid.x * grid.y);
+  else k.gpart = nullptr;
   switch (a.C) {
-    case 4: hipLaunchKernelGGL((k_res_bwd<4>), grid, block, 0, s, a); break;
-    case 8: hipLaunchKernelGGL((k_res_bwd<8>), grid, block, 0, s, a); break;
-    case 12: hipLaunchKernelGGL((k_res_bwd<12>), grid, block, 0, s, a); break;
-    case 16: hipLaunchKernelGGL((k_res_bwd<16>), grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((k_res_bwd<4>), grid, block, 0, s, k); break;
+    case 8: hipLaunchKernelGGL((k_res_bwd<8>), grid, block, 0, s, k); break;
+    case 12: hipLaunchKernelGGL((k_res_bwd<12>), grid, block, 0, s, k); break;
+    case 16: hipLaunchKernelGGL((k_res_bwd<16>), grid, block, 0, s, k); break;
   }
   DQ_LAUNCH_CHECK();
   return 0;
