@@ -36,7 +36,7 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
     ResBuf r;
     r.u1 = take_nz(rows * c * n); r.a1 = take_nz(rows * c * n); r.u2 = take_nz(rows * c * n); r.out = take(rows * c * n);
     // one slot per ResnetBlock (the ordered reduce runs on the side stream and may lag behind the next block's backward)
-    r.gpart_floats = (int64_t)B * ((rows / B * n + 255) / 256) * 2 * c;
+    r.gpart_floats = (int64_t)B * std::max((rows / B * n + 255) / 256, (rows / B + 15) / 16) * 2 * c;  // k_res_bwd / k_res_bwd_cp grids
     r.gpart = take_nz(r.gpart_floats);
     return r;
   };

@@ -367,7 +367,7 @@ int launch_res_bwd(const ResBwd& a, hipStream_t s) {
   DQ_REQUIRE(a.wr || (a.cinA == a.C && a.cinB == 0), "res_bwd: identity residual needs C input channels");
   DQ_REQUIRE(a.cinA + a.cinB <= 2 * a.C, "res_bwd: a block input wider than two C-channel tensors is not built");
   if (a.gblocks) *a.gblocks = 0;
-  if (res_cp_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_bwd_cp(a, s);  // (keeps its atomics: few blocks there)
+  if (res_cp_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_bwd_cp(a, s);
   const int B = a.rows / a.rows_per_sample;
   dim3 grid(cdiv((int64_t)a.rows_per_sample * a.n, 256), B), block(256);
   ResBwd k = a;

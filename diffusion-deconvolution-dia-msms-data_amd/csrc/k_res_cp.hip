@@ -347,7 +347,8 @@ __global__ void __launch_bounds__(256) k_res_bwd_cp(ResBwd a) {
 #pragma unroll
     for (int r = 0; r < GR; ++r) v += red[r][what * 16 + c];
     if (c < C) {
-      if (what == 0) atomicAdd(a.dg2 + c, v);
+      if (what < 2 && a.gpart) a.gpart[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * C) + what * C + c] = v;  // [dg2 | dg1]
+      else if (what == 0) atomicAdd(a.dg2 + c, v);
       else if (what == 1) atomicAdd(a.dg1 + c, v);
       else if (what == 2) atomicAdd(a.dss + (int64_t)b * a.ss_stride + c, v);
       else atomicAdd(a.dss + (int64_t)b * a.ss_stride + C + c, v);
@@ -377,8 +378,11 @@ int launch_res_fwd_cp(const ResFwd& a, hipStream_t s) {
 int launch_res_bwd_cp(const ResBwd& a, hipStream_t s) {
   const int B = a.rows / a.rows_per_sample;
   dim3 grid(cdiv(a.rows_per_sample, GR), B), block(256);
+  ResBwd k = a;  // norm-gain partials (see ResBwd::gpart): used when the caller's slot holds one entry per block
+  if (k.gpart && k.gblocks && k.gpart_floats >= (int64_t)grid.x * grid.y * 2 * a.C) *k.gblocks = (int)(grid.x * grid.y);
+  else k.gpart = nullptr;
 #define DQ_CP(CC, NN) \
-  if (a.C == CC && a.n == NN) { hipLaunchKernelGGL((k_res_bwd_cp<CC, NN>), grid, block, 0, s, a); DQ_LAUNCH_CHECK(); return 0; }
+  if (a.C == CC && a.n == NN) { hipLaunchKernelGGL((k_res_bwd_cp<CC, NN>), grid, block, 0, s, k); DQ_LAUNCH_CHECK(); return 0; }
   DQ_CP(12, 1) DQ_CP(12, 2) DQ_CP(12, 4) DQ_CP(12, 8) DQ_CP(16, 1) DQ_CP(16, 2) DQ_CP(16, 4) DQ_CP(16, 8)
 #undef DQ_CP
   set_error("res_bwd_cp: unsupported (C, n)");
