@@ -304,7 +304,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10)  # a fresh box needs ~50 ms of work before its clocks settle
     ap.add_argument("--no-sample", action="store_true", help="skip the sampling leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-transformer", action="store_true", help="skip the CustomTransformer leg (rank 0, single-GPU runs only)")
