@@ -330,15 +330,22 @@ __global__ void __launch_bounds__(256) k_conv_bwd_data(ConvBwdData a) {
       }
     }
   }
+  // the old values of an accumulating launch are all requested before the first store (a `*dst += v` per channel is NCI serial
+  // round trips: the next load may not pass the previous store)
+  float* dsts[NCI];
+  float oldv[NCI];
 #pragma unroll
   for (int i = 0; i < NCI; ++i) {
     const int ci = ci0 + i;
-    if (ci >= cin) continue;
-    float* dst;
-    if (ci < a.cinA) { if (!a.dinA) continue; dst = a.dinA + ((int64_t)row * a.cinA + ci) * a.n_in + m; }
-    else { if (!a.dinB) continue; dst = a.dinB + ((int64_t)row * a.cinB + (ci - a.cinA)) * a.n_in + m; }
-    *dst = a.accumulate ? *dst + acc[i] : acc[i];
+    float* dst = nullptr;
+    if (ci < a.cinA) { if (a.dinA) dst = a.dinA + ((int64_t)row * a.cinA + ci) * a.n_in + m; }
+    else if (ci < cin) { if (a.dinB) dst = a.dinB + ((int64_t)row * a.cinB + (ci - a.cinA)) * a.n_in + m; }
+    dsts[i] = dst;
+    oldv[i] = (dst && a.accumulate) ? *dst : 0.f;
   }
+#pragma unroll
+  for (int i = 0; i < NCI; ++i)
+    if (dsts[i]) *dsts[i] = oldv[i] + acc[i];
 }
 
 int launch_conv_bwd_data(const ConvBwdData& a, hipStream_t s) {
