@@ -572,6 +572,20 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
       }
 
       // ---- d xh of this head: both halves' partial sums, then each lane keeps its own channels
+      if (!PREFETCH) {
+        // no registers to hold these across the MFMA work: requested here, but all of them before the first store below (a
+        // load placed after a store to the same array waits for it -- 8 serial round trips per unit and head otherwise)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int c = rmap(j, half);
+            const int64_t off = ((int64_t)row * C + c) * N + (N >= 32 ? b * 32 + col : col % N);
+            const bool ok = row_ok && c < C;
+            pdxh[b][j] = (ok && hd > 0) ? a.dxh[off] : 0.f;
+            pdx[b][j] = (ok && hd == 3) ? a.dx[off] : 0.f;
+          }
+      }
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const int pos = N >= 32 ? b * 32 + col : col % N;
@@ -586,7 +600,7 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
           if (row_ok && c < C) {
             float* dst = a.dxh + ((int64_t)row * C + c) * N + pos;
             // head 0 initialises, heads 1, 2 accumulate (same lane, same address); C > 8 has no registers for the prefetch
-            const float prev = PREFETCH ? pdxh[b][j] : (hd > 0 ? *dst : 0.f);
+            const float prev = pdxh[b][j];
             if (hd < 3) *dst = prev + val;
             else lo = prev + val;
           }
@@ -622,7 +636,7 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
             if (row_ok && c < C) {
               const int64_t off = ((int64_t)row * C + c) * N + pos;
               const float du = clamped ? tot[j] * inv : inv * (tot[j] - xv[j] * dot);
-              a.dx[off] = ((PREFETCH ? pdx[b][j] : a.dx[off]) + cd[b][j]) + du;  // cd: raw dy of this unit, still in registers
+              a.dx[off] = (pdx[b][j] + cd[b][j]) + du;  // cd: raw dy of this unit, still in registers
             }
           }
         }
