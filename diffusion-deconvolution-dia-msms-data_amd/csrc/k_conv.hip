@@ -218,11 +218,13 @@ __global__ void __launch_bounds__(256) k_block_bwd(BlockBwd a) {
         d[c] = dw * sc[c];
       }
     }
+    float oldv[C];  // an accumulating launch reads all C old values before its first store
+#pragma unroll
+    for (int c = 0; c < C; ++c) oldv[c] = a.accumulate ? a.du[base + (int64_t)c * a.n] : 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       dbs[c] += d[c];
-      float* dst = a.du + base + (int64_t)c * a.n;
-      *dst = a.accumulate ? *dst + d[c] : d[c];
+      a.du[base + (int64_t)c * a.n] = oldv[c] + d[c];
     }
   }
 

@@ -263,13 +263,16 @@ __global__ void __launch_bounds__(256) k_linattn_fwd_long(LinAttn a) {
     }
     ssq += swap_half(ssq);
     const float inv = sqrtf((float)C) / fmaxf(sqrtf(ssq), RMS_EPS);
+    float go[NJ];  // gains read before the first store of this position (a load behind a store waits for it)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) go[j] = rmap(j, half) < C ? a.g_out[rmap(j, half)] : 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int c = rmap(j, half);
       if (c < C) {
         const int64_t off = (row * C + c) * N + pos;
         if (a.ypre) a.ypre[off] = yv[j];
-        a.y[off] = fmaf(yv[j] * a.g_out[c], inv, x[j]);
+        a.y[off] = fmaf(yv[j] * go[j], inv, x[j]);
       }
     }
   }

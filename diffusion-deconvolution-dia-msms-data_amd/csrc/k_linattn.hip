@@ -308,7 +308,15 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
     }
   }
 
-  // ---- bias, post-norm, residual, store (this lane's channels c = rowmap(j, half))
+  // ---- bias, post-norm, residual, store (this lane's channels c = rowmap(j, half)).  The gains and biases are read before the
+  // first store: a load issued after a store waits for it, and the loop below would be 2 NJ serial round trips per block
+  float gout_r[NJ], bout_r[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = rowmap(j, half);
+    gout_r[j] = c < C ? a.g_out[c] : 0.f;
+    bout_r[j] = c < C ? a.b_out[c] : 0.f;
+  }
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk) {
     const int pos = N >= 32 ? blk * 32 + col : col % N;
@@ -317,7 +325,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int c = rowmap(j, half);
-      yv[j] = c < C ? yown[blk][j] + a.b_out[c] : 0.f;
+      yv[j] = c < C ? yown[blk][j] + bout_r[j] : 0.f;
       ssq = fmaf(yv[j], yv[j], ssq);
     }
     ssq += swap32(ssq);
@@ -328,7 +336,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
       if (row_ok && c < C) {
         const int64_t off = ((int64_t)row * C + c) * N + pos;
         if (a.ypre) a.ypre[off] = yv[j];
-        a.y[off] = fmaf(yv[j] * a.g_out[c], inv, X[blk][j]);
+        a.y[off] = fmaf(yv[j] * gout_r[j], inv, X[blk][j]);
       }
     }
   }
