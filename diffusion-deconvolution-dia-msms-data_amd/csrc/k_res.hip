@@ -335,28 +335,38 @@ __global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
   }
 }
 
-// dg2[c] += sum_blocks gpart[block][c] ; dg1[c] += sum_blocks gpart[block][C + c] : 256 threads = (256 / 2C groups) x 2C outputs,
-// every group sums a strided share in block order, the groups meet in LDS in group order (fixed order: repeatable)
+// dg2[c] += sum_blocks gpart[block][c] ; dg1[c] += sum_blocks gpart[block][C + c] : one block per output, 256 threads sum a
+// strided share in block order and meet in LDS in thread order (fixed order: repeatable)
 __global__ void __launch_bounds__(256) k_res_gain_reduce(const float* __restrict__ gpart, int blocks, int C2, float* __restrict__ dg2,
                                                          float* __restrict__ dg1) {
   __shared__ float red[256];
-  const int i = threadIdx.x % C2, g = threadIdx.x / C2, G = 256 / C2;
-  float s = 0.f;
-  if (g < G)
-    for (int j = g; j < blocks; j += G) s += gpart[(int64_t)j * C2 + i];
-  red[threadIdx.x] = s;
+  const int i = blockIdx.x;
+  float s0 = 0.f, s1 = 0.f;
+  int j = threadIdx.x;
+  for (; j + 256 < blocks; j += 512) {
+    s0 += gpart[(int64_t)j * C2 + i];
+    s1 += gpart[(int64_t)(j + 256) * C2 + i];
+  }
+  if (j < blocks) s0 += gpart[(int64_t)j * C2 + i];
+  red[threadIdx.x] = s0 + s1;
   __syncthreads();
-  if (threadIdx.x < C2) {
+  if (threadIdx.x < 16) {  // 16 threads x 16 consecutive partials, then one thread over the 16
     float t = 0.f;
-    for (int k = 0; k < G; ++k) t += red[k * C2 + threadIdx.x];
+    for (int k = 0; k < 16; ++k) t += red[threadIdx.x * 16 + k];
+    red[threadIdx.x * 16] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int k = 0; k < 16; ++k) t += red[k * 16];
     const int C = C2 / 2;
-    if (threadIdx.x < C) dg2[threadIdx.x] += t;
-    else dg1[threadIdx.x - C] += t;
+    if (i < C) dg2[i] += t;
+    else dg1[i - C] += t;
   }
 }
 int launch_res_gain_reduce(const float* gpart, int blocks, int C, float* dg2, float* dg1, hipStream_t s) {
   if (blocks == 0) return 0;
-  hipLaunchKernelGGL(k_res_gain_reduce, dim3(1), dim3(256), 0, s, gpart, blocks, 2 * C, dg2, dg1);
+  hipLaunchKernelGGL(k_res_gain_reduce, dim3(2 * C), dim3(256), 0, s, gpart, blocks, 2 * C, dg2, dg1);
   DQ_LAUNCH_CHECK();
   return 0;
 }
