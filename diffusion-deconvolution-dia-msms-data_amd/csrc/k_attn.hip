@@ -195,12 +195,15 @@ __global__ void __launch_bounds__(64) k_attn_bwd_q(const float* __restrict__ q, 
 }
 
 // ---- backward, key side: dV_j = sum_i P_ij dO_i ; dK_j = 32^-0.5 * sum_i P_ij (dP_ij - delta_i) Q_i
-__global__ void __launch_bounds__(64) k_attn_bwd_kv(const float* __restrict__ q, int64_t q_bs, const float* __restrict__ k,
-                                                    int64_t k_bs, const float* __restrict__ v, int64_t v_bs,
-                                                    const float* __restrict__ d_o, const float* __restrict__ lse,
-                                                    const float* __restrict__ delta, float* __restrict__ dk, int64_t dk_bs,
-                                                    float* __restrict__ dv, int64_t dv_bs, int RT) {
-  const int lane = threadIdx.x, col = lane & 31, half = lane >> 5;
+// Four waves per key block, each taking every fourth query block (the query loop of one wave is a serial chain of ~13 steps
+// with one or two waves per SIMD to hide it: 207 us at batch 32); the four partial (dK, dV) tiles meet in LDS and are summed
+// in wave order by wave 0 (fixed order: repeatable).
+__global__ void __launch_bounds__(256, 2) k_attn_bwd_kv(const float* __restrict__ q, int64_t q_bs, const float* __restrict__ k,
+                                                     int64_t k_bs, const float* __restrict__ v, int64_t v_bs,
+                                                     const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                     const float* __restrict__ delta, float* __restrict__ dk, int64_t dk_bs,
+                                                     float* __restrict__ dv, int64_t dv_bs, int RT) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
   const int bh = blockIdx.y, b = bh >> 2, h = bh & 3;
   const int j0 = blockIdx.x * 32, j = j0 + col;
   const float* qb = q + b * q_bs + (int64_t)h * 32 * RT;
@@ -210,21 +213,14 @@ __global__ void __launch_bounds__(64) k_attn_bwd_kv(const float* __restrict__ q,
   const f32x16 Kt = tile_ch_rows(kb, RT, j0, col, half, 1.f);  // rows d, col j
   const f32x16 Vt = tile_ch_rows(vb, RT, j0, col, half, 1.f);  // rows e, col j
   f32x16 dKa = {0}, dVa = {0};                                 // rows d / e, col j
-  // The (rows i, col d) orientations of Q and dO come from the (rows d, col i) tiles through a wave-private LDS transpose: read
-  // from memory in that orientation every lane of a load touches its own cache line (stride RT), 32 loads per tile and query
-  // block.  The next query block's tiles are requested before this block's MFMAs.
-  __shared__ float ttile[32 * 33];
-  f32x16 Qn = tile_ch_rows(qb, RT, 0, col, half, ATT_SCALE), dOn = tile_ch_rows(dob, RT, 0, col, half, 1.f);
-  f32x16 lsn = rows_scalar(lse + (int64_t)bh * RT, RT, 0, half, INFINITY), dln = rows_scalar(delta + (int64_t)bh * RT, RT, 0, half, 0.f);
-  for (int i0 = 0; i0 < RT; i0 += 32) {
-    const f32x16 Qt = Qn, dOt = dOn;      // rows d / e, col i
-    const f32x16 lsr = lsn, dlr = dln;    // lse: exp(s - inf) = 0 masks the tail
-    if (i0 + 32 < RT) {
-      Qn = tile_ch_rows(qb, RT, i0 + 32, col, half, ATT_SCALE);
-      dOn = tile_ch_rows(dob, RT, i0 + 32, col, half, 1.f);
-      lsn = rows_scalar(lse + (int64_t)bh * RT, RT, i0 + 32, half, INFINITY);
-      dln = rows_scalar(delta + (int64_t)bh * RT, RT, i0 + 32, half, 0.f);
-    }
+  // The (rows i, col d) orientations of Q and dO come from the (rows d, col i) tiles through a wave-private LDS transpose.
+  __shared__ float ttiles[4][32 * 33];
+  __shared__ float acc_lds[3][2][16][64];  // partial (dK, dV) of waves 1..3
+  float* ttile = ttiles[wv];
+  for (int i0 = wv * 32; i0 < RT; i0 += 128) {
+    const f32x16 Qt = tile_ch_rows(qb, RT, i0, col, half, ATT_SCALE), dOt = tile_ch_rows(dob, RT, i0, col, half, 1.f);  // rows d / e, col i
+    const f32x16 lsr = rows_scalar(lse + (int64_t)bh * RT, RT, i0, half, INFINITY);  // exp(s - inf) = 0 masks the tail
+    const f32x16 dlr = rows_scalar(delta + (int64_t)bh * RT, RT, i0, half, 0.f);
     const f32x16 Qx = transpose_tile(Qt, ttile, col, half);    // rows i, col d
     const f32x16 dOx = transpose_tile(dOt, ttile, col, half);  // rows i, col e
     f32x16 S = xty(Qt, Kt, f32x16{0});              // rows i, col j
@@ -237,13 +233,20 @@ __global__ void __launch_bounds__(64) k_attn_bwd_kv(const float* __restrict__ q,
     dVa = xty(dOx, S, dVa);
     dKa = xty(Qx, dP, dKa);
   }
-  if (j < RT) {
+  if (wv > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc_lds[wv - 1][0][r][lane] = dKa[r]; acc_lds[wv - 1][1][r][lane] = dVa[r]; }
+  }
+  __syncthreads();
+  if (wv == 0 && j < RT) {
     float* dkb = dk + b * dk_bs + (int64_t)h * 32 * RT;
     float* dvb = dv + b * dv_bs + (int64_t)h * 32 * RT;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      dkb[(int64_t)rmap(r, half) * RT + j] = dKa[r];  // Qx already carries the 32^-0.5
-      dvb[(int64_t)rmap(r, half) * RT + j] = dVa[r];
+      const float sk = ((dKa[r] + acc_lds[0][0][r][lane]) + acc_lds[1][0][r][lane]) + acc_lds[2][0][r][lane];
+      const float sv = ((dVa[r] + acc_lds[0][1][r][lane]) + acc_lds[1][1][r][lane]) + acc_lds[2][1][r][lane];
+      dkb[(int64_t)rmap(r, half) * RT + j] = sk;  // Qx already carries the 32^-0.5
+      dvb[(int64_t)rmap(r, half) * RT + j] = sv;
     }
   }
 }
@@ -255,7 +258,7 @@ int launch_attn_bwd(const float* q, int64_t q_bs, const float* k, int64_t k_bs, 
   dim3 grid(cdiv(RT, 32), B * 4), block(64);
   hipLaunchKernelGGL(k_attn_bwd_q, grid, block, 0, s, q, q_bs, k, k_bs, v, v_bs, o, d_o, lse, delta, dq, dq_bs, RT);
   DQ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_attn_bwd_kv, grid, block, 0, s, q, q_bs, k, k_bs, v, v_bs, d_o, lse, delta, dk, dk_bs, dv, dv_bs, RT);
+  hipLaunchKernelGGL(k_attn_bwd_kv, grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, d_o, lse, delta, dk, dk_bs, dv, dv_bs, RT);
   DQ_LAUNCH_CHECK();
   return 0;
 }
