@@ -301,6 +301,11 @@ def log(msg):
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON: anything libraries print there (RCCL's version banner at process-group creation,
+    # for one) is sent to stderr by pointing fd 1 at fd 2 for the duration of the run
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -401,7 +406,8 @@ def main():
             "last_loss": round(last_loss, 6),
             "sample": sample, "roofline": roof, "cpu_baseline": cpu, "batch_formation": form, "transformer": tfm,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist_on:
         torch.distributed.destroy_process_group()
 
