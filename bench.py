@@ -409,6 +409,7 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist_on:
+        torch.distributed.barrier()  # rank 0 ran the extra single-rank legs: leave together
         torch.distributed.destroy_process_group()
 
 

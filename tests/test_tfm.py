@@ -248,3 +248,62 @@ def test_ddim_adapter_trains_the_transformer():
     assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
     xs, noise = dm.sample(torch.randn(2, 10, 64, device="cuda"), c2, c1, num_steps=3)
     assert xs.shape == (2, 10, 64) and torch.isfinite(xs).all()
+
+
+# ------------------------------------------------------------------------------------------------ data-parallel (CPU, gloo)
+def _dp_worker(rank, world, port, q):
+    import os
+    import sys
+
+    import torch.distributed as dist
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    sys.path.insert(0, os.path.join(repo, "diffusion-deconvolution-dia-msms-data_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dquartic.model.building_blocks import CustomTransformer, DDIMTransformerAdapter
+        from oracle import dq_oracle_tfm as O
+
+        D, H, heads, layers = 24, 16, 2, 1
+        params = O.init_params(D, H, layers, seed=1)
+        net = DDIMTransformerAdapter(CustomTransformer(D, H, heads, layers))
+        net.load_state_dict(params)
+        g = torch.Generator().manual_seed(3)
+        X, C, T = torch.randn(4, 5, D, generator=g), torch.randn(4, 3, generator=g), torch.tensor([1, 50, 700, 999])
+        probe = torch.randn(4, 5, D, generator=g)
+
+        def flat_grad(idx):  # gradient of the mean over `idx` of the per-sample objective, in the module's flat layout
+            p = {k: v.clone().requires_grad_() for k, v in params.items()}
+            y = O.forward(p, X[idx], T[idx], C[idx], heads)
+            ((y * probe[idx]).flatten(1).sum(1)).mean().backward()
+            return torch.cat([p[n].grad.reshape(-1) for n, _ in net.trainable_named()])
+
+        mine = list(range(rank, 4, world))  # rank r owns windows r, r + world, ...
+        buf = net.flat_grads(zero=True)
+        buf.copy_(flat_grad(mine))
+        dist.all_reduce(buf)  # the ONE exchange step of the train step (model_interface.py: flat RCCL all-reduce)
+        buf.mul_(1.0 / world)  # FlatAdamW.grad_scale
+        ref = flat_grad(list(range(4)))
+        q.put((rank, float((buf - ref).abs().max() / ref.abs().max()), buf.numel()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_transformer_data_parallel_exchange_gloo_world2():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29631
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    out = sorted(q.get(timeout=5) for _ in range(2))
+    assert [r for r, _, _ in out] == [0, 1]
+    for _, err, n in out:
+        assert err < 1e-5 and n > 0
+    assert all(p.exitcode == 0 for p in procs)
