@@ -115,7 +115,7 @@ def roofline_linattn(device):
             "unit": "TFLOP/s", "frac": round(ach_b / F32_MFMA_PEAK_TFLOPS, 4),
             # HBM-side bytes per launch from the PMC passes of this shape (profiles/r01_pmc_linattn.md: 2 x FETCH_SIZE +
             # WRITE_SIZE, FETCH_SIZE calibrated on k_q_sample); PMC cannot be collected inside this process
-            "traffic": 302.7e6,
+            "traffic": 290.4e6,
             "launch_us": round(t_b * 1e6, 2), "flops_per_launch": 2 * fl_f,
             "executed_flops_per_launch": ex_b, "executed_frac": round(ex_b / t_b / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
             "fwd_kernel": {"kernel": "k_linattn_fwd<4,64>", "achieved": round(ach_f, 3), "frac": round(ach_f / F32_MFMA_PEAK_TFLOPS, 4),
