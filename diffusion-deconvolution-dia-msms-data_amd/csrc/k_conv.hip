@@ -279,10 +279,23 @@ template <int NCI, int K, int MODE>
 __global__ void __launch_bounds__(256) k_conv_bwd_data(ConvBwdData a) {
   const int64_t item = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)a.rows * a.n_in;
-  if (item >= total) return;
-  const int row = (int)(item / a.n_in), m = (int)(item % a.n_in);
   const int cin = a.cinA + a.cinB;
   const int ci0 = blockIdx.y * NCI;
+  // This block's weights W[co][ci0 .. ci0 + NCI)[k] staged in LDS once: read from memory inside the output-channel loop they are
+  // a scalar load per iteration that nothing overlaps -- at the deep levels (a few hundred waves) the kernel was a chain of
+  // cout such round trips, 30-50 us whatever the level's size
+  constexpr int WSH = 4096;
+  __shared__ float wsh[WSH];
+  const bool use_lds = a.cout * NCI * K <= WSH;
+  if (use_lds) {
+    for (int i = threadIdx.x; i < a.cout * NCI * K; i += blockDim.x) {
+      const int co = i / (NCI * K), r = i - co * (NCI * K), ci = ci0 + r / K, k = r % K;
+      wsh[i] = ci < cin ? a.w[((int64_t)co * cin + ci) * K + k] : 0.f;
+    }
+    __syncthreads();
+  }
+  if (item >= total) return;
+  const int row = (int)(item / a.n_in), m = (int)(item % a.n_in);
 
   // contributing (p, k) pairs of input position m
   constexpr int NT = (MODE == CONV_S1) ? K : (MODE == CONV_DOWN ? 2 : 6);
@@ -319,16 +332,31 @@ __global__ void __launch_bounds__(256) k_conv_bwd_data(ConvBwdData a) {
   float acc[NCI];
 #pragma unroll
   for (int i = 0; i < NCI; ++i) acc[i] = 0.f;
-  for (int co = 0; co < a.cout; ++co) {
-    const float* du = a.du + ((int64_t)row * a.cout + co) * a.n_out;
-    const float* w = a.w + (int64_t)co * cin * K;
+  if (use_lds) {
+#pragma unroll 2
+    for (int co = 0; co < a.cout; ++co) {
+      const float* du = a.du + ((int64_t)row * a.cout + co) * a.n_out;
+      const float* w = wsh + co * (NCI * K);
+      float dv[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const float dv = tp[t] >= 0 ? du[tp[t]] : 0.f;
+      for (int t = 0; t < NT; ++t) dv[t] = tp[t] >= 0 ? du[tp[t]] : 0.f;
 #pragma unroll
-      for (int i = 0; i < NCI; ++i) {
-        const int ci = ci0 + i;
-        if (ci < cin) acc[i] = fmaf(w[(int64_t)ci * K + tk[t]], dv, acc[i]);
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < NCI; ++i) acc[i] = fmaf(w[i * K + tk[t]], dv[t], acc[i]);  // (zero weights beyond cin)
+    }
+  } else {
+    for (int co = 0; co < a.cout; ++co) {
+      const float* du = a.du + ((int64_t)row * a.cout + co) * a.n_out;
+      const float* w = a.w + (int64_t)co * cin * K;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float dv = tp[t] >= 0 ? du[tp[t]] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NCI; ++i) {
+          const int ci = ci0 + i;
+          if (ci < cin) acc[i] = fmaf(w[(int64_t)ci * K + tk[t]], dv, acc[i]);
+        }
       }
     }
   }
