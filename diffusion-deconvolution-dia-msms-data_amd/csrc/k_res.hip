@@ -207,6 +207,16 @@ template <int C>
 __global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
   __shared__ float sh[C][256 + 2];
   __shared__ float red[4][4 * C];
+  // the block's weights in LDS: read from memory inside the channel loops they are scalar loads that nothing overlaps
+  __shared__ float w2s[C * C * 3], w1s[C * 2 * C * 3], wrs[C * 2 * C];
+  {
+    const int cin_ = a.cinA + a.cinB;  // <= 2 C (checked by the launcher)
+    for (int i = threadIdx.x; i < C * C * 3; i += blockDim.x) w2s[i] = a.w2[i];
+    for (int i = threadIdx.x; i < C * cin_ * 3; i += blockDim.x) w1s[i] = a.w1[i];
+    if (a.wr)
+      for (int i = threadIdx.x; i < C * cin_; i += blockDim.x) wrs[i] = a.wr[i];
+    __syncthreads();
+  }
   const int b = blockIdx.y;
   const int per_sample = a.rows_per_sample * a.n;
   const bool wave_local = a.n <= 64 && (64 % a.n) == 0;
@@ -246,7 +256,7 @@ __global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
 #pragma unroll 1
   for (int co = 0; co < C; ++co) {
     const float dr = hasR ? sh[co][threadIdx.x + 2] : 0.f, dc = sh[co][threadIdx.x + 1], dl = hasL ? sh[co][threadIdx.x] : 0.f;
-    const float* w = a.w2 + (int64_t)co * C * 3;
+    const float* w = w2s + co * C * 3;
 #pragma unroll
     for (int ci = 0; ci < C; ++ci) da1[ci] = fmaf(w[ci * 3 + 0], dr, fmaf(w[ci * 3 + 1], dc, fmaf(w[ci * 3 + 2], dl, da1[ci])));
   }
@@ -281,9 +291,9 @@ __global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
 #pragma unroll
         for (int ci = 0; ci < CM; ++ci) {
           if (ci < cin) {
-            const float* w = a.w1 + ((int64_t)co * cin + ci) * 3;
+            const float* w = w1s + (co * cin + ci) * 3;
             v[ci] = fmaf(w[0], dr, fmaf(w[1], dc, fmaf(w[2], dl, v[ci])));
-            v[ci] = fmaf(a.wr[(int64_t)co * cin + ci], dco, v[ci]);
+            v[ci] = fmaf(wrs[co * cin + ci], dco, v[ci]);
           }
         }
       }
@@ -309,7 +319,7 @@ __global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
 #pragma unroll 1
       for (int co = 0; co < C; ++co) {
         const float dr = hasR ? sh[co][threadIdx.x + 2] : 0.f, dc = sh[co][threadIdx.x + 1], dl = hasL ? sh[co][threadIdx.x] : 0.f;
-        const float* w = a.w1 + (int64_t)co * C * 3;
+        const float* w = w1s + co * C * 3;
 #pragma unroll
         for (int ci = 0; ci < C; ++ci) dx[ci] = fmaf(w[ci * 3 + 0], dr, fmaf(w[ci * 3 + 1], dc, fmaf(w[ci * 3 + 2], dl, dx[ci])));
       }
