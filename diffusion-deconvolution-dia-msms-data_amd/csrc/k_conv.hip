@@ -35,10 +35,23 @@ template <int COUT, int K, int MODE>
 __global__ void __launch_bounds__(256) k_conv_fwd(ConvFwd a) {
   const int64_t item = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)a.rows * a.n_out;
-  if (item >= total) return;
-  const int row = (int)(item / a.n_out), p = (int)(item % a.n_out);
   const int co_base = blockIdx.y * COUT;  // output-channel chunk (only for the norm-free 1x1 projections)
   const int cin = a.cinA + a.cinB;
+  // this block's weights, transposed to [ci][co][k], in LDS: inside the input-channel loop they were COUT x K scattered scalar
+  // loads per iteration with nothing to overlap them
+  constexpr int WSH = 4096;
+  __shared__ __attribute__((aligned(16))) float wsh[WSH];
+  const bool use_lds = COUT * cin * K <= WSH;
+  if (use_lds) {
+    const float* wg = a.w + (int64_t)co_base * cin * K;
+    for (int i = threadIdx.x; i < COUT * cin * K; i += blockDim.x) {
+      const int co = i / (cin * K), r = i - co * (cin * K), ci = r / K, k = r - ci * K;
+      wsh[(ci * COUT + co) * K + k] = wg[i];
+    }
+    __syncthreads();
+  }
+  if (item >= total) return;
+  const int row = (int)(item / a.n_out), p = (int)(item % a.n_out);
 
   float acc[COUT];
 #pragma unroll
@@ -55,10 +68,19 @@ __global__ void __launch_bounds__(256) k_conv_fwd(ConvFwd a) {
     float xv[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) xv[k] = q[k] >= 0 ? src[q[k]] : 0.f;
+    if (use_lds) {
+      const float* wl = wsh + ci * (COUT * K);
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) {
+      for (int co = 0; co < COUT; ++co) {
 #pragma unroll
-      for (int k = 0; k < K; ++k) acc[co] = fmaf(w[((int64_t)co * cin + ci) * K + k], xv[k], acc[co]);
+        for (int k = 0; k < K; ++k) acc[co] = fmaf(wl[co * K + k], xv[k], acc[co]);
+      }
+    } else {
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[co] = fmaf(w[((int64_t)co * cin + ci) * K + k], xv[k], acc[co]);
+      }
     }
   }
 
