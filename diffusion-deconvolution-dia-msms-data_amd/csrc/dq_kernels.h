@@ -142,8 +142,15 @@ struct LinAttn {
   const float* g_pre = nullptr; const float* g_out = nullptr;
   int C = 0, rows = 0, n = 0;
   float* ypre = nullptr;  // optional: pre-norm output Wo*out + b (rows, C, n), saved for the backward
+  // optional: this layer's LA_PREP_FLOATS prepared weights from launch_linattn_prepare (W2 = Wo Wv per head and the MFMA operand
+  // image of Wq | Wk); without it every block of the forward derives them itself (a 64-load-deep prologue per 4 rows)
+  const float* prep = nullptr;
 };
 int launch_linattn_fwd(const LinAttn& a, hipStream_t s);
+constexpr int LA_PREP_FLOATS = 1024 + 4096;  // [w2: 4 * 16 * 16][wqk: 2 * 4 * 8 * 2 * 32]
+struct LaPrepItem { const float* w_qkv; const float* w_out; int C; float* prep; };
+constexpr int LA_PREP_MAX = 16;
+int launch_linattn_prepare(const LaPrepItem* items, int count, hipStream_t s);  // all LinearAttention layers of a forward: one launch
 struct LinAttnBwd {
   LinAttn f;
   const float* dy = nullptr; float* dx = nullptr;  // dx +=

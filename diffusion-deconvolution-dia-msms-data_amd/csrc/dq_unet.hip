@@ -86,6 +86,7 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
   for (const LevelP& l : p.ups) a.la_part_floats += la_part_reserve(l.la.C);
   a.la_part_floats = std::max<int64_t>(a.la_part_floats, (int64_t)LA_MAX_WAVES * 512 * 16);
   a.la_part = take_nz(a.la_part_floats);
+  a.la_prep = take_nz((int64_t)LA_PREP_MAX * LA_PREP_FLOATS);  // prepared LinearAttention weights, one slot per layer (downs, then ups)
   a.wtmp = take_nz(2 * HID * 64);  // 16-byte aligned copy of a projection weight for the GEMM route of the wide 1x1 convs
   a.ts_tab = take_nz(1024); a.step = take_nz(64);  // graph replay: timestep table (int32) and the device-side step counter
   a.c2_stage = take_nz(R * p.mz); a.c1_stage = take_nz(R);  // conditions staged at fixed addresses for the captured step
@@ -263,11 +264,28 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
   return 0;
 }
 
-int la_fwd(const Ctx& c, const LAP& l, const float* x, float* y, float* ypre, int rows, int n) {
+// slot: this layer's index in the prepared-weights buffer (la_prepare_all), or -1
+int la_fwd(const Ctx& c, const LAP& l, const float* x, float* y, float* ypre, int rows, int n, int slot = -1) {
   LinAttn a;
   a.x = x; a.y = y; a.ypre = ypre; a.w_qkv = c.prm(l.qkv_w); a.w_out = c.prm(l.out_w); a.b_out = c.prm(l.out_b);
   a.g_pre = c.prm(l.g_pre); a.g_out = c.prm(l.g_out); a.C = l.C; a.rows = rows; a.n = n;
+  if (slot >= 0 && n <= 64) a.prep = c.w(c.ar.la_prep) + (int64_t)slot * LA_PREP_FLOATS;
   return launch_linattn_fwd(a, c.s);
+}
+// W2 = Wo Wv and the MFMA operand image of Wq | Wk of every LinearAttention layer, once per forward (one launch) instead of once
+// per block of every layer's kernel
+int la_prepare_all(const Ctx& c) {
+  const Plan& p = c.p;
+  LaPrepItem items[LA_PREP_MAX];
+  int count = 0;
+  auto add = [&](const LAP& l) {
+    items[count] = LaPrepItem{c.prm(l.qkv_w), c.prm(l.out_w), l.C, c.w(c.ar.la_prep) + (int64_t)count * LA_PREP_FLOATS};
+    ++count;
+  };
+  if ((int)(p.downs.size() + p.ups.size()) > LA_PREP_MAX) return 0;  // (callers then pass slot -1)
+  for (const LevelP& l : p.downs) add(l.la);
+  for (const LevelP& l : p.ups) add(l.la);
+  return launch_linattn_prepare(items, count, c.s);
 }
 
 // the collected slot reductions, one launch
@@ -279,13 +297,15 @@ int la_flush(const Ctx& c) {
   return 0;
 }
 
-int la_bwd(const Ctx& c, const LAP& l, const LevelBuf& b, const float* x, const float* dy, float* dx, int rows, int n) {
+int la_bwd(const Ctx& c, const LAP& l, const LevelBuf& b, const float* x, const float* dy, float* dx, int rows, int n, int slot = -1) {
   LinAttnBwd a;
   a.ypre = c.w(b.la_pre); a.dyp = c.g(b.la_pre); a.dxh = c.g(b.la_tmp);
   a.part = c.w(c.ar.la_part); a.part_floats = c.ar.la_part_floats;
   a.f.x = x; a.f.w_qkv = c.prm(l.qkv_w); a.f.w_out = c.prm(l.out_w); a.f.b_out = c.prm(l.out_b);
   a.f.g_pre = c.prm(l.g_pre); a.f.g_out = c.prm(l.g_out); a.f.C = l.C; a.f.rows = rows; a.f.n = n;
   a.dy = dy; a.dx = dx;
+  // W2 of this layer as the forward of this step prepared it (la_prepare_all): same weights, same numbers
+  if (slot >= 0 && n <= 64 && (int)(c.p.downs.size() + c.p.ups.size()) <= LA_PREP_MAX) a.f.prep = c.w(c.ar.la_prep) + (int64_t)slot * LA_PREP_FLOATS;
   a.dw_qkv = c.dprm(l.qkv_w); a.dw_out = c.dprm(l.out_w); a.db_out = c.dprm(l.out_b); a.dg_pre = c.dprm(l.g_pre);
   a.dg_out = c.dprm(l.g_out);
   Ctx::LaDefer* d = c.la_defer;
@@ -367,6 +387,8 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
   const Plan& p = c.p;
   const Arena& a = c.ar;
   const int B = c.B, RT = c.RT, R = B * RT, L = p.levels;
+  const bool prep_ok = (int)(p.downs.size() + p.ups.size()) <= LA_PREP_MAX;
+  DQ_TRY(la_prepare_all(c));
   // K1: time embedding + every scale/shift head (unet1d.py:1105, 315-318, 677)
   DQ_TRY(launch_time_embed_fwd(p, dt, c.P, t, t_scalar, c.w(a.tbuf), c.w(a.ss), B, step_tab, step_ptr, c.s));
   // K2: mixture conditioning + concat (unet1d.py:1107-1115), then init_conv k7 (:1117)
@@ -388,7 +410,7 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     const int C = l.r0.cin;
     DQ_TRY(res_fwd(c, l.r0, b.r0, cur, C, nullptr, 0, R, l.n, RT));
     DQ_TRY(res_fwd(c, l.r1, b.r1, c.w(b.r0.out), C, nullptr, 0, R, l.n, RT));
-    DQ_TRY(la_fwd(c, l.la, c.w(b.r1.out), c.w(b.la), c.save ? c.w(b.la_pre) : nullptr, R, l.n));
+    DQ_TRY(la_fwd(c, l.la, c.w(b.r1.out), c.w(b.la), c.save ? c.w(b.la_pre) : nullptr, R, l.n, prep_ok ? lv : -1));
     DQ_TRY(conv_plain_fwd(c, l.resample, l.last ? CONV_S1 : CONV_DOWN, c.w(b.la), c.w(b.rs), R, l.n, l.n_next));
     cur = c.w(b.rs);
   }
@@ -434,7 +456,7 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     const int cx = l.r0.cout, cs = l.r0.cin - l.r0.cout;
     DQ_TRY(res_fwd(c, l.r0, b.r0, cur, cx, c.w(a.downs[lv].la), cs, R, l.n, RT));
     DQ_TRY(res_fwd(c, l.r1, b.r1, c.w(b.r0.out), cx, c.w(a.downs[lv].r0.out), cs, R, l.n, RT));
-    DQ_TRY(la_fwd(c, l.la, c.w(b.r1.out), c.w(b.la), c.save ? c.w(b.la_pre) : nullptr, R, l.n));
+    DQ_TRY(la_fwd(c, l.la, c.w(b.r1.out), c.w(b.la), c.save ? c.w(b.la_pre) : nullptr, R, l.n, prep_ok ? L + ui : -1));
     DQ_TRY(conv_plain_fwd(c, l.resample, l.last ? CONV_S1 : CONV_UP, c.w(b.la), c.w(b.rs), R, l.n, l.n_next));
     cur = c.w(b.rs);
   }
@@ -465,7 +487,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     const int cx = l.r0.cout, cs = l.r0.cin - l.r0.cout;
     const int64_t in_off = ui == 0 ? a.mid_back : a.ups[ui - 1].rs;
     DQ_TRY(conv_plain_bwd(c, l.resample, l.last ? CONV_S1 : CONV_UP, c.w(b.la), c.g(b.rs), c.g(b.la), R, l.n, l.n_next, 1));
-    DQ_TRY(la_bwd(c, l.la, b, c.w(b.r1.out), c.g(b.la), c.g(b.r1.out), R, l.n));
+    DQ_TRY(la_bwd(c, l.la, b, c.w(b.r1.out), c.g(b.la), c.g(b.r1.out), R, l.n, L + ui));
     DQ_TRY(res_bwd(c, l.r1, b.r1, c.w(b.r0.out), c.g(b.r0.out), cx, c.w(a.downs[lv].r0.out), c.g(a.downs[lv].r0.out), cs, R, l.n, RT));
     DQ_TRY(res_bwd(c, l.r0, b.r0, c.w(in_off), c.g(in_off), cx, c.w(a.downs[lv].la), c.g(a.downs[lv].la), cs, R, l.n, RT));
   }
@@ -503,7 +525,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     const int C = l.r0.cin;
     const int64_t in_off = lv == 0 ? a.h0 : a.downs[lv - 1].rs;
     DQ_TRY(conv_plain_bwd(c, l.resample, l.last ? CONV_S1 : CONV_DOWN, c.w(b.la), c.g(b.rs), c.g(b.la), R, l.n, l.n_next, 1));
-    DQ_TRY(la_bwd(c, l.la, b, c.w(b.r1.out), c.g(b.la), c.g(b.r1.out), R, l.n));
+    DQ_TRY(la_bwd(c, l.la, b, c.w(b.r1.out), c.g(b.la), c.g(b.r1.out), R, l.n, lv));
     DQ_TRY(res_bwd(c, l.r1, b.r1, c.w(b.r0.out), c.g(b.r0.out), C, nullptr, nullptr, 0, R, l.n, RT));
     DQ_TRY(res_bwd(c, l.r0, b.r0, c.w(in_off), c.g(in_off), C, nullptr, nullptr, 0, R, l.n, RT));
   }

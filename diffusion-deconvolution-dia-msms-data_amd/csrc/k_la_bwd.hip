@@ -53,6 +53,7 @@ struct LinAttnBwdK {
   const float* w_qkv; const float* w_out; const float* g_pre; const float* g_out;
   float* part;  // per-wave partial slots: [wave][LA_SLOT(C)] = dWqkv (384C) | dWo (128C) | d g_out | d b_out | d g_pre
   int rows; int units_per_wave;
+  const float* prep;  // nullable: W2 (4 C C floats) prepared by launch_linattn_prepare
 #ifdef DQ_LA_PROBE
   unsigned long long* probe;  // tools/probe/la_bwd_time.hip: [wave][16] shader-clock stamps
 #endif
@@ -111,12 +112,16 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
     const int r = i & 15, c = (i >> 4) % C, hh = (i / (16 * C)) & 1, hd = (i / (32 * C)) & 3, m = i / (128 * C);
     wp_lds[i] = a.w_qkv[(m * 128 + hd * 32 + rmap(r, hh)) * C + c];
   }
-  for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) {
-    const int c = i % C, cp = (i / C) % C, hd = i / (C * C);
-    float s = 0.f;
+  if (a.prep) {
+    for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) w2_lds[i] = a.prep[i];
+  } else {
+    for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) {
+      const int c = i % C, cp = (i / C) % C, hd = i / (C * C);
+      float s = 0.f;
 #pragma unroll
-    for (int e = 0; e < 32; ++e) s = fmaf(a.w_out[cp * 128 + hd * 32 + e], a.w_qkv[(256 + hd * 32 + e) * C + c], s);
-    w2_lds[i] = s;
+      for (int e = 0; e < 32; ++e) s = fmaf(a.w_out[cp * 128 + hd * 32 + e], a.w_qkv[(256 + hd * 32 + e) * C + c], s);
+      w2_lds[i] = s;
+    }
   }
   __syncthreads();
   DQ_STAMP(1);
@@ -899,6 +904,7 @@ int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s) {
   LinAttnBwdK k;
   k.x = a.f.x; k.ypre = a.ypre; k.dy = a.dy; k.dx = a.dx; k.dxh = a.dxh; k.w_qkv = a.f.w_qkv; k.w_out = a.f.w_out;
   k.g_pre = a.f.g_pre; k.g_out = a.f.g_out; k.part = a.part; k.rows = rows; k.units_per_wave = 1;
+  k.prep = a.f.prep;
   switch (C) {
     case 4: return linattn_bwd_n<4>(k, n, a, s);
     case 8: return linattn_bwd_n<8>(k, n, a, s);

@@ -56,12 +56,16 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   constexpr bool QUAD = N > 1 && N < 32 && !SEGM;  // masked quadratic form (rows of 2 / 4 positions)
   __shared__ float tiles[QUAD ? 4 : 1][QUAD ? 32 * 33 : 1];  // wave-private transpose tiles (quadratic form only)
   float* tile = tiles[QUAD ? (threadIdx.x >> 6) : 0];
-  for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) {
-    const int c = i % C, cp = (i / C) % C, hd = i / (C * C);
-    float s = 0.f;
+  if (a.prep) {
+    for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) w2_lds[i] = a.prep[i];
+  } else {
+    for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) {
+      const int c = i % C, cp = (i / C) % C, hd = i / (C * C);
+      float s = 0.f;
 #pragma unroll
-    for (int e = 0; e < 32; ++e) s = fmaf(a.w_out[cp * 128 + hd * 32 + e], a.w_qkv[(256 + hd * 32 + e) * C + c], s);
-    w2_lds[i] = s;
+      for (int e = 0; e < 32; ++e) s = fmaf(a.w_out[cp * 128 + hd * 32 + e], a.w_qkv[(256 + hd * 32 + e) * C + c], s);
+      w2_lds[i] = s;
+    }
   }
   // MFMA weight operands, laid out [q|k][head][j][half][col] so that a wave reads 2 x 32 consecutive floats; channels beyond C
   // are zero.  The rows carry log2(e): both softmaxes then use exp2 (v_exp_f32) directly, which changes nothing
@@ -69,10 +73,14 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   constexpr int WQ = 2 * 4 * NJ * 2 * 32;
   __shared__ float wqk_lds[N > 1 ? WQ : 1];
   if (N > 1) {
-    for (int i = threadIdx.x; i < WQ; i += blockDim.x) {
-      const int cc = i & 31, hh = (i >> 5) & 1, j = (i >> 6) % NJ, hd = (i / (64 * NJ)) & 3, m = i / (256 * NJ);
-      const int c = rowmap(j, hh);
-      wqk_lds[i] = c < C ? a.w_qkv[(m * 128 + hd * 32 + cc) * C + c] * 1.4426950408889634f : 0.f;
+    if (a.prep) {
+      for (int i = threadIdx.x; i < WQ; i += blockDim.x) wqk_lds[i] = a.prep[1024 + i];
+    } else {
+      for (int i = threadIdx.x; i < WQ; i += blockDim.x) {
+        const int cc = i & 31, hh = (i >> 5) & 1, j = (i >> 6) % NJ, hd = (i / (64 * NJ)) & 3, m = i / (256 * NJ);
+        const int c = rowmap(j, hh);
+        wqk_lds[i] = c < C ? a.w_qkv[(m * 128 + hd * 32 + cc) * C + c] * 1.4426950408889634f : 0.f;
+      }
     }
   }
   __syncthreads();
@@ -358,6 +366,39 @@ static int linattn_fwd_n(const LinAttn& a, hipStream_t s) {
       return 2;
   }
 #undef DQ_LA
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// The weights every forward block needs, derived once per launch sequence instead of once per block: block = layer; same
+// expressions (and fmaf order) as the in-kernel prologue, so the results are bit-identical.
+struct LaPrepMulti { LaPrepItem it[LA_PREP_MAX]; };
+__global__ void __launch_bounds__(256) k_linattn_prepare(LaPrepMulti m) {
+  const LaPrepItem& it = m.it[blockIdx.x];
+  const int C = it.C, NJ = C <= 8 ? 4 : 8;
+  for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) {
+    const int c = i % C, cp = (i / C) % C, hd = i / (C * C);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) s = fmaf(it.w_out[cp * 128 + hd * 32 + e], it.w_qkv[(256 + hd * 32 + e) * C + c], s);
+    it.prep[i] = s;
+  }
+  const int WQ = 2 * 4 * NJ * 2 * 32;
+  for (int i = threadIdx.x; i < WQ; i += blockDim.x) {
+    const int cc = i & 31, hh = (i >> 5) & 1, j = (i >> 6) % NJ, hd = (i / (64 * NJ)) & 3, mm = i / (256 * NJ);
+    const int c = rowmap(j, hh);
+    it.prep[1024 + i] = c < C ? it.w_qkv[(mm * 128 + hd * 32 + cc) * C + c] * 1.4426950408889634f : 0.f;
+  }
+}
+int launch_linattn_prepare(const LaPrepItem* items, int count, hipStream_t s) {
+  if (count == 0) return 0;
+  DQ_REQUIRE(count <= LA_PREP_MAX, "linattn prepare: too many layers");
+  LaPrepMulti m;
+  for (int i = 0; i < count; ++i) {
+    DQ_REQUIRE(items[i].C % 4 == 0 && items[i].C <= 16, "linattn prepare: unsupported channel count");
+    m.it[i] = items[i];
+  }
+  hipLaunchKernelGGL(k_linattn_prepare, dim3(count), dim3(256), 0, s, m);
   DQ_LAUNCH_CHECK();
   return 0;
 }
