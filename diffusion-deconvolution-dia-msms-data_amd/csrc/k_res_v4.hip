@@ -11,6 +11,25 @@
 
 namespace dq {
 
+// Packed fp32 FMAs (v_pk_fma_f32: two FMAs per lane and instruction -- the vector fp32 peak of the machine assumes them): the
+// four positions of a thread as two pairs.  Element by element the nesting is the scalar one, fmaf(w0, x[q], fmaf(w1, x[q+1],
+// fmaf(w2, x[q+2], acc))), so the results are bit-identical.
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v fma2(float w, f2v x, f2v a) { return __builtin_elementwise_fma(f2v{w, w}, x, a); }
+__device__ __forceinline__ void conv3_pk(float (&acc)[4], const float (&x)[6], float w0, float w1, float w2) {
+  const f2v p0 = {x[0], x[1]}, p1 = {x[1], x[2]}, p2 = {x[2], x[3]}, p3 = {x[3], x[4]}, p4 = {x[4], x[5]};
+  f2v a0 = {acc[0], acc[1]}, a1 = {acc[2], acc[3]};
+  a0 = fma2(w0, p0, fma2(w1, p1, fma2(w2, p2, a0)));
+  a1 = fma2(w0, p2, fma2(w1, p3, fma2(w2, p4, a1)));
+  acc[0] = a0.x; acc[1] = a0.y; acc[2] = a1.x; acc[3] = a1.y;
+}
+__device__ __forceinline__ void axpy4_pk(float (&acc)[4], const float (&x)[6], float w) {  // acc[q] += w * x[q + 1]
+  f2v a0 = {acc[0], acc[1]}, a1 = {acc[2], acc[3]};
+  a0 = fma2(w, f2v{x[1], x[2]}, a0);
+  a1 = fma2(w, f2v{x[3], x[4]}, a1);
+  acc[0] = a0.x; acc[1] = a0.y; acc[2] = a1.x; acc[3] = a1.y;
+}
+
 template <int C>
 __global__ void __launch_bounds__(256) k_res_fwd_v4(ResFwd a) {
   __shared__ float eL[C][256], eR[C][256];
@@ -58,8 +77,7 @@ __global__ void __launch_bounds__(256) k_res_fwd_v4(ResFwd a) {
     for (int co = 0; co < C; ++co) {
       const float* w = a.w1 + ((int64_t)co * cin + ci) * 3;
       const float w0 = w[0], w1 = w[1], w2 = w[2];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[co][q] = fmaf(w0, xa[ci][q], fmaf(w1, xa[ci][q + 1], fmaf(w2, xa[ci][q + 2], acc[co][q])));
+      conv3_pk(acc[co], xa[ci], w0, w1, w2);
     }
   if (a.cinB) {
 #pragma unroll
@@ -69,8 +87,7 @@ __global__ void __launch_bounds__(256) k_res_fwd_v4(ResFwd a) {
         for (int co = 0; co < C; ++co) {
           const float* w = a.w1 + ((int64_t)co * cin + C + ci) * 3;
           const float w0 = w[0], w1 = w[1], w2 = w[2];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc[co][q] = fmaf(w0, xb[ci][q], fmaf(w1, xb[ci][q + 1], fmaf(w2, xb[ci][q + 2], acc[co][q])));
+          conv3_pk(acc[co], xb[ci], w0, w1, w2);
         }
       }
     }
@@ -121,8 +138,7 @@ __global__ void __launch_bounds__(256) k_res_fwd_v4(ResFwd a) {
     for (int co = 0; co < C; ++co) {
       const float* w = a.w2 + ((int64_t)co * C + ci) * 3;
       const float w0 = w[0], w1 = w[1], w2 = w[2];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) o[co][q] = fmaf(w0, win[q], fmaf(w1, win[q + 1], fmaf(w2, win[q + 2], o[co][q])));
+      conv3_pk(o[co], win, w0, w1, w2);
     }
   }
   if (!live) return;
@@ -153,8 +169,7 @@ __global__ void __launch_bounds__(256) k_res_fwd_v4(ResFwd a) {
 #pragma unroll
       for (int co = 0; co < C; ++co) {
         const float w = a.wr[(int64_t)co * cin + ci];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o[co][q] = fmaf(w, xa[ci][q + 1], o[co][q]);
+        axpy4_pk(o[co], xa[ci], w);
       }
 #pragma unroll
     for (int ci = 0; ci < C; ++ci) {
@@ -162,8 +177,7 @@ __global__ void __launch_bounds__(256) k_res_fwd_v4(ResFwd a) {
 #pragma unroll
         for (int co = 0; co < C; ++co) {
           const float w = a.wr[(int64_t)co * cin + C + ci];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) o[co][q] = fmaf(w, xb[ci][q + 1], o[co][q]);
+          axpy4_pk(o[co], xb[ci], w);
         }
       }
     }
