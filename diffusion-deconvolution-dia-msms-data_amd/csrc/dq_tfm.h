@@ -41,7 +41,7 @@ int launch_cond_embed(const float* x_cond, const float* w, const float* bias, co
                       int H, hipStream_t s);
 // backward of launch_cond_embed: dw, db (+=, H each) and dx_cond (nullable, (B, S)) from dc (B, S, H); scratch: 2 * H * 64 floats
 int launch_cond_embed_bwd(const float* dc, const float* x_cond, const float* w, const float* sin_t, const float* cos_t, float* dw, float* db,
-                          float* dx_cond, float* scratch, int B, int S, int H, hipStream_t s);
+                          float* dx_cond, float* scratch, int B, int S, int H, hipStream_t s, int accumulate = 1);
 // e[b][:] = [sin(t_b f) | cos(t_b f)], f: (H/2) host table
 int launch_time_features(const int64_t* t, const float* freqs, float* e, int B, int H, hipStream_t s);
 int launch_gelu(const float* x, float* y, int64_t n, hipStream_t s);
@@ -52,13 +52,13 @@ int launch_layernorm_fwd(const float* x, const float* r, const float* g, const f
 // dy (+)= d LayerNorm ; dg, db += ; scratch: 2 * H * LN_BWD_BLOCKS floats
 constexpr int LN_BWD_BLOCKS = 256;
 int launch_layernorm_bwd(const float* y, const float* stats, const float* g, const float* dout, float* dy, float* dg, float* db, float* scratch,
-                         int rows, int H, hipStream_t s);
+                         int rows, int H, hipStream_t s, int accumulate = 1);
 // rows of length n (row stride ld): p = softmax(scale * p) in place ; ds = p * (dp - sum(p dp)) * scale in place of dp
 int launch_softmax_rows(float* p, int64_t rows, int n, int ld, float scale, hipStream_t s);
 int launch_softmax_rows_bwd(const float* p, float* dp, int64_t rows, int n, int ld, float scale, hipStream_t s);
-// out[n] += sum_m x[m * ld + n]  (bias gradients); scratch: COLSUM_BLOCKS * N floats
+// out[n] (+)= sum_m x[m * ld + n]  (bias gradients; accumulate = 0: plain store); scratch: COLSUM_BLOCKS * N floats
 constexpr int COLSUM_BLOCKS = 64;
-int launch_colsum(const float* x, int M, int N, int64_t ld, float* out, float* scratch, hipStream_t s);
+int launch_colsum(const float* x, int M, int N, int64_t ld, float* out, float* scratch, hipStream_t s, int accumulate = 1);
 // out[b][n] = sum_s x[(b * S + s) * N + n]  (time-embedding gradient: plain store)
 int launch_seqsum(const float* x, int B, int S, int N, float* out, hipStream_t s);
 

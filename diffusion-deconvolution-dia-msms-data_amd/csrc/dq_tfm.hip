@@ -89,13 +89,13 @@ int linear_fwd(const float* x, const float* w, const float* b, float* y, int M, 
 }
 // dW (N, K) += dy^T x ; db (N) += column sums of dy ; dx (M, K) (+)= dy W  (dx nullable)
 int linear_bwd(const float* x, const float* w, const float* dy, float* dw, float* db, float* dx, int dx_accumulate, int M, int N, int K,
-               const Ws& ws, hipStream_t s) {
+               const Ws& ws, hipStream_t s, int acc) {
   Gemm g;
-  g.A = dy; g.a_kmajor = 0; g.lda = N; g.B = x; g.b_kmajor = 0; g.ldb = K; g.C = dw; g.ldc = K; g.M = N; g.N = K; g.K = M; g.accumulate = 1;
+  g.A = dy; g.a_kmajor = 0; g.lda = N; g.B = x; g.b_kmajor = 0; g.ldb = K; g.C = dw; g.ldc = K; g.M = N; g.N = K; g.K = M; g.accumulate = acc;
   g.partial = ws.partial; g.partial_floats = PARTIAL_FLOATS;
   if (int rc = launch_gemm(g, s)) return rc;
   if (db)
-    if (int rc = launch_colsum(dy, M, N, N, db, ws.colscr, s)) return rc;
+    if (int rc = launch_colsum(dy, M, N, N, db, ws.colscr, s, acc)) return rc;
   if (dx) {
     Gemm h;
     h.A = dy; h.lda = N; h.B = w; h.b_kmajor = 0; h.ldb = K; h.C = dx; h.ldc = K; h.M = M; h.N = K; h.K = N; h.accumulate = dx_accumulate;
@@ -269,8 +269,8 @@ int dq_tfm_fwd(dq_tfm* p, const float* params, const float* rope_sin, const floa
 }
 
 int dq_tfm_bwd(dq_tfm* p, const float* params, const float* rope_sin, const float* rope_cos, const float* x_t, const float* x_cond,
-               const float* dout, float* grads, float* dx_t, float* dx_cond, void* workspace, int64_t workspace_bytes, int B, int S1, int S2,
-               void* stream) {
+               const float* dout, float* grads, int accumulate, float* dx_t, float* dx_cond, void* workspace, int64_t workspace_bytes, int B,
+               int S1, int S2, void* stream) {
   if (int rc = check_shapes(p, B, S1, S2)) return rc;
   DQ_REQUIRE(params && rope_sin && rope_cos && x_t && x_cond && dout && grads && workspace, "dq_tfm_bwd: missing operand");
   DQ_REQUIRE(p->saved_ws == workspace && p->saved_B == B && p->saved_S1 == S1 && p->saved_S2 == S2,
@@ -279,6 +279,7 @@ int dq_tfm_bwd(dq_tfm* p, const float* params, const float* rope_sin, const floa
   Ws w = carve(*p, (float*)workspace, B, S1, S2, true);
   DQ_REQUIRE(workspace_bytes >= w.floats * (int64_t)sizeof(float), "dq_tfm_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
+  const int acc = accumulate ? 1 : 0;  // 0: every parameter gradient is written exactly once by this backward -> plain stores
   const int H = p->H, D = p->D, R1 = B * S1, R2 = B * S2, Sk = S1 + S2;
   const float* P = params;
   float* G = grads;
@@ -287,29 +288,29 @@ int dq_tfm_bwd(dq_tfm* p, const float* params, const float* rope_sin, const floa
   // output projection
   float* dx = w.dxa;
   float* other = w.dxb;
-  if (int rc = linear_bwd(w.L[p->layers - 1].xo, P + p->out_w, dout, G + p->out_w, G + p->out_b, dx, 0, R1, D, H, w, s)) return rc;
+  if (int rc = linear_bwd(w.L[p->layers - 1].xo, P + p->out_w, dout, G + p->out_w, G + p->out_b, dx, 0, R1, D, H, w, s, acc)) return rc;
   for (int l = p->layers - 1; l >= 0; --l) {
     const TfmLayer& a = p->L[l];
     const Ws::Layer& b = w.L[l];
     const float* xin = l == 0 ? w.x0 : w.L[l - 1].xo;
     // norm2 + feed-forward: d1 = d y2 (= d x1 through the residual) ...
     float* d1 = other;
-    if (int rc = launch_layernorm_bwd(b.y2, b.st2, P + a.n2_g, dx, d1, G + a.n2_g, G + a.n2_b, w.lnscr, R1, H, s)) return rc;
-    if (int rc = linear_bwd(b.hact, P + a.f2_w, d1, G + a.f2_w, G + a.f2_b, w.dh, 0, R1, H, 4 * H, w, s)) return rc;
+    if (int rc = launch_layernorm_bwd(b.y2, b.st2, P + a.n2_g, dx, d1, G + a.n2_g, G + a.n2_b, w.lnscr, R1, H, s, acc)) return rc;
+    if (int rc = linear_bwd(b.hact, P + a.f2_w, d1, G + a.f2_w, G + a.f2_b, w.dh, 0, R1, H, 4 * H, w, s, acc)) return rc;
     if (int rc = launch_gelu_bwd(b.hpre, w.dh, w.dh, (int64_t)R1 * 4 * H, s)) return rc;
-    if (int rc = linear_bwd(b.x1, P + a.f0_w, w.dh, G + a.f0_w, G + a.f0_b, d1, 1, R1, 4 * H, H, w, s)) return rc;  // ... + through ff
+    if (int rc = linear_bwd(b.x1, P + a.f0_w, w.dh, G + a.f0_w, G + a.f0_b, d1, 1, R1, 4 * H, H, w, s, acc)) return rc;  // ... + through ff
     // norm1 + attention: d2 = d y1 (= d x_in through the residual) ...
     float* d2 = dx;
-    if (int rc = launch_layernorm_bwd(b.y1, b.st1, P + a.n1_g, d1, d2, G + a.n1_g, G + a.n1_b, w.lnscr, R1, H, s)) return rc;
-    if (int rc = linear_bwd(b.ao, P + a.out_w, d2, G + a.out_w, G + a.out_b, w.dao, 0, R1, H, H, w, s)) return rc;
+    if (int rc = launch_layernorm_bwd(b.y1, b.st1, P + a.n1_g, d1, d2, G + a.n1_g, G + a.n1_b, w.lnscr, R1, H, s, acc)) return rc;
+    if (int rc = linear_bwd(b.ao, P + a.out_w, d2, G + a.out_w, G + a.out_b, w.dao, 0, R1, H, H, w, s, acc)) return rc;
     if (int rc = attn_gemm(2, ad, w.dao, b.kv, w.dprob, nullptr, w, s)) return rc;            // dP = dO V^T
     if (int rc = attn_gemm(3, ad, w.dao, nullptr, b.prob, w.dkv, w, s)) return rc;             // dV = P^T dO
     if (int rc = launch_softmax_rows_bwd(b.prob, w.dprob, (int64_t)B * p->heads * S1, Sk, (int)ad.ldp, 1.0f / sqrtf((float)ad.dh), s)) return rc;
     if (int rc = attn_gemm(4, ad, nullptr, b.kv, w.dprob, w.dq, w, s)) return rc;              // dQ = dS K
     if (int rc = attn_gemm(5, ad, b.q, nullptr, w.dprob, w.dkv, w, s)) return rc;              // dK = dS^T Q
-    if (int rc = linear_bwd(xin, P + a.in_w, w.dq, G + a.in_w, G + a.in_b, d2, 1, R1, H, H, w, s)) return rc;  // ... + through q
+    if (int rc = linear_bwd(xin, P + a.in_w, w.dq, G + a.in_w, G + a.in_b, d2, 1, R1, H, H, w, s, acc)) return rc;  // ... + through q
     if (int rc = linear_bwd(b.comb, P + a.in_w + (int64_t)H * H, w.dkv, G + a.in_w + (int64_t)H * H, G + a.in_b + H, w.dcomb, 0, B * Sk, 2 * H, H,
-                            w, s))
+                            w, s, acc))
       return rc;
     hipLaunchKernelGGL(k_split_comb, dim3(grid_for((int64_t)B * Sk * H)), dim3(256), 0, s, w.dcomb, w.dcp, d2, B, S1, S2, H);
     DQ_LAUNCH_CHECK();
@@ -318,12 +319,12 @@ int dq_tfm_bwd(dq_tfm* p, const float* params, const float* rope_sin, const floa
   // x0 = rope(x_t Win^T + b) + temb
   if (int rc = launch_seqsum(dx, B, S1, H, w.dtemb, s)) return rc;
   if (int rc = launch_rope_add(dx, rope_sin, rope_cos, nullptr, B, S1, H, 1, s)) return rc;
-  if (int rc = linear_bwd(x_t, P + p->in_w, dx, G + p->in_w, G + p->in_b, dx_t, 0, R1, H, D, w, s)) return rc;
-  if (int rc = launch_cond_embed_bwd(w.dcp, x_cond, P + p->c_w, rope_sin, rope_cos, G + p->c_w, G + p->c_b, dx_cond, w.colscr, B, S2, H, s)) return rc;
+  if (int rc = linear_bwd(x_t, P + p->in_w, dx, G + p->in_w, G + p->in_b, dx_t, 0, R1, H, D, w, s, acc)) return rc;
+  if (int rc = launch_cond_embed_bwd(w.dcp, x_cond, P + p->c_w, rope_sin, rope_cos, G + p->c_w, G + p->c_b, dx_cond, w.colscr, B, S2, H, s, acc)) return rc;
   // time MLP
-  if (int rc = linear_bwd(w.tg, P + p->t2_w, w.dtemb, G + p->t2_w, G + p->t2_b, w.dtg, 0, B, H, 4 * H, w, s)) return rc;
+  if (int rc = linear_bwd(w.tg, P + p->t2_w, w.dtemb, G + p->t2_w, G + p->t2_b, w.dtg, 0, B, H, 4 * H, w, s, acc)) return rc;
   if (int rc = launch_gelu_bwd(w.th, w.dtg, w.dtg, (int64_t)B * 4 * H, s)) return rc;
-  if (int rc = linear_bwd(w.tfeat, P + p->t1_w, w.dtg, G + p->t1_w, G + p->t1_b, nullptr, 0, B, 4 * H, H, w, s)) return rc;
+  if (int rc = linear_bwd(w.tfeat, P + p->t1_w, w.dtg, G + p->t1_w, G + p->t1_b, nullptr, 0, B, 4 * H, H, w, s, acc)) return rc;
   return 0;
 }
 

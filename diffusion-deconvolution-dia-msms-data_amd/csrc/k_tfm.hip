@@ -72,7 +72,8 @@ __global__ void __launch_bounds__(256) k_cond_bwd_cols(const float* __restrict__
   p[H + 2 * j] = b1; p[H + 2 * j + 1] = b2;
 }
 // out[i] += sum over nb partial vectors (stride `stride`), fixed order
-__global__ void __launch_bounds__(256) k_partial_reduce(const float* __restrict__ part, int nb, int64_t stride, int n, float* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_partial_reduce(const float* __restrict__ part, int nb, int64_t stride, int n, float* __restrict__ out,
+                                                        int accumulate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float s = 0.f;
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(256) k_partial_reduce(const float* __restrict_
     for (int k = 0; k < 8; ++k) s += v[k];
   }
   for (; b < nb; ++b) s += part[(int64_t)b * stride + i];
-  out[i] += s;
+  out[i] = accumulate ? out[i] + s : s;
 }
 // row part: dx_cond[row] = sum_h dv[row][h] * w[h]   (one wave per row)
 __global__ void __launch_bounds__(256) k_cond_bwd_rows(const float* __restrict__ dc, const float* __restrict__ w, const float* __restrict__ sin_t,
@@ -314,13 +315,13 @@ int launch_cond_embed(const float* x_cond, const float* w, const float* bias, co
   return 0;
 }
 int launch_cond_embed_bwd(const float* dc, const float* x_cond, const float* w, const float* sin_t, const float* cos_t, float* dw, float* db,
-                          float* dx_cond, float* scratch, int B, int S, int H, hipStream_t s) {
+                          float* dx_cond, float* scratch, int B, int S, int H, hipStream_t s, int accumulate) {
   const int rows = B * S;
   if (rows == 0) return 0;
   const int nb = std::min(rows, 64);
   hipLaunchKernelGGL(k_cond_bwd_cols, dim3(cdiv(H / 2, 256), nb), dim3(256), 0, s, dc, x_cond, sin_t, cos_t, scratch, rows, S, H);
-  hipLaunchKernelGGL(k_partial_reduce, dim3(cdiv(H, 256)), dim3(256), 0, s, scratch, nb, (int64_t)2 * H, H, dw);
-  hipLaunchKernelGGL(k_partial_reduce, dim3(cdiv(H, 256)), dim3(256), 0, s, scratch + H, nb, (int64_t)2 * H, H, db);
+  hipLaunchKernelGGL(k_partial_reduce, dim3(cdiv(H, 256)), dim3(256), 0, s, scratch, nb, (int64_t)2 * H, H, dw, accumulate);
+  hipLaunchKernelGGL(k_partial_reduce, dim3(cdiv(H, 256)), dim3(256), 0, s, scratch + H, nb, (int64_t)2 * H, H, db, accumulate);
   if (dx_cond) hipLaunchKernelGGL(k_cond_bwd_rows, dim3(cdiv(rows, 4)), dim3(256), 0, s, dc, w, sin_t, cos_t, dx_cond, rows, S, H);
   DQ_LAUNCH_CHECK();
   return 0;
@@ -352,15 +353,15 @@ int launch_layernorm_fwd(const float* x, const float* r, const float* g, const f
   return 0;
 }
 int launch_layernorm_bwd(const float* y, const float* stats, const float* g, const float* dout, float* dy, float* dg, float* db, float* scratch,
-                         int rows, int H, hipStream_t s) {
+                         int rows, int H, hipStream_t s, int accumulate) {
   if (rows == 0) return 0;
   if (H <= 256) hipLaunchKernelGGL(k_layernorm_bwd_rows_reg<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, y, stats, g, dout, dy, rows, H);
   else if (H <= 1024) hipLaunchKernelGGL(k_layernorm_bwd_rows_reg<16>, dim3(cdiv(rows, 4)), dim3(256), 0, s, y, stats, g, dout, dy, rows, H);
   else hipLaunchKernelGGL(k_layernorm_bwd_rows, dim3(cdiv(rows, 4)), dim3(256), 0, s, y, stats, g, dout, dy, rows, H);
   const int nb = std::min(rows, LN_BWD_BLOCKS);
   hipLaunchKernelGGL(k_layernorm_bwd_cols, dim3(cdiv(H, 256), nb), dim3(256), 0, s, y, stats, dout, scratch, rows, H);
-  hipLaunchKernelGGL(k_partial_reduce, dim3(cdiv(H, 256)), dim3(256), 0, s, scratch, nb, (int64_t)2 * H, H, dg);
-  hipLaunchKernelGGL(k_partial_reduce, dim3(cdiv(H, 256)), dim3(256), 0, s, scratch + H, nb, (int64_t)2 * H, H, db);
+  hipLaunchKernelGGL(k_partial_reduce, dim3(cdiv(H, 256)), dim3(256), 0, s, scratch, nb, (int64_t)2 * H, H, dg, accumulate);
+  hipLaunchKernelGGL(k_partial_reduce, dim3(cdiv(H, 256)), dim3(256), 0, s, scratch + H, nb, (int64_t)2 * H, H, db, accumulate);
   DQ_LAUNCH_CHECK();
   return 0;
 }
@@ -376,11 +377,11 @@ int launch_softmax_rows_bwd(const float* p, float* dp, int64_t rows, int n, int 
   DQ_LAUNCH_CHECK();
   return 0;
 }
-int launch_colsum(const float* x, int M, int N, int64_t ld, float* out, float* scratch, hipStream_t s) {
+int launch_colsum(const float* x, int M, int N, int64_t ld, float* out, float* scratch, hipStream_t s, int accumulate) {
   if (M == 0 || N == 0) return 0;
   const int nb = std::min(M, COLSUM_BLOCKS);
   hipLaunchKernelGGL(k_colsum, dim3(cdiv(N, 256), nb), dim3(256), 0, s, x, M, N, ld, scratch);
-  hipLaunchKernelGGL(k_partial_reduce, dim3(cdiv(N, 256)), dim3(256), 0, s, scratch, nb, (int64_t)N, N, out);
+  hipLaunchKernelGGL(k_partial_reduce, dim3(cdiv(N, 256)), dim3(256), 0, s, scratch, nb, (int64_t)N, N, out, accumulate);
   DQ_LAUNCH_CHECK();
   return 0;
 }

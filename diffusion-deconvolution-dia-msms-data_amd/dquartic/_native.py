@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DQ_HIP_LIB", os.path.join(os.path.dirname(_HERE), "libdq_hip.so"))
 
 _lib = None
-ABI_VERSION = 3  # DQ_ABI_VERSION of include/dq_hip.h this table was written against
+ABI_VERSION = 4  # DQ_ABI_VERSION of include/dq_hip.h this table was written against
 PRED_TYPES = {"eps": 0, "x0": 1}  # DQ_PRED_EPS / DQ_PRED_X0
 
 # name -> (restype, argtypes); this table is checked against include/dq_hip.h by tests/test_abi.py
@@ -49,7 +49,7 @@ PROTOTYPES = {
     "dq_tfm_param_info": (c_int, [c_void_p, c_int, c_char_p, c_int, POINTER(c_int64), POINTER(c_int), POINTER(c_int64)]),
     "dq_tfm_workspace_bytes": (c_int64, [c_void_p, c_int, c_int, c_int, c_int]),
     "dq_tfm_fwd": (c_int, [c_void_p] * 9 + [c_int, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
-    "dq_tfm_bwd": (c_int, [c_void_p] * 11 + [c_int64, c_int, c_int, c_int, c_void_p]),
+    "dq_tfm_bwd": (c_int, [c_void_p] * 8 + [c_int] + [c_void_p] * 3 + [c_int64, c_int, c_int, c_int, c_void_p]),
     "dq_gemm_scratch_floats": (c_int64, [c_int, c_int, c_int]),
     "dq_gemm": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int64,
                         c_void_p]),

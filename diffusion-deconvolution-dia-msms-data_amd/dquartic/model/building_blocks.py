@@ -194,7 +194,7 @@ class CustomTransformer(nn.Module):
                                    N.ptr(out), 1 if training else 0, N.ptr(ws), ws.numel(), B, S1, S2, N.stream_ptr()), "dq_tfm_fwd")
         return out
 
-    def _run_bwd(self, xs, cs, gout, grads, want_dx, want_dc):
+    def _run_bwd(self, xs, cs, gout, grads, want_dx, want_dc, accumulate=True):
         B, S1, _ = xs.shape
         S2 = cs.shape[1]
         ws = self.workspace(B, S1, S2, True)
@@ -202,7 +202,7 @@ class CustomTransformer(nn.Module):
         gx = torch.empty_like(xs) if want_dx else None
         gc = torch.empty_like(cs) if want_dc else None
         N.check(N.lib().dq_tfm_bwd(self._tfm, N.ptr(self._flat), N.ptr(sin), N.ptr(cos), N.ptr(xs), N.ptr(cs), N.ptr(gout), N.ptr(grads),
-                                   N.ptr(gx), N.ptr(gc), N.ptr(ws), ws.numel(), B, S1, S2, N.stream_ptr()), "dq_tfm_bwd")
+                                   1 if accumulate else 0, N.ptr(gx), N.ptr(gc), N.ptr(ws), ws.numel(), B, S1, S2, N.stream_ptr()), "dq_tfm_bwd")
         return gx, gc
 
 
@@ -219,8 +219,8 @@ class _TfmFn(torch.autograd.Function):
         net = ctx.net
         xs, cs = ctx.saved_tensors
         gout = gout.contiguous().to(torch.float32)
-        grads = torch.zeros_like(net._flat)
-        gx, gc = net._run_bwd(xs, cs, gout, grads, *ctx.needs)
+        grads = torch.empty_like(net._flat)  # written (not accumulated into) by the backward: no zeroing pass
+        gx, gc = net._run_bwd(xs, cs, gout, grads, *ctx.needs, accumulate=False)
         pg = [grads[o:o + math.prod(shape)].view(shape) for _, o, shape in net._layout]
         return (None, gx, None, gc, *pg)
 

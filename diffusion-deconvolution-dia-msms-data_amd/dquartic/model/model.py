@@ -282,7 +282,7 @@ class DDIMDiffusionModel(ModelInterface):
         c1n = self.normalize(c1).contiguous()  # (B, RT) values: the only torch op of the step
         tfm._ensure_flat()
         out = tfm._run_fwd(x_t, t, c1n, training=True)
-        grads = tfm.flat_grads(zero=zero_grads)
+        grads = tfm.flat_grads(zero=False)  # zero_grads: the backward below overwrites instead of accumulating
         loss = torch.empty((), dtype=torch.float32, device=dev)
         dout = torch.empty_like(out)
         if getattr(self, "_mse_scratch", None) is None or self._mse_scratch.device != dev:
@@ -295,5 +295,5 @@ class DDIMDiffusionModel(ModelInterface):
             N.check(lib.dq_mse_loss_weighted_fwd_bwd(N.ptr(out), N.ptr(x_0), 2.0 if norm else 1.0, -1.0 if norm else 0.0, N.ptr(lw), N.ptr(t),
                                                      N.ptr(loss), N.ptr(dout), N.ptr(self._mse_scratch), B, per, N.stream_ptr()),
                     "dq_mse_loss_weighted_fwd_bwd")
-        tfm._run_bwd(x_t, c1n, dout, grads, False, False)
+        tfm._run_bwd(x_t, c1n, dout, grads, False, False, accumulate=not zero_grads)
         return loss

@@ -31,9 +31,10 @@ typedef struct dq_plan dq_plan;
 /* Text of the last error on this thread ("" if none). */
 const char* dq_last_error(void);
 /* ABI version of this header (bumped on any signature change).  2: pred_type arguments, dq_ddim_step_x0,
- * dq_mse_loss_weighted_fwd_bwd, dq_pair_batch.  3: dq_tfm_* (CustomTransformer), dq_gemm. */
+ * dq_mse_loss_weighted_fwd_bwd, dq_pair_batch.  3: dq_tfm_* (CustomTransformer), dq_gemm.
+ * 4: dq_tfm_bwd takes an accumulate flag. */
 int dq_abi_version(void);
-#define DQ_ABI_VERSION 3
+#define DQ_ABI_VERSION 4
 
 /* DDIMDiffusionModel.pred_type (model.py:205-213, 269-280, 354-389); any other value is rejected ("Unknown pred_type"). */
 enum { DQ_PRED_EPS = 0, DQ_PRED_X0 = 1 };
@@ -158,11 +159,13 @@ int64_t dq_tfm_workspace_bytes(const dq_tfm* tfm, int B, int S1, int S2, int tra
 int dq_tfm_fwd(dq_tfm* tfm, const float* params, const float* rope_sin, const float* rope_cos, const float* time_freqs,
                const float* x_t, const int64_t* t, const float* x_cond, float* out, int save_for_bwd, void* workspace,
                int64_t workspace_bytes, int B, int S1, int S2, void* stream);
-/* Backward of the last dq_tfm_fwd(save_for_bwd = 1) on the same workspace: grads (flat, same layout as params) +=;
+/* Backward of the last dq_tfm_fwd(save_for_bwd = 1) on the same workspace.  grads: flat, same layout as params; accumulate != 0:
+ * += (autograd's convention); accumulate == 0: plain stores -- every parameter gradient is produced exactly once per backward,
+ * so a training step needs no zeroing pass over the 764 MB buffer of the reference configuration.
  * dx_t (B,S1,input_dim) and dx_cond (B,S2) are plain stores and may be NULL. */
 int dq_tfm_bwd(dq_tfm* tfm, const float* params, const float* rope_sin, const float* rope_cos, const float* x_t,
-               const float* x_cond, const float* dout, float* grads, float* dx_t, float* dx_cond, void* workspace,
-               int64_t workspace_bytes, int B, int S1, int S2, void* stream);
+               const float* x_cond, const float* dout, float* grads, int accumulate, float* dx_t, float* dx_cond,
+               void* workspace, int64_t workspace_bytes, int B, int S1, int S2, void* stream);
 /* The fp32 matrix-core GEMM underneath (exported for the parity tests and the roofline measurement):
  * C (M,N; ldc) = A B (+ bias[n]) with A(m,k) = a_kmajor ? A[m*lda+k] : A[k*lda+m] and B(k,n) = b_kmajor ? B[n*ldb+k] :
  * B[k*ldb+n]; splits = 0 lets the library choose a split-K factor; scratch: dq_gemm_scratch_floats(M,N,K) floats. */
