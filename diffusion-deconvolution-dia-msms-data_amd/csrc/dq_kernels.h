@@ -150,7 +150,10 @@ int launch_linattn_fwd(const LinAttn& a, hipStream_t s);
 constexpr int LA_PREP_FLOATS = 1024 + 4096;  // [w2: 4 * 16 * 16][wqk: 2 * 4 * 8 * 2 * 32]
 struct LaPrepItem { const float* w_qkv; const float* w_out; int C; float* prep; };
 constexpr int LA_PREP_MAX = 16;
-int launch_linattn_prepare(const LaPrepItem* items, int count, hipStream_t s);  // all LinearAttention layers of a forward: one launch
+struct PrepCopy { const float* src; float* dst; int n; };  // plain copies riding in the same launch (aligned weight slots)
+constexpr int PREP_COPY_MAX = 4;
+// all LinearAttention layers of a forward (+ up to PREP_COPY_MAX copies): one launch
+int launch_linattn_prepare(const LaPrepItem* items, int count, hipStream_t s, const PrepCopy* copies = nullptr, int n_copies = 0);
 struct LinAttnBwd {
   LinAttn f;
   const float* dy = nullptr; float* dx = nullptr;  // dx +=

@@ -14,6 +14,8 @@
 
 namespace dq {
 
+constexpr int64_t WTMP_SLOT = 2 * HID * 64;  // floats per aligned weight slot (conv_is_gemm admits no larger weight)
+
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 
@@ -87,7 +89,7 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
   a.la_part_floats = std::max<int64_t>(a.la_part_floats, (int64_t)LA_MAX_WAVES * 512 * 16);
   a.la_part = take_nz(a.la_part_floats);
   a.la_prep = take_nz((int64_t)LA_PREP_MAX * LA_PREP_FLOATS);  // prepared LinearAttention weights, one slot per layer (downs, then ups)
-  a.wtmp = take_nz(2 * HID * 64);  // 16-byte aligned copy of a projection weight for the GEMM route of the wide 1x1 convs
+  a.wtmp = take_nz(3 * WTMP_SLOT);  // 16-byte aligned copy of a projection weight for the GEMM route of the wide 1x1 convs
   a.ts_tab = take_nz(1024); a.step = take_nz(64);  // graph replay: timestep table (int32) and the device-side step counter
   a.c2_stage = take_nz(R * p.mz); a.c1_stage = take_nz(R);  // conditions staged at fixed addresses for the captured step
   a.zero_floats = off;
@@ -285,7 +287,15 @@ int la_prepare_all(const Ctx& c) {
   if ((int)(p.downs.size() + p.ups.size()) > LA_PREP_MAX) return 0;  // (callers then pass slot -1)
   for (const LevelP& l : p.downs) add(l.la);
   for (const LevelP& l : p.ups) add(l.la);
-  return launch_linattn_prepare(items, count, c.s);
+  // aligned copies of the bottleneck attention's projection weights for the GEMM route (slots 0: q|v, 1: k, 2: to_out), when
+  // the flat parameter buffer leaves them off a 16-byte boundary
+  PrepCopy cps[PREP_COPY_MAX];
+  int nc = 0;
+  const int64_t wsrc[3] = {p.qv_w, p.k_w, p.ao_w};
+  const int wn[3] = {2 * HID * p.mid_c, HID * p.cond_dim, p.mid_c * HID};
+  for (int i = 0; i < 3; ++i)
+    if (((uintptr_t)c.prm(wsrc[i]) & 15) != 0 && wn[i] <= WTMP_SLOT) cps[nc++] = PrepCopy{c.prm(wsrc[i]), c.w(c.ar.wtmp) + i * WTMP_SLOT, wn[i]};
+  return launch_linattn_prepare(items, count, c.s, cps, nc);
 }
 
 // the collected slot reductions, one launch
@@ -329,22 +339,23 @@ int la_bwd(const Ctx& c, const LAP& l, const LevelBuf& b, const float* x, const 
 // chain of 128-256 dependent FMAs there (47 us forward, 108 us data gradient at batch 32; ~10 us as a GEMM).
 bool conv_is_gemm(const Ctx& c, const ConvP& cp, int mode, int n_in, int n_out) {
   return cp.k == 1 && mode == CONV_S1 && cp.b < 0 && n_in == n_out && n_in % 4 == 0 && cp.cin % 4 == 0 && (cp.cout >= 64 || cp.cin >= 64) &&
-         (int64_t)cp.cout * cp.cin <= 2 * HID * 64;
+         (int64_t)cp.cout * cp.cin <= WTMP_SLOT;
 }
 // the GEMM reads its operands with 16-byte loads; a weight slice of the flat parameter buffer that does not start on a 16-byte
 // boundary is copied (<= 32 KB, device to device, same stream) to an aligned slot of the arena first
-int gemm_weight(const Ctx& c, const ConvP& cp, const float** w) {
+// slot (0: q|v, 1: k, 2: to_out): the copy was made by the forward's prepare launch (la_prepare_all) -- the backward of the same
+// step reads the same slot
+int gemm_weight(const Ctx& c, const ConvP& cp, const float** w, int slot) {
   *w = c.prm(cp.w);
-  if (((uintptr_t)*w & 15) == 0) return 0;
-  DQ_TRY(launch_copy(c.w(c.ar.wtmp), *w, (int64_t)cp.cout * cp.cin, c.s));
-  *w = c.w(c.ar.wtmp);
+  if (((uintptr_t)*w & 15) != 0) *w = c.w(c.ar.wtmp) + (int64_t)slot * WTMP_SLOT;
   return 0;
 }
 
-int conv_plain_fwd(const Ctx& c, const ConvP& cp, int mode, const float* in, float* out, int rows, int n_in, int n_out) {
-  if (conv_is_gemm(c, cp, mode, n_in, n_out)) {
+// wslot: aligned weight slot prepared by the forward (-1: none; the GEMM route is then only taken for an aligned weight)
+int conv_plain_fwd(const Ctx& c, const ConvP& cp, int mode, const float* in, float* out, int rows, int n_in, int n_out, int wslot = -1) {
+  if (conv_is_gemm(c, cp, mode, n_in, n_out) && (wslot >= 0 || ((uintptr_t)c.prm(cp.w) & 15) == 0)) {
     Gemm g;
-    DQ_TRY(gemm_weight(c, cp, &g.A));
+    DQ_TRY(gemm_weight(c, cp, &g.A, wslot));
     g.lda = cp.cin; g.B = in; g.b_kmajor = 0; g.ldb = n_in; g.C = out; g.ldc = n_in;
     g.M = cp.cout; g.N = n_in; g.K = cp.cin; g.batch = rows; g.sBo = (int64_t)cp.cin * n_in; g.sCo = (int64_t)cp.cout * n_in;
     return launch_gemm(g, c.s);
@@ -356,15 +367,15 @@ int conv_plain_fwd(const Ctx& c, const ConvP& cp, int mode, const float* in, flo
 }
 
 int conv_plain_bwd(const Ctx& c, const ConvP& cp, int mode, const float* in, const float* dout, float* din, int rows, int n_in,
-                   int n_out, int accumulate) {
+                   int n_out, int accumulate, int wslot = -1) {
   ConvWgrad wg;
   wg.scratch = c.w(c.ar.wg); wg.scratch_floats = c.ar.wg_floats;
   wg.du = dout; wg.inA = in; wg.cinA = cp.cin; wg.cout = cp.cout; wg.K = cp.k; wg.mode = mode; wg.rows = rows; wg.n_in = n_in;
   wg.n_out = n_out; wg.dw = c.dprm(cp.w); wg.dbias = cp.b >= 0 ? c.dprm(cp.b) : nullptr;
   DQ_TRY(wgrad_async(c, wg));
-  if (din && conv_is_gemm(c, cp, mode, n_in, n_out)) {  // dX_b (cin x n) (+)= W^T (cin x cout) dY_b (cout x n)
+  if (din && conv_is_gemm(c, cp, mode, n_in, n_out) && (wslot >= 0 || ((uintptr_t)c.prm(cp.w) & 15) == 0)) {  // dX_b (cin x n) (+)= W^T (cin x cout) dY_b (cout x n)
     Gemm g;
-    DQ_TRY(gemm_weight(c, cp, &g.A));
+    DQ_TRY(gemm_weight(c, cp, &g.A, wslot));
     g.a_kmajor = 0; g.lda = cp.cin; g.B = dout; g.b_kmajor = 0; g.ldb = n_in; g.C = din; g.ldc = n_in;
     g.M = cp.cin; g.N = n_in; g.K = cp.cout; g.batch = rows; g.sBo = (int64_t)cp.cout * n_in; g.sCo = (int64_t)cp.cin * n_in;
     g.accumulate = accumulate;
@@ -420,8 +431,8 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
   {
     // Residual(PreNorm(Attention(use_xattn))) (unet1d.py:552-567)
     DQ_TRY(launch_rmsnorm_fwd(c.w(a.mid1.out), c.prm(p.ag), c.w(a.xn), p.mid_c, B, RT, c.s));
-    DQ_TRY(conv_plain_fwd(c, proj(p.qv_w, 2 * HID, p.mid_c), CONV_S1, c.w(a.xn), c.w(a.qv), B, RT, RT));
-    DQ_TRY(conv_plain_fwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.w(a.kk), B, RT, RT));
+    DQ_TRY(conv_plain_fwd(c, proj(p.qv_w, 2 * HID, p.mid_c), CONV_S1, c.w(a.xn), c.w(a.qv), B, RT, RT, prep_ok ? 0 : -1));
+    DQ_TRY(conv_plain_fwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.w(a.kk), B, RT, RT, prep_ok ? 1 : -1));
     if (rope) {
       DQ_TRY(launch_rope(c.w(a.qv), rope, B, (int64_t)2 * HID * RT, RT, 1.f, c.s));  // q = first 128 channels of each sample's 256
       DQ_TRY(launch_rope(c.w(a.kk), rope, B, (int64_t)HID * RT, RT, 1.f, c.s));
@@ -429,11 +440,11 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     const int64_t qvbs = (int64_t)2 * HID * RT, kbs = (int64_t)HID * RT;
     DQ_TRY(launch_attn_fwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.w(a.lse), B, RT, c.s));
     const ConvP ao = proj(p.ao_w, p.mid_c, HID);
-    if (conv_is_gemm(c, ao, CONV_S1, RT, RT)) {
+    if (conv_is_gemm(c, ao, CONV_S1, RT, RT) && (prep_ok || ((uintptr_t)c.prm(ao.w) & 15) == 0)) {
       // to_out (1x1 conv, 128 -> mid_c channels, with bias) + the residual: attn_out = x ; attn_out += W o + b as a GEMM per sample
       DQ_TRY(launch_copy(c.w(a.attn_out), c.w(a.mid1.out), (int64_t)B * p.mid_c * RT, c.s));
       Gemm g;
-      DQ_TRY(gemm_weight(c, ao, &g.A));
+      DQ_TRY(gemm_weight(c, ao, &g.A, 2));
       g.lda = HID; g.B = c.w(a.o); g.b_kmajor = 0; g.ldb = RT; g.C = c.w(a.attn_out); g.ldc = RT; g.M = p.mid_c; g.N = RT; g.K = HID;
       g.batch = B; g.sBo = (int64_t)HID * RT; g.sCo = (int64_t)p.mid_c * RT; g.bias_m = c.prm(p.ao_b); g.accumulate = 1;
       DQ_TRY(launch_gemm(g, c.s));
@@ -507,8 +518,9 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
       DQ_TRY(launch_rope(c.g(a.qv), rope, B, (int64_t)2 * HID * RT, RT, -1.f, c.s));
       DQ_TRY(launch_rope(c.g(a.kk), rope, B, (int64_t)HID * RT, RT, -1.f, c.s));
     }
-    DQ_TRY(conv_plain_bwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.g(a.kk), c.g(a.ms1f), B, RT, RT, 0));
-    DQ_TRY(conv_plain_bwd(c, proj(p.qv_w, 2 * HID, p.mid_c), CONV_S1, c.w(a.xn), c.g(a.qv), c.g(a.xn), B, RT, RT, 0));
+    const int ws_ok = (int)(p.downs.size() + p.ups.size()) <= LA_PREP_MAX ? 0 : -2;  // slots as the forward of this step filled them
+    DQ_TRY(conv_plain_bwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.g(a.kk), c.g(a.ms1f), B, RT, RT, 0, ws_ok + 1));
+    DQ_TRY(conv_plain_bwd(c, proj(p.qv_w, 2 * HID, p.mid_c), CONV_S1, c.w(a.xn), c.g(a.qv), c.g(a.xn), B, RT, RT, 0, ws_ok));
     // PreNorm backward: xn = rmsnorm(mid1.out) * g  (pointwise kernel, no scale/shift, no activation)
     BlockBwd nb;
     nb.u = c.w(a.mid1.out); nb.dy = c.g(a.xn); nb.du = c.g(a.xn); nb.C = p.mid_c; nb.rows = B; nb.n = RT; nb.rows_per_sample = 1;

@@ -372,8 +372,13 @@ static int linattn_fwd_n(const LinAttn& a, hipStream_t s) {
 
 // The weights every forward block needs, derived once per launch sequence instead of once per block: block = layer; same
 // expressions (and fmaf order) as the in-kernel prologue, so the results are bit-identical.
-struct LaPrepMulti { LaPrepItem it[LA_PREP_MAX]; };
+struct LaPrepMulti { LaPrepItem it[LA_PREP_MAX]; PrepCopy cp[PREP_COPY_MAX]; int count; };
 __global__ void __launch_bounds__(256) k_linattn_prepare(LaPrepMulti m) {
+  if ((int)blockIdx.x >= m.count) {  // the trailing blocks are plain copies
+    const PrepCopy& c = m.cp[blockIdx.x - m.count];
+    for (int i = threadIdx.x; i < c.n; i += blockDim.x) c.dst[i] = c.src[i];
+    return;
+  }
   const LaPrepItem& it = m.it[blockIdx.x];
   const int C = it.C, NJ = C <= 8 ? 4 : 8;
   for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) {
@@ -390,15 +395,17 @@ __global__ void __launch_bounds__(256) k_linattn_prepare(LaPrepMulti m) {
     it.prep[1024 + i] = c < C ? it.w_qkv[(mm * 128 + hd * 32 + cc) * C + c] * 1.4426950408889634f : 0.f;
   }
 }
-int launch_linattn_prepare(const LaPrepItem* items, int count, hipStream_t s) {
-  if (count == 0) return 0;
-  DQ_REQUIRE(count <= LA_PREP_MAX, "linattn prepare: too many layers");
+int launch_linattn_prepare(const LaPrepItem* items, int count, hipStream_t s, const PrepCopy* copies, int n_copies) {
+  if (count + n_copies == 0) return 0;
+  DQ_REQUIRE(count <= LA_PREP_MAX && n_copies <= PREP_COPY_MAX, "linattn prepare: too many layers / copies");
   LaPrepMulti m;
+  m.count = count;
+  for (int i = 0; i < n_copies; ++i) m.cp[i] = copies[i];
   for (int i = 0; i < count; ++i) {
     DQ_REQUIRE(items[i].C % 4 == 0 && items[i].C <= 16, "linattn prepare: unsupported channel count");
     m.it[i] = items[i];
   }
-  hipLaunchKernelGGL(k_linattn_prepare, dim3(count), dim3(256), 0, s, m);
+  hipLaunchKernelGGL(k_linattn_prepare, dim3(count + n_copies), dim3(256), 0, s, m);
   DQ_LAUNCH_CHECK();
   return 0;
 }
