@@ -124,6 +124,11 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
     }
   }
   __syncthreads();
+  if (N == 1) {  // rows of one position use sum_h W2_h only (closed form below): fold the heads into slot 0
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x)
+      w2_lds[i] = ((w2_lds[i] + w2_lds[C * C + i]) + w2_lds[2 * C * C + i]) + w2_lds[3 * C * C + i];
+    __syncthreads();
+  }
   DQ_STAMP(1);
 
   const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wv = threadIdx.x >> 6;
@@ -182,6 +187,10 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
 
 #pragma unroll 1
   for (int hd = 0; hd < 4; ++hd) {
+    // rows of ONE position: every head contributes the same closed form (see below), so the rows are walked once (in the
+    // hd = 0 pass, which then is the first AND the last head's pass) and the passes hd = 1..3 only flush their dWv / dWo
+    const bool first = N == 1 || hd == 0, last = N == 1 || hd == 3;
+    const bool walk = N != 1 || hd == 0;
     float wq[NJ], wk[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -201,8 +210,9 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
       for (int g2 = 0; g2 < CG; ++g2) gw2[g][g2] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     float nacc0[NJ], nacc1[NJ];  // norm-gain / bias gradient partials: head 0: (d g_out, d b_out); head 3: (d g_pre, -)
+    float nacc2[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) nacc0[j] = nacc1[j] = 0.f;
+    for (int j = 0; j < NJ; ++j) nacc0[j] = nacc1[j] = nacc2[j] = 0.f;
 
     // raw operands of one unit (row block): loaded one unit AHEAD when the registers allow it (C <= 8), so that the global
     // latency hides behind the previous unit's MFMAs -- with one wave per SIMD nothing else would cover it
@@ -227,7 +237,7 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
     if (PREFETCH) load_unit(u0);
 
 #pragma unroll 1
-    for (int u = u0; u < u1; ++u) {
+    for (int u = u0; u < (walk ? u1 : u0); ++u) {
       const int row = u * RW + rl;
       const bool row_ok = row < a.rows;
       // ---- x, ypre, dy; pre-norm recompute; post-norm backward (same arithmetic as k_block_bwd) -> DY = dYpre
@@ -249,8 +259,8 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
           const int c = rmap(j, half);
           const int64_t off = ((int64_t)row * C + c) * N + (N >= 32 ? b * 32 + col : col % N);
           const bool ok = row_ok && c < C;
-          pdxh[b][j] = (PREFETCH && ok && hd > 0) ? a.dxh[off] : 0.f;
-          pdx[b][j] = (PREFETCH && ok && hd == 3) ? a.dx[off] : 0.f;
+          pdxh[b][j] = (PREFETCH && ok && !first) ? a.dxh[off] : 0.f;
+          pdx[b][j] = (PREFETCH && ok && last) ? a.dx[off] : 0.f;
         }
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
@@ -272,7 +282,7 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
         for (int j = 0; j < NJ; ++j) {
           Xh[b][j] = xv[j] * inv * gpre[j];
           const float uh = uv[j] * uinv;
-          if (hd == 0) nacc0[j] = fmaf(dv_[j], uh * sqC, nacc0[j]);  // d g_out
+          if (first) nacc0[j] = fmaf(dv_[j], uh * sqC, nacc0[j]);  // d g_out
           const float gd = dv_[j] * gout[j] * sqC;
           uv[j] = uh;
           dv_[j] = gd;
@@ -283,7 +293,7 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           DY[b][j] = clamped ? dv_[j] * uinv : uinv * (dv_[j] - uv[j] * dot);
-          if (hd == 0) nacc1[j] += DY[b][j];  // d b_out (bias of to_out)
+          if (first) nacc1[j] += DY[b][j];  // d b_out (bias of to_out)
         }
       }
       // stage xh and dYpre as [c][n]: 4x4x1 A operands, and every lane needs ALL channels of dYpre at its position
@@ -587,8 +597,8 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
             const int c = rmap(j, half);
             const int64_t off = ((int64_t)row * C + c) * N + (N >= 32 ? b * 32 + col : col % N);
             const bool ok = row_ok && c < C;
-            pdxh[b][j] = (ok && hd > 0) ? a.dxh[off] : 0.f;
-            pdx[b][j] = (ok && hd == 3) ? a.dx[off] : 0.f;
+            pdxh[b][j] = (ok && !first) ? a.dxh[off] : 0.f;
+            pdx[b][j] = (ok && last) ? a.dx[off] : 0.f;
           }
       }
 #pragma unroll
@@ -606,12 +616,12 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
             float* dst = a.dxh + ((int64_t)row * C + c) * N + pos;
             // head 0 initialises, heads 1, 2 accumulate (same lane, same address); C > 8 has no registers for the prefetch
             const float prev = pdxh[b][j];
-            if (hd < 3) *dst = prev + val;
+            if (!last) *dst = prev + val;
             else lo = prev + val;
           }
           tot[j] = lo;
         }
-        if (hd == 3) {
+        if (last) {
           // ---- residual + pre-norm backward on the completed dXh (own channels c = rmap(j, half)); dx += dy + d/dx
           float xv[NJ];
           float ssq = 0.f;
@@ -627,7 +637,8 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
             const float uh = xv[j] * inv;
-            nacc0[j] = fmaf(tot[j], uh * sqC, nacc0[j]);  // d g_pre
+            if (N == 1) nacc2[j] = fmaf(tot[j], uh * sqC, nacc2[j]);  // d g_pre (its own accumulator when one pass is first and last)
+            else nacc0[j] = fmaf(tot[j], uh * sqC, nacc0[j]);
             const float gd = tot[j] * gpre[j] * sqC;
             xv[j] = uh;
             tot[j] = gd;
@@ -678,6 +689,7 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
     }
     constexpr int NV4 = CG * CG * 16;  // floats one row contributes: [value vi = (g1 * CG + g2) * 4 + i][j = lane & 3]
     wfence();
+    if (walk) {  // (1-position rows: dW2 is the same for every head and stays in w2g from the hd = 0 pass)
 #pragma unroll
     for (int g1 = 0; g1 < CG; ++g1)
 #pragma unroll
@@ -699,6 +711,7 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
         w2g[(4 * g1 + i) * C + 4 * g2 + j] = v;
         w2g[C * C + (4 * g2 + j) * C + 4 * g1 + i] = v;  // transposed copy: both halves below read along their reduction index
       }
+    }
     }
     wfence();
     if (hd == 1) DQ_STAMP(11);
@@ -722,13 +735,16 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
       }
     }
     if (hd == 1) DQ_STAMP(12);
-    if (hd == 0 || hd == 3) {  // norm gains / bias: sum over the 32 positions-lanes of this half, one lane stores
+    if (hd == 0 || (hd == 3 && N != 1)) {  // norm gains / bias: sum over the 32 positions-lanes of this half, one lane stores
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int c = rmap(j, half);
-        const float s0 = half_sum(nacc0[j]), s1 = half_sum(nacc1[j]);
+        const float s0 = half_sum(nacc0[j]), s1 = half_sum(nacc1[j]), s2 = N == 1 ? half_sum(nacc2[j]) : 0.f;
         if (col == 0 && c < C) {
-          if (hd == 0) { slot[512 * C + c] = s0; slot[513 * C + c] = s1; }
+          if (hd == 0) {
+            slot[512 * C + c] = s0; slot[513 * C + c] = s1;
+            if (N == 1) slot[514 * C + c] = s2;
+          }
           else slot[514 * C + c] = s0;
         }
       }
