@@ -307,3 +307,32 @@ def test_transformer_data_parallel_exchange_gloo_world2():
     for _, err, n in out:
         assert err < 1e-5 and n > 0
     assert all(p.exitcode == 0 for p in procs)
+
+
+def test_checkpoint_roundtrip_with_the_adapter(tmp_path):
+    """The harness's checkpoint (reference model_interface.py:561-626) with the transformer behind its adapter: model keys are
+    the transformer's own (a reference CustomTransformer checkpoint loads), the optimizer state has torch AdamW's layout."""
+    from dquartic.model.building_blocks import CustomTransformer, DDIMTransformerAdapter
+    from dquartic.model.model import DDIMDiffusionModel
+
+    def make(seed):
+        torch.manual_seed(seed)
+        return DDIMDiffusionModel(model_class=DDIMTransformerAdapter(CustomTransformer(24, 16, 2, 1)), device="cpu")
+
+    dm = make(0)
+    dm._set_optimizer(1e-5)
+    dm.optimizer._buffers()
+    dm.optimizer._m.uniform_(-1, 1); dm.optimizer._v.uniform_(0, 1); dm.optimizer._step = 5
+    dm.optimizer._publish_state()
+    sch = dm._get_lr_schedule_with_warmup(2, 10)
+    path = str(tmp_path / "tfm.ckpt")
+    dm.save_checkpoint(sch, 2, 0.5, path)
+    ck = torch.load(path, weights_only=False)
+    assert list(ck["model_state_dict"])[0] == "input_projection.weight"
+    assert len(ck["optimizer_state_dict"]["state"]) == len(ck["model_state_dict"])
+    dm2 = make(1)
+    dm2._set_optimizer(1e-5)
+    ep, best, _ = dm2.load_checkpoint(dm2._get_lr_schedule_with_warmup(2, 10), path, "cpu")
+    assert (ep, best) == (2, 0.5)
+    assert torch.equal(dm2.model.flat_params, dm.model.flat_params)
+    assert torch.equal(dm2.optimizer._m, dm.optimizer._m) and torch.equal(dm2.optimizer._v, dm.optimizer._v) and dm2.optimizer._step == 5
