@@ -101,6 +101,9 @@ struct ResBwd {
   const float* g1 = nullptr; const float* g2 = nullptr; const float* ss = nullptr; int ss_stride = 0;
   float* du1 = nullptr; float* du2 = nullptr;          // written (the weight-gradient kernels read them)
   float* dA = nullptr; float* dB = nullptr; int cinA = 0, cinB = 0;  // += gradient of the block input (nullable)
+  // dA_store / dB_store: this launch is the FIRST writer of that gradient tensor in the backward pass -> plain store, the old
+  // contents (zeros) are not read (13 MB per tensor and launch at the wide levels)
+  int dA_store = 0, dB_store = 0;
   float* dg1 = nullptr; float* dg2 = nullptr; float* dss = nullptr;  // atomic += (dg1 / dg2: only when gpart is null)
   // gpart (nullable, k_res_bwd only): the norm-gain sums of every block go to gpart[block][2 C] = [dg2 | dg1] instead of 2 C
   // atomics per block on the same cache line (3,200 blocks at batch 32: 0.17 ms per step of serialised atomics); *gblocks
@@ -156,7 +159,8 @@ constexpr int PREP_COPY_MAX = 4;
 int launch_linattn_prepare(const LaPrepItem* items, int count, hipStream_t s, const PrepCopy* copies = nullptr, int n_copies = 0);
 struct LinAttnBwd {
   LinAttn f;
-  const float* dy = nullptr; float* dx = nullptr;  // dx +=
+  const float* dy = nullptr; float* dx = nullptr;  // dx += (dx_store: the only writer of dx in this backward -> plain store)
+  int dx_store = 0;
   const float* ypre = nullptr;                     // saved by the forward
   float* dyp = nullptr; float* dxh = nullptr;      // scratch (rows, C, n) each
   float* part = nullptr; int64_t part_floats = 0;  // per-wave dW partial slots: >= LA_MAX_WAVES * 512 * C floats

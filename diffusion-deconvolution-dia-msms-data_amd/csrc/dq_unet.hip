@@ -179,8 +179,10 @@ int res_fwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, int 
 }
 
 // ResnetBlock backward: d(out) is complete in the twin of b.out; adds into dA / dB (twins of the inputs; null => skipped)
+// storeA / storeB: this block is the first writer of dA / dB in the backward pass (fused path only; the step-by-step path
+// below accumulates into the cleared buffers as before)
 int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, float* dA, int cinA, const float* inB, float* dB, int cinB,
-            int rows, int n, int rows_per_sample) {
+            int rows, int n, int rows_per_sample, int storeA = 0, int storeB = 0) {
   const float* dout = c.g(b.out);
   if (rows_per_sample > 1 && res_fusable(n, r.cout)) {
     // m/z levels: the whole data path in one launch, then the three weight-gradient launches
@@ -189,6 +191,7 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
     k.w1 = c.prm(r.c1.w); k.w2 = c.prm(r.c2.w); k.wr = r.res.cout ? c.prm(r.res.w) : nullptr;
     k.g1 = c.prm(r.g1); k.g2 = c.prm(r.g2); k.ss = c.w(c.ar.ss) + r.ss_off; k.ss_stride = c.p.ss_total;
     k.du1 = c.g(b.u1); k.du2 = c.g(b.u2); k.dA = dA; k.dB = dB; k.cinA = cinA; k.cinB = cinB;
+    k.dA_store = storeA; k.dB_store = storeB;
     k.dg1 = c.dprm(r.g1); k.dg2 = c.dprm(r.g2); k.dss = c.g(c.ar.ss) + r.ss_off;
     k.C = r.cout; k.rows = rows; k.n = n; k.rows_per_sample = rows_per_sample;
     int gblocks = 0;
@@ -330,6 +333,7 @@ int la_bwd(const Ctx& c, const LAP& l, const LevelBuf& b, const float* x, const 
   if (slot >= 0 && n <= 64 && (int)(c.p.downs.size() + c.p.ups.size()) <= LA_PREP_MAX) a.f.prep = c.w(c.ar.la_prep) + (int64_t)slot * LA_PREP_FLOATS;
   a.dw_qkv = c.dprm(l.qkv_w); a.dw_out = c.dprm(l.out_w); a.db_out = c.dprm(l.out_b); a.dg_pre = c.dprm(l.g_pre);
   a.dg_out = c.dprm(l.g_out);
+  a.dx_store = n <= 64 ? 1 : 0;  // the block's input feeds nothing else: this launch is the only writer of its gradient
   Ctx::LaDefer* d = c.la_defer;
   if (!d) return launch_linattn_bwd(a, c.s);
   const int64_t need = n <= 64 ? la_part_reserve(l.C) : c.ar.la_part_floats;
@@ -503,7 +507,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
   // head
   DQ_TRY(conv_plain_bwd(c, p.final_conv, CONV_S1, c.w(a.fin.out), grad_out, c.g(a.fin.out), R, p.mz, p.mz, 0));
   const LevelBuf& lastup = a.ups[L - 1];
-  DQ_TRY(res_bwd(c, p.fin, a.fin, c.w(lastup.rs), c.g(lastup.rs), p.dim, c.w(a.h0), c.g(a.h0), p.dim, R, p.mz, RT));
+  DQ_TRY(res_bwd(c, p.fin, a.fin, c.w(lastup.rs), c.g(lastup.rs), p.dim, c.w(a.h0), c.g(a.h0), p.dim, R, p.mz, RT, 1, 1));  // first writers of d rs, d h0
   // up path, reversed
   for (int ui = L - 1; ui >= 0; --ui) {
     const LevelP& l = p.ups[ui];
@@ -513,8 +517,9 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     const int64_t in_off = ui == 0 ? a.mid_back : a.ups[ui - 1].rs;
     DQ_TRY(conv_plain_bwd(c, l.resample, l.last ? CONV_S1 : CONV_UP, c.w(b.la), c.g(b.rs), c.g(b.la), R, l.n, l.n_next, 1));
     DQ_TRY(la_bwd(c, l.la, b, c.w(b.r1.out), c.g(b.la), c.g(b.r1.out), R, l.n, L + ui));
-    DQ_TRY(res_bwd(c, l.r1, b.r1, c.w(b.r0.out), c.g(b.r0.out), cx, c.w(a.downs[lv].r0.out), c.g(a.downs[lv].r0.out), cs, R, l.n, RT));
-    DQ_TRY(res_bwd(c, l.r0, b.r0, c.w(in_off), c.g(in_off), cx, c.w(a.downs[lv].la), c.g(a.downs[lv].la), cs, R, l.n, RT));
+    // the up path is the first writer of its own tensors AND of the skip tensors (the down path accumulates into them later)
+    DQ_TRY(res_bwd(c, l.r1, b.r1, c.w(b.r0.out), c.g(b.r0.out), cx, c.w(a.downs[lv].r0.out), c.g(a.downs[lv].r0.out), cs, R, l.n, RT, 1, 1));
+    DQ_TRY(res_bwd(c, l.r0, b.r0, c.w(in_off), c.g(in_off), cx, c.w(a.downs[lv].la), c.g(a.downs[lv].la), cs, R, l.n, RT, 1, 1));
     DQ_TRY(side_flush(c));  // this level's resample-conv and two ResnetBlock weight gradients behind one event
   }
   // bottleneck
@@ -554,7 +559,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     DQ_TRY(conv_plain_bwd(c, l.resample, l.last ? CONV_S1 : CONV_DOWN, c.w(b.la), c.g(b.rs), c.g(b.la), R, l.n, l.n_next, 1));
     DQ_TRY(la_bwd(c, l.la, b, c.w(b.r1.out), c.g(b.la), c.g(b.r1.out), R, l.n, lv));
     DQ_TRY(res_bwd(c, l.r1, b.r1, c.w(b.r0.out), c.g(b.r0.out), C, nullptr, nullptr, 0, R, l.n, RT));
-    DQ_TRY(res_bwd(c, l.r0, b.r0, c.w(in_off), c.g(in_off), C, nullptr, nullptr, 0, R, l.n, RT));
+    DQ_TRY(res_bwd(c, l.r0, b.r0, c.w(in_off), c.g(in_off), C, nullptr, nullptr, 0, R, l.n, RT, lv > 0 ? 1 : 0, 0));  // (d h0 has the final block's part already)
     DQ_TRY(side_flush(c));
   }
   // MS1 feature path

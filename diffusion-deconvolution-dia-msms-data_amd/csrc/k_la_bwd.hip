@@ -54,6 +54,7 @@ struct LinAttnBwdK {
   float* part;  // per-wave partial slots: [wave][LA_SLOT(C)] = dWqkv (384C) | dWo (128C) | d g_out | d b_out | d g_pre
   int rows; int units_per_wave;
   const float* prep;  // nullable: W2 (4 C C floats) prepared by launch_linattn_prepare
+  int dx_store;       // dx is written, not accumulated into (its old contents are not read)
 #ifdef DQ_LA_PROBE
   unsigned long long* probe;  // tools/probe/la_bwd_time.hip: [wave][16] shader-clock stamps
 #endif
@@ -260,7 +261,7 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
           const int64_t off = ((int64_t)row * C + c) * N + (N >= 32 ? b * 32 + col : col % N);
           const bool ok = row_ok && c < C;
           pdxh[b][j] = (PREFETCH && ok && !first) ? a.dxh[off] : 0.f;
-          pdx[b][j] = (PREFETCH && ok && last) ? a.dx[off] : 0.f;
+          pdx[b][j] = (PREFETCH && ok && last && !a.dx_store) ? a.dx[off] : 0.f;
         }
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
@@ -598,7 +599,7 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
             const int64_t off = ((int64_t)row * C + c) * N + (N >= 32 ? b * 32 + col : col % N);
             const bool ok = row_ok && c < C;
             pdxh[b][j] = (ok && !first) ? a.dxh[off] : 0.f;
-            pdx[b][j] = (ok && last) ? a.dx[off] : 0.f;
+            pdx[b][j] = (ok && last && !a.dx_store) ? a.dx[off] : 0.f;
           }
       }
 #pragma unroll
@@ -920,7 +921,7 @@ int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s) {
   LinAttnBwdK k;
   k.x = a.f.x; k.ypre = a.ypre; k.dy = a.dy; k.dx = a.dx; k.dxh = a.dxh; k.w_qkv = a.f.w_qkv; k.w_out = a.f.w_out;
   k.g_pre = a.f.g_pre; k.g_out = a.f.g_out; k.part = a.part; k.rows = rows; k.units_per_wave = 1;
-  k.prep = a.f.prep;
+  k.prep = a.f.prep; k.dx_store = a.dx_store;
   switch (C) {
     case 4: return linattn_bwd_n<4>(k, n, a, s);
     case 8: return linattn_bwd_n<8>(k, n, a, s);

@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
     dout[c] = live ? a.dout[obase + (int64_t)c * a.n] : 0.f;
     u[c] = live ? a.u2[obase + (int64_t)c * a.n] : 1.f;
     u1v[c] = live ? a.u1[obase + (int64_t)c * a.n] : 1.f;
-    dold[c] = (live && !a.wr && a.dA) ? a.dA[obase + (int64_t)c * a.n] : 0.f;
+    dold[c] = (live && !a.wr && a.dA && !a.dA_store) ? a.dA[obase + (int64_t)c * a.n] : 0.f;
     d[c] = dout[c];
   }
   norm_act_bwd<C, false>(u, d, a.g2, nullptr, dg2, nullptr, nullptr);
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
         float* dst = nullptr;
         if (ci < a.cinA) { if (a.dA) dst = a.dA + ((int64_t)row * a.cinA + ci) * a.n + p; }
         else if (ci < cin) { if (a.dB) dst = a.dB + ((int64_t)row * a.cinB + (ci - a.cinA)) * a.n + p; }
-        oldv[ci] = dst ? *dst : 0.f;
+        oldv[ci] = (dst && !(ci < a.cinA ? a.dA_store : a.dB_store)) ? *dst : 0.f;
       }
 #pragma unroll
       for (int ci = 0; ci < CM; ++ci) {

@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(256) k_res_bwd_cp(ResBwd a) {
         float* o = dst + ((int64_t)row * cpart + ch) * N;
         float oldv[N];
 #pragma unroll
-        for (int p = 0; p < N; ++p) oldv[p] = o[p];  // all reads before the first store
+        for (int p = 0; p < N; ++p) oldv[p] = (pass == 0 ? a.dA_store : a.dB_store) ? 0.f : o[p];  // all reads before the first store
 #pragma unroll
         for (int p = 0; p < N; ++p) o[p] = oldv[p] + dx[p];
       }

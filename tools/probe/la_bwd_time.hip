@@ -39,7 +39,7 @@ static void run(int rows, int max_waves) {
   k.units_per_wave = std::max(1, cdiv(units, max_waves));
   const int waves = cdiv(units, k.units_per_wave);
   float* part; CK(hipMalloc(&part, (size_t)waves * la_slot(C) * sizeof(float)));
-  k.part = part; k.rows = rows; k.prep = nullptr;
+  k.part = part; k.rows = rows; k.prep = nullptr; k.dx_store = 0;
   unsigned long long* probe; CK(hipMalloc(&probe, (size_t)(waves + 4) * 16 * 8));
   CK(hipMemset(probe, 0, (size_t)(waves + 4) * 16 * 8));
   k.probe = nullptr;
