@@ -34,9 +34,13 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
   auto take = [&](int64_t n) { int64_t o = off; off += (n + 63) / 64 * 64; return o; };  // 256-B aligned
   auto take_nz = [&](int64_t n) { int64_t o = off_nz; off_nz += (n + 63) / 64 * 64; return o; };
   const int64_t R = (int64_t)B * RT;
-  auto res = [&](int64_t rows, int c, int n) {
+  // zero_out: the gradient of the block's output is accumulated into before anything stores to it (the bottleneck blocks'
+  // step-by-step backward); everywhere else the first writer of a gradient tensor stores (unet_backward), so the twin of that
+  // tensor needs no clearing -- the zero-fill per backward went from 452 MB to the few small tensors that are left in `take`
+  auto res = [&](int64_t rows, int c, int n, bool zero_out = false) {
     ResBuf r;
-    r.u1 = take_nz(rows * c * n); r.a1 = take_nz(rows * c * n); r.u2 = take_nz(rows * c * n); r.out = take(rows * c * n);
+    r.u1 = take_nz(rows * c * n); r.a1 = take_nz(rows * c * n); r.u2 = take_nz(rows * c * n);
+    r.out = zero_out ? take(rows * c * n) : take_nz(rows * c * n);
     // one slot per ResnetBlock (the ordered reduce runs on the side stream and may lag behind the next block's backward)
     r.gpart_floats = (int64_t)B * std::max((rows / B * n + 255) / 256, (rows / B + 15) / 16) * 2 * c;  // k_res_bwd / k_res_bwd_cp grids
     r.gpart = take_nz(r.gpart_floats);
@@ -47,29 +51,29 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
   a.cat0 = take(R * 2 * p.mz);
   a.ms1n = take(R);
   a.ms1_u = take(R * p.cond_dim); a.ms1_a = take(R * p.cond_dim); a.ms1f = take(R * p.cond_dim);
-  a.h0 = take(R * p.dim * p.mz);
+  a.h0 = take_nz(R * p.dim * p.mz);
   for (int lv = 0; lv < p.levels; ++lv) {
     const LevelP& l = p.downs[lv];
     LevelBuf b;
     b.r0 = res(R, l.r0.cout, l.n); b.r1 = res(R, l.r1.cout, l.n);
-    b.la = take(R * l.la.C * l.n); b.la_pre = take_nz(R * l.la.C * l.n); b.la_tmp = take(R * l.la.C * l.n);
-    b.rs = take(R * l.resample.cout * l.n_next);
+    b.la = take_nz(R * l.la.C * l.n); b.la_pre = take_nz(R * l.la.C * l.n); b.la_tmp = take_nz(R * l.la.C * l.n);
+    b.rs = take_nz(R * l.resample.cout * l.n_next);
     a.downs.push_back(b);
   }
   a.mid_in = take(R * p.mid_c);
-  a.mid1 = res(B, p.mid_c, RT);
+  a.mid1 = res(B, p.mid_c, RT, true);
   a.xn = take(R * p.mid_c);
   a.qv = take(R * 2 * HID); a.kk = take(R * HID); a.o = take(R * HID);
   a.lse = take(R * HEADS); a.delta = take(R * HEADS);
   a.attn_out = take(R * p.mid_c);
-  a.mid2 = res(B, p.mid_c, RT);
+  a.mid2 = res(B, p.mid_c, RT, true);
   a.mid_back = take(R * p.mid_c);
   for (int ui = 0; ui < p.levels; ++ui) {
     const LevelP& l = p.ups[ui];
     LevelBuf b;
     b.r0 = res(R, l.r0.cout, l.n); b.r1 = res(R, l.r1.cout, l.n);
-    b.la = take(R * l.la.C * l.n); b.la_pre = take_nz(R * l.la.C * l.n); b.la_tmp = take(R * l.la.C * l.n);
-    b.rs = take(R * l.resample.cout * l.n_next);
+    b.la = take_nz(R * l.la.C * l.n); b.la_pre = take_nz(R * l.la.C * l.n); b.la_tmp = take_nz(R * l.la.C * l.n);
+    b.rs = take_nz(R * l.resample.cout * l.n_next);
     a.ups.push_back(b);
   }
   a.fin = res(R, p.dim, p.mz);
@@ -333,7 +337,7 @@ int la_bwd(const Ctx& c, const LAP& l, const LevelBuf& b, const float* x, const 
   if (slot >= 0 && n <= 64 && (int)(c.p.downs.size() + c.p.ups.size()) <= LA_PREP_MAX) a.f.prep = c.w(c.ar.la_prep) + (int64_t)slot * LA_PREP_FLOATS;
   a.dw_qkv = c.dprm(l.qkv_w); a.dw_out = c.dprm(l.out_w); a.db_out = c.dprm(l.out_b); a.dg_pre = c.dprm(l.g_pre);
   a.dg_out = c.dprm(l.g_out);
-  a.dx_store = n <= 64 ? 1 : 0;  // the block's input feeds nothing else: this launch is the only writer of its gradient
+  a.dx_store = 1;  // the block's input feeds nothing else: this launch is the only writer of its gradient (not pre-cleared)
   Ctx::LaDefer* d = c.la_defer;
   if (!d) return launch_linattn_bwd(a, c.s);
   const int64_t need = n <= 64 ? la_part_reserve(l.C) : c.ar.la_part_floats;
@@ -515,7 +519,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     const int lv = L - 1 - ui;
     const int cx = l.r0.cout, cs = l.r0.cin - l.r0.cout;
     const int64_t in_off = ui == 0 ? a.mid_back : a.ups[ui - 1].rs;
-    DQ_TRY(conv_plain_bwd(c, l.resample, l.last ? CONV_S1 : CONV_UP, c.w(b.la), c.g(b.rs), c.g(b.la), R, l.n, l.n_next, 1));
+    DQ_TRY(conv_plain_bwd(c, l.resample, l.last ? CONV_S1 : CONV_UP, c.w(b.la), c.g(b.rs), c.g(b.la), R, l.n, l.n_next, 0));  // only writer of d la (up): store
     DQ_TRY(la_bwd(c, l.la, b, c.w(b.r1.out), c.g(b.la), c.g(b.r1.out), R, l.n, L + ui));
     // the up path is the first writer of its own tensors AND of the skip tensors (the down path accumulates into them later)
     DQ_TRY(res_bwd(c, l.r1, b.r1, c.w(b.r0.out), c.g(b.r0.out), cx, c.w(a.downs[lv].r0.out), c.g(a.downs[lv].r0.out), cs, R, l.n, RT, 1, 1));
@@ -549,7 +553,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     DQ_TRY(launch_axpy(c.g(a.mid1.out), c.g(a.xn), (int64_t)R * p.mid_c, c.s));
   }
   DQ_TRY(res_bwd(c, p.mid1, a.mid1, c.w(a.mid_in), c.g(a.mid_in), p.mid_c, nullptr, nullptr, 0, B, RT, 1));
-  DQ_TRY(launch_fold(c.g(a.mid_in), c.g(a.downs[L - 1].rs), B, RT, p.mid_c, 0, 1, c.s));
+  DQ_TRY(launch_fold(c.g(a.mid_in), c.g(a.downs[L - 1].rs), B, RT, p.mid_c, 0, 0, c.s));  // first and only writer: store
   // down path, reversed
   for (int lv = L - 1; lv >= 0; --lv) {
     const LevelP& l = p.downs[lv];

@@ -902,6 +902,9 @@ int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s) {
   static const bool long_all = [] { const char* e = std::getenv("DQ_LA_BWD_LONG"); return e && e[0] == '1'; }();
   if (n > 64 || (long_all && n >= 32 && C <= 8)) {
     // rows of 128 / 256 positions: the sweep kernel between two pointwise norm-backward launches
+    // (these launches accumulate into dx: a caller that asked for a plain store gets a cleared dx first)
+    if (a.dx_store)
+      if (int rz = launch_zero(a.dx, (int64_t)rows * C * n, s)) return rz;
     BlockBwd b2;  // (1) post-norm backward: dyp = d loss / d ypre, d g_out, d b_out
     b2.u = a.ypre; b2.dy = a.dy; b2.du = a.dyp; b2.C = C; b2.rows = rows; b2.n = n; b2.rows_per_sample = rows;
     b2.g = a.f.g_out; b2.dg = a.dg_out; b2.dbias = a.db_out;
