@@ -215,6 +215,67 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd_rows_reg(const float* __r
   }
 }
 
+// H <= 1024, H % 4 == 0: one block per row, one float4 per thread -- a single round of loads and two LDS reductions (with a few
+// dozen rows per launch the kernel is one dependent chain; its length, not its bandwidth, is what the batch-1 step pays 16 times)
+__device__ __forceinline__ float block4_sum(float v, float* red, int slot) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[slot * 4 + (threadIdx.x >> 6)] = v;
+  __syncthreads();
+  return (red[slot * 4] + red[slot * 4 + 1]) + (red[slot * 4 + 2] + red[slot * 4 + 3]);
+}
+__global__ void __launch_bounds__(256) k_layernorm_fwd_blk(const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ g,
+                                                           const float* __restrict__ b, float* __restrict__ y, float* __restrict__ out,
+                                                           float* __restrict__ stats, int H) {
+  __shared__ float red[8];
+  const int row = blockIdx.x, h = threadIdx.x * 4;
+  const bool ok = h < H;
+  const int64_t at = (int64_t)row * H + h;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f), gg = v, bb = v;
+  if (ok) {
+    v = *reinterpret_cast<const float4*>(x + at);
+    gg = *reinterpret_cast<const float4*>(g + h);
+    bb = *reinterpret_cast<const float4*>(b + h);
+    if (r) {
+      const float4 rv = *reinterpret_cast<const float4*>(r + at);
+      v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+    }
+    *reinterpret_cast<float4*>(y + at) = v;
+  }
+  const float mean = block4_sum((v.x + v.y) + (v.z + v.w), red, 0) / (float)H;
+  float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) d = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+  const float rstd = 1.0f / sqrtf(block4_sum(fmaf(d.x, d.x, d.y * d.y) + fmaf(d.z, d.z, d.w * d.w), red, 1) / (float)H + 1e-5f);
+  if (ok) *reinterpret_cast<float4*>(out + at) = make_float4(d.x * rstd * gg.x + bb.x, d.y * rstd * gg.y + bb.y, d.z * rstd * gg.z + bb.z,
+                                                             d.w * rstd * gg.w + bb.w);
+  if (threadIdx.x == 0 && stats) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+__global__ void __launch_bounds__(256) k_layernorm_bwd_rows_blk(const float* __restrict__ y, const float* __restrict__ stats,
+                                                                const float* __restrict__ g, const float* __restrict__ dout, float* __restrict__ dy,
+                                                                int H) {
+  __shared__ float red[8];
+  const int row = blockIdx.x, h = threadIdx.x * 4;
+  const bool ok = h < H;
+  const int64_t at = (int64_t)row * H + h;
+  const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+  float4 dxh = make_float4(0.f, 0.f, 0.f, 0.f), xh = dxh;
+  if (ok) {
+    const float4 dv = *reinterpret_cast<const float4*>(dout + at), gg = *reinterpret_cast<const float4*>(g + h);
+    const float4 yv = *reinterpret_cast<const float4*>(y + at);
+    dxh = make_float4(dv.x * gg.x, dv.y * gg.y, dv.z * gg.z, dv.w * gg.w);
+    xh = make_float4((yv.x - mean) * rstd, (yv.y - mean) * rstd, (yv.z - mean) * rstd, (yv.w - mean) * rstd);
+  }
+  float s1 = (dxh.x + dxh.y) + (dxh.z + dxh.w);
+  float s2 = fmaf(dxh.x, xh.x, dxh.y * xh.y) + fmaf(dxh.z, xh.z, dxh.w * xh.w);
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s1; red[4 + (threadIdx.x >> 6)] = s2; }
+  __syncthreads();
+  s1 = ((red[0] + red[1]) + (red[2] + red[3])) / (float)H;
+  s2 = ((red[4] + red[5]) + (red[6] + red[7])) / (float)H;
+  if (ok) *reinterpret_cast<float4*>(dy + at) = make_float4(rstd * (dxh.x - s1 - xh.x * s2), rstd * (dxh.y - s1 - xh.y * s2),
+                                                            rstd * (dxh.z - s1 - xh.z * s2), rstd * (dxh.w - s1 - xh.w * s2));
+}
+
 // dy = rstd * (dxh - mean(dxh) - xh * mean(dxh * xh)), dxh = dout * g, xh = (y - mean) * rstd
 __global__ void __launch_bounds__(256) k_layernorm_bwd_rows(const float* __restrict__ y, const float* __restrict__ stats, const float* __restrict__ g,
                                                             const float* __restrict__ dout, float* __restrict__ dy, int rows, int H) {
@@ -346,7 +407,9 @@ int launch_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, hipSt
 int launch_layernorm_fwd(const float* x, const float* r, const float* g, const float* b, float* y, float* out, float* stats, int rows, int H,
                          hipStream_t s) {
   if (rows == 0) return 0;
-  if (H <= 256) hipLaunchKernelGGL(k_layernorm_fwd_reg<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, r, g, b, y, out, stats, rows, H);
+  const bool vec = H % 4 == 0 && ((((uintptr_t)x | (uintptr_t)r | (uintptr_t)g | (uintptr_t)b | (uintptr_t)y | (uintptr_t)out) & 15) == 0);
+  if (vec && H > 256 && H <= 1024) hipLaunchKernelGGL(k_layernorm_fwd_blk, dim3(rows), dim3(256), 0, s, x, r, g, b, y, out, stats, H);
+  else if (H <= 256) hipLaunchKernelGGL(k_layernorm_fwd_reg<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, r, g, b, y, out, stats, rows, H);
   else if (H <= 1024) hipLaunchKernelGGL(k_layernorm_fwd_reg<16>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, r, g, b, y, out, stats, rows, H);
   else hipLaunchKernelGGL(k_layernorm_fwd, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, r, g, b, y, out, stats, rows, H);
   DQ_LAUNCH_CHECK();
@@ -355,7 +418,9 @@ int launch_layernorm_fwd(const float* x, const float* r, const float* g, const f
 int launch_layernorm_bwd(const float* y, const float* stats, const float* g, const float* dout, float* dy, float* dg, float* db, float* scratch,
                          int rows, int H, hipStream_t s, int accumulate) {
   if (rows == 0) return 0;
-  if (H <= 256) hipLaunchKernelGGL(k_layernorm_bwd_rows_reg<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, y, stats, g, dout, dy, rows, H);
+  const bool vec = H % 4 == 0 && ((((uintptr_t)y | (uintptr_t)g | (uintptr_t)dout | (uintptr_t)dy) & 15) == 0);
+  if (vec && H > 256 && H <= 1024) hipLaunchKernelGGL(k_layernorm_bwd_rows_blk, dim3(rows), dim3(256), 0, s, y, stats, g, dout, dy, H);
+  else if (H <= 256) hipLaunchKernelGGL(k_layernorm_bwd_rows_reg<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, y, stats, g, dout, dy, rows, H);
   else if (H <= 1024) hipLaunchKernelGGL(k_layernorm_bwd_rows_reg<16>, dim3(cdiv(rows, 4)), dim3(256), 0, s, y, stats, g, dout, dy, rows, H);
   else hipLaunchKernelGGL(k_layernorm_bwd_rows, dim3(cdiv(rows, 4)), dim3(256), 0, s, y, stats, g, dout, dy, rows, H);
   const int nb = std::min(rows, LN_BWD_BLOCKS);

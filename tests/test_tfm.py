@@ -143,7 +143,8 @@ def test_hip_forward_backward_match_reference_fixtures(golden, tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("D,H,heads,layers,B,S1,S2", [(200, 64, 4, 2, 3, 34, 20), (1000, 128, 1, 1, 2, 70, 9), (64, 256, 8, 3, 5, 17, 34)])
+@pytest.mark.parametrize("D,H,heads,layers,B,S1,S2", [(200, 64, 4, 2, 3, 34, 20), (1000, 128, 1, 1, 2, 70, 9), (64, 256, 8, 3, 5, 17, 34),
+                                                     (96, 512, 8, 1, 2, 34, 34), (72, 1008, 4, 1, 1, 9, 5), (48, 1032, 2, 1, 1, 5, 7)])
 def test_hip_matches_oracle_at_larger_shapes(D, H, heads, layers, B, S1, S2):
     from dquartic.model.building_blocks import CustomTransformer
 
