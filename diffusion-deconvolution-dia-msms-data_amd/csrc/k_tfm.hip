@@ -425,8 +425,12 @@ int launch_layernorm_bwd(const float* y, const float* stats, const float* g, con
   else hipLaunchKernelGGL(k_layernorm_bwd_rows, dim3(cdiv(rows, 4)), dim3(256), 0, s, y, stats, g, dout, dy, rows, H);
   const int nb = std::min(rows, LN_BWD_BLOCKS);
   hipLaunchKernelGGL(k_layernorm_bwd_cols, dim3(cdiv(H, 256), nb), dim3(256), 0, s, y, stats, dout, scratch, rows, H);
-  hipLaunchKernelGGL(k_partial_reduce, dim3(cdiv(H, 256)), dim3(256), 0, s, scratch, nb, (int64_t)2 * H, H, dg, accumulate);
-  hipLaunchKernelGGL(k_partial_reduce, dim3(cdiv(H, 256)), dim3(256), 0, s, scratch + H, nb, (int64_t)2 * H, H, db, accumulate);
+  if (db == dg + H) {  // gain and bias adjacent (the flat parameter layout): the [dg | db] partial rows reduce in one launch
+    hipLaunchKernelGGL(k_partial_reduce, dim3(cdiv(2 * H, 256)), dim3(256), 0, s, scratch, nb, (int64_t)2 * H, 2 * H, dg, accumulate);
+  } else {
+    hipLaunchKernelGGL(k_partial_reduce, dim3(cdiv(H, 256)), dim3(256), 0, s, scratch, nb, (int64_t)2 * H, H, dg, accumulate);
+    hipLaunchKernelGGL(k_partial_reduce, dim3(cdiv(H, 256)), dim3(256), 0, s, scratch + H, nb, (int64_t)2 * H, H, db, accumulate);
+  }
   DQ_LAUNCH_CHECK();
   return 0;
 }
@@ -444,7 +448,12 @@ int launch_softmax_rows_bwd(const float* p, float* dp, int64_t rows, int n, int 
 }
 int launch_colsum(const float* x, int M, int N, int64_t ld, float* out, float* scratch, hipStream_t s, int accumulate) {
   if (M == 0 || N == 0) return 0;
-  const int nb = std::min(M, COLSUM_BLOCKS);
+  if (M <= COLSUM_BLOCKS) {  // a few dozen rows: they are the partial vectors already
+    hipLaunchKernelGGL(k_partial_reduce, dim3(cdiv(N, 256)), dim3(256), 0, s, x, M, ld, N, out, accumulate);
+    DQ_LAUNCH_CHECK();
+    return 0;
+  }
+  const int nb = COLSUM_BLOCKS;
   hipLaunchKernelGGL(k_colsum, dim3(cdiv(N, 256), nb), dim3(256), 0, s, x, M, N, ld, scratch);
   hipLaunchKernelGGL(k_partial_reduce, dim3(cdiv(N, 256)), dim3(256), 0, s, scratch, nb, (int64_t)N, N, out, accumulate);
   DQ_LAUNCH_CHECK();
