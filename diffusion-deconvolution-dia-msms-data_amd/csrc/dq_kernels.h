@@ -55,13 +55,26 @@ int launch_conv_fwd(const ConvFwd& a, hipStream_t s);
 struct BlockBwd {
   const float* u = nullptr; const float* dy = nullptr; float* du = nullptr;
   int C = 0, rows = 0, n = 0, rows_per_sample = 1;
-  const float* g = nullptr; float* dg = nullptr;                           // norm gain and its grad (atomic +=)
-  const float* ss = nullptr; float* dss = nullptr; int ss_stride = 0;     // per-sample scale/shift and grads (atomic +=)
+  const float* g = nullptr; float* dg = nullptr;                           // norm gain and its grad (+=)
+  const float* ss = nullptr; float* dss = nullptr; int ss_stride = 0;     // per-sample scale/shift and grads (+=)
   int act = ACT_NONE;
-  float* dbias = nullptr;  // optional: sum of du over rows and positions (atomic +=)
+  float* dbias = nullptr;  // optional: sum of du over rows and positions (+=)
   int accumulate = 0;      // 1: du += instead of du =
+  // per-block partial sums [dg | dscale | dshift | dbias] (needed when any of dg / dss / dbias is set): >= 64 * groups * 4 C
+  // floats; the launcher sums them in block order right behind the kernel (no float atomics: repeatable to the bit)
+  float* part = nullptr; int64_t part_floats = 0;
 };
 int launch_block_bwd(const BlockBwd& a, hipStream_t s);
+
+// ordered sums of per-block partials part[(b * gx + x) * nv + i] (b < B groups, x < gx blocks per group): up to three "global"
+// segments [start, start + len) -> dst[j] += sum over every block, and one per-group segment [s0, s0 + sn) ->
+// sdst[b * sstride + j] += sum over the group's blocks.  Fixed summation order.
+struct PartReduce {
+  const float* part = nullptr; int B = 0, gx = 0, nv = 0;
+  int nseg = 0; int seg_start[3] = {0, 0, 0}, seg_len[3] = {0, 0, 0}; float* seg_dst[3] = {nullptr, nullptr, nullptr};
+  int s0 = 0, sn = 0; float* sdst = nullptr; int sstride = 0;
+};
+int launch_part_reduce(const PartReduce& a, hipStream_t s);
 
 // dX (+=) of a conv: dinA/dinB receive the gradient of the concat input (either may be null => skipped)
 struct ConvBwdData {
@@ -104,10 +117,11 @@ struct ResBwd {
   // dA_store / dB_store: this launch is the FIRST writer of that gradient tensor in the backward pass -> plain store, the old
   // contents (zeros) are not read (13 MB per tensor and launch at the wide levels)
   int dA_store = 0, dB_store = 0;
-  float* dg1 = nullptr; float* dg2 = nullptr; float* dss = nullptr;  // atomic += (dg1 / dg2: only when gpart is null)
-  // gpart (nullable, k_res_bwd only): the norm-gain sums of every block go to gpart[block][2 C] = [dg2 | dg1] instead of 2 C
-  // atomics per block on the same cache line (3,200 blocks at batch 32: 0.17 ms per step of serialised atomics); *gblocks
-  // receives the block count and launch_res_gain_reduce adds the ordered sums to dg2 / dg1 (deterministic)
+  float* dg1 = nullptr; float* dg2 = nullptr; float* dss = nullptr;  // destinations of the ordered sums (res_part_reduce)
+  // gpart: every block's sums go to gpart[block][4 C] = [dg2 | dg1 | dscale | dshift] (block = sample * blocks_per_sample + x)
+  // instead of float atomics (2 C of them per block on one cache line from 3,200 blocks cost 0.17 ms per step, and atomics
+  // are not repeatable); *gblocks receives the blocks per sample; launch_part_reduce (res_part_reduce) adds the ordered sums
+  // to dg2 / dg1 / dss
   float* gpart = nullptr; int64_t gpart_floats = 0; int* gblocks = nullptr;
   int C = 0, rows = 0, n = 0, rows_per_sample = 1;
 };
@@ -121,7 +135,15 @@ bool res_v4_usable(int n, int C, int cinA, int cinB);
 int launch_res_fwd_v4(const ResFwd& a, hipStream_t s);
 int launch_res_fwd(const ResFwd& a, hipStream_t s);
 int launch_res_bwd(const ResBwd& a, hipStream_t s);
-int launch_res_gain_reduce(const float* gpart, int blocks, int C, float* dg2, float* dg1, hipStream_t s);
+// the descriptor of a fused ResnetBlock backward's partial sums for launch_part_reduce
+inline PartReduce res_part_reduce(const float* gpart, int gx, int B, int C, float* dg2, float* dg1, float* dss, int ss_stride) {
+  PartReduce r;
+  r.part = gpart; r.B = B; r.gx = gx; r.nv = 4 * C; r.nseg = 2;
+  r.seg_start[0] = 0; r.seg_len[0] = C; r.seg_dst[0] = dg2;
+  r.seg_start[1] = C; r.seg_len[1] = C; r.seg_dst[1] = dg1;
+  r.s0 = 2 * C; r.sn = 2 * C; r.sdst = dss; r.sstride = ss_stride;
+  return r;
+}
 
 // standalone RMSNorm forward (PreNorm of the bottleneck attention)
 int launch_rmsnorm_fwd(const float* x, const float* g, float* y, int C, int rows, int n, hipStream_t s);
@@ -132,9 +154,9 @@ int launch_fold(const float* in, float* out, int B, int RT, int cn, int to_mid, 
 // first layer inputs: cat0 = [cond_n*(scale+1)+shift, x] as (rows, 2, MZ); ms1n = ms1*cm+ca
 int launch_prep_inputs(const float* x, const float* cond, const float* ms1, const float* ss, int ss_stride, int ss_off, float cm,
                        float ca, float* cat0, float* ms1n, int B, int RT, int MZ, hipStream_t s);
-// d(scale), d(shift) of init_cond_proj from dcat0 channel 0 (atomic += into dss)
+// d(scale), d(shift) of init_cond_proj from dcat0 channel 0 (+= into dss; part: >= 64 * B floats of per-block partials)
 int launch_prep_inputs_bwd(const float* dcat0, const float* cond, float cm, float ca, float* dss, int ss_stride, int ss_off, int B,
-                           int RT, int MZ, hipStream_t s);
+                           int RT, int MZ, float* part, int64_t part_floats, hipStream_t s);
 
 // ---- k_time.hip (declared in dq_unet.h: needs the plan)
 

@@ -42,7 +42,9 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
     r.u1 = take_nz(rows * c * n); r.a1 = take_nz(rows * c * n); r.u2 = take_nz(rows * c * n);
     r.out = zero_out ? take(rows * c * n) : take_nz(rows * c * n);
     // one slot per ResnetBlock (the ordered reduce runs on the side stream and may lag behind the next block's backward)
-    r.gpart_floats = (int64_t)B * std::max((rows / B * n + 255) / 256, (rows / B + 15) / 16) * 2 * c;  // k_res_bwd / k_res_bwd_cp grids
+    // per-block partial sums [dg2 | dg1 | dscale | dshift]: k_res_bwd / k_res_bwd_cp grids, or the <= 64 blocks per sample of
+    // k_block_bwd on the step-by-step path
+    r.gpart_floats = (int64_t)B * std::max<int64_t>({(rows / B * n + 255) / 256, (rows / B + 15) / 16, 64}) * 4 * c;
     r.gpart = take_nz(r.gpart_floats);
     return r;
   };
@@ -93,6 +95,8 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
   a.la_part_floats = std::max<int64_t>(a.la_part_floats, (int64_t)LA_MAX_WAVES * 512 * 16);
   a.la_part = take_nz(a.la_part_floats);
   a.la_prep = take_nz((int64_t)LA_PREP_MAX * LA_PREP_FLOATS);  // prepared LinearAttention weights, one slot per layer (downs, then ups)
+  a.bb_part_floats = (int64_t)64 * B * 4 * std::max(p.mid_c, 2);  // partial sums of the PreNorm backward / the input affine
+  a.bb_part = take_nz(a.bb_part_floats);
   a.wtmp = take_nz(3 * WTMP_SLOT);  // 16-byte aligned copy of a projection weight for the GEMM route of the wide 1x1 convs
   a.ts_tab = take_nz(1024); a.step = take_nz(64);  // graph replay: timestep table (int32) and the device-side step counter
   a.c2_stage = take_nz(R * p.mz); a.c1_stage = take_nz(R);  // conditions staged at fixed addresses for the captured step
@@ -125,7 +129,7 @@ struct Ctx {
   // set by unet_backward: the side-stream launches (weight gradients, norm-gain reduces) are collected and issued by side_flush
   // behind ONE event per group instead of one per ResnetBlock / conv (an event record costs ~4 us on the main stream: 29 + 14
   // of them were 0.13 ms per step); everything they read is final when it is queued and stays untouched until the join
-  struct SideItem { int kind; ConvWgrad w[3]; int count; const float* gpart; int gblocks; int C; float* dg2; float* dg1; };
+  struct SideItem { int kind; ConvWgrad w[3]; int count; PartReduce red; };
   std::vector<SideItem>* side_defer = nullptr;
   float* w(int64_t off) const { return W + off; }
   float* g(int64_t off) const { return G + off; }
@@ -220,16 +224,19 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
       count = 3;
     }
     DQ_TRY(wgrad_async_multi(c, w, count));
-    // the ordered sum of the per-block norm-gain partials: behind the weight gradients on the side stream (which has waited for
-    // the event recorded after k_res_bwd), or on the main stream without one
+    // the ordered sums of the per-block partials (norm gains, this block's d(scale), d(shift) of every sample): behind the
+    // weight gradients on the side stream (which has waited for the event recorded after k_res_bwd), or on the main stream
+    // without one.  The time-embedding backward, which reads d(scale, shift), runs after the join.
     if (gblocks > 0) {
+      const PartReduce red = res_part_reduce(c.w(b.gpart), gblocks, rows / rows_per_sample, r.cout, c.dprm(r.g2), c.dprm(r.g1),
+                                             c.g(c.ar.ss) + r.ss_off, c.p.ss_total);
       if (c.side_defer && c.owner) {
         Ctx::SideItem it{};
-        it.kind = 2; it.gpart = c.w(b.gpart); it.gblocks = gblocks; it.C = r.cout; it.dg2 = c.dprm(r.g2); it.dg1 = c.dprm(r.g1);
+        it.kind = 2; it.red = red;
         c.side_defer->push_back(it);
       } else {
         hipStream_t rs = (c.owner && c.owner->side_stream) ? c.owner->side_stream : c.s;
-        DQ_TRY(launch_res_gain_reduce(c.w(b.gpart), gblocks, r.cout, c.dprm(r.g2), c.dprm(r.g1), rs));
+        DQ_TRY(launch_part_reduce(red, rs));
       }
     }
     return 0;
@@ -238,6 +245,7 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
   BlockBwd bb;
   bb.u = c.w(b.u2); bb.dy = dout; bb.du = c.g(b.u2); bb.C = r.cout; bb.rows = rows; bb.n = n; bb.rows_per_sample = rows_per_sample;
   bb.g = c.prm(r.g2); bb.dg = c.dprm(r.g2); bb.act = ACT_SILU;
+  bb.part = c.w(b.gpart); bb.part_floats = b.gpart_floats;
   DQ_TRY(launch_block_bwd(bb, c.s));
   ConvWgrad wg;
   wg.scratch = c.w(c.ar.wg); wg.scratch_floats = c.ar.wg_floats;
@@ -253,6 +261,7 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
   b1.u = c.w(b.u1); b1.dy = c.g(b.a1); b1.du = c.g(b.u1); b1.C = r.cout; b1.rows = rows; b1.n = n; b1.rows_per_sample = rows_per_sample;
   b1.g = c.prm(r.g1); b1.dg = c.dprm(r.g1); b1.act = ACT_SILU;
   b1.ss = c.w(c.ar.ss) + r.ss_off; b1.dss = c.g(c.ar.ss) + r.ss_off; b1.ss_stride = c.p.ss_total;
+  b1.part = c.w(b.gpart); b1.part_floats = b.gpart_floats;
   DQ_TRY(launch_block_bwd(b1, c.s));
   ConvWgrad w1;
   w1.scratch = c.w(c.ar.wg); w1.scratch_floats = c.ar.wg_floats;
@@ -549,6 +558,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     BlockBwd nb;
     nb.u = c.w(a.mid1.out); nb.dy = c.g(a.xn); nb.du = c.g(a.xn); nb.C = p.mid_c; nb.rows = B; nb.n = RT; nb.rows_per_sample = 1;
     nb.g = c.prm(p.ag); nb.dg = c.dprm(p.ag);
+    nb.part = c.w(a.bb_part); nb.part_floats = a.bb_part_floats;
     DQ_TRY(launch_block_bwd(nb, c.s));
     DQ_TRY(launch_axpy(c.g(a.mid1.out), c.g(a.xn), (int64_t)R * p.mid_c, c.s));
   }
@@ -577,17 +587,19 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
   }
   // init conv + mixture conditioning
   DQ_TRY(conv_plain_bwd(c, p.init_conv, CONV_S1, c.w(a.cat0), c.g(a.h0), c.g(a.cat0), R, p.mz, p.mz, 0));
-  DQ_TRY(launch_prep_inputs_bwd(c.g(a.cat0), init_cond, cm, ca, c.g(a.ss), p.ss_total, p.ss_init, B, RT, p.mz, c.s));
+  DQ_TRY(launch_prep_inputs_bwd(c.g(a.cat0), init_cond, cm, ca, c.g(a.ss), p.ss_total, p.ss_init, B, RT, p.mz, c.w(a.bb_part),
+                                a.bb_part_floats, c.s));
   if (grad_x) {
     // channel 1 of d(cat0) is d loss / d x
     DQ_HIP_OK(hipMemcpy2DAsync(grad_x, sizeof(float) * p.mz, c.g(a.cat0) + p.mz, sizeof(float) * 2 * p.mz, sizeof(float) * p.mz, R,
                                hipMemcpyDeviceToDevice, c.s));
   }
-  // time embedding: all scale/shift heads + the MLP
-  DQ_TRY(launch_time_embed_bwd(p, dt, c.P, c.dP, c.w(a.tbuf), c.g(a.ss), B, c.s));
   DQ_TRY(la_flush(c));
   DQ_TRY(side_flush(c));
-  return join_side(c);
+  DQ_TRY(join_side(c));
+  // time embedding: all scale/shift heads + the MLP -- after the join: the per-sample d(scale, shift) of the fused ResnetBlocks are
+  // summed on the side stream
+  return launch_time_embed_bwd(p, dt, c.P, c.dP, c.w(a.tbuf), c.g(a.ss), B, c.s);
 }
 
 int wgrad_async(const Ctx& c, const ConvWgrad& w) {
@@ -648,7 +660,7 @@ int side_flush(const Ctx& c) {
   for (Ctx::SideItem& it : items) {
     if (it.kind == 2) {
       hipStream_t rs = pl->side_stream ? pl->side_stream : c.s;
-      DQ_TRY(launch_res_gain_reduce(it.gpart, it.gblocks, it.C, it.dg2, it.dg1, rs));
+      DQ_TRY(launch_part_reduce(it.red, rs));
       continue;
     }
     if (first || !pl->side_stream) {  // one event for the whole group (wgrad_async also creates the stream on first use)

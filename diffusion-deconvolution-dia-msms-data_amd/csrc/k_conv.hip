@@ -258,12 +258,77 @@ __global__ void __launch_bounds__(256) k_block_bwd(BlockBwd a) {
     if (lane == 0) { red[wv][c] = s0; red[wv][C + c] = s1; red[wv][2 * C + c] = s2; red[wv][3 * C + c] = s3; }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) {
-    const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
-    if (i < C) { if (a.dg) atomicAdd(a.dg + i, v); }
-    else if (i < 3 * C) { if (a.dss) atomicAdd(a.dss + (int64_t)b * a.ss_stride + (i - C), v); }  // [dscale(C) | dshift(C)]
-    else if (a.dbias) atomicAdd(a.dbias + (i - 3 * C), v);
+  // [dg | dscale | dshift | dbias] of this block into its own slot; launch_part_reduce sums the slots in block order
+  if (a.part)
+    for (int i = threadIdx.x; i < 4 * C; i += blockDim.x)
+      a.part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (4 * C) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Ordered reduction of per-block partial sums: part[(b * gx + x) * nv + i], b < B groups (samples), x < gx blocks per group.
+//   "global" segments  [start, start + len) -> dst[j] += sum over all (b, x)      (norm gains, biases)
+//   one per-group segment [s0, s0 + sn)     -> sdst[b * sstride + j] += sum over x (a sample's d(scale), d(shift))
+// Every sum is taken in a fixed order (strided per thread, then an LDS tree in thread order): repeatable to the bit, which the
+// float atomics this replaces were not.
+// -------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_part_reduce(PartReduce a, int nglobal) {
+  __shared__ float red[256];
+  if ((int)blockIdx.x < nglobal) {
+    int j = blockIdx.x, seg = 0;
+    while (j >= a.seg_len[seg]) { j -= a.seg_len[seg]; ++seg; }
+    const int col = a.seg_start[seg] + j;
+    const int blocks = a.B * a.gx;
+    float s0 = 0.f, s1 = 0.f;
+    int k = threadIdx.x;
+    for (; k + 256 < blocks; k += 512) {
+      s0 += a.part[(int64_t)k * a.nv + col];
+      s1 += a.part[(int64_t)(k + 256) * a.nv + col];
+    }
+    if (k < blocks) s0 += a.part[(int64_t)k * a.nv + col];
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (threadIdx.x < 16) {  // 16 threads x 16 consecutive partials, then one thread over the 16
+      float t = 0.f;
+      for (int q = 0; q < 16; ++q) t += red[threadIdx.x * 16 + q];
+      red[threadIdx.x * 16] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int q = 0; q < 16; ++q) t += red[q * 16];
+      a.seg_dst[seg][j] += t;
+    }
+    return;
   }
+  // group b: thread (slice, i) sums x = slice, slice + S, ... of value s0 + i; the S slices meet in LDS in slice order
+  const int b = blockIdx.x - nglobal;
+  for (int i0 = 0; i0 < a.sn; i0 += 32) {
+    const int i = i0 + (threadIdx.x & 31), slice = threadIdx.x >> 5;
+    float t = 0.f;
+    if (i < a.sn)
+      for (int x = slice; x < a.gx; x += 8) t += a.part[((int64_t)b * a.gx + x) * a.nv + a.s0 + i];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    if (slice == 0 && i < a.sn) {
+      float v = 0.f;
+      for (int q = 0; q < 8; ++q) v += red[q * 32 + (threadIdx.x & 31)];
+      a.sdst[(int64_t)b * a.sstride + i] += v;
+    }
+    __syncthreads();
+  }
+}
+
+int launch_part_reduce(const PartReduce& a, hipStream_t s) {
+  DQ_REQUIRE(a.part && a.B > 0 && a.gx > 0 && a.nv > 0 && a.nseg >= 0 && a.nseg <= 3, "part_reduce: bad descriptor");
+  int nglobal = 0;
+  for (int i = 0; i < a.nseg; ++i) nglobal += a.seg_len[i];
+  const int groups = (a.sn > 0 && a.sdst) ? a.B : 0;
+  if (nglobal + groups == 0) return 0;
+  PartReduce k = a;
+  if (!groups) k.sn = 0;
+  hipLaunchKernelGGL(k_part_reduce, dim3(nglobal + groups), dim3(256), 0, s, k, nglobal);
+  DQ_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_block_bwd(const BlockBwd& a, hipStream_t s) {
@@ -278,6 +343,9 @@ int launch_block_bwd(const BlockBwd& a, hipStream_t s) {
   // ~4 items per thread, at most 64 blocks per sample
   const int bps = std::max(1, std::min(64, cdiv(per_sample, 1024)));
   dim3 grid(bps, B), block(256);
+  const bool need_sums = a.dg || a.dss || a.dbias;
+  DQ_REQUIRE(!need_sums || (a.part && a.part_floats >= (int64_t)bps * B * 4 * a.C), "block_bwd: partial-sum slot missing or too small");
+  if (!need_sums) a2.part = nullptr;
 #define DQ_BB(CC)                                                     \
   case CC:                                                            \
     hipLaunchKernelGGL((k_block_bwd<CC>), grid, block, 0, s, a_);     \
@@ -290,7 +358,14 @@ int launch_block_bwd(const BlockBwd& a, hipStream_t s) {
   }
 #undef DQ_BB
   DQ_LAUNCH_CHECK();
-  return 0;
+  if (!need_sums) return 0;
+  // the ordered sums of the per-block partials, right behind the kernel on the same stream (the slot is free again afterwards)
+  PartReduce r;
+  r.part = a.part; r.B = B; r.gx = bps; r.nv = 4 * a.C;
+  if (a.dg) { r.seg_start[r.nseg] = 0; r.seg_len[r.nseg] = a.C; r.seg_dst[r.nseg] = a.dg; ++r.nseg; }
+  if (a.dbias) { r.seg_start[r.nseg] = 3 * a.C; r.seg_len[r.nseg] = a.C; r.seg_dst[r.nseg] = a.dbias; ++r.nseg; }
+  if (a.dss) { r.s0 = a.C; r.sn = 2 * a.C; r.sdst = a.dss; r.sstride = a.ss_stride; }
+  return launch_part_reduce(r, s);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -820,8 +895,7 @@ int launch_prep_inputs(const float* x, const float* cond, const float* ms1, cons
 }
 
 __global__ void __launch_bounds__(256) k_prep_inputs_bwd(const float* __restrict__ dcat0, const float* __restrict__ cond, float cm,
-                                                         float ca, float* __restrict__ dss, int ss_stride, int ss_off, int RT,
-                                                         int MZ) {
+                                                         float ca, float* __restrict__ part, int RT, int MZ) {
   const int b = blockIdx.y;
   const int64_t per = (int64_t)RT * MZ;
   float dsc = 0.f, dsh = 0.f;
@@ -837,19 +911,22 @@ __global__ void __launch_bounds__(256) k_prep_inputs_bwd(const float* __restrict
   dsh = wave_sum(dsh);
   if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = dsc; red[threadIdx.x >> 6][1] = dsh; }
   __syncthreads();
-  if (threadIdx.x < 2)
-    atomicAdd(dss + (int64_t)b * ss_stride + ss_off + threadIdx.x,
-              red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (threadIdx.x < 2)  // [dscale, dshift] of this block; summed over the sample's blocks in order by launch_part_reduce
+    part[((int64_t)b * gridDim.x + blockIdx.x) * 2 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 int launch_prep_inputs_bwd(const float* dcat0, const float* cond, float cm, float ca, float* dss, int ss_stride, int ss_off, int B,
-                           int RT, int MZ, hipStream_t s) {
+                           int RT, int MZ, float* part, int64_t part_floats, hipStream_t s) {
   const int64_t per = (int64_t)RT * MZ;
   if (per == 0 || B == 0) return 0;
   dim3 grid(std::max(1, std::min(32, cdiv(per, 1024))), B);
-  hipLaunchKernelGGL(k_prep_inputs_bwd, grid, dim3(256), 0, s, dcat0, cond, cm, ca, dss, ss_stride, ss_off, RT, MZ);
+  DQ_REQUIRE(part && part_floats >= (int64_t)grid.x * B * 2, "prep_inputs_bwd: partial-sum slot missing or too small");
+  hipLaunchKernelGGL(k_prep_inputs_bwd, grid, dim3(256), 0, s, dcat0, cond, cm, ca, part, RT, MZ);
   DQ_LAUNCH_CHECK();
-  return 0;
+  PartReduce r;
+  r.part = part; r.B = B; r.gx = (int)grid.x; r.nv = 2; r.s0 = 0; r.sn = 2; r.sdst = dss + ss_off; r.sstride = ss_stride;
+  return launch_part_reduce(r, s);
 }
 
 }  // namespace dq

@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
       for (int ci = 0; ci < C; ++ci) a.dA[obase + (int64_t)ci * a.n] = dold[ci] + dx[ci];
     }
   }
-  // ---- reductions: dg2, dg1 (atomic), per-sample d(scale), d(shift) (atomic)
+  // ---- reductions: dg2, dg1, this sample's d(scale), d(shift)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int c = 0; c < C; ++c) {
@@ -335,50 +335,10 @@ __global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
     if (lane == 0) { red[wv][c] = s0; red[wv][C + c] = s1; red[wv][2 * C + c] = s2; red[wv][3 * C + c] = s3; }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) {
-    const float v = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
-    if (i < 2 * C) {
-      if (a.gpart) a.gpart[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * C) + i] = v;  // [dg2 | dg1] of this block
-      else if (i < C) atomicAdd(a.dg2 + i, v);
-      else atomicAdd(a.dg1 + (i - C), v);
-    } else atomicAdd(a.dss + (int64_t)b * a.ss_stride + (i - 2 * C), v);  // [dscale(C) | dshift(C)]: contended per sample only
-  }
-}
-
-// dg2[c] += sum_blocks gpart[block][c] ; dg1[c] += sum_blocks gpart[block][C + c] : one block per output, 256 threads sum a
-// strided share in block order and meet in LDS in thread order (fixed order: repeatable)
-__global__ void __launch_bounds__(256) k_res_gain_reduce(const float* __restrict__ gpart, int blocks, int C2, float* __restrict__ dg2,
-                                                         float* __restrict__ dg1) {
-  __shared__ float red[256];
-  const int i = blockIdx.x;
-  float s0 = 0.f, s1 = 0.f;
-  int j = threadIdx.x;
-  for (; j + 256 < blocks; j += 512) {
-    s0 += gpart[(int64_t)j * C2 + i];
-    s1 += gpart[(int64_t)(j + 256) * C2 + i];
-  }
-  if (j < blocks) s0 += gpart[(int64_t)j * C2 + i];
-  red[threadIdx.x] = s0 + s1;
-  __syncthreads();
-  if (threadIdx.x < 16) {  // 16 threads x 16 consecutive partials, then one thread over the 16
-    float t = 0.f;
-    for (int k = 0; k < 16; ++k) t += red[threadIdx.x * 16 + k];
-    red[threadIdx.x * 16] = t;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int k = 0; k < 16; ++k) t += red[k * 16];
-    const int C = C2 / 2;
-    if (i < C) dg2[i] += t;
-    else dg1[i - C] += t;
-  }
-}
-int launch_res_gain_reduce(const float* gpart, int blocks, int C, float* dg2, float* dg1, hipStream_t s) {
-  if (blocks == 0) return 0;
-  hipLaunchKernelGGL(k_res_gain_reduce, dim3(2 * C), dim3(256), 0, s, gpart, blocks, 2 * C, dg2, dg1);
-  DQ_LAUNCH_CHECK();
-  return 0;
+  // every block leaves its four sums [dg2 | dg1 | dscale | dshift] in its own slot of gpart; launch_part_reduce adds them up in
+  // block order (repeatable to the bit: no float atomics)
+  for (int i = threadIdx.x; i < 4 * C; i += blockDim.x)
+    a.gpart[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (4 * C) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
 
 int launch_res_bwd(const ResBwd& a, hipStream_t s) {
@@ -391,8 +351,8 @@ int launch_res_bwd(const ResBwd& a, hipStream_t s) {
   const int B = a.rows / a.rows_per_sample;
   dim3 grid(cdiv((int64_t)a.rows_per_sample * a.n, 256), B), block(256);
   ResBwd k = a;
-  if (k.gpart && k.gblocks && k.gpart_floats >= (int64_t)grid.x * grid.y * 2 * a.C) *k.gblocks = (int)(grid.x * grid.y);
-  else k.gpart = nullptr;
+  DQ_REQUIRE(k.gpart && k.gblocks && k.gpart_floats >= (int64_t)grid.x * grid.y * 4 * a.C, "res_bwd: partial-sum slot missing or too small");
+  *k.gblocks = (int)grid.x;  // blocks per sample
   switch (a.C) {
     case 4: hipLaunchKernelGGL((k_res_bwd<4>), grid, block, 0, s, k); break;
     case 8: hipLaunchKernelGGL((k_res_bwd<8>), grid, block, 0, s, k); break;

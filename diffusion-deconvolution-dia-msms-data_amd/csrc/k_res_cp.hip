@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(256) k_res_fwd_cp(ResFwd a, int iters) {  // i
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-// backward data path (same outputs as k_res_bwd: dU2, dU1 for the weight-gradient kernels, dA/dB +=, dg1/dg2/dss atomics)
+// backward data path (same outputs as k_res_bwd: dU2, dU1 for the weight-gradient kernels, dA/dB +=, per-block partial sums of dg1/dg2/dss)
 // -----------------------------------------------------------------------------------------------------------------
 namespace {
 // pointwise backward of RMSNorm -> (scale+1, shift) -> SiLU for this lane's channel at one position; the two channel
@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(256) k_res_bwd_cp(ResBwd a) {
       }
     }
   }
-  // ---- reductions over the block's 16 rows: dg2, dg1 (atomic), this sample's d(scale), d(shift) (atomic)
+  // ---- reductions over the block's 16 rows: dg2, dg1, this sample's d(scale), d(shift)
   red[g][ch] = dg2; red[g][16 + ch] = dg1; red[g][32 + ch] = dsc; red[g][48 + ch] = dsh;
   __syncthreads();
   if (threadIdx.x < 64) {
@@ -349,13 +349,8 @@ __global__ void __launch_bounds__(256) k_res_bwd_cp(ResBwd a) {
     float v = 0.f;
 #pragma unroll
     for (int r = 0; r < GR; ++r) v += red[r][what * 16 + c];
-    if (c < C) {
-      if (what < 2 && a.gpart) a.gpart[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * C) + what * C + c] = v;  // [dg2 | dg1]
-      else if (what == 0) atomicAdd(a.dg2 + c, v);
-      else if (what == 1) atomicAdd(a.dg1 + c, v);
-      else if (what == 2) atomicAdd(a.dss + (int64_t)b * a.ss_stride + c, v);
-      else atomicAdd(a.dss + (int64_t)b * a.ss_stride + C + c, v);
-    }
+    // [dg2 | dg1 | dscale | dshift] of this block into its own slot (summed in block order by launch_part_reduce)
+    if (c < C) a.gpart[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (4 * C) + what * C + c] = v;
   }
 }
 
@@ -381,9 +376,9 @@ int launch_res_fwd_cp(const ResFwd& a, hipStream_t s) {
 int launch_res_bwd_cp(const ResBwd& a, hipStream_t s) {
   const int B = a.rows / a.rows_per_sample;
   dim3 grid(cdiv(a.rows_per_sample, GR), B), block(256);
-  ResBwd k = a;  // norm-gain partials (see ResBwd::gpart): used when the caller's slot holds one entry per block
-  if (k.gpart && k.gblocks && k.gpart_floats >= (int64_t)grid.x * grid.y * 2 * a.C) *k.gblocks = (int)(grid.x * grid.y);
-  else k.gpart = nullptr;
+  ResBwd k = a;  // partial sums of the norm gains and scale / shift (see ResBwd::gpart)
+  DQ_REQUIRE(k.gpart && k.gblocks && k.gpart_floats >= (int64_t)grid.x * grid.y * 4 * a.C, "res_bwd_cp: partial-sum slot missing or too small");
+  *k.gblocks = (int)grid.x;  // blocks per sample
 #define DQ_CP(CC, NN) \
   if (a.C == CC && a.n == NN) { hipLaunchKernelGGL((k_res_bwd_cp<CC, NN>), grid, block, 0, s, k); DQ_LAUNCH_CHECK(); return 0; }
   DQ_CP(12, 1) DQ_CP(12, 2) DQ_CP(12, 4) DQ_CP(12, 8) DQ_CP(16, 1) DQ_CP(16, 2) DQ_CP(16, 4) DQ_CP(16, 8)

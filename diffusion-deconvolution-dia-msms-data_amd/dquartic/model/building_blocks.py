@@ -62,6 +62,7 @@ class CustomTransformer(nn.Module):
             _attach(self, pname, p)
         self._reset_parameters()
         self._ws = {}
+        self._ws_pool = {}  # training workspaces of the autograd bridge: one per forward that still awaits its backward
         self._tables = {}
 
     @torch.no_grad()
@@ -142,6 +143,25 @@ class CustomTransformer(nn.Module):
             self._ws[key] = ws
         return ws
 
+    def checkout_train_workspace(self, B, S1, S2):
+        """A training workspace owned by ONE forward of the autograd bridge until its backward returns it (see UNet1d)."""
+        dev = self._flat.device
+        key = (B, S1, S2, str(dev))
+        pool = self._ws_pool.get(key)
+        if pool:
+            return pool.pop()
+        nbytes = N.lib().dq_tfm_workspace_bytes(self._tfm, B, S1, S2, 1)
+        if nbytes <= 0:
+            raise RuntimeError("dq_tfm_workspace_bytes failed")
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+
+    def return_train_workspace(self, B, S1, S2, ws):
+        key = (B, S1, S2, str(ws.device))
+        self._ws_pool = {k: v for k, v in self._ws_pool.items() if k == key}
+        pool = self._ws_pool.setdefault(key, [])
+        if len(pool) < 2:
+            pool.append(ws)
+
     def tables(self, S, device):
         key = (S, str(device))
         t = self._tables.get(key)
@@ -184,20 +204,22 @@ class CustomTransformer(nn.Module):
             return _TfmFn.apply(self, x_in, ts, c_in, *[p for _, p in self.trainable_named()])
         return self._run_fwd(xs, ts, cs, training=False)
 
-    def _run_fwd(self, xs, ts, cs, training):
+    def _run_fwd(self, xs, ts, cs, training, ws=None):
         B, S1, _ = xs.shape
         S2 = cs.shape[1]
-        ws = self.workspace(B, S1, S2, training)
+        if ws is None:
+            ws = self.workspace(B, S1, S2, training)
         sin, cos, freqs = self.tables(max(S1, S2), xs.device)
         out = torch.empty_like(xs)
         N.check(N.lib().dq_tfm_fwd(self._tfm, N.ptr(self._flat), N.ptr(sin), N.ptr(cos), N.ptr(freqs), N.ptr(xs), N.ptr(ts), N.ptr(cs),
                                    N.ptr(out), 1 if training else 0, N.ptr(ws), ws.numel(), B, S1, S2, N.stream_ptr()), "dq_tfm_fwd")
         return out
 
-    def _run_bwd(self, xs, cs, gout, grads, want_dx, want_dc, accumulate=True):
+    def _run_bwd(self, xs, cs, gout, grads, want_dx, want_dc, accumulate=True, ws=None):
         B, S1, _ = xs.shape
         S2 = cs.shape[1]
-        ws = self.workspace(B, S1, S2, True)
+        if ws is None:
+            ws = self.workspace(B, S1, S2, True)
         sin, cos, _ = self.tables(max(S1, S2), xs.device)
         gx = torch.empty_like(xs) if want_dx else None
         gc = torch.empty_like(cs) if want_dc else None
@@ -212,15 +234,20 @@ class _TfmFn(torch.autograd.Function):
         ctx.net = net
         ctx.save_for_backward(xs.detach(), cs.detach())
         ctx.needs = (xs.requires_grad, cs.requires_grad)
-        return net._run_fwd(xs.detach(), ts, cs.detach(), training=True)
+        ctx.ws = net.checkout_train_workspace(xs.shape[0], xs.shape[1], cs.shape[1])
+        return net._run_fwd(xs.detach(), ts, cs.detach(), training=True, ws=ctx.ws)
 
     @staticmethod
     def backward(ctx, gout):
         net = ctx.net
         xs, cs = ctx.saved_tensors
         gout = gout.contiguous().to(torch.float32)
+        if ctx.ws is None:
+            raise RuntimeError("CustomTransformer: backward through the same forward twice is not supported (its workspace was released)")
         grads = torch.empty_like(net._flat)  # written (not accumulated into) by the backward: no zeroing pass
-        gx, gc = net._run_bwd(xs, cs, gout, grads, *ctx.needs, accumulate=False)
+        gx, gc = net._run_bwd(xs, cs, gout, grads, *ctx.needs, accumulate=False, ws=ctx.ws)
+        net.return_train_workspace(xs.shape[0], xs.shape[1], cs.shape[1], ctx.ws)
+        ctx.ws = None
         pg = [grads[o:o + math.prod(shape)].view(shape) for _, o, shape in net._layout]
         return (None, gx, None, gc, *pg)
 

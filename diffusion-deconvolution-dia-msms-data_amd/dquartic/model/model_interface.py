@@ -180,13 +180,20 @@ class ModelInterface(object):
 
     def train(self, dataloader, batch_size, epochs, warmup_epochs: int = 5, learning_rate: float = 1e-4, use_wandb: bool = False,
               checkpoint_path: str = "best_model.ckpt", **kwargs):
-        """Epoch loop (reference :453-559).  ``warmup_epochs > 0`` uses the warm-up/cosine schedule, else a constant lr."""
-        self.train_with_warmup(dataloader, batch_size, epochs, max(0, int(warmup_epochs)), learning_rate, use_wandb, checkpoint_path,
-                               constant_lr=warmup_epochs <= 0, **kwargs)
+        """Epoch loop (reference :453-559).  ``warmup_epochs > 0`` uses the warm-up/cosine schedule, else a constant lr.
+        ``batch_size`` is accepted and unused, as in the reference (the dataloader carries it)."""
+        if warmup_epochs > 0:
+            self.train_with_warmup(dataloader, epochs, num_warmup_steps=int(warmup_epochs), learning_rate=learning_rate,
+                                   use_wandb=use_wandb, checkpoint_path=checkpoint_path, **kwargs)
+        else:
+            self.train_with_warmup(dataloader, epochs, num_warmup_steps=0, learning_rate=learning_rate, use_wandb=use_wandb,
+                                   checkpoint_path=checkpoint_path, constant_lr=True, **kwargs)
 
-    def train_with_warmup(self, dataloader, batch_size, num_epochs, num_warmup_steps: int = 5, learning_rate: float = 1e-4,
-                          use_wandb: bool = False, checkpoint_path: str = "best_model.ckpt", log_every_n_epochs: int = 100,
-                          constant_lr: bool = False, **kwargs):
+    def train_with_warmup(self, dataloader, num_epochs, num_warmup_steps=5, learning_rate=1e-4, use_wandb=True,
+                          log_every_n_epochs=100, checkpoint_path="best_model.ckpt", *, constant_lr: bool = False, **kwargs):
+        """Reference :348-450, same positional order (dataloader, num_epochs, num_warmup_steps, learning_rate, use_wandb,
+        log_every_n_epochs, checkpoint_path).  ``constant_lr`` (keyword-only, this build) is how ``train`` runs its
+        ``warmup_epochs <= 0`` branch (reference :498-559) through the same loop."""
         self.use_wandb_epoch = bool(use_wandb)
         wandb = _wandb() if use_wandb else None
         self._prepare_training(learning_rate)
@@ -195,6 +202,7 @@ class ModelInterface(object):
         ckpt_dir = os.path.dirname(checkpoint_path) or "."
         latest = os.path.join(ckpt_dir, "dquartic_latest_checkpoint.ckpt")
         start_epoch, best_loss, lr_scheduler = self.load_checkpoint(lr_scheduler, latest, self.device)
+        self._sync_replicas()  # data-parallel: every rank continues from rank 0's weights / moments (also after a resume)
         best_epoch = start_epoch
         rank0 = _rank() == 0
         for epoch in range(start_epoch, num_epochs):
@@ -203,7 +211,7 @@ class ModelInterface(object):
             batch_loss = self._train_one_epoch(epoch, dataloader)
             if lr_scheduler is not None:
                 lr_scheduler.step(epoch, np.mean(batch_loss))
-            avg = float(np.mean(batch_loss))
+            avg = self._global_mean(float(np.mean(batch_loss)))  # DP: the mean over ranks (one float, logging only)
             lr_now = self.optimizer.param_groups[0]["lr"]
             if wandb is not None and rank0:
                 wandb.log({"epoch": epoch, "train/loss": avg, "learning_rate": lr_now})
@@ -213,11 +221,47 @@ class ModelInterface(object):
                 if avg < best_loss:
                     best_loss, best_epoch = avg, epoch + 1
                     self.save_checkpoint(lr_scheduler, epoch, best_loss, checkpoint_path)
+            elif avg < best_loss:
+                best_loss, best_epoch = avg, epoch + 1
             if not self.callback_handler.epoch_callback(epoch=epoch, epoch_loss=avg):
                 print(f"Training stopped at epoch {epoch}")
                 break
         if rank0:
             print(f"Best model checkpoint saved at epoch {best_epoch} with loss: {best_loss:.6f}")
+
+    # ---- data-parallel helpers (new work: the reference is single-process)
+    def _sync_replicas(self, src: int = 0):
+        """Make every rank's replica identical to rank ``src``'s: the flat parameter buffer and, when an optimiser exists, its
+        AdamW moments and step count.  Each process builds its network from its own default-seeded RNG, and only gradients are
+        exchanged per step, so without this the replicas would start (or resume) from different weights and never meet."""
+        d = torch.distributed
+        if not (d.is_available() and d.is_initialized()) or d.get_world_size() == 1:
+            return
+        if hasattr(self.model, "flat_params"):
+            d.broadcast(self.model.flat_params, src=src)
+            for b in self.model.buffers():
+                d.broadcast(b, src=src)
+            if isinstance(self.optimizer, FlatAdamW):
+                self.optimizer._buffers()
+                d.broadcast(self.optimizer._m, src=src)
+                d.broadcast(self.optimizer._v, src=src)
+                step = torch.tensor([float(self.optimizer._step)], device=self.optimizer._m.device)
+                d.broadcast(step, src=src)
+                self.optimizer._step = int(step.item())
+        else:
+            for t in list(self.model.parameters()) + list(self.model.buffers()):
+                d.broadcast(t.data, src=src)
+
+    def _global_mean(self, value: float) -> float:
+        """Mean over the ranks of a per-rank scalar (the epoch's mean loss): identical on every rank afterwards, so the
+        "best" decision, the callback and the log line agree."""
+        d = torch.distributed
+        if not (d.is_available() and d.is_initialized()) or d.get_world_size() == 1:
+            return value
+        dev = self.model.flat_params.device if hasattr(self.model, "flat_params") else next(self.model.parameters()).device
+        t = torch.tensor([value], dtype=torch.float64, device=dev)
+        d.all_reduce(t)
+        return float(t.item()) / d.get_world_size()
 
     def load_checkpoint(self, scheduler, checkpoint_path, device):
         if os.path.exists(checkpoint_path):
@@ -258,6 +302,7 @@ class ModelInterface(object):
     def _prepare_training(self, lr: float, **kwargs):
         self.model.train()
         self._set_lr(lr)
+        self._sync_replicas()
 
     def _native_net(self) -> bool:
         from .building_blocks import DDIMTransformerAdapter

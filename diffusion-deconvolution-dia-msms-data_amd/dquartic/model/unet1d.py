@@ -117,6 +117,7 @@ class UNet1d(nn.Module):
             _attach(self, pname, self._by_name[pname])
         self._reset_parameters()
         self._ws = {}
+        self._ws_pool = {}  # training workspaces of the autograd bridge: one per forward that still awaits its backward
         self.use_rope = True
 
     # ------------------------------------------------------------------ initialisation
@@ -211,6 +212,27 @@ class UNet1d(nn.Module):
             self._ws[key] = ws
         return ws
 
+    def checkout_train_workspace(self, B: int, RT: int) -> torch.Tensor:
+        """A training workspace (activation arena + gradient twin) owned by ONE forward of the autograd bridge until its
+        backward hands it back: two forwards with grad enabled before a backward (micro-batches whose losses are summed, a
+        consistency term) each keep their own saved activations instead of overwriting a shared buffer."""
+        dev = self._flat.device
+        key = (B, RT, str(dev))
+        pool = self._ws_pool.get(key)
+        if pool:
+            return pool.pop()
+        nbytes = N.lib().dq_unet_workspace_bytes(self._plan, B, RT, 1)
+        if nbytes < 0:
+            raise RuntimeError("dq_unet_workspace_bytes failed")
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+
+    def return_train_workspace(self, B: int, RT: int, ws: torch.Tensor):
+        key = (B, RT, str(ws.device))
+        self._ws_pool = {k: v for k, v in self._ws_pool.items() if k == key}  # keep buffers of the current shape only
+        pool = self._ws_pool.setdefault(key, [])
+        if len(pool) < 2:
+            pool.append(ws)
+
     def __del__(self):
         try:
             if getattr(self, "_plan", None):
@@ -261,9 +283,10 @@ class UNet1d(nn.Module):
             out = self._run_fwd(xs, ts, ic, ac, training=False)
         return out[0] if squeeze else out
 
-    def _run_fwd(self, xs, ts, ic, ac, training, cond_mul=1.0, cond_add=0.0):
+    def _run_fwd(self, xs, ts, ic, ac, training, cond_mul=1.0, cond_add=0.0, ws=None):
         B, RT, MZ = xs.shape
-        ws = self.workspace(B, RT, training)
+        if ws is None:
+            ws = self.workspace(B, RT, training)
         out = torch.empty_like(xs)
         fr = self.rope_freqs()
         N.check(N.lib().dq_unet_fwd(self._plan, N.ptr(self._flat), N.ptr(fr), N.ptr(xs), N.ptr(ts), 0, N.ptr(ic), N.ptr(ac),
@@ -282,19 +305,24 @@ class _UNetFn(torch.autograd.Function):
         ctx.save_for_backward(ic)
         ctx.shape = xs.shape
         ctx.x_needs = xs.requires_grad
-        return net._run_fwd(xs.detach(), ts, ic, ac, training=True)
+        ctx.ws = net.checkout_train_workspace(xs.shape[0], xs.shape[1])  # this forward's saved activations live here
+        return net._run_fwd(xs.detach(), ts, ic, ac, training=True, ws=ctx.ws)
 
     @staticmethod
     def backward(ctx, gout):
         net = ctx.net
         (ic,) = ctx.saved_tensors
         B, RT, MZ = ctx.shape
-        ws = net.workspace(B, RT, True)
+        ws = ctx.ws
+        if ws is None:
+            raise RuntimeError("UNet1d: backward through the same forward twice is not supported (its workspace was released)")
         gout = gout.contiguous().to(torch.float32)
         grads = torch.zeros_like(net._flat)
         gx = torch.empty(ctx.shape, dtype=torch.float32, device=gout.device) if ctx.x_needs else None
         fr = net.rope_freqs()
         N.check(N.lib().dq_unet_bwd(net._plan, N.ptr(net._flat), N.ptr(fr), N.ptr(ic), 1.0, 0.0, N.ptr(gout), N.ptr(grads), N.ptr(gx),
                                     N.ptr(ws), ws.numel(), B, RT, N.stream_ptr()), "dq_unet_bwd")
+        ctx.ws = None
+        net.return_train_workspace(B, RT, ws)
         pg = [grads[o:o + math.prod(shape)].view(shape) for _, o, shape in net._layout]
         return (None, gx, None, None, None, *pg)

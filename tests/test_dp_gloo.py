@@ -70,3 +70,69 @@ def test_flat_gradient_allreduce_equals_global_batch_gradient():
     for rank, gerr, lerr, n, gsum in res:
         assert gerr < 1e-5 and lerr < 1e-6 and n == 3 and gsum > 0  # every rank holds the global-batch gradient; .grad views alias it
     assert res[0][4] == res[1][4]
+
+
+def _replica_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "diffusion-deconvolution-dia-msms-data_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dquartic.model.model import DDIMDiffusionModel
+        from dquartic.model.unet1d import UNet1d
+        from oracle import dq_oracle as O
+
+        # NO manual seed: every process draws its own default initialisation, like `dquartic train` under torchrun does
+        net = UNet1d(dim=4, channels=1, dim_mults=(1, 2), conditional=True, init_cond_channels=1, attn_cond_channels=1,
+                     downsample_dim=8, simple=True)
+        dm = DDIMDiffusionModel(model_class=net, device="cpu")
+        before = net.flat_params.clone()
+        dm._set_optimizer(1e-3)
+        if rank == 1:  # a stale optimiser state on one rank (e.g. only rank 0 found a checkpoint to resume from)
+            dm.optimizer._buffers()
+            dm.optimizer._m.fill_(3.0)
+            dm.optimizer._step = 7
+        dm._prepare_training(1e-3)  # -> _sync_replicas(): rank 0's weights and moments everywhere
+        synced = net.flat_params.clone()
+        cfg = O.UNetConfig(dim_mults=(1, 2), downsample_dim=8)
+        g = torch.Generator().manual_seed(5)
+        X, C2, C1 = torch.rand(4, 12, 8, generator=g), torch.rand(4, 12, 8, generator=g), torch.rand(4, 12, generator=g)
+        Tt, Nz = torch.tensor([3, 500, 999, 42]), torch.randn(4, 12, 8, generator=g)
+        mine = list(range(rank, 4, world))
+        m, v = dm.optimizer._m, dm.optimizer._v
+        for step in range(1, 4):  # three data-parallel steps; the update itself is the oracle's AdamW (no kernels on the CPU)
+            p = {k: t.detach().clone().requires_grad_(not k.endswith("freqs")) for k, t in net.state_dict().items()}
+            loss, _ = O.Diffusion(p, cfg).train_loss(X[mine], C2[mine], C1[mine], Tt[mine], Nz[mine])
+            loss.backward()
+            grads = net.flat_grads(zero=True)
+            grads.copy_(torch.cat([p[n].grad.reshape(-1) for n, _ in net.trainable_named()]))
+            dist.all_reduce(grads)
+            grads.mul_(1.0 / world)
+            with torch.no_grad():
+                O.adamw_step(net.flat_params, grads, m, v, dm.optimizer._step + step, 1e-3)
+        gathered = [torch.empty_like(net.flat_params) for _ in range(world)]
+        dist.all_gather(gathered, net.flat_params)
+        avg = dm._global_mean(float(rank + 1))
+        q.put((rank, bool(torch.equal(before, synced)), bool(torch.equal(gathered[0], gathered[1])), float(m.abs().max()),
+               dm.optimizer._step, avg, float((gathered[0] - synced).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_unseeded_replicas_are_synchronised_and_stay_identical():
+    """ranks build their networks from per-process RNG state; ``_prepare_training`` must broadcast rank 0's
+    parameters / AdamW moments / step count so that the all-reduced gradient is taken at ONE parameter point on every rank."""
+    world, port = 2, 30100 + (os.getpid() % 500)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_replica_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (r0, same0, eq0, m0, st0, avg0, moved0), (r1, same1, eq1, m1, st1, avg1, moved1) = res
+    assert same0 and not same1          # rank 0 kept its weights, rank 1's own initialisation was replaced
+    assert eq0 and eq1                  # after three steps the replicas are bit-identical
+    assert st0 == 0 and st1 == 0        # rank 1's stale step count / moments were overwritten by rank 0's
+    assert avg0 == avg1 == 1.5          # the logged loss is the mean over ranks on every rank
+    assert moved0 > 0

@@ -210,3 +210,46 @@ def test_train_one_epoch_builds_the_reference_triple(golden):
     assert out == [0.0]
     for k in ("x_0", "ms2_cond", "ms1_cond"):
         assert np.array_equal(seen[k].numpy(), g[f"out/{k}"]), k
+
+
+def test_train_signatures_keep_the_reference_positional_order(tmp_path):
+    """``train_with_warmup(loader, 100, 5, 1e-4)`` must mean 100 epochs, 5 warm-up epochs, lr 1e-4 as in the reference
+    (model_interface.py:348-357), and ``train`` keeps (dataloader, batch_size, epochs, warmup_epochs, learning_rate, use_wandb,
+    checkpoint_path) (:453-463)."""
+    import inspect
+
+    from dquartic.model.model_interface import ModelInterface
+
+    names = lambda f: [p.name for p in inspect.signature(f).parameters.values() if p.kind == p.POSITIONAL_OR_KEYWORD][1:]
+    assert names(ModelInterface.train_with_warmup) == ["dataloader", "num_epochs", "num_warmup_steps", "learning_rate", "use_wandb",
+                                                       "log_every_n_epochs", "checkpoint_path"]
+    assert names(ModelInterface.train) == ["dataloader", "batch_size", "epochs", "warmup_epochs", "learning_rate", "use_wandb",
+                                           "checkpoint_path"]
+
+    class Harness(ModelInterface):
+        def __init__(self):
+            super().__init__(device="cpu")
+            self.build(torch.nn.Linear(2, 2))
+            self.seen = []
+
+        def _train_one_batch(self, x_0, ms2_cond=None, ms1_cond=None, noise=None, ms1_loss_weight=0.0, **kw):
+            self.seen.append(self.optimizer.param_groups[0]["lr"])
+            return 1.0 / len(self.seen)
+
+    class DS(list):
+        def reset_epoch(self):
+            pass
+
+    class Loader(list):
+        dataset = DS()
+
+    z = torch.zeros(1, 2, 2)
+    h = Harness()
+    h.train_with_warmup(Loader([(z, z[..., 0], z, z[..., 0])]), 6, 3, 1e-2, False, 100, str(tmp_path / "best.ckpt"))
+    assert len(h.seen) == 6                                        # 6 epochs, not "3"
+    assert abs(h.seen[0] - 1e-2 / 3) < 1e-12 and abs(h.seen[2] - 1e-2) < 1e-12   # 3 warm-up epochs up to lr = 1e-2
+    assert (tmp_path / "best.ckpt").exists() and (tmp_path / "dquartic_latest_checkpoint.ckpt").exists()
+    h2 = Harness()
+    (tmp_path / "c").mkdir()
+    h2.train(Loader([(z, z[..., 0], z, z[..., 0])]), 1, 2, 0, 5e-3, False, str(tmp_path / "c" / "b.ckpt"))
+    assert h2.seen == [5e-3, 5e-3]                                 # warmup_epochs <= 0: constant lr (reference :498-559)

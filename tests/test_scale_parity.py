@@ -1,0 +1,180 @@
+"""GPU parity AT THE SIZES THE BENCH IS QUOTED ON (BASELINE.json configs[1], [3], [4]), all through the C ABI, against the oracle:
+
+  * configs[1]: ``_train_one_batch`` semantics at (32, 400, 64) -- loss and all 395 parameter gradients vs the per-sample oracle
+    loop (batched semantics = the B = 1 reference applied to every sample, loss = mean over samples);
+  * configs[3]: ``sample`` at B = 512, 50 steps, hipGraph replay -- windows 0..1 vs the oracle (per-step eps <= 1e-4 relative,
+    the tolerance north_star states), batch independence (windows 0..1 of the B = 512 run == a B = 2 run), x_T untouched,
+    second output == mixture - denoised;
+  * configs[4]: one (2000, 256) window -- forward eps, loss and all gradients vs the oracle;
+  * determinism: two ``dq_train_step`` calls on the same inputs give bit-identical flat gradients and loss.
+
+Tolerances (fp32): loss 2e-5 relative; per-step eps 1e-4 of the step's eps scale; parameter gradients 2e-5 of
+max(|ref|, 1e-4 * largest gradient) per tensor -- ten times what the kernels show (a gradient that is analytically zero is round-off in the oracle too).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GRAD_TOL = 2e-5   # observed on MI355X: 1.1e-6 (batch 32), 1.8e-6 (2000 x 256)
+EPS_TOL = 1e-4    # the tolerance north_star states; observed 3.5e-6 (50 steps), 7.8e-6 (2000 x 256)
+
+
+def _net(mz, seed, perturb=0.05):
+    from dquartic.model.unet1d import UNet1d
+
+    torch.manual_seed(seed)
+    net = UNet1d(dim=4, channels=1, dim_mults=(1, 2, 2, 3, 3, 4, 4), conditional=True, init_cond_channels=1,
+                 attn_cond_channels=1, downsample_dim=mz, simple=True)
+    with torch.no_grad():  # no fixture may hide a transposed or ignored weight: move every tensor off its init (gains off 1)
+        for p in net.parameters():
+            if p.requires_grad:
+                p.add_(perturb * torch.randn_like(p))
+    params = {k: v.detach().clone().cpu() for k, v in net.state_dict().items()}
+    return net, params
+
+
+def _oracle_grads(params, mz, x0, c2, c1, t, nz):
+    """per-sample loop of the B = 1 oracle: loss = mean_b loss_b, gradients accumulated"""
+    from oracle import dq_oracle as O
+
+    po = {k: v.clone().requires_grad_(not k.endswith("freqs")) for k, v in params.items()}
+    od = O.Diffusion(po, O.UNetConfig(downsample_dim=mz))
+    B = x0.shape[0]
+    losses, eps = [], []
+    for b in range(B):
+        lb, eb = od.train_loss(x0[b:b + 1], c2[b:b + 1], c1[b:b + 1], t[b:b + 1], nz[b:b + 1])
+        (lb / B).backward()
+        losses.append(float(lb))
+        eps.append(eb.detach())
+    return sum(losses) / B, torch.cat(eps), po
+
+
+def _check_grads(net, po, tol=GRAD_TOL):
+    from oracle import dq_oracle as O
+
+    keys = O.trainable_keys(po)
+    gmax = max(float(po[k].grad.abs().max()) for k in keys)
+    named = dict(net.named_parameters())
+    worst = ("", 0.0)
+    for k in keys:
+        ref = po[k].grad
+        e = float((named[k].grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-4 * gmax)
+        if e > worst[1]:
+            worst = (k, e)
+    assert len(keys) == 395
+    assert worst[1] <= tol, worst
+    return worst
+
+
+def test_train_one_batch_at_bench_size_vs_oracle():
+    """configs[1]: batch 32 of (400, 64) windows -- the exact workload ``bench.py``'s ``value`` is quoted on."""
+    from dquartic.model.model import DDIMDiffusionModel
+
+    net, params = _net(64, 11)
+    dm = DDIMDiffusionModel(model_class=net.cuda(), device="cuda")
+    B, RT, MZ = 32, 400, 64
+    g = torch.Generator().manual_seed(5)
+    x0, c2, c1 = torch.rand(B, RT, MZ, generator=g), torch.rand(B, RT, MZ, generator=g), torch.rand(B, RT, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    t[0], t[1] = 0, 999  # both ends of the schedule are in the batch
+    nz = torch.randn(B, RT, MZ, generator=g)
+    lo, _, po = _oracle_grads(params, MZ, x0, c2, c1, t, nz)
+    net.train()
+    loss = dm.train_step_fused(x0.cuda(), c2.cuda(), c1.cuda(), t=t.cuda(), noise=nz.cuda())
+    assert abs(float(loss) - lo) < 2e-5 * abs(lo), (float(loss), lo)
+    worst = _check_grads(net, po)
+    print("batch-32 train step: loss", float(loss), "oracle", lo, "worst grad", worst)
+    # the optimiser half of _train_one_batch on the same gradients: pre-clip norm vs the oracle's
+    gn_ref = float(torch.sqrt(sum((po[k].grad.double() ** 2).sum() for k in po if po[k].grad is not None)))
+    dm._set_optimizer(1e-5)
+    dm.optimizer.grad_scale = 1.0
+    dm.optimizer.step()
+    assert abs(float(dm.optimizer.last_grad_norm) - gn_ref) < 1e-4 * gn_ref
+
+
+def test_train_step_is_bitwise_repeatable():
+    """two dq_train_step calls on the same inputs: identical loss and flat gradient, bit for bit (no order-dependent float
+    atomics anywhere on the path; SURVEY section 5 'race detection')"""
+    from dquartic.model.model import DDIMDiffusionModel
+
+    net, _ = _net(64, 12)
+    dm = DDIMDiffusionModel(model_class=net.cuda(), device="cuda")
+    B, RT, MZ = 32, 400, 64
+    g = torch.Generator().manual_seed(6)
+    x0, c2, c1 = (torch.rand(B, RT, MZ, generator=g).cuda(), torch.rand(B, RT, MZ, generator=g).cuda(), torch.rand(B, RT, generator=g).cuda())
+    t, nz = torch.randint(0, 1000, (B,), generator=g).cuda(), torch.randn(B, RT, MZ, generator=g).cuda()
+    runs = []
+    for _ in range(3):
+        loss = dm.train_step_fused(x0, c2, c1, t=t, noise=nz)
+        torch.cuda.synchronize()
+        runs.append((loss.clone(), net.flat_grads().clone()))
+    for l, gr in runs[1:]:
+        assert torch.equal(l, runs[0][0])
+        assert torch.equal(gr, runs[0][1]), int((gr != runs[0][1]).sum())
+
+
+def test_sample_batch512_graph_vs_oracle_and_batch_independence():
+    """configs[3]: 50-step DDIM sampling of 512 windows through the hipGraph-captured step."""
+    from dquartic.model.model import DDIMDiffusionModel
+    from oracle import dq_oracle as O
+
+    net, params = _net(64, 13)
+    dm = DDIMDiffusionModel(model_class=net.cuda(), device="cuda")
+    assert dm.use_graph
+    B, RT, MZ, NS = 512, 400, 64, 50
+    g = torch.Generator().manual_seed(7)
+    xT, c2, c1 = torch.randn(B, RT, MZ, generator=g), torch.rand(B, RT, MZ, generator=g), torch.rand(B, RT, generator=g)
+    xd = xT.cuda()
+    net.eval()
+    with torch.no_grad():
+        s, pn = dm.sample(xd, c2.cuda(), c1.cuda(), num_steps=NS)
+    torch.cuda.synchronize()
+    assert torch.equal(xd.cpu(), xT)                                         # x_T untouched
+    assert float((pn - (c2.cuda() - s)).abs().max()) < 1e-6                  # model.py:321-322: mixture - denoised
+    assert bool(torch.isfinite(s).all())
+    # batch independence: windows 0..1 of the B = 512 run == a B = 2 run, graph on and off
+    with torch.no_grad():
+        s2, pn2 = dm.sample(xd[:2].contiguous(), c2[:2].cuda(), c1[:2].cuda(), num_steps=NS)
+        dm.use_graph = False
+        s2e, _, tx, te = dm.sample(xd[:2].contiguous(), c2[:2].cuda(), c1[:2].cuda(), num_steps=NS, return_trajectory=True)
+        dm.use_graph = True
+    assert torch.equal(s2, s2e)
+    assert torch.equal(s[:2], s2) and torch.equal(pn[:2], pn2)
+    # windows 0..1 against the oracle: per-step eps (<= 1e-4 of the step's eps scale) and the denoised window
+    tr = []
+    with torch.no_grad():
+        so, _ = O.Diffusion(params, O.UNetConfig(downsample_dim=64)).sample(xT[:2], c2[:2], c1[:2], NS, trace=tr)
+    worst = 0.0
+    for i, (_, _, e) in enumerate(tr):
+        worst = max(worst, float((te[i].cpu() - e).abs().max() / e.abs().max()))
+    print("50-step sampling: worst per-step eps rel err", worst, "final MSE", float(((s[:2].cpu() - so) ** 2).mean()))
+    assert worst < EPS_TOL, worst
+    assert float(((s[:2].cpu() - so) ** 2).mean()) < 1e-8                    # denoised-MS2 MSE
+    assert float((s[:2].cpu() - so).abs().max() / so.abs().max()) < 5e-4
+
+
+def test_large_window_2000x256_vs_oracle():
+    """configs[4]: one (2000, 256) window: 63 key blocks in the bottleneck attention, LinearAttention rows of 256 / 128 positions,
+    bottleneck width 64.  Forward eps, loss and all gradients vs the oracle."""
+    from dquartic.model.model import DDIMDiffusionModel
+    from oracle import dq_oracle as O
+
+    net, params = _net(256, 14)
+    dm = DDIMDiffusionModel(model_class=net.cuda(), device="cuda")
+    B, RT, MZ = 1, 2000, 256
+    g = torch.Generator().manual_seed(8)
+    x0, c2, c1 = torch.rand(B, RT, MZ, generator=g), torch.rand(B, RT, MZ, generator=g), torch.rand(B, RT, generator=g)
+    t, nz = torch.tensor([412]), torch.randn(B, RT, MZ, generator=g)
+    lo, eps_o, po = _oracle_grads(params, MZ, x0, c2, c1, t, nz)
+    net.train()
+    loss = dm.train_step_fused(x0.cuda(), c2.cuda(), c1.cuda(), t=t.cuda(), noise=nz.cuda())
+    assert abs(float(loss) - lo) < 2e-5 * abs(lo), (float(loss), lo)
+    worst = _check_grads(net, po)
+    net.eval()
+    with torch.no_grad():
+        xt = O.q_sample(O.make_schedule()["alpha_bars"], O.normalize(x0), t, nz)
+        y = net(xt.cuda(), t.cuda(), O.normalize(c2).cuda(), O.normalize(c1).cuda())
+    e = float((y.cpu() - eps_o).abs().max() / eps_o.abs().max())
+    print("2000x256 window: loss", float(loss), "oracle", lo, "eps rel err", e, "worst grad", worst)
+    assert e < EPS_TOL, e
