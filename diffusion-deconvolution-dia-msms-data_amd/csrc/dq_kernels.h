@@ -21,6 +21,11 @@ int launch_sample_finish(const float* x, const float* ms2_cond, float* out_x, fl
 int launch_mse_fwd_bwd(const float* eps, const float* noise, float* loss_out, float* grad_out, float* partials, int64_t n,
                        hipStream_t s, const float* lw = nullptr, const int64_t* t = nullptr, int64_t per_sample = 0, float tm = 1.f,
                        float ta = 0.f);  // lw: per-timestep loss weights (x0 objective); target' = target*tm + ta
+// the MS1 term of train_step with ms1_loss_weight = w > 0 (k_stream.hip): on entry loss_out / grad hold the MSE part, on exit the
+// combined loss (1 - w) * MSE + w * additional and its gradient w.r.t. the network output; x_t null = x0 objective;
+// scratch: 5 * B * RT + B floats
+int launch_ms1_loss(const float* out, const float* x_t, const float* ms1, float cm, float ca, const float* lw, const int64_t* t, float w,
+                    int B, int RT, int MZ, float* grad, float* loss_out, float* scratch, hipStream_t s);
 int launch_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, float* partials, float gscale, float max_norm,
                       double lr, double b1, double b2, double eps, double wd, int step, float* gnorm_out, hipStream_t s);
 

@@ -136,4 +136,14 @@ std::string build_plan(Plan& p, int dim, int n_mults, const int* mults, int mz, 
   return "";
 }
 
+// A one-block plan for the stand-alone ResnetBlock entry points (dq_resblock_*): the block's tensors in state_dict order
+// [mlp.1.weight, mlp.1.bias, block1.proj.weight, block1.proj.bias, block1.norm.g, block2.proj.weight, block2.proj.bias,
+// block2.norm.g (, res_conv.weight, res_conv.bias iff cin != cout)] as one flat buffer.
+void build_resblock_plan(Plan& p, ResP& r, int cin, int cout) {
+  p = Plan();
+  p.dim = 4; p.time_dim = 16;
+  Builder b{p};
+  r = b.res("block", cin, cout);
+}
+
 }  // namespace dq

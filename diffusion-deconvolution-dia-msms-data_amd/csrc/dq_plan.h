@@ -77,4 +77,6 @@ struct Plan {
 // Builds the plan; returns empty string on success, else an error message.
 std::string build_plan(Plan& p, int dim, int n_mults, const int* mults, int mz, int T);
 
+void build_resblock_plan(Plan& p, ResP& r, int cin, int cout);  // one ResnetBlock as its own flat parameter buffer
+
 }  // namespace dq

@@ -16,6 +16,9 @@ struct DevTables {
 
 int launch_time_embed_fwd(const Plan& p, const DevTables& dt, const float* params, const int64_t* t, int t_scalar, float* tbuf,
                           float* ss, int B, const int* step_tab, const int* step_ptr, hipStream_t s);
+int launch_ss_heads(const float* temb, const float* w, const float* bias, float* ss, int B, int m, hipStream_t s);
+int launch_time_mlp_fwd(const float* w1, const float* b1, const float* w2, const float* b2, const int64_t* t, float* tbuf, int B,
+                        hipStream_t s);
 int launch_time_embed_bwd(const Plan& p, const DevTables& dt, const float* params, float* grads, float* tbuf, const float* dss,
                           int B, hipStream_t s);
 
@@ -29,7 +32,7 @@ struct Arena {
   int64_t zero_floats = 0;  // prefix whose gradient twin must be zeroed before a backward (the accumulated-into tensors)
   int64_t tbuf, ss, cat0, ms1n, ms1_u, ms1_a, ms1f, h0;
   std::vector<LevelBuf> downs, ups;
-  int64_t mid_in, xn, qv, kk, o, lse, delta, attn_out, mid_back, eps, partials, loss, coef, xa, xb, wg, wg_floats, la_part, la_part_floats, ts_tab, step, c2_stage, c1_stage, wtmp, la_prep, bb_part, bb_part_floats;
+  int64_t mid_in, xn, qv, kk, o, lse, delta, attn_out, mid_back, eps, partials, loss, coef, xa, xb, wg, wg_floats, la_part, la_part_floats, ts_tab, step, c2_stage, c1_stage, wtmp, la_prep, bb_part, bb_part_floats, ms1_scratch;
   ResBuf mid1, mid2, fin;
 };
 void layout_arena(const Plan& p, int B, int RT, Arena& a);

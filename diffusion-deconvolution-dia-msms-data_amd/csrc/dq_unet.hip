@@ -97,6 +97,7 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
   a.la_prep = take_nz((int64_t)LA_PREP_MAX * LA_PREP_FLOATS);  // prepared LinearAttention weights, one slot per layer (downs, then ups)
   a.bb_part_floats = (int64_t)64 * B * 4 * std::max(p.mid_c, 2);  // partial sums of the PreNorm backward / the input affine
   a.bb_part = take_nz(a.bb_part_floats);
+  a.ms1_scratch = take_nz(5 * R + B + 64);  // the MS1 loss term (ms1_loss_weight > 0): per-row sums / maxima and their gradients
   a.wtmp = take_nz(3 * WTMP_SLOT);  // 16-byte aligned copy of a projection weight for the GEMM route of the wide 1x1 convs
   a.ts_tab = take_nz(1024); a.step = take_nz(64);  // graph replay: timestep table (int32) and the device-side step counter
   a.c2_stage = take_nz(R * p.mz); a.c1_stage = take_nz(R);  // conditions staged at fixed addresses for the captured step
@@ -807,6 +808,15 @@ int dq_mse_loss_fwd_bwd(const float* eps, const float* noise, float* loss_out, f
   return launch_mse_fwd_bwd(eps, noise, loss_out, grad_out, scratch, n, (hipStream_t)stream);
 }
 
+int dq_ms1_loss_fwd_bwd(const float* pred, const float* x_t, const float* ms1_cond, float cond_mul, float cond_add,
+                        const float* loss_weight_dev, const int64_t* t, float ms1_loss_weight, float* loss_inout, float* grad_inout,
+                        float* scratch, int B, int RT, int MZ, void* stream) {
+  DQ_REQUIRE(pred && ms1_cond && loss_inout && scratch, "dq_ms1_loss_fwd_bwd: null argument");
+  DQ_REQUIRE(ms1_loss_weight > 0.f && ms1_loss_weight <= 1.f, "dq_ms1_loss_fwd_bwd: ms1_loss_weight must lie in (0, 1]");
+  return launch_ms1_loss(pred, x_t, ms1_cond, cond_mul, cond_add, loss_weight_dev, t, ms1_loss_weight, B, RT, MZ, grad_inout, loss_inout,
+                         scratch, (hipStream_t)stream);
+}
+
 int dq_mse_loss_weighted_fwd_bwd(const float* pred, const float* target, float target_mul, float target_add,
                                  const float* loss_weight_dev, const int64_t* t, float* loss_out, float* grad_out, float* scratch,
                                  int B, int64_t per_sample, void* stream) {
@@ -826,13 +836,14 @@ int dq_adamw_clip_step(float* params, const float* grads, float* exp_avg, float*
 
 int dq_train_step(dq_plan* plan, const float* params, const float* rope_freqs, const float* alpha_bars_dev, const float* x0,
                   const float* ms2_cond, const float* ms1_cond, const int64_t* t, const float* noise, int auto_normalize,
-                  int pred_type, const float* loss_weight_dev, float* grads, float* loss_out, void* workspace,
+                  int pred_type, const float* loss_weight_dev, float ms1_loss_weight, float* grads, float* loss_out, void* workspace,
                   int64_t workspace_bytes, int B, int RT, void* stream) {
   DQ_REQUIRE(plan && params && alpha_bars_dev && x0 && ms2_cond && ms1_cond && t && noise && grads && loss_out && workspace,
              "dq_train_step: null argument");
   DQ_REQUIRE(pred_type == DQ_PRED_EPS || pred_type == DQ_PRED_X0, "dq_train_step: Unknown pred_type");
   DQ_REQUIRE(pred_type == DQ_PRED_EPS || loss_weight_dev, "dq_train_step: pred_type x0 needs the loss-weight (SNR) table");
   DQ_REQUIRE(B > 0 && RT > 0, "dq_train_step: B and RT must be positive");
+  DQ_REQUIRE(ms1_loss_weight >= 0.f && ms1_loss_weight <= 1.f, "dq_train_step: ms1_loss_weight must lie in [0, 1]");
   DQ_TRY(ensure_arena(plan, B, RT));
   const Arena& a = plan->arena;
   DQ_REQUIRE(workspace_bytes >= 2 * (int64_t)sizeof(float) * a.floats, "dq_train_step: workspace too small (training=1)");
@@ -849,12 +860,16 @@ int dq_train_step(dq_plan* plan, const float* params, const float* rope_freqs, c
     DQ_TRY(launch_mse_fwd_bwd(c.w(a.eps), x0, loss_out, c.w(a.xb), c.w(a.partials), B * per, s, loss_weight_dev, t, per, cm, ca));
   else
     DQ_TRY(launch_mse_fwd_bwd(c.w(a.eps), noise, loss_out, c.w(a.xb), c.w(a.partials), B * per, s));         // model.py:361
+  if (ms1_loss_weight > 0.f)  // model.py:364-371 / 379-386, 398-402 (semantics: DESIGN.md section 12)
+    DQ_TRY(launch_ms1_loss(c.w(a.eps), pred_type == DQ_PRED_X0 ? nullptr : c.w(a.xa), ms1_cond, cm, ca,
+                           pred_type == DQ_PRED_X0 ? loss_weight_dev : nullptr, t, ms1_loss_weight, B, RT, plan->plan.mz, c.w(a.xb), loss_out,
+                           c.w(a.ms1_scratch), s));
   DQ_TRY(unet_backward(c, rope_freqs, ms2_cond, cm, ca, plan->dev, c.w(a.xb), nullptr));
   return 0;
 }
 
-int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, const float* alpha_bars_host, const float* x_T,
-                   const float* ms2_cond, const float* ms1_cond, int auto_normalize, int pred_type,
+int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, const float* alpha_bars_host, int num_timesteps,
+                   const float* x_T, const float* ms2_cond, const float* ms1_cond, int auto_normalize, int pred_type,
                    const int32_t* timesteps_host, int num_steps, float* out_x, float* out_noise, float* traj_x, float* traj_eps,
                    int use_graph, void* workspace, int64_t workspace_bytes, int B, int RT, void* stream) {
   DQ_REQUIRE(plan && params && alpha_bars_host && x_T && ms2_cond && ms1_cond && timesteps_host && out_x && out_noise && workspace,
@@ -869,7 +884,8 @@ int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, 
   float* W = (float*)workspace;
   Ctx c{plan->plan, a, params, W, nullptr, nullptr, B, RT, s};
   c.save = false;
-  const int T = plan->plan.T;
+  const int T = num_timesteps;  // length of alpha_bars_host (DDIMDiffusionModel.num_timesteps: the schedule is the caller's)
+  DQ_REQUIRE(T >= 1, "dq_ddim_sample: num_timesteps must be >= 1");
   const int64_t n = (int64_t)B * RT * plan->plan.mz;
   const float cm = auto_normalize ? 2.f : 1.f, ca = auto_normalize ? -1.f : 0.f;
   const int32_t* ts = timesteps_host;  // trunc(linspace(T-1, 0, num_steps)) formed by the caller exactly as model.py:313 does
@@ -998,6 +1014,120 @@ int dq_linattn_bwd(const float* x, const float* ypre, const float* dy, float* dx
   a.part = scratch + 2 * (int64_t)rows * C * n; a.part_floats = (int64_t)LA_MAX_WAVES * 512 * C;
   a.dy = dy; a.dx = dx; a.dw_qkv = dw_qkv; a.dw_out = dw_out; a.db_out = db_out; a.dg_pre = dg_pre; a.dg_out = dg_out;
   return launch_linattn_bwd(a, (hipStream_t)stream);
+}
+
+// ---- stand-alone building blocks for the per-block parity tests (tests/test_blocks_gpu.py) ---------------------------------
+int dq_rmsnorm_fwd(const float* x, const float* g, float* y, int C, int rows, int n, void* stream) {
+  DQ_REQUIRE(x && g && y, "dq_rmsnorm_fwd: null argument");
+  return launch_rmsnorm_fwd(x, g, y, C, rows, n, (hipStream_t)stream);
+}
+
+int dq_time_mlp_fwd(const float* w1, const float* b1, const float* w2, const float* b2, const int64_t* t, float* sinu_out,
+                    float* temb_out, float* scratch, int B, void* stream) {
+  DQ_REQUIRE(w1 && b1 && w2 && b2 && t && scratch && B > 0, "dq_time_mlp_fwd: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  DQ_TRY(launch_time_mlp_fwd(w1, b1, w2, b2, t, scratch, B, s));
+  // per-sample scratch layout (k_time.hip): [0, 4) sinusoidal features, [36, 52) time embedding
+  if (sinu_out) DQ_HIP_OK(hipMemcpy2DAsync(sinu_out, 4 * sizeof(float), scratch, TBUF_FLOATS * sizeof(float), 4 * sizeof(float), B, hipMemcpyDeviceToDevice, s));
+  if (temb_out) DQ_HIP_OK(hipMemcpy2DAsync(temb_out, 16 * sizeof(float), scratch + 36, TBUF_FLOATS * sizeof(float), 16 * sizeof(float), B, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+int dq_scale_shift_fwd(const float* temb, const float* w, const float* b, float* ss, int B, int m, void* stream) {
+  DQ_REQUIRE(temb && w && b && ss, "dq_scale_shift_fwd: null argument");
+  return launch_ss_heads(temb, w, b, ss, B, m, (hipStream_t)stream);
+}
+
+int dq_prep_inputs_fwd(const float* x, const float* cond, const float* ms1, const float* ss, float cond_mul, float cond_add, float* cat0,
+                       float* ms1n, int B, int RT, int MZ, void* stream) {
+  DQ_REQUIRE(x && cond && ms1 && ss && cat0 && ms1n, "dq_prep_inputs_fwd: null argument");
+  return launch_prep_inputs(x, cond, ms1, ss, 2, 0, cond_mul, cond_add, cat0, ms1n, B, RT, MZ, (hipStream_t)stream);
+}
+
+int dq_conv_fwd(const float* x, const float* w, const float* bias, const float* norm_g, int act, float* y, int cout, int cin, int K, int mode,
+                int rows, int n_in, int n_out, void* stream) {
+  DQ_REQUIRE(x && w && y && rows > 0 && n_in > 0 && n_out > 0, "dq_conv_fwd: null argument");
+  DQ_REQUIRE(mode == CONV_S1 || mode == CONV_DOWN || mode == CONV_UP, "dq_conv_fwd: mode must be 0 (stride 1), 1 (down) or 2 (up)");
+  DQ_REQUIRE(act == ACT_NONE || act == ACT_SILU || act == ACT_GELU, "dq_conv_fwd: act must be 0 (none), 1 (SiLU) or 2 (GELU)");
+  ConvFwd f;
+  f.inA = x; f.cinA = cin; f.w = w; f.bias = bias; f.cout = cout; f.K = K; f.mode = mode; f.rows = rows; f.n_in = n_in; f.n_out = n_out;
+  f.y_out = y; f.g = norm_g; f.act = act;
+  return launch_conv_fwd(f, (hipStream_t)stream);
+}
+
+namespace {
+// workspace of the stand-alone ResnetBlock calls: a forward arena and its gradient twin, laid out like the network's
+struct BlockWs { Plan plan; ResP r; Arena ar; ResBuf rb; int64_t half = 0; int B = 0; };
+int block_ws(BlockWs& w, int cin, int cout, int rows, int n, int rows_per_sample) {
+  DQ_REQUIRE(cin > 0 && cout > 0 && rows > 0 && n > 0 && rows_per_sample > 0 && rows % rows_per_sample == 0, "dq_resblock: bad shape");
+  build_resblock_plan(w.plan, w.r, cin, cout);
+  w.B = rows / rows_per_sample;
+  int64_t off = 0;
+  auto take = [&](int64_t f) { int64_t o = off; off += (f + 63) / 64 * 64; return o; };
+  const int64_t t = (int64_t)rows * cout * n;
+  w.ar.ss = take((int64_t)w.B * w.plan.ss_total);
+  w.rb.u1 = take(t); w.rb.a1 = take(t); w.rb.u2 = take(t); w.rb.out = take(t);
+  w.rb.gpart_floats = (int64_t)w.B * std::max<int64_t>({((int64_t)rows_per_sample * n + 255) / 256, (rows_per_sample + 15) / 16, 64}) * 4 * cout;
+  w.rb.gpart = take(w.rb.gpart_floats);
+  w.ar.wg_floats = (int64_t)WGRAD_MAX_PARTS * ((int64_t)cout * std::max(cin, cout) * 3 + cout) * 3;
+  w.ar.wg = take(w.ar.wg_floats);
+  w.ar.B = w.B; w.ar.RT = rows_per_sample;
+  w.half = off;
+  return 0;
+}
+}  // namespace
+
+int64_t dq_resblock_workspace_floats(int cin, int cout, int rows, int n, int rows_per_sample) {
+  BlockWs w;
+  if (block_ws(w, cin, cout, rows, n, rows_per_sample)) return -1;
+  return 2 * w.half;
+}
+
+int dq_resblock_fwd(const float* params, const float* xA, int cinA, const float* xB, int cinB, const float* temb, float* out, int cout,
+                    int rows, int n, int rows_per_sample, int save_for_bwd, float* workspace, int64_t workspace_floats, void* stream) {
+  DQ_REQUIRE(params && xA && temb && out && workspace, "dq_resblock_fwd: null argument");
+  BlockWs w;
+  DQ_TRY(block_ws(w, cinA + cinB, cout, rows, n, rows_per_sample));
+  DQ_REQUIRE(workspace_floats >= 2 * w.half, "dq_resblock_fwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  Ctx c{w.plan, w.ar, params, workspace, workspace + w.half, nullptr, w.B, rows_per_sample, s};
+  c.save = save_for_bwd != 0;
+  DQ_TRY(launch_ss_heads(temb, params + w.r.mlp_w, params + w.r.mlp_b, c.w(w.ar.ss), w.B, 2 * cout, s));  // unet1d.py:315-318
+  DQ_TRY(res_fwd(c, w.r, w.rb, xA, cinA, cinB ? xB : nullptr, cinB, rows, n, rows_per_sample));
+  return launch_copy(out, c.w(w.rb.out), (int64_t)rows * cout * n, s);
+}
+
+int dq_resblock_bwd(const float* params, const float* xA, int cinA, const float* xB, int cinB, const float* dout, float* dxA, float* dxB,
+                    float* grads, float* dss, int cout, int rows, int n, int rows_per_sample, float* workspace, int64_t workspace_floats,
+                    void* stream) {
+  DQ_REQUIRE(params && xA && dout && grads && dss && workspace, "dq_resblock_bwd: null argument");
+  BlockWs w;
+  DQ_TRY(block_ws(w, cinA + cinB, cout, rows, n, rows_per_sample));
+  DQ_REQUIRE(workspace_floats >= 2 * w.half, "dq_resblock_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  Ctx c{w.plan, w.ar, params, workspace, workspace + w.half, grads, w.B, rows_per_sample, s};  // no side stream: everything on s
+  DQ_TRY(launch_zero(c.g(w.ar.ss), (int64_t)w.B * w.plan.ss_total, s));
+  DQ_TRY(launch_copy(c.g(w.rb.out), dout, (int64_t)rows * cout * n, s));
+  DQ_TRY(res_bwd(c, w.r, w.rb, xA, dxA, cinA, cinB ? xB : nullptr, cinB ? dxB : nullptr, cinB, rows, n, rows_per_sample, 0, 0));
+  return launch_copy(dss, c.g(w.ar.ss), (int64_t)w.B * w.plan.ss_total, s);
+}
+
+int dq_rope(float* qk, const float* freqs, int B, int64_t batch_stride, int RT, float sign, void* stream) {
+  DQ_REQUIRE(qk && freqs, "dq_rope: null argument");
+  return launch_rope(qk, freqs, B, batch_stride, RT, sign, (hipStream_t)stream);
+}
+
+int dq_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int RT, void* stream) {
+  DQ_REQUIRE(q && k && v && o && lse, "dq_attn_fwd: null argument");
+  const int64_t bs = (int64_t)HID * RT;
+  return launch_attn_fwd(q, bs, k, bs, v, bs, o, lse, B, RT, (hipStream_t)stream);
+}
+
+int dq_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse, float* delta,
+                float* dq_, float* dk, float* dv, int B, int RT, void* stream) {
+  DQ_REQUIRE(q && k && v && o && d_o && lse && delta && dq_ && dk && dv, "dq_attn_bwd: null argument");
+  const int64_t bs = (int64_t)HID * RT;
+  return launch_attn_bwd(q, bs, k, bs, v, bs, o, d_o, lse, delta, dq_, bs, dk, bs, dv, bs, B, RT, (hipStream_t)stream);
 }
 
 }  // extern "C"

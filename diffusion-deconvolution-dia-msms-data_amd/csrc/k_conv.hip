@@ -826,6 +826,9 @@ int launch_rmsnorm_fwd(const float* x, const float* g, float* y, int C, int rows
   if (total == 0) return 0;
   dim3 grid(cdiv(total, 256)), block(256);
   switch (C) {
+    case 4: hipLaunchKernelGGL((k_rmsnorm_fwd<4>), grid, block, 0, s, x, g, y, rows, n); break;
+    case 8: hipLaunchKernelGGL((k_rmsnorm_fwd<8>), grid, block, 0, s, x, g, y, rows, n); break;
+    case 12: hipLaunchKernelGGL((k_rmsnorm_fwd<12>), grid, block, 0, s, x, g, y, rows, n); break;
     case 16: hipLaunchKernelGGL((k_rmsnorm_fwd<16>), grid, block, 0, s, x, g, y, rows, n); break;
     case 32: hipLaunchKernelGGL((k_rmsnorm_fwd<32>), grid, block, 0, s, x, g, y, rows, n); break;
     case 64: hipLaunchKernelGGL((k_rmsnorm_fwd<64>), grid, block, 0, s, x, g, y, rows, n); break;

@@ -908,6 +908,7 @@ int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s) {
     BlockBwd b2;  // (1) post-norm backward: dyp = d loss / d ypre, d g_out, d b_out
     b2.u = a.ypre; b2.dy = a.dy; b2.du = a.dyp; b2.C = C; b2.rows = rows; b2.n = n; b2.rows_per_sample = rows;
     b2.g = a.f.g_out; b2.dg = a.dg_out; b2.dbias = a.db_out;
+    b2.part = a.part; b2.part_floats = a.part_floats;  // per-block partial sums: the slot scratch is free until the sweep kernel runs
     if (int rc = launch_block_bwd(b2, s)) return rc;
     int waves = 0;
     if (int rc = launch_linattn_bwd_long(a.f.x, a.dyp, a.dxh, a.f.w_qkv, a.f.w_out, a.f.g_pre, a.part, C, rows, n, &waves, s)) return rc;
@@ -919,6 +920,7 @@ int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s) {
     BlockBwd b1;
     b1.u = a.f.x; b1.dy = a.dxh; b1.du = a.dx; b1.C = C; b1.rows = rows; b1.n = n; b1.rows_per_sample = rows;
     b1.g = a.f.g_pre; b1.dg = a.dg_pre; b1.accumulate = 1;
+    b1.part = a.part; b1.part_floats = a.part_floats;  // (free again: the slot reduce above has consumed it, in stream order)
     return launch_block_bwd(b1, s);
   }
   LinAttnBwdK k;

@@ -209,6 +209,146 @@ int launch_mse_fwd_bwd(const float* eps, const float* noise, float* loss_out, fl
   return 0;
 }
 
+// ---- the MS1 term of train_step (reference model.py:364-371, 379-386, 398-402; semantics chosen in DESIGN.md section 12 because
+// the reference's branch raises): per sample b, with D = x_t - eps_pred ('eps') or x0_pred ('x0'),
+//   additional_b = sum over f in {sum, mean, max over m/z} of mean_rt (s_f[rt] / max_rt s_f - ms1n[rt] / max_rt ms1n)^2
+//   loss_b = (1 - w) * MSE_b + w * additional_b ; loss = mean_b loss_weight[t_b] * loss_b
+// (1) k_ms1_rows: one wave per (b, rt) row -> sum, max and arg-max over m/z;
+// (2) k_ms1_sample: one block per sample -> the three normalisers, additional_b and d additional_b / d s_f[rt];
+// (3) k_ms1_apply: grad = (1 - w) * grad_MSE + sign * w * loss_weight_b / B * (d/d s_sum + d/d s_mean / MZ + [mz == argmax] d/d s_max)
+//     and the loss scalar.  Fixed-order reductions throughout.
+__global__ void __launch_bounds__(256) k_ms1_rows(const float* __restrict__ out, const float* __restrict__ x_t, int64_t rows, int MZ,
+                                                  float* __restrict__ rsum, float* __restrict__ rmax, int* __restrict__ ramax) {
+  const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float sm = 0.f, mx = -INFINITY;
+  int am = 0;
+  for (int mz = lane; mz < MZ; mz += 64) {
+    const float o = out[row * MZ + mz];
+    const float d = x_t ? x_t[row * MZ + mz] - o : o;
+    sm += d;
+    if (d > mx) { mx = d; am = mz; }
+  }
+  sm = wave_sum(sm);
+  // arg-max over the lanes: larger value wins, the smaller index on ties (torch.max returns the first maximum)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float omx = __shfl_xor(mx, o, 64);
+    const int oam = __shfl_xor(am, o, 64);
+    if (omx > mx || (omx == mx && oam < am)) { mx = omx; am = oam; }
+  }
+  if (lane == 0) { rsum[row] = sm; rmax[row] = mx; ramax[row] = am; }
+}
+
+__device__ __forceinline__ void block_argmax(float& v, int& idx, float* sv, int* si) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = v; si[threadIdx.x >> 6] = idx; }
+  __syncthreads();
+  v = sv[0]; idx = si[0];
+  for (int k = 1; k < 4; ++k)
+    if (sv[k] > v || (sv[k] == v && si[k] < idx)) { v = sv[k]; idx = si[k]; }
+}
+__device__ __forceinline__ float block_sum4(float v, float* sv) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sv[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sv[0] + sv[1]) + (sv[2] + sv[3]);
+}
+
+__global__ void __launch_bounds__(256) k_ms1_sample(const float* __restrict__ rsum, const float* __restrict__ rmax,
+                                                    const float* __restrict__ ms1, float cm, float ca, int RT, int MZ,
+                                                    const float* __restrict__ lw, const int64_t* __restrict__ t,
+                                                    float* __restrict__ dsum, float* __restrict__ dmax, float* __restrict__ addl) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int b = blockIdx.x;
+  const float* s_sum = rsum + (int64_t)b * RT;
+  const float* s_max = rmax + (int64_t)b * RT;
+  const float* m1 = ms1 + (int64_t)b * RT;
+  const float invMZ = 1.0f / (float)MZ;
+  // the four row maxima (and where they sit): sum, mean (= sum / MZ: same place), max, and the MS1 chromatogram
+  float a0 = -INFINITY, a2 = -INFINITY, a3 = -INFINITY;
+  int i0 = 0, i2 = 0, i3 = 0;
+  for (int rt = threadIdx.x; rt < RT; rt += 256) {
+    const float v0 = s_sum[rt], v2 = s_max[rt], v3 = fmaf(m1[rt], cm, ca);
+    if (v0 > a0) { a0 = v0; i0 = rt; }
+    if (v2 > a2) { a2 = v2; i2 = rt; }
+    if (v3 > a3) { a3 = v3; i3 = rt; }
+  }
+  block_argmax(a0, i0, sv, si);
+  block_argmax(a2, i2, sv, si);
+  block_argmax(a3, i3, sv, si);
+  const float m_sum = a0, m_mean = a0 * invMZ, m_max = a2, m_ms1 = a3;
+  // A_f = mean_rt (u_f - v)^2 ; c_f = sum_rt g_f s_f / m_f^2 with g_f = 2 (u_f - v) / RT
+  float A0 = 0.f, A1 = 0.f, A2 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+  const float gs = 2.0f / (float)RT;
+  for (int rt = threadIdx.x; rt < RT; rt += 256) {
+    const float v = fmaf(m1[rt], cm, ca) / m_ms1;
+    const float s0 = s_sum[rt], s1 = s0 * invMZ, s2 = s_max[rt];
+    const float e0 = s0 / m_sum - v, e1 = s1 / m_mean - v, e2 = s2 / m_max - v;
+    A0 = fmaf(e0, e0, A0); A1 = fmaf(e1, e1, A1); A2 = fmaf(e2, e2, A2);
+    c0 = fmaf(gs * e0, s0, c0); c1 = fmaf(gs * e1, s1, c1); c2 = fmaf(gs * e2, s2, c2);
+  }
+  A0 = block_sum4(A0, sv); A1 = block_sum4(A1, sv); A2 = block_sum4(A2, sv);
+  c0 = block_sum4(c0, sv) / (m_sum * m_sum); c1 = block_sum4(c1, sv) / (m_mean * m_mean); c2 = block_sum4(c2, sv) / (m_max * m_max);
+  for (int rt = threadIdx.x; rt < RT; rt += 256) {
+    const float v = fmaf(m1[rt], cm, ca) / m_ms1;
+    const float s0 = s_sum[rt], s1 = s0 * invMZ, s2 = s_max[rt];
+    const float d0 = gs * (s0 / m_sum - v) / m_sum - (rt == i0 ? c0 : 0.f);
+    const float d1 = gs * (s1 / m_mean - v) / m_mean - (rt == i0 ? c1 : 0.f);
+    const float d2 = gs * (s2 / m_max - v) / m_max - (rt == i2 ? c2 : 0.f);
+    dsum[(int64_t)b * RT + rt] = fmaf(d1, invMZ, d0);
+    dmax[(int64_t)b * RT + rt] = d2;
+  }
+  if (threadIdx.x == 0) addl[b] = (lw ? lw[t[b]] : 1.0f) * (((A0 + A1) + A2) / (float)RT);
+}
+
+__global__ void __launch_bounds__(256) k_ms1_apply(float* __restrict__ grad, const float* __restrict__ dsum, const float* __restrict__ dmax,
+                                                   const int* __restrict__ ramax, const float* __restrict__ lw,
+                                                   const int64_t* __restrict__ t, const float* __restrict__ addl, float w, float sign,
+                                                   int B, int RT, int MZ, float* __restrict__ loss) {
+  const int64_t n = (int64_t)B * RT * MZ;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / MZ;
+    const int mz = (int)(i - row * MZ);
+    const int b = (int)(row / RT);
+    const float k = sign * w * (lw ? lw[t[b]] : 1.0f) / (float)B;
+    const float extra = dsum[row] + (mz == ramax[row] ? dmax[row] : 0.f);
+    if (grad) grad[i] = fmaf(1.0f - w, grad[i], k * extra);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += addl[b];
+    loss[0] = (1.0f - w) * loss[0] + w * acc / (float)B;
+  }
+}
+
+// scratch: 5 * B * RT + B floats.  loss_out / grad hold the MSE part on entry (launch_mse_fwd_bwd) and the combined loss on exit.
+int launch_ms1_loss(const float* out, const float* x_t, const float* ms1, float cm, float ca, const float* lw, const int64_t* t, float w,
+                    int B, int RT, int MZ, float* grad, float* loss_out, float* scratch, hipStream_t s) {
+  DQ_REQUIRE(out && ms1 && loss_out && scratch && B > 0 && RT > 0 && MZ > 0, "ms1 loss: missing operand");
+  DQ_REQUIRE(!lw || t, "ms1 loss: per-timestep weights need t");
+  const int64_t rows = (int64_t)B * RT;
+  float* rsum = scratch; float* rmax = rsum + rows; int* ramax = reinterpret_cast<int*>(rmax + rows);
+  float* dsum = rmax + 2 * rows; float* dmax = dsum + rows; float* addl = dmax + rows;
+  hipLaunchKernelGGL(k_ms1_rows, dim3(cdiv(rows, 4)), dim3(256), 0, s, out, x_t, rows, MZ, rsum, rmax, ramax);
+  DQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_ms1_sample, dim3(B), dim3(256), 0, s, rsum, rmax, ms1, cm, ca, RT, MZ, lw, t, dsum, dmax, addl);
+  DQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_ms1_apply, dim3((int)std::min<int64_t>(cdiv(rows * MZ, 256), 4096)), dim3(256), 0, s, grad, dsum, dmax, ramax, lw, t,
+                     addl, w, x_t ? -1.0f : 1.0f, B, RT, MZ, loss_out);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- K11: global L2 norm (two-stage, deterministic) + clip + AdamW, flat buffers.
 // norm pass: 4 B / param ; update pass: 28 B / param (read p,g,m,v ; write p,m,v).
 __global__ void __launch_bounds__(256) k_sumsq(const float* __restrict__ g, int64_t n, float gscale, float* __restrict__ partials) {

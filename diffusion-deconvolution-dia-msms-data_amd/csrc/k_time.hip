@@ -13,10 +13,19 @@
 namespace dq {
 
 // tbuf per sample: [0,4) sinu | [4,20) h_pre | [20,36) h_act | [36,52) temb | [52,68) silu(temb) | [68,84) dtemb | [84,100) dh_pre
+// one SiLU -> Linear(16, .) output: bias + sum_i w[i] * silu(temb)[i], in this order everywhere it is evaluated
+__device__ __forceinline__ float ss_head_row(const float* __restrict__ w, float bias, const float* st) {
+  float v = bias;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v = fmaf(w[i], st[i], v);
+  return v;
+}
+
 __global__ void __launch_bounds__(64) k_time_fwd(const float* __restrict__ P, const int64_t* __restrict__ t, int t_scalar,
                                                  float* __restrict__ tbuf, float* __restrict__ ss, int ss_total,
                                                  const int64_t* __restrict__ ss_w_off, const int64_t* __restrict__ ss_b_off,
-                                                 int64_t t1w, int64_t t1b, int64_t t2w, int64_t t2b, int dim, float theta,
+                                                 const float* __restrict__ t1w, const float* __restrict__ t1b,
+                                                 const float* __restrict__ t2w, const float* __restrict__ t2b, int dim, float theta,
                                                  const int* __restrict__ step_tab, const int* __restrict__ step_ptr) {
   const int b = blockIdx.x, tid = threadIdx.x;
   float* tb = tbuf + (int64_t)b * TBUF_FLOATS;
@@ -35,8 +44,8 @@ __global__ void __launch_bounds__(64) k_time_fwd(const float* __restrict__ P, co
   }
   __syncthreads();
   if (tid < 16) {
-    float h = P[t1b + tid];
-    for (int i = 0; i < dim; ++i) h = fmaf(P[t1w + tid * dim + i], sinu[i], h);
+    float h = t1b[tid];
+    for (int i = 0; i < dim; ++i) h = fmaf(t1w[tid * dim + i], sinu[i], h);
     tb[4 + tid] = h;
     const float a = gelu_f(h);
     tb[20 + tid] = a;
@@ -44,29 +53,50 @@ __global__ void __launch_bounds__(64) k_time_fwd(const float* __restrict__ P, co
   }
   __syncthreads();
   if (tid < 16) {
-    float e = P[t2b + tid];
+    float e = t2b[tid];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) e = fmaf(P[t2w + tid * 16 + i], hact[i], e);
+    for (int i = 0; i < 16; ++i) e = fmaf(t2w[tid * 16 + i], hact[i], e);
     tb[36 + tid] = e;
     const float sv = silu_f(e);
     tb[52 + tid] = sv;
     st[tid] = sv;
   }
   __syncthreads();
-  for (int r = tid; r < ss_total; r += 64) {
-    const float* w = P + ss_w_off[r];
-    float v = P[ss_b_off[r]];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v = fmaf(w[i], st[i], v);
-    ss[(int64_t)b * ss_total + r] = v;
-  }
+  for (int r = tid; r < ss_total; r += 64) ss[(int64_t)b * ss_total + r] = ss_head_row(P + ss_w_off[r], P[ss_b_off[r]], st);
+}
+
+// stand-alone heads (dq_scale_shift_fwd): ss[b][r] = Linear(SiLU(temb_b))[r] for a caller-supplied temb
+__global__ void __launch_bounds__(64) k_ss_heads(const float* __restrict__ temb, const float* __restrict__ w, const float* __restrict__ bias,
+                                                 float* __restrict__ ss, int m) {
+  __shared__ float st[16];
+  const int b = blockIdx.x;
+  if (threadIdx.x < 16) st[threadIdx.x] = silu_f(temb[(int64_t)b * 16 + threadIdx.x]);
+  __syncthreads();
+  for (int r = threadIdx.x; r < m; r += 64) ss[(int64_t)b * m + r] = ss_head_row(w + (int64_t)r * 16, bias[r], st);
+}
+
+int launch_ss_heads(const float* temb, const float* w, const float* bias, float* ss, int B, int m, hipStream_t s) {
+  if (B == 0 || m == 0) return 0;
+  hipLaunchKernelGGL(k_ss_heads, dim3(B), dim3(64), 0, s, temb, w, bias, ss, m);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// stand-alone time MLP (dq_time_mlp_fwd): fills tbuf only (no heads)
+int launch_time_mlp_fwd(const float* w1, const float* b1, const float* w2, const float* b2, const int64_t* t, float* tbuf, int B,
+                        hipStream_t s) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(k_time_fwd, dim3(B), dim3(64), 0, s, (const float*)nullptr, t, 0, tbuf, (float*)nullptr, 0, (const int64_t*)nullptr,
+                     (const int64_t*)nullptr, w1, b1, w2, b2, 4, 10000.0f, (const int*)nullptr, (const int*)nullptr);
+  DQ_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_time_embed_fwd(const Plan& p, const DevTables& dt, const float* params, const int64_t* t, int t_scalar, float* tbuf,
                           float* ss, int B, const int* step_tab, const int* step_ptr, hipStream_t s) {
   if (B == 0) return 0;
   hipLaunchKernelGGL(k_time_fwd, dim3(B), dim3(64), 0, s, params, t, t_scalar, tbuf, ss, p.ss_total, dt.ss_w_off, dt.ss_b_off,
-                     p.t1_w, p.t1_b, p.t2_w, p.t2_b, p.dim, 10000.0f, step_tab, step_ptr);
+                     params + p.t1_w, params + p.t1_b, params + p.t2_w, params + p.t2_b, p.dim, 10000.0f, step_tab, step_ptr);
   DQ_LAUNCH_CHECK();
   return 0;
 }

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DQ_HIP_LIB", os.path.join(os.path.dirname(_HERE), "libdq_hip.so"))
 
 _lib = None
-ABI_VERSION = 4  # DQ_ABI_VERSION of include/dq_hip.h this table was written against
+ABI_VERSION = 5  # DQ_ABI_VERSION of include/dq_hip.h this table was written against
 PRED_TYPES = {"eps": 0, "x0": 1}  # DQ_PRED_EPS / DQ_PRED_X0
 
 # name -> (restype, argtypes); this table is checked against include/dq_hip.h by tests/test_abi.py
@@ -34,8 +34,10 @@ PROTOTYPES = {
     "dq_adamw_clip_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_double,
                                    c_double, c_double, c_double, c_double, c_int, c_void_p, c_void_p]),
     "dq_train_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                              c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
-    "dq_ddim_sample": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_float), c_void_p, c_void_p, c_void_p, c_int, c_int,
+                              c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "dq_ms1_loss_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                    c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dq_ddim_sample": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_float), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                POINTER(c_int32), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int,
                                c_void_p]),
     "dq_pair_batch_scratch_bytes": (c_int64, [c_int]),
@@ -55,6 +57,17 @@ PROTOTYPES = {
                         c_void_p]),
     "dq_linattn_fwd": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p]),
     "dq_linattn_bwd": (c_int, [c_void_p] * 15 + [c_int, c_int, c_int, c_void_p]),
+    "dq_rmsnorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dq_time_mlp_fwd": (c_int, [c_void_p] * 8 + [c_int, c_void_p]),
+    "dq_scale_shift_fwd": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
+    "dq_prep_inputs_fwd": (c_int, [c_void_p] * 4 + [c_float, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dq_conv_fwd": (c_int, [c_void_p] * 4 + [c_int, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "dq_resblock_workspace_floats": (c_int64, [c_int] * 5),
+    "dq_resblock_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_int64, c_void_p]),
+    "dq_resblock_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p, c_int64, c_void_p]),
+    "dq_rope": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_void_p]),
+    "dq_attn_fwd": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
+    "dq_attn_bwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_void_p]),
 }
 
 

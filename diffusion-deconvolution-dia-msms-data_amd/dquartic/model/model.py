@@ -8,8 +8,8 @@ gradient buffer).  Any other ``nn.Module`` is driven with plain tensor ops exact
 stays usable as a generic harness -- but that is the caller's network, not this package's hot path.
 
 Documented deviations: batches are supported and ``train_step`` returns a 0-dim loss (the mean over
-samples of the reference's B = 1 loss); both ``pred_type`` values are built, ``ms1_loss_weight > 0`` is not (the
-reference's branch raises TypeError).
+samples of the reference's B = 1 loss); both ``pred_type`` values are built; ``ms1_loss_weight > 0`` is built with chosen
+semantics (the reference's branch raises TypeError).
 """
 import ctypes
 import math
@@ -113,7 +113,10 @@ class DDIMDiffusionModel(ModelInterface):
         """model.py:225-242; ``x_0`` is already normalised by the caller, as in the reference."""
         if noise is None:
             noise = torch.randn_like(x_0)
-        if x_0.is_cuda:
+        # the native kernel when nothing upstream wants a gradient through the noising (the training paths of this package
+        # draw x_0 / noise as leaves); otherwise the reference's tensor expressions, which keep the autograd history
+        wants_grad = torch.is_grad_enabled() and (x_0.requires_grad or noise.requires_grad)
+        if x_0.is_cuda and not wants_grad:
             x0c, nz = x_0.detach().float().contiguous(), noise.detach().float().contiguous()
             tt = t.reshape(-1).to(device=x_0.device, dtype=torch.int64).contiguous()
             ab = self.alpha_bars.to(x_0.device)
@@ -136,7 +139,8 @@ class DDIMDiffusionModel(ModelInterface):
         if self.pred_type not in N.PRED_TYPES:
             raise ValueError(f"Unknown pred_type: {self.pred_type}")
         out = self.model(x_t, t_tensor, init_cond, attn_cond)  # eps_pred or x0_pred (model.py:271 / :276)
-        if x_t.is_cuda:
+        wants_grad = torch.is_grad_enabled() and (x_t.requires_grad or out.requires_grad)
+        if x_t.is_cuda and not wants_grad:
             if t > 0:
                 abp = self.alpha_bars[t - 1]
                 coef = torch.stack([sa, sb, torch.sqrt(abp), torch.sqrt(1.0 - abp)]).to(x_t.device, torch.float32)
@@ -151,7 +155,8 @@ class DDIMDiffusionModel(ModelInterface):
             N.check(N.lib().dq_ddim_step_x0(N.ptr(xt), N.ptr(o), N.ptr(x_prev), N.ptr(eps_pred), N.ptr(coef), xt.numel(),
                                             N.stream_ptr()), "dq_ddim_step_x0")
             return x_prev, eps_pred
-        # host tensors (only reachable with a non-native network): the reference's arithmetic as is
+        # host tensors (only reachable with a non-native network) or a caller differentiating through the step: the reference's
+        # arithmetic as is
         if self.pred_type == "eps":
             eps_pred, x0_pred = out, (x_t - sb * out) / sa
         else:
@@ -191,7 +196,8 @@ class DDIMDiffusionModel(ModelInterface):
         out_x, out_n = torch.empty_like(x_T), torch.empty_like(x_T)
         traj_x = torch.empty((num_steps, B, RT, MZ), device=x_T.device) if return_trajectory else None
         traj_e = torch.empty((num_steps, B, RT, MZ), device=x_T.device) if return_trajectory else None
-        N.check(N.lib().dq_ddim_sample(net._plan, N.ptr(flat), N.ptr(net.rope_freqs()), self._alpha_bars_host(), N.ptr(x_T), N.ptr(c2),
+        N.check(N.lib().dq_ddim_sample(net._plan, N.ptr(flat), N.ptr(net.rope_freqs()), self._alpha_bars_host(), int(self.num_timesteps),
+                                       N.ptr(x_T), N.ptr(c2),
                                        N.ptr(c1), 1 if self.auto_normalize else 0, N.PRED_TYPES[self.pred_type], ts_c, num_steps,
                                        N.ptr(out_x), N.ptr(out_n),
                                        N.ptr(traj_x), N.ptr(traj_e), 1 if (self.use_graph and not return_trajectory) else 0, N.ptr(ws),
@@ -202,12 +208,11 @@ class DDIMDiffusionModel(ModelInterface):
 
     # ------------------------------------------------------------------ training objective
     def train_step(self, x_0, ms2_cond=None, ms1_cond=None, noise=None, ms1_loss_weight=0.0, t=None):
-        """model.py:326-406 (both pred types, ms1_loss_weight = 0).  Draw order as in the reference: ``randint`` then
+        """model.py:326-406 (both pred types; ``ms1_loss_weight > 0`` with the semantics of DESIGN.md section 12: the reference's
+        branch raises).  Draw order as in the reference: ``randint`` then
         ``randn_like``.  A passed ``noise`` is mapped 2*noise-1 like the reference does (model.py:346).  Returns a 0-dim loss
         (mean over samples of loss_weight[t_b] * MSE_b) that carries autograd history through the native network (generic
         path; the fused path is ``train_step_fused``)."""
-        if ms1_loss_weight and ms1_loss_weight > 0.0:
-            raise NotImplementedError("ms1_loss_weight > 0 is not built (the reference's branch raises TypeError; SURVEY 8f)")
         if self.pred_type not in N.PRED_TYPES:
             raise ValueError(f"Unknown pred_type: {self.pred_type}")
         batch_size = x_0.size(0)
@@ -219,18 +224,28 @@ class DDIMDiffusionModel(ModelInterface):
         ms1n = self.normalize(ms1_cond) if ms1_cond is not None else None
         x_t = self.q_sample(x_0, t, noise=noise)
         out = self.model(x_t, t, ms2n, ms1n)
-        if self.pred_type == "eps":
+        w = float(ms1_loss_weight or 0.0)
+        if self.pred_type == "eps" and w <= 0.0:
             return F.mse_loss(out, noise) * 1.0  # loss_weight is all-ones for the eps objective (model.py:208-209, 404)
-        per_sample = ((out - x_0) ** 2).flatten(1).mean(dim=1)  # model.py:376 at B = 1, per sample here
+        target = noise if self.pred_type == "eps" else x_0
+        per_sample = ((out - target) ** 2).flatten(1).mean(dim=1)  # model.py:361 / :376 at B = 1, per sample here
+        if w > 0.0:  # model.py:364-371, 379-386, 398-402 with the chosen semantics (this generic path: plain tensor expressions)
+            d = (x_t - out) if self.pred_type == "eps" else out
+            m1 = ms1n if ms1n.dim() == 2 else ms1n[..., 0]
+            tgt = m1 / m1.max(dim=-1, keepdim=True).values
+            add = torch.zeros_like(per_sample)
+            for sic in (d.sum(dim=-1), d.mean(dim=-1), d.max(dim=-1).values):
+                add = add + ((sic / sic.max(dim=-1, keepdim=True).values - tgt) ** 2).mean(dim=-1)
+            per_sample = (1 - w) * per_sample + w * add
         return (per_sample * self.loss_weight.to(per_sample.device)[t]).mean()  # model.py:404
 
-    def train_step_fused(self, x_0, ms2_cond, ms1_cond, t=None, noise=None, zero_grads=True):
+    def train_step_fused(self, x_0, ms2_cond, ms1_cond, t=None, noise=None, zero_grads=True, ms1_loss_weight=0.0):
         """One native call: normalise, q_sample, U-Net forward, MSE, backward into ``model.flat_grads()`` (+=).
         Returns the loss as a 0-dim device tensor (no host sync)."""
         from .building_blocks import DDIMTransformerAdapter
 
         if isinstance(self.model, DDIMTransformerAdapter):
-            return self._train_step_fused_tfm(x_0, ms1_cond, t, noise, zero_grads)
+            return self._train_step_fused_tfm(x_0, ms1_cond, t, noise, zero_grads, float(ms1_loss_weight or 0.0))
         net: UNet1d = self.model
         if not self.native:
             raise RuntimeError("train_step_fused needs this package's UNet1d or a DDIMTransformerAdapter")
@@ -253,10 +268,11 @@ class DDIMDiffusionModel(ModelInterface):
         lw = self.loss_weight.to(device=x_0.device, dtype=torch.float32).contiguous()
         N.check(N.lib().dq_train_step(net._plan, N.ptr(flat), N.ptr(net.rope_freqs()), N.ptr(ab), N.ptr(x_0), N.ptr(c2), N.ptr(c1),
                                       N.ptr(t), N.ptr(noise), 1 if self.auto_normalize else 0, N.PRED_TYPES[self.pred_type], N.ptr(lw),
-                                      N.ptr(grads), N.ptr(loss), N.ptr(ws), ws.numel(), B, RT, N.stream_ptr()), "dq_train_step")
+                                      float(ms1_loss_weight or 0.0), N.ptr(grads), N.ptr(loss), N.ptr(ws), ws.numel(), B, RT,
+                                      N.stream_ptr()), "dq_train_step")
         return loss
 
-    def _train_step_fused_tfm(self, x_0, ms1_cond, t=None, noise=None, zero_grads=True):
+    def _train_step_fused_tfm(self, x_0, ms1_cond, t=None, noise=None, zero_grads=True, ms1_loss_weight=0.0):
         """train_step for the CustomTransformer behind its adapter: the same sequence as the U-Net's dq_train_step (normalise +
         q_sample, network forward, MSE and its gradient, network backward into the flat gradient buffer), each stage one native
         call -- dq_q_sample, dq_tfm_fwd, dq_mse_loss(_weighted)_fwd_bwd, dq_tfm_bwd -- issued back to back on the current stream."""
@@ -295,5 +311,13 @@ class DDIMDiffusionModel(ModelInterface):
             N.check(lib.dq_mse_loss_weighted_fwd_bwd(N.ptr(out), N.ptr(x_0), 2.0 if norm else 1.0, -1.0 if norm else 0.0, N.ptr(lw), N.ptr(t),
                                                      N.ptr(loss), N.ptr(dout), N.ptr(self._mse_scratch), B, per, N.stream_ptr()),
                     "dq_mse_loss_weighted_fwd_bwd")
+        if ms1_loss_weight > 0.0:  # the MS1 term on top of the MSE part (same kernels as the U-Net's train step)
+            B_, RT_, MZ_ = x_0.shape
+            sc = torch.empty(5 * B_ * RT_ + B_ + 64, dtype=torch.float32, device=dev)
+            lw_x0 = self.loss_weight.to(device=dev, dtype=torch.float32).contiguous() if self.pred_type == "x0" else None  # (kept alive past the call)
+            lwp = N.ptr(lw_x0)
+            N.check(lib.dq_ms1_loss_fwd_bwd(N.ptr(out), N.ptr(x_t) if self.pred_type == "eps" else None, N.ptr(c1), 2.0 if norm else 1.0,
+                                            -1.0 if norm else 0.0, lwp, N.ptr(t), float(ms1_loss_weight), N.ptr(loss), N.ptr(dout), N.ptr(sc),
+                                            B_, RT_, MZ_, N.stream_ptr()), "dq_ms1_loss_fwd_bwd")
         tfm._run_bwd(x_t, c1n, dout, grads, False, False, accumulate=not zero_grads)
         return loss

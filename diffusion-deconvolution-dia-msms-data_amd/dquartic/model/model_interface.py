@@ -348,12 +348,11 @@ class ModelInterface(object):
 
     def _train_one_batch(self, x_0, ms2_cond=None, ms1_cond=None, noise=None, ms1_loss_weight=0.0, t=None, sync=True):
         """Reference :1090-1123.  Returns the loss as a float (``sync=False``: a 0-dim device tensor, no host sync)."""
-        fused = self._native_net() and isinstance(self.optimizer, FlatAdamW) and x_0.is_cuda and hasattr(self, "train_step_fused") \
-            and not (ms1_loss_weight and ms1_loss_weight > 0.0)
+        fused = self._native_net() and isinstance(self.optimizer, FlatAdamW) and x_0.is_cuda and hasattr(self, "train_step_fused")
         if fused:
             if noise is not None:
                 noise = self.normalize(noise)  # reference quirk: a passed noise is mapped 2n-1 (model.py:346)
-            loss = self.train_step_fused(x_0, ms2_cond, ms1_cond, t=t, noise=noise, zero_grads=True)
+            loss = self.train_step_fused(x_0, ms2_cond, ms1_cond, t=t, noise=noise, zero_grads=True, ms1_loss_weight=ms1_loss_weight or 0.0)
             world = _world()
             if torch.distributed.is_available() and torch.distributed.is_initialized():
                 torch.distributed.all_reduce(self.model.flat_grads())  # one flat RCCL all-reduce (sum) of 515 KB

@@ -9,13 +9,21 @@
  *
  * Conventions
  *   - plain C types only: device pointers (float* / int64_t*), sizes, a HIP stream passed as void*;
- *   - every call is asynchronous on the given stream, allocates no device memory and keeps no pointer after it
- *     returns; the caller supplies the workspace (size from dq_unet_workspace_bytes);
+ *   - every call is asynchronous on the given stream and keeps no pointer after it returns, with two documented
+ *     exceptions: dq_ddim_sample synchronises the stream twice on entry (its host-side coefficient / timestep tables must
+ *     be on the device before the caller's arrays go out of scope, and a hipGraph capture must not see pending copies), and
+ *     caches the captured step graph inside the plan;
+ *   - the caller supplies every workspace (sizes from dq_unet_workspace_bytes / dq_tfm_workspace_bytes /
+ *     dq_resblock_workspace_floats).  The library's only device allocation is made by the first call that uses a plan:
+ *     two ~10 KB tables of parameter offsets (hipMalloc, freed by dq_plan_destroy); a side stream and its events are
+ *     created by the first backward;
  *   - returns 0 on success; non-zero => dq_last_error() (thread-local text) says why;
  *   - tensors are contiguous fp32; MS2 windows are (B, RT, MZ) with MZ contiguous, MS1 chromatograms (B, RT),
  *     timesteps int64 (B);
  *   - parameters/gradients/AdamW moments are single flat fp32 buffers whose layout is described by
- *     dq_plan_param_info (tensor names == the reference's state_dict keys, reference registration order);
+ *     dq_plan_param_info (tensor names == the reference's state_dict keys, reference registration order).  SURVEY 8b
+ *     sketched a packed-weights handle (dq_weights_pack / dq_weights_free); the flat buffer replaces it: the caller's
+ *     tensor IS the packed form, so there is nothing to pack, free or keep in sync;
  *   - calls that share a dq_plan must not run concurrently; distinct plans are independent.
  */
 #ifndef DQ_HIP_H
@@ -32,9 +40,11 @@ typedef struct dq_plan dq_plan;
 const char* dq_last_error(void);
 /* ABI version of this header (bumped on any signature change).  2: pred_type arguments, dq_ddim_step_x0,
  * dq_mse_loss_weighted_fwd_bwd, dq_pair_batch.  3: dq_tfm_* (CustomTransformer), dq_gemm.
- * 4: dq_tfm_bwd takes an accumulate flag. */
+ * 4: dq_tfm_bwd takes an accumulate flag.  5: dq_ddim_sample takes num_timesteps (the plan no longer fixes T); stand-alone
+ * building blocks (dq_rmsnorm_fwd, dq_time_mlp_fwd, dq_scale_shift_fwd, dq_prep_inputs_fwd, dq_conv_fwd, dq_resblock_*,
+ * dq_rope, dq_attn_*); dq_train_step takes ms1_loss_weight, dq_ms1_loss_fwd_bwd. */
 int dq_abi_version(void);
-#define DQ_ABI_VERSION 4
+#define DQ_ABI_VERSION 5
 
 /* DDIMDiffusionModel.pred_type (model.py:205-213, 269-280, 354-389); any other value is rejected ("Unknown pred_type"). */
 enum { DQ_PRED_EPS = 0, DQ_PRED_X0 = 1 };
@@ -42,7 +52,8 @@ enum { DQ_PRED_EPS = 0, DQ_PRED_X0 = 1 };
 /* ---- network description -------------------------------------------------------------------------------------
  * Replaces UNet1d.__init__ (unet1d.py:918-1084) for simple=True, conditional=True, channels=1,
  * init_cond_channels=1, attn_cond_channels=1: builds the layer list and the flat parameter layout.
- * mz == downsample_dim.  Returns NULL on an unsupported configuration (see dq_last_error). */
+ * mz == downsample_dim.  num_timesteps is informational (kept for ABI continuity): the schedule tables come with each call.
+ * Returns NULL on an unsupported configuration (see dq_last_error). */
 dq_plan* dq_plan_create(int dim, int n_mults, const int* dim_mults, int mz, int num_timesteps);
 void dq_plan_destroy(dq_plan* plan);
 /* Number of trainable tensors / total trainable floats in the flat buffer. */
@@ -103,26 +114,40 @@ int dq_adamw_clip_step(float* params, const float* grads, float* exp_avg, float*
                        float grad_scale, float max_norm, double lr, double beta1, double beta2, double eps, double weight_decay,
                        int step, float* gnorm_out, void* stream);
 
-/* ---- DDIMDiffusionModel.train_step (model.py:326-406, ms1_loss_weight = 0) fused with its backward --------------
+/* ---- the MS1 term of train_step with ms1_loss_weight = w in (0, 1] (model.py:364-371, 379-386, 398-402) -----------------
+ * The reference's branch raises (torch.max(x, dim=-1) returns a tuple that is then divided), so the semantics are chosen
+ * (DESIGN.md section 12): per sample b, D = x_t - pred ('eps': pass x_t) or pred ('x0': x_t = NULL), s_f[rt] = f over m/z of
+ * D[rt][:] for f in {sum, mean, max (values)}, ms1n = ms1_cond*cond_mul+cond_add (B, RT),
+ *   additional_b = sum_f mean_rt (s_f[rt] / max_rt s_f - ms1n[rt] / max_rt ms1n)^2 .
+ * On entry loss_inout (1 device float) / grad_inout (B,RT,MZ; nullable) hold the MSE part (dq_mse_loss[_weighted]_fwd_bwd);
+ * on exit loss = (1-w) * MSE + w * mean_b lw_b additional_b and its gradient w.r.t. pred (lw = loss_weight_dev[t_b], NULL = 1).
+ * scratch: 5*B*RT + B floats. */
+int dq_ms1_loss_fwd_bwd(const float* pred, const float* x_t, const float* ms1_cond, float cond_mul, float cond_add,
+                        const float* loss_weight_dev, const int64_t* t, float ms1_loss_weight, float* loss_inout, float* grad_inout,
+                        float* scratch, int B, int RT, int MZ, void* stream);
+
+/* ---- DDIMDiffusionModel.train_step (model.py:326-406) fused with its backward ----------------------------------------
  * normalise x0/conds, q_sample, network forward, MSE loss, backward into grads (+=).  t (B) int64 and noise (B,RT,MZ) are
  * drawn by the caller (the reference draws randint then randn_like, model.py:344-346).  pred_type DQ_PRED_EPS: target =
  * noise, loss_weight_dev ignored (may be NULL); DQ_PRED_X0: target = normalised x0, every sample weighted by
- * loss_weight_dev[t_b] (model.py:209-210, 404).  loss_out: 1 device float = mean over the batch of the per-sample loss. */
+ * loss_weight_dev[t_b] (model.py:209-210, 404).  ms1_loss_weight in [0, 1]: 0 = the MSE alone; > 0 adds the MS1 term
+ * (dq_ms1_loss_fwd_bwd above).  loss_out: 1 device float = mean over the batch of the per-sample loss. */
 int dq_train_step(dq_plan* plan, const float* params, const float* rope_freqs, const float* alpha_bars_dev, const float* x0,
                   const float* ms2_cond, const float* ms1_cond, const int64_t* t, const float* noise, int auto_normalize,
-                  int pred_type, const float* loss_weight_dev, float* grads, float* loss_out, void* workspace,
+                  int pred_type, const float* loss_weight_dev, float ms1_loss_weight, float* grads, float* loss_out, void* workspace,
                   int64_t workspace_bytes, int B, int RT, void* stream);
 
 /* ---- DDIMDiffusionModel.sample (model.py:293-324) --------------------------------------------------------------
  * Runs the whole strided loop natively over timesteps_host[num_steps] (host ints; the caller forms them as
  * trunc(linspace(T-1, 0, num_steps)), model.py:313): each step = network forward + K9 (landing on alpha_bars[t-1],
- * model.py:284), then the epilogue (model.py:319-322).  alpha_bars_host: T host floats.  x_T (B,RT,MZ) is not modified.  out_x = denoised in [0,1]; out_noise = mixture -
+ * model.py:284), then the epilogue (model.py:319-322).  alpha_bars_host: num_timesteps host floats (DDIMDiffusionModel.alpha_bars;
+ * every timestep must lie in [0, num_timesteps)); num_steps <= 1024.  x_T (B,RT,MZ) is not modified.  out_x = denoised in [0,1]; out_noise = mixture -
  * denoised.  traj_x / traj_eps (nullable): (num_steps,B,RT,MZ) per-step x_{t-1} and eps.  use_graph != 0 (and no trajectory
  * requested; traj_eps always holds eps_pred, derived from the x0 prediction under DQ_PRED_X0): one step is captured
  * into a hipGraph (cached in the plan while params/workspace/B/RT stay the same) and
  * replayed num_steps times; the conditions are staged inside the workspace, the step index lives on the device. */
-int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, const float* alpha_bars_host, const float* x_T,
-                   const float* ms2_cond, const float* ms1_cond, int auto_normalize, int pred_type,
+int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, const float* alpha_bars_host, int num_timesteps,
+                   const float* x_T, const float* ms2_cond, const float* ms1_cond, int auto_normalize, int pred_type,
                    const int32_t* timesteps_host, int num_steps, float* out_x, float* out_noise, float* traj_x, float* traj_eps,
                    int use_graph, void* workspace, int64_t workspace_bytes, int B, int RT, void* stream);
 
@@ -175,6 +200,8 @@ int dq_gemm(const float* A, const float* B, float* C, const float* bias, int M, 
             void* stream);
 
 /* ---- building blocks exported for the per-block parity tests (tests/test_blocks_gpu.py) ------------------------
+ * Each runs the SAME kernels / dispatch the network uses, on caller-supplied tensors, so that the reference's per-block
+ * fixtures (tests/golden/blocks.npz) reach the HIP code directly.
  * Residual(PreNorm(LinearAttention)) (unet1d.py:446-496, 1017) on (rows, C, n). */
 int dq_linattn_fwd(const float* x, float* y, float* ypre /* nullable: pre-norm output saved for the backward */,
                    const float* w_qkv, const float* w_out, const float* b_out, const float* g_pre, const float* g_out, int C,
@@ -183,6 +210,48 @@ int dq_linattn_fwd(const float* x, float* y, float* ypre /* nullable: pre-norm o
 int dq_linattn_bwd(const float* x, const float* ypre, const float* dy, float* dx, const float* w_qkv, const float* w_out,
                    const float* b_out, const float* g_pre, const float* g_out, float* dw_qkv, float* dw_out, float* db_out,
                    float* dg_pre, float* dg_out, float* scratch, int C, int rows, int n, void* stream);
+/* RMSNorm (unet1d.py:113-140): y = x / max(||x||_2 over C, 1e-12) * g * sqrt(C) on (rows, C, n); C in {4, 8, 12, 16, 32, 64}. */
+int dq_rmsnorm_fwd(const float* x, const float* g, float* y, int C, int rows, int n, void* stream);
+/* SinusoidalPosEmb(4) -> Linear(4,16) -> GELU -> Linear(16,16) (unet1d.py:196-218, 956-960): t (B) int64 -> sinu_out (B,4),
+ * temb_out (B,16) (either nullable).  scratch: 100 * B floats. */
+int dq_time_mlp_fwd(const float* w1, const float* b1, const float* w2, const float* b2, const int64_t* t, float* sinu_out,
+                    float* temb_out, float* scratch, int B, void* stream);
+/* SiLU -> Linear(16, m) head hanging off the time embedding (ResnetBlock.mlp unet1d.py:292-296; ConditionalScaleShift
+ * :662-678): temb (B,16), w (m,16), b (m) -> ss (B,m). */
+int dq_scale_shift_fwd(const float* temb, const float* w, const float* b, float* ss, int B, int m, void* stream);
+/* The first layer's inputs (unet1d.py:1107-1115, 1122-1124): cat0 (B*RT, 2, MZ) = [ (cond*cond_mul+cond_add) * (scale_b + 1) +
+ * shift_b , x ], ms1n (B, RT) = ms1*cond_mul+cond_add; ss (B, 2) = [scale, shift] per sample. */
+int dq_prep_inputs_fwd(const float* x, const float* cond, const float* ms1, const float* ss, float cond_mul, float cond_add, float* cat0,
+                       float* ms1n, int B, int RT, int MZ, void* stream);
+/* Conv1d (+ optional fused RMSNorm with gain norm_g, + optional activation) on (rows, cin, n_in) -> (rows, cout, n_out):
+ * mode 0 = stride 1 'same' (K in {1,3,7}), 1 = Downsample k4 s2 p1 (unet1d.py:99-110), 2 = Upsample nearest x2 then k3 p1
+ * (:82-96).  act: 0 none, 1 SiLU, 2 GELU.  bias / norm_g nullable. */
+int dq_conv_fwd(const float* x, const float* w, const float* bias, const float* norm_g, int act, float* y, int cout, int cin, int K, int mode,
+                int rows, int n_in, int n_out, void* stream);
+/* ResnetBlock (unet1d.py:271-323) on input cat(xA (rows,cinA,n), xB (rows,cinB,n)) (xB nullable with cinB = 0) with the time
+ * embedding temb (rows / rows_per_sample, 16).  params: the block's tensors in state_dict order as ONE flat buffer
+ * [mlp.1.weight, mlp.1.bias, block1.proj.weight, block1.proj.bias, block1.norm.g, block2.proj.weight, block2.proj.bias,
+ * block2.norm.g (, res_conv.weight, res_conv.bias iff cinA+cinB != cout)].  rows_per_sample: RT at the m/z levels, 1 at the
+ * bottleneck.  workspace: dq_resblock_workspace_floats floats, shared by the forward (save_for_bwd = 1) and its backward. */
+int64_t dq_resblock_workspace_floats(int cin, int cout, int rows, int n, int rows_per_sample);
+int dq_resblock_fwd(const float* params, const float* xA, int cinA, const float* xB, int cinB, const float* temb, float* out, int cout,
+                    int rows, int n, int rows_per_sample, int save_for_bwd, float* workspace, int64_t workspace_floats, void* stream);
+/* Backward of the call above: dxA / dxB += (zero them first; nullable), grads (same layout as params) += for the conv / norm
+ * tensors; dss (rows / rows_per_sample, 2*cout) = d loss / d [scale | shift] (the mlp's gradients follow from it:
+ * d mlp.1.bias = sum_b dss_b, d mlp.1.weight = sum_b dss_b (x) SiLU(temb_b); the network does that in its time-embedding backward). */
+int dq_resblock_bwd(const float* params, const float* xA, int cinA, const float* xB, int cinB, const float* dout, float* dxA, float* dxB,
+                    float* grads, float* dss, int cout, int rows, int n, int rows_per_sample, float* workspace, int64_t workspace_floats,
+                    void* stream);
+/* RoPE of the bottleneck attention (rotary_embedding_torch 'lang' mode as restated in DESIGN.md section 5; unet1d.py:529,
+ * 560-561), in place on the 4 heads x 32 channels at the start of each sample of qk (B, >=128, RT); batch_stride in floats;
+ * sign +1 forward, -1 the transposed rotation (backward). */
+int dq_rope(float* qk, const float* freqs, int B, int64_t batch_stride, int RT, float sign, void* stream);
+/* softmax(q k^T 32^-0.5) v over RT (unet1d.py:428-443) for q, k, v, o (B, 128, RT) = 4 heads x 32 channels, RT contiguous;
+ * lse (B*4*RT) receives the log-sum-exp the backward needs. */
+int dq_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int RT, void* stream);
+/* Backward: dq, dk, dv (B, 128, RT) are plain stores; delta: B*4*RT floats of scratch. */
+int dq_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse, float* delta,
+                float* dq, float* dk, float* dv, int B, int RT, void* stream);
 
 /* Test hook: offset (in floats) of a named activation inside the workspace laid out by the last call on this plan
  * ("h0", "ms1f", "down3", "down3.la", "mid1", "attn_out", "up0", "fin", ...), or -1. */

@@ -387,16 +387,36 @@ class Diffusion:
         x = unnormalize(x)
         return x, unnormalize(c2) - x
 
-    def train_loss(self, x0, ms2_cond, ms1_cond, t, noise):
+    def train_loss(self, x0, ms2_cond, ms1_cond, t, noise, ms1_loss_weight: float = 0.0):
         """model.py:344-361, 372-376, 404 with explicit (t, noise): mean over the batch of
-        loss_weight[t_b] * MSE_b (target = noise for 'eps', normalised x0 for 'x0'; ms1_loss_weight = 0).
-        At B = 1 this equals the reference's (1,)-shaped loss.  Returns (loss, network output)."""
+        loss_weight[t_b] * loss_b, loss_b = MSE_b (target = noise for 'eps', normalised x0 for 'x0') when ms1_loss_weight = 0.
+        At B = 1 this equals the reference's (1,)-shaped loss.  Returns (loss, network output).
+
+        ms1_loss_weight > 0 (model.py:364-371, 379-386, 398-402): loss_b = (1 - w) * MSE_b + w * additional_b.  The reference's
+        branch cannot run (``torch.max(x, dim=-1)`` returns a (values, indices) tuple that is then divided -> TypeError), so its
+        semantics are CHOSEN here, as close to the text of the branch as a runnable program gets:
+          * ``func(..., dim=-1)`` for func = torch.max means its ``.values``;
+          * the MS1 chromatogram (B, RT) is the (B, RT, 1) tensor the network itself folds it into (unet1d.py:1122-1124), so
+            ``func(ms1_cond, dim=-1)`` is the chromatogram for all three funcs;
+          * ``x / torch.max(x)`` normalises by the maximum of that SAMPLE's chromatogram (batched semantics = the B = 1 reference
+            per sample, SURVEY F1/F2; at B = 1 this is the reference's global max);
+          * sic = func(x_t - eps_pred) for 'eps' and func(x0_pred) for 'x0', exactly as written; additional_b = sum over
+            the three funcs of MSE over RT."""
         x0n, c2, c1 = normalize(x0), normalize(ms2_cond), normalize(ms1_cond)
         x_t = q_sample(self.alpha_bars, x0n, t, noise)
         out = self.net(x_t, t, c2, c1)
-        if self.pred_type == "eps":
+        target = noise if self.pred_type == "eps" else x0n
+        per = ((out - target) ** 2).flatten(1).mean(dim=1)
+        if ms1_loss_weight > 0.0:
+            d = (x_t - out) if self.pred_type == "eps" else out
+            ms1 = c1 if c1.dim() == 2 else c1[..., 0]
+            tgt = ms1 / ms1.max(dim=-1, keepdim=True).values
+            add = torch.zeros_like(per)
+            for sic in (d.sum(dim=-1), d.mean(dim=-1), d.max(dim=-1).values):
+                add = add + ((sic / sic.max(dim=-1, keepdim=True).values - tgt) ** 2).mean(dim=-1)
+            per = (1 - ms1_loss_weight) * per + ms1_loss_weight * add
+        elif self.pred_type == "eps":
             return F.mse_loss(out, noise), out
-        per = ((out - x0n) ** 2).flatten(1).mean(dim=1)
         return (per * self.loss_weight[t]).mean(), out
 
 

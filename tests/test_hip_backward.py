@@ -251,3 +251,67 @@ def test_default_net_grads_multiblock_attention(RT):
         ref = po[k].grad
         err = float((named[k].grad.cpu() - ref).abs().max())
         assert err <= 1e-3 * max(float(ref.abs().max()), 1e-4 * gmax), (k, err)
+
+
+def test_two_forwards_before_backward_keep_their_own_activations(golden):
+    """two evaluations with grad enabled before one backward (micro-batches whose losses are summed) -- each forward
+    owns its training workspace until its backward ran, so the summed gradient equals the sum of the separate gradients."""
+    g = golden("tiny_diffusion.npz")
+    dm = _tiny_dm(g)
+    net = dm.model
+    xb, cb, mb, t = (T(g[k]).cuda() for k in ("batch/x", "batch/init_cond", "batch/attn_cond", "batch/t"))
+
+    def grads_of(fn):
+        net.flat_grads(zero=True)
+        for p in net.parameters():
+            p.grad = None
+        fn().backward()
+        return torch.cat([p.grad.reshape(-1) for _, p in net.trainable_named()]).clone()
+
+    f1 = lambda: (net(xb[:1], t[:1], cb[:1], mb[:1]) ** 2).mean()
+    f2 = lambda: (net(xb[1:], t[1:], cb[1:], mb[1:]) ** 3).mean()
+    g1, g2 = grads_of(f1), grads_of(f2)
+    both = grads_of(lambda: f1() + f2())   # forward 1, forward 2, then ONE backward through both
+    assert rel_err(both, g1 + g2) < 1e-5
+    # a fused step in between a forward and its backward must not disturb it either
+    y = net(xb[:1], t[:1], cb[:1], mb[:1])
+    dm.train_step_fused(xb, cb, mb, t=t, noise=T(g["batch/noise"]).cuda())
+    for p in net.parameters():
+        p.grad = None
+    (y ** 2).mean().backward()
+    again = torch.cat([p.grad.reshape(-1) for _, p in net.trainable_named()])
+    assert rel_err(again, g1) < 1e-5
+
+
+def test_train_one_batch_under_rccl_process_group_world1():
+    """The data-parallel product path on the GPU: an RCCL ("nccl") process group of one rank, then ``_prepare_training`` (replica
+    sync) and ``_train_one_batch`` -- the flat-gradient all-reduce line, ``grad_scale = 1 / world`` and the optimiser -- against the
+    same step without a process group (world = 1: the sum over ranks is the identity, so the two must agree bit for bit)."""
+    import os
+
+    import torch.distributed as dist
+    from dquartic.model.model import DDIMDiffusionModel
+    from dquartic.model.unet1d import UNet1d
+
+    def run(with_pg):
+        torch.manual_seed(21)
+        net = UNet1d(dim=4, channels=1, dim_mults=(1, 2, 2, 3, 3, 4, 4), conditional=True, init_cond_channels=1,
+                     attn_cond_channels=1, downsample_dim=64, simple=True).cuda()
+        dm = DDIMDiffusionModel(model_class=net, device="cuda")
+        dm._prepare_training(1e-4)
+        gen = torch.Generator().manual_seed(2)
+        x0, c2, c1 = torch.rand(4, 40, 64, generator=gen).cuda(), torch.rand(4, 40, 64, generator=gen).cuda(), torch.rand(4, 40, generator=gen).cuda()
+        t, nz = torch.tensor([1, 300, 640, 999]).cuda(), torch.rand(4, 40, 64, generator=gen).cuda()
+        losses = [dm._train_one_batch(x0, ms2_cond=c2, ms1_cond=c1, noise=nz, t=t) for _ in range(3)]
+        return losses, net.flat_params.clone(), float(dm.last_grad_norm), dm._global_mean(losses[-1])
+
+    ref = run(False)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        got = run(True)
+    finally:
+        dist.destroy_process_group()
+    assert got[0] == ref[0] and torch.equal(got[1], ref[1]) and got[2] == ref[2] and got[3] == ref[3]
+    assert all(np.isfinite(l) for l in got[0])

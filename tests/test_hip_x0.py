@@ -145,7 +145,7 @@ def test_unknown_pred_type_rejected():
     with pytest.raises(ValueError, match="Unknown pred_type"):
         DDIMDiffusionModel(model_class=net, pred_type="v", device="cuda")
     # the C ABI rejects an unknown enum value too (no silent default)
-    rc = N.lib().dq_ddim_sample(None, None, None, None, None, None, None, 1, 7, None, 1, None, None, None, None, 0, None, 0, 1, 1, None)
+    rc = N.lib().dq_ddim_sample(None, None, None, None, 1000, None, None, None, 1, 7, None, 1, None, None, None, None, 0, None, 0, 1, 1, None)
     assert rc != 0
     assert isinstance(N.lib().dq_last_error(), (bytes, type(None)))
     assert ctypes.c_int(N.lib().dq_abi_version()).value == N.ABI_VERSION
