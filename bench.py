@@ -29,6 +29,11 @@ TRAIN_BATCH = 32
 SAMPLE_BATCH = 512
 SAMPLE_STEPS = 50
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+HBM_PEAK_GBS = 8000.0         # same guide: HBM3E 8 TB/s spec (6.3 TB/s achievable with a float4 copy)
+# algorithmic work per window at 400 x 64 (torch.utils.flop_counter on the reference, 2*MAC, conv/matmul only)
+FLOPS_FWD, FLOPS_TRAIN = 2_549_672_128, 7_648_971_456
+BYTES_SAMPLE_STEP = 308_800                                  # read x_t, mixture, MS1; write x_{t-1}
+BYTES_TRAIN = lambda batch: 206_400 + 515_388 / batch       # read x0, mixture, MS1 + the batch-amortised gradient
 # algorithmic FLOPs (2*MAC) of one LinearAttention forward per m/z row of n positions with C channels:
 #   to_qkv 2*384*C*n + ctx 2*4*32*32*n + out 2*4*32*32*n + to_out 2*128*C*n      
 
@@ -74,13 +79,32 @@ def time_kernel(fn, iters=20):
     return e0.elapsed_time(e1) * 1e-3 / iters  # seconds per launch
 
 
-def roofline_linattn(device):
-    """Dominant kernel of the train step: k_linattn_bwd<4,64> (level-0 LinearAttention backward over 32*400 rows).
-    Timed live with HIP events on the launch stream; FLOPs are algorithmic (2x the forward's), not what the kernel
-    re-executes."""
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel from the committed counter passes (profiles/pmc_linattn.json, written by
+    tools/pmc_passes.sh on the GPU box) -- only if they were taken on THIS build of the native sources; a stale file gives null."""
     from dquartic import _native as N
 
-    C, n, rows = 4, 64, TRAIN_BATCH * RT
+    path = os.path.join(REPO, "profiles", "pmc_linattn.json")
+    if not os.path.exists(path):
+        return None, "no profiles/pmc_linattn.json"
+    with open(path) as fh:
+        pmc = json.load(fh)
+    if pmc.get("build_id") != N.build_id():
+        return None, f"profiles/pmc_linattn.json is from build {pmc.get('build_id')}, this build is {N.build_id()}: stale, not quoted"
+    for name, v in pmc["kernels"].items():
+        if name.startswith(kernel_prefix):
+            return float(v["hbm_bytes"]), f"profiles/pmc_linattn.json (2 x FETCH_SIZE + WRITE_SIZE, build {pmc['build_id']})"
+    return None, f"{kernel_prefix} not in profiles/pmc_linattn.json"
+
+
+def roofline_linattn(device, rows=TRAIN_BATCH * RT, with_bwd=True):
+    """Dominant kernels: k_linattn_bwd<4,64> (train step; level-0 LinearAttention backward over 32*400 rows) and
+    k_linattn_fwd<4,64> (sampling leg at rows = 512*400).  Timed live with HIP events on the launch stream; `achieved` prices the
+    launch at the ALGORITHMIC FLOPs of the reference's association (2x the forward's for the backward), `executed_frac` at the
+    FLOPs the re-associated kernels really issue, `hbm_frac` at the algorithmic bytes against the HBM peak."""
+    from dquartic import _native as N
+
+    C, n = 4, 64
     g = torch.Generator(device="cpu").manual_seed(0)
     x = torch.randn(rows, C, n, generator=g).to(device)
     dy = torch.randn(rows, C, n, generator=g).to(device)
@@ -102,25 +126,35 @@ def roofline_linattn(device):
                                  N.stream_ptr()), "dq_linattn_bwd")
 
     t_f = time_kernel(fwd)
-    t_b = time_kernel(bwd)  # the fused backward launch + the ordered slot reduce (~3 % of it)
     fl_f = la_flops_fwd(C, n) * rows
-    ach_f, ach_b = fl_f / t_f / 1e12, 2 * fl_f / t_b / 1e12
+    ex_f = 4 * (4 * 2 * 32 * C * n + 2 * C * C * n) * rows
+    by_f = 8 * C * n * rows  # x in, y out (inference; training adds the 4*C*n pre-norm save)
+    tr_f, src_f = pmc_traffic("k_linattn_fwd<4, 64>")
+    fwd_obj = {"bound": "mfma", "kernel": "k_linattn_fwd<4,64>", "rows": rows, "launch_us": round(t_f * 1e6, 2),
+               "achieved": round(fl_f / t_f / 1e12, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+               # the re-association removed work: the algorithmic rate can exceed the pipe's peak, so `frac` is stated on the FLOPs
+               # the kernel executes; the algorithmic figure stays in `achieved`
+               "frac": round(ex_f / t_f / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), "frac_basis": "executed FLOPs",
+               "flops_per_launch": fl_f, "executed_flops_per_launch": ex_f,
+               "hbm_frac": round(by_f / t_f / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": by_f,
+               "traffic": tr_f if rows == TRAIN_BATCH * RT else None, "traffic_source": src_f}
+    if not with_bwd:
+        return fwd_obj
+    t_b = time_kernel(bwd)  # the fused backward launch + the ordered slot reduce (~3 % of it)
+    ach_b = 2 * fl_f / t_b / 1e12
     # `achieved` prices the launch at the ALGORITHMIC FLOPs of the reference's formulation.  The kernels
     # re-associate the value path (M = K xh^T, P = M^T Q, W2 = Wo Wv) and EXECUTE fewer: per row and head
-    # 4 (forward) resp. 12 (backward) products of 2*32*C*n FLOP plus 1 resp. 3 of 2*C*C*n -- reported next to it, so that a
-    # fraction near or above 1 is read as "work removed", not as a pipe running past its peak.
-    ex_f = 4 * (4 * 2 * 32 * C * n + 2 * C * C * n) * rows
+    # 4 (forward) resp. 12 (backward) products of 2*32*C*n FLOP plus 1 resp. 3 of 2*C*C*n -- reported next to it.
     ex_b = 4 * (12 * 2 * 32 * C * n + 3 * 2 * C * C * n) * rows
+    by_b = 20 * C * n * rows  # read x, ypre, dy, (dx) ; write dx
+    tr_b, src_b = pmc_traffic("k_linattn_bwd<4, 64>")
     return {"bound": "mfma", "kernel": "k_linattn_bwd<4,64>", "achieved": round(ach_b, 3), "peak": F32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(ach_b / F32_MFMA_PEAK_TFLOPS, 4),
-            # HBM-side bytes per launch from the PMC passes of this shape (profiles/r01_pmc_linattn.md: 2 x FETCH_SIZE +
-            # WRITE_SIZE, FETCH_SIZE calibrated on k_q_sample); PMC cannot be collected inside this process
-            "traffic": 290.4e6,
+            "traffic": tr_b, "traffic_source": src_b,
             "launch_us": round(t_b * 1e6, 2), "flops_per_launch": 2 * fl_f,
             "executed_flops_per_launch": ex_b, "executed_frac": round(ex_b / t_b / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
-            "fwd_kernel": {"kernel": "k_linattn_fwd<4,64>", "achieved": round(ach_f, 3), "frac": round(ach_f / F32_MFMA_PEAK_TFLOPS, 4),
-                           "launch_us": round(t_f * 1e6, 2), "flops_per_launch": fl_f, "executed_flops_per_launch": ex_f,
-                           "executed_frac": round(ex_f / t_f / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}}
+            "hbm_frac": round(by_b / t_b / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": by_b,
+            "fwd_kernel": fwd_obj}
 
 
 def batch_formation(device):
@@ -248,7 +282,7 @@ def transformer_leg(device, with_cpu):
     out["roofline"] = {"bound": "mfma", "kernel": "k_gemm<A k-major, B k-major, 128x128x32> on (1088 x 1024) x (1024 x 40000)",
                        "achieved": round(fl / sec / 1e12, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "frac": round(fl / sec / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
-                       "traffic": 704.1e6,  # HBM bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_gemm.md
+                       "traffic": None,  # not re-measured on this build (round 1, profiles/r01_pmc_gemm.md: 704.1 MB per launch)
                        "flops_per_launch": fl, "us_per_launch": round(sec * 1e6, 1)}
     del net, dm, A, Bm, C
     torch.cuda.empty_cache()
@@ -313,8 +347,11 @@ def main():
     ap.add_argument("--no-sample", action="store_true", help="skip the sampling leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-transformer", action="store_true", help="skip the CustomTransformer leg (rank 0, single-GPU runs only)")
+    ap.add_argument("--train-only", action="store_true", help="only the train leg (clean per-kernel profiles of the train step)")
     ap.add_argument("--sample-batch", type=int, default=SAMPLE_BATCH)
     args = ap.parse_args()
+    if args.train_only:
+        args.no_sample = args.no_cpu = args.no_transformer = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -379,12 +416,20 @@ def main():
         ts = torch.tensor([ds], device=device, dtype=torch.float64)
         if dist_on:
             torch.distributed.all_reduce(ts, op=torch.distributed.ReduceOp.MAX)
-        sample = {"metric": "MS2 windows/s (50-step DDIM sample)", "value": round(world * B / float(ts), 2), "batch_per_gpu": B,
-                  "steps": SAMPLE_STEPS, "seconds": round(float(ts), 4)}
+        swps = world * B / float(ts)
+        sample = {"metric": "MS2 windows/s (50-step DDIM sample)", "value": round(swps, 2), "batch_per_gpu": B,
+                  "steps": SAMPLE_STEPS, "seconds": round(float(ts), 4),
+                  # whole-leg fractions per GPU: algorithmic FLOPs (50 forwards per window) against the f32 matrix peak, compulsory
+                  # bytes (x_t, mixture, MS1 in; x_{t-1} out, per step) against the HBM peak
+                  "whole_leg": {"flop_frac": round(swps / world * SAMPLE_STEPS * FLOPS_FWD / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                                "hbm_frac": round(swps / world * SAMPLE_STEPS * BYTES_SAMPLE_STEP / 1e9 / HBM_PEAK_GBS, 6)}}
+        if rank == 0:
+            log("sampling roofline leg")
+            sample["roofline"] = roofline_linattn(device, rows=B * RT, with_bwd=False)
 
     log("roofline leg")
-    roof = roofline_linattn(device) if rank == 0 else None
-    form = batch_formation(device) if rank == 0 else None
+    roof = roofline_linattn(device) if (rank == 0 and not args.train_only) else None
+    form = batch_formation(device) if (rank == 0 and not args.train_only) else None
     log("cpu baseline leg")
     cpu = cpu_baseline(net) if (rank == 0 and world == 1 and not args.no_cpu) else None
     tfm = None
@@ -404,6 +449,10 @@ def main():
                                    "windows 400 RT x 64 m/z, batch 32 per GPU, fp32", "global_batch": world * TRAIN_BATCH,
                        "window": [RT, MZ], "parallelism": f"dp{world}"},
             "last_loss": round(last_loss, 6),
+            "build_id": __import__("dquartic._native", fromlist=["x"]).build_id(),
+            # whole-step fractions per GPU: algorithmic FLOPs of fwd + bwd against the f32 matrix peak; compulsory bytes against HBM
+            "whole_step": {"flop_frac": round(train_wps / world * FLOPS_TRAIN / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                           "hbm_frac": round(train_wps / world * BYTES_TRAIN(TRAIN_BATCH) / 1e9 / HBM_PEAK_GBS, 6)},
             "sample": sample, "roofline": roof, "cpu_baseline": cpu, "batch_formation": form, "transformer": tfm,
         }
         sys.stdout.flush()

@@ -153,8 +153,9 @@ inline PartReduce res_part_reduce(const float* gpart, int gx, int B, int C, floa
 // standalone RMSNorm forward (PreNorm of the bottleneck attention)
 int launch_rmsnorm_fwd(const float* x, const float* g, float* y, int C, int rows, int n, hipStream_t s);
 
-// (rows=B*RT, C, n) <-> (B, C*n, RT) fold of the bottleneck (unet1d.py:1144-1148); add=1 accumulates
-int launch_fold(const float* in, float* out, int B, int RT, int cn, int to_mid, int add, hipStream_t s);
+// (rows=B*RT, C, n) <-> (B, C*n, RT) fold of the bottleneck (unet1d.py:1144-1148); add=1 accumulates; pitch: row pitch of the
+// (B, C*n, .) side (0 = RT; the wide bottleneck pads it, and the pad columns of a to_mid output are zeroed)
+int launch_fold(const float* in, float* out, int B, int RT, int cn, int to_mid, int add, hipStream_t s, int pitch = 0);
 
 // first layer inputs: cat0 = [cond_n*(scale+1)+shift, x] as (rows, 2, MZ); ms1n = ms1*cm+ca
 int launch_prep_inputs(const float* x, const float* cond, const float* ms1, const float* ss, int ss_stride, int ss_off, float cm,
@@ -162,6 +163,19 @@ int launch_prep_inputs(const float* x, const float* cond, const float* ms1, cons
 // d(scale), d(shift) of init_cond_proj from dcat0 channel 0 (+= into dss; part: >= 64 * B floats of per-block partials)
 int launch_prep_inputs_bwd(const float* dcat0, const float* cond, float cm, float ca, float* dss, int ss_stride, int ss_off, int B,
                            int RT, int MZ, float* part, int64_t part_floats, hipStream_t s);
+
+// ---- k_wide.hip : the bottleneck when it is wide (mid_dim * downsampled_n channels not in {16, 32, 64}); tensors (B, C, P), P = RT
+// padded to a multiple of 4, pad columns written as zeros
+int launch_im2col3(const float* x, float* xcol, int B, int C, int RT, int P, hipStream_t s);                  // (B,C,P) -> (B,3C,P)
+int launch_col2im3(const float* dxcol, float* dx, int B, int C, int RT, int P, int accumulate, hipStream_t s);  // transpose of it
+int launch_repitch(float* dst, int dpitch, const float* src, int spitch, int64_t rows, int n, hipStream_t s);
+int launch_wnorm_fwd(const float* u, const float* g, const float* ss, int ss_stride, int act, const float* res, float* y, int B, int C,
+                     int RT, int P, hipStream_t s);
+// scratch: B * (2 P + 2 C) floats; dg / dss / dbias +=
+int launch_wnorm_bwd(const float* u, const float* dy, const float* g, const float* ss, int ss_stride, int act, float* du, float* dg,
+                     float* dss, float* dbias, float* scratch, int B, int C, int RT, int P, hipStream_t s);
+int launch_rowsum(const float* x, int64_t rows, int RT, int P, float* out, hipStream_t s);
+int launch_sum_b(const float* part, int B, int C, float* dst, hipStream_t s);
 
 // ---- k_time.hip (declared in dq_unet.h: needs the plan)
 

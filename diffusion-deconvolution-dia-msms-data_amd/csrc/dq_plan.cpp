@@ -10,7 +10,11 @@ namespace {
 
 struct Builder {
   Plan& p;
+  // align4: start the tensor on a 16-byte boundary of the flat buffer (the tensors the GEMM reads as an operand; the few floats
+  // skipped stay zero in the parameter, gradient and moment buffers and belong to no tensor)
+  bool align4 = false;
   int64_t add(const std::string& name, std::initializer_list<int64_t> shape) {
+    if (align4) p.total_floats = (p.total_floats + 3) / 4 * 4;
     ParamInfo pi;
     pi.name = name;
     pi.offset = p.total_floats;
@@ -76,7 +80,10 @@ std::string build_plan(Plan& p, int dim, int n_mults, const int* mults, int mz, 
     if (d > 16) return "channel widths above 16 are not built (dim*mult <= 16)";
   p.mid_n = mz >> (L - 1);
   p.mid_c = p.dims[L] * p.mid_n;
-  if (p.mid_c != 16 && p.mid_c != 32 && p.mid_c != 64) return "bottleneck width dims[-1]*MZ/2**(L-1) must be 16, 32 or 64";
+  // 16 / 32 / 64 channels: the register-resident bottleneck kernels (the BASELINE shapes); anything else, e.g. the 10,000 of the
+  // reference's shipped downsample_dim 40000 (unet1d.py:1027-1029): the wide path
+  p.wide_mid = !(p.mid_c == 16 || p.mid_c == 32 || p.mid_c == 64);
+  if (p.wide_mid && p.mid_c % 4) return "bottleneck width dims[-1]*MZ/2**(L-1) must be a multiple of 4";
   p.cond_dim = 2 * dim;
   if (p.cond_dim != 8) return "attn_cond_init_dim (2*dim) must be 8";
   if (p.time_dim != 16) return "time_dim (4*dim) must be 16";
@@ -124,6 +131,7 @@ std::string build_plan(Plan& p, int dim, int n_mults, const int* mults, int mz, 
     l.n_next = l.last ? l.n : l.n * 2;
     p.ups.push_back(l);
   }
+  b.align4 = p.wide_mid;
   p.mid1 = b.res("mid_block1", p.mid_c, p.mid_c);
   p.qv_w = b.add("mid_attn.fn.fn.to_qv.weight", {2 * HID, p.mid_c, 1});
   p.k_w = b.add("mid_attn.fn.fn.to_k.weight", {HID, p.cond_dim, 1});
@@ -131,6 +139,7 @@ std::string build_plan(Plan& p, int dim, int n_mults, const int* mults, int mz, 
   p.ao_b = b.add("mid_attn.fn.fn.to_out.bias", {p.mid_c});
   p.ag = b.add("mid_attn.fn.norm.g", {1, p.mid_c, 1});
   p.mid2 = b.res("mid_block2", p.mid_c, p.mid_c);
+  b.align4 = false;
   p.fin = b.res("final_res_block", 2 * dim, dim);
   p.final_conv = b.conv("final_conv", 1, dim, 1);
   return "";

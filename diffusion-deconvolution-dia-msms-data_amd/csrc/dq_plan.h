@@ -52,6 +52,7 @@ struct Plan {
   std::vector<int> dims;  // [init_dim, dim*mult...]
   int mid_n = 0;          // downsampled_n (unet1d.py:1027)
   int mid_c = 0;          // mid_dim * downsampled_n
+  bool wide_mid = false;  // mid_c not in {16, 32, 64}: the bottleneck runs on im2col + GEMM + channel-axis norm (k_wide.hip)
   int cond_dim = 0;       // attn_cond_init_dim = 2*dim (unet1d.py:970)
   int ss_total = 0;       // floats per sample in the ss vector (all ResnetBlock mlps + init_cond_proj)
   int ss_init = 0;        // offset of init_cond_proj's [scale, shift]

@@ -25,7 +25,8 @@ int launch_time_embed_bwd(const Plan& p, const DevTables& dt, const float* param
 // Activation arena: offsets (in floats) of every tensor the forward produces for a given (B, RT).  The backward's
 // gradient of a tensor lives at the same offset in a second arena of the same size ("twin").
 struct ResBuf { int64_t u1, a1, u2, out; int64_t gpart = 0, gpart_floats = 0; };  // gpart: per-block norm-gain sums of the backward
-struct LevelBuf { ResBuf r0, r1; int64_t la, la_pre, la_tmp, rs; };  // la_pre: saved pre-norm LA output; la_tmp: backward scratch (twin only)
+struct LevelBuf { ResBuf r0, r1; int64_t la, la_pre, la_tmp, rs; };
+struct WideResBuf { int64_t u1 = 0, a1 = 0, u2 = 0, out = 0; };  // (B, mid_c, P) each: a ResnetBlock of the wide bottleneck  // la_pre: saved pre-norm LA output; la_tmp: backward scratch (twin only)
 struct Arena {
   int B = 0, RT = 0;
   int64_t floats = 0;       // total arena size
@@ -34,6 +35,10 @@ struct Arena {
   std::vector<LevelBuf> downs, ups;
   int64_t mid_in, xn, qv, kk, o, lse, delta, attn_out, mid_back, eps, partials, loss, coef, xa, xb, wg, wg_floats, la_part, la_part_floats, ts_tab, step, c2_stage, c1_stage, wtmp, la_prep, bb_part, bb_part_floats, ms1_scratch;
   ResBuf mid1, mid2, fin;
+  // wide bottleneck (Plan::wide_mid): P = RT padded to a multiple of 4; every tensor below is (B, channels, P)
+  int P = 0;
+  WideResBuf wmid1, wmid2;
+  int64_t w_mid_in = 0, w_xcol = 0, w_xn = 0, w_qv = 0, w_o = 0, w_attn_out = 0, w_stats = 0, w_gemm_part = 0, w_gemm_part_floats = 0;
 };
 void layout_arena(const Plan& p, int B, int RT, Arena& a);
 

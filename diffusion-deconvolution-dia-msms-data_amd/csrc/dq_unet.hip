@@ -62,13 +62,33 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
     b.rs = take_nz(R * l.resample.cout * l.n_next);
     a.downs.push_back(b);
   }
-  a.mid_in = take(R * p.mid_c);
-  a.mid1 = res(B, p.mid_c, RT, true);
-  a.xn = take(R * p.mid_c);
+  if (p.wide_mid) {
+    // the wide bottleneck (k_wide.hip): padded (B, C, P) tensors; every gradient twin is stored by its first writer
+    const int P = (RT + 3) / 4 * 4, Cm = p.mid_c;
+    a.P = P;
+    const int64_t t = (int64_t)B * Cm * P;
+    a.w_mid_in = take_nz(t);
+    for (WideResBuf* w : {&a.wmid1, &a.wmid2}) { w->u1 = take_nz(t); w->a1 = take_nz(t); w->u2 = take_nz(t); w->out = take_nz(t); }
+    a.w_xcol = take_nz(3 * t);
+    a.w_xn = take_nz(t);
+    a.w_qv = take_nz((int64_t)B * 2 * HID * P);
+    a.w_o = take_nz((int64_t)B * HID * P);
+    a.w_attn_out = take_nz(t);
+    a.w_stats = take_nz((int64_t)B * (2 * P + 2 * std::max(Cm, 2 * HID)) + 64);
+    int64_t gp = 0;
+    const int shapes[9][4] = {{Cm, RT, 3 * Cm, B}, {3 * Cm, RT, Cm, B}, {Cm, 3 * Cm, RT, 1}, {2 * HID, RT, Cm, B}, {Cm, RT, 2 * HID, B},
+                              {2 * HID, Cm, RT, 1}, {Cm, RT, HID, B}, {HID, RT, Cm, B}, {Cm, HID, RT, 1}};
+    for (const auto& sh : shapes) gp = std::max(gp, gemm_partial_floats(sh[0], sh[1], sh[2], sh[3]));
+    a.w_gemm_part_floats = gp;
+    a.w_gemm_part = take_nz(gp + 64);
+  }
+  a.mid_in = take(R * (p.wide_mid ? 1 : p.mid_c));
+  a.mid1 = res(B, p.wide_mid ? 4 : p.mid_c, RT, true);
+  a.xn = take(R * (p.wide_mid ? 1 : p.mid_c));
   a.qv = take(R * 2 * HID); a.kk = take(R * HID); a.o = take(R * HID);
   a.lse = take(R * HEADS); a.delta = take(R * HEADS);
-  a.attn_out = take(R * p.mid_c);
-  a.mid2 = res(B, p.mid_c, RT, true);
+  a.attn_out = take(R * (p.wide_mid ? 1 : p.mid_c));
+  a.mid2 = res(B, p.wide_mid ? 4 : p.mid_c, RT, true);
   a.mid_back = take(R * p.mid_c);
   for (int ui = 0; ui < p.levels; ++ui) {
     const LevelP& l = p.ups[ui];
@@ -85,7 +105,9 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
   a.partials = take_nz(MSE_MAX_BLOCKS);
   a.loss = take_nz(64);
   a.coef = take_nz(4 * 1024);  // DDIM coefficient table (<= 1024 steps)
-  a.wg_floats = (int64_t)WGRAD_MAX_PARTS * (std::max({16 * 32 * 3, p.mid_c * p.mid_c * 3, 2 * HID * p.mid_c}) + 2 * HID);
+  // (the wide bottleneck's weight gradients are GEMMs into the gradient buffer itself: no partial sums)
+  a.wg_floats = (int64_t)WGRAD_MAX_PARTS * (std::max({16 * 32 * 3, p.wide_mid ? HID * p.cond_dim : p.mid_c * p.mid_c * 3,
+                                                        p.wide_mid ? 0 : 2 * HID * p.mid_c}) + 2 * HID);
   a.wg = take_nz(a.wg_floats);  // partial sums of the weight-gradient kernels
   // per-wave dW partial slots of the LinearAttention backward: one reservation per LinearAttention layer, so that all slot
   // reductions of a backward pass can be deferred into ONE launch at its end (15 launches of ~14 us on the main stream before)
@@ -95,7 +117,7 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
   a.la_part_floats = std::max<int64_t>(a.la_part_floats, (int64_t)LA_MAX_WAVES * 512 * 16);
   a.la_part = take_nz(a.la_part_floats);
   a.la_prep = take_nz((int64_t)LA_PREP_MAX * LA_PREP_FLOATS);  // prepared LinearAttention weights, one slot per layer (downs, then ups)
-  a.bb_part_floats = (int64_t)64 * B * 4 * std::max(p.mid_c, 2);  // partial sums of the PreNorm backward / the input affine
+  a.bb_part_floats = (int64_t)64 * B * 4 * std::max(p.wide_mid ? 2 : p.mid_c, 2);  // partial sums of the PreNorm backward / the input affine
   a.bb_part = take_nz(a.bb_part_floats);
   a.ms1_scratch = take_nz(5 * R + B + 64);  // the MS1 loss term (ms1_loss_weight > 0): per-row sums / maxima and their gradients
   a.wtmp = take_nz(3 * WTMP_SLOT);  // 16-byte aligned copy of a projection weight for the GEMM route of the wide 1x1 convs
@@ -272,7 +294,9 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
   if (dA || dB) {
     ConvBwdData d1;
     d1.du = c.g(b.u1); d1.w = c.prm(r.c1.w); d1.cout = r.cout; d1.K = 3; d1.mode = CONV_S1; d1.rows = rows; d1.n_in = n; d1.n_out = n;
-    d1.dinA = dA; d1.dinB = dB; d1.cinA = cinA; d1.cinB = cinB; d1.accumulate = 1;
+    // first writer of dA / dB in this backward pass (the m/z levels whose row length the fused kernels do not take): plain store;
+    // otherwise (the bottleneck blocks: cleared twins) accumulate
+    d1.dinA = dA; d1.dinB = dB; d1.cinA = cinA; d1.cinB = cinB; d1.accumulate = (storeA || storeB) ? 0 : 1;
     DQ_TRY(launch_conv_bwd_data(d1, c.s));
   }
   // residual path
@@ -295,12 +319,15 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
   return 0;
 }
 
+// rows the register-resident kernels handle (k_linattn.hip / k_la_bwd.hip); anything else goes through the sweep kernels (k_la_long.hip)
+bool la_short_row(int n) { return n <= 64 && (n & (n - 1)) == 0; }
+
 // slot: this layer's index in the prepared-weights buffer (la_prepare_all), or -1
 int la_fwd(const Ctx& c, const LAP& l, const float* x, float* y, float* ypre, int rows, int n, int slot = -1) {
   LinAttn a;
   a.x = x; a.y = y; a.ypre = ypre; a.w_qkv = c.prm(l.qkv_w); a.w_out = c.prm(l.out_w); a.b_out = c.prm(l.out_b);
   a.g_pre = c.prm(l.g_pre); a.g_out = c.prm(l.g_out); a.C = l.C; a.rows = rows; a.n = n;
-  if (slot >= 0 && n <= 64) a.prep = c.w(c.ar.la_prep) + (int64_t)slot * LA_PREP_FLOATS;
+  if (slot >= 0 && la_short_row(n)) a.prep = c.w(c.ar.la_prep) + (int64_t)slot * LA_PREP_FLOATS;
   return launch_linattn_fwd(a, c.s);
 }
 // W2 = Wo Wv and the MFMA operand image of Wq | Wk of every LinearAttention layer, once per forward (one launch) instead of once
@@ -344,13 +371,13 @@ int la_bwd(const Ctx& c, const LAP& l, const LevelBuf& b, const float* x, const 
   a.f.g_pre = c.prm(l.g_pre); a.f.g_out = c.prm(l.g_out); a.f.C = l.C; a.f.rows = rows; a.f.n = n;
   a.dy = dy; a.dx = dx;
   // W2 of this layer as the forward of this step prepared it (la_prepare_all): same weights, same numbers
-  if (slot >= 0 && n <= 64 && (int)(c.p.downs.size() + c.p.ups.size()) <= LA_PREP_MAX) a.f.prep = c.w(c.ar.la_prep) + (int64_t)slot * LA_PREP_FLOATS;
+  if (slot >= 0 && la_short_row(n) && (int)(c.p.downs.size() + c.p.ups.size()) <= LA_PREP_MAX) a.f.prep = c.w(c.ar.la_prep) + (int64_t)slot * LA_PREP_FLOATS;
   a.dw_qkv = c.dprm(l.qkv_w); a.dw_out = c.dprm(l.out_w); a.db_out = c.dprm(l.out_b); a.dg_pre = c.dprm(l.g_pre);
   a.dg_out = c.dprm(l.g_out);
   a.dx_store = 1;  // the block's input feeds nothing else: this launch is the only writer of its gradient (not pre-cleared)
   Ctx::LaDefer* d = c.la_defer;
   if (!d) return launch_linattn_bwd(a, c.s);
-  const int64_t need = n <= 64 ? la_part_reserve(l.C) : c.ar.la_part_floats;
+  const int64_t need = la_short_row(n) ? la_part_reserve(l.C) : c.ar.la_part_floats;
   if (d->count == LA_REDUCE_MAX || d->cursor + need > c.ar.la_part_floats) DQ_TRY(la_flush(c));  // (long rows use the whole buffer)
   int waves = 0;
   a.part = c.w(c.ar.la_part) + d->cursor; a.part_floats = c.ar.la_part_floats - d->cursor;
@@ -422,6 +449,131 @@ int conv_plain_bwd(const Ctx& c, const ConvP& cp, int mode, const float* in, con
 
 ConvP proj(int64_t w, int cout, int cin) { ConvP c; c.w = w; c.b = -1; c.cout = cout; c.cin = cin; c.k = 1; return c; }
 
+// ---------------------------------------------------------------------------------------------------------------
+// the wide bottleneck (Plan::wide_mid; k_wide.hip): ResnetBlocks and attention projections over (B, mid_c, P) tensors as
+// im2col + GEMM + channel-axis norm.  Same op order as the register-resident path (unet1d.py:1144-1148, 302-323, 552-567).
+// ---------------------------------------------------------------------------------------------------------------
+// C_b (M x N; ldc) (+)= op(A) op(B_b) for every sample b; A is a weight (shared), B and C are (B, rows, P) tensors
+int wide_gemm(const Ctx& c, const float* A, int a_kmajor, int64_t lda, const float* Bm, int64_t b_rows, float* C, int64_t c_rows, int M,
+              int N, int K, const float* bias_m, int accumulate) {
+  Gemm g;
+  g.A = A; g.a_kmajor = a_kmajor; g.lda = lda; g.B = Bm; g.b_kmajor = 0; g.ldb = c.ar.P; g.C = C; g.ldc = c.ar.P;
+  g.M = M; g.N = N; g.K = K; g.batch = c.B; g.sBo = b_rows * c.ar.P; g.sCo = c_rows * c.ar.P;
+  g.bias_m = bias_m; g.accumulate = accumulate;
+  g.partial = c.w(c.ar.w_gemm_part); g.partial_floats = c.ar.w_gemm_part_floats;
+  return launch_gemm(g, c.s);
+}
+// dW (M x N; ldc = N) += sum_b dY_b (M x RT) X_b^T (RT x N): dY, X are (B, ., P) tensors; one product per sample, accumulated in order
+int wide_wgrad(const Ctx& c, const float* dY, const float* X, float* dW, int M, int N) {
+  for (int b = 0; b < c.B; ++b) {
+    Gemm g;
+    g.A = dY + (int64_t)b * M * c.ar.P; g.a_kmajor = 1; g.lda = c.ar.P;
+    g.B = X + (int64_t)b * N * c.ar.P; g.b_kmajor = 1; g.ldb = c.ar.P;
+    g.C = dW; g.ldc = N; g.M = M; g.N = N; g.K = c.RT; g.accumulate = 1;
+    g.partial = c.w(c.ar.w_gemm_part); g.partial_floats = c.ar.w_gemm_part_floats;
+    DQ_TRY(launch_gemm(g, c.s));
+  }
+  return 0;
+}
+
+int wide_res_fwd(const Ctx& c, const ResP& r, const WideResBuf& wb, const float* in) {
+  const int B = c.B, RT = c.RT, P = c.ar.P, Cm = r.cout;
+  float* xcol = c.w(c.ar.w_xcol);
+  DQ_TRY(launch_im2col3(in, xcol, B, Cm, RT, P, c.s));
+  DQ_TRY(wide_gemm(c, c.prm(r.c1.w), 1, 3 * Cm, xcol, 3 * Cm, c.w(wb.u1), Cm, Cm, RT, 3 * Cm, c.prm(r.c1.b), 0));
+  DQ_TRY(launch_wnorm_fwd(c.w(wb.u1), c.prm(r.g1), c.w(c.ar.ss) + r.ss_off, c.p.ss_total, ACT_SILU, nullptr, c.w(wb.a1), B, Cm, RT, P, c.s));
+  DQ_TRY(launch_im2col3(c.w(wb.a1), xcol, B, Cm, RT, P, c.s));
+  DQ_TRY(wide_gemm(c, c.prm(r.c2.w), 1, 3 * Cm, xcol, 3 * Cm, c.w(wb.u2), Cm, Cm, RT, 3 * Cm, c.prm(r.c2.b), 0));
+  // block2's norm + SiLU, then the identity residual (mid blocks: dim -> dim, unet1d.py:300, 1045, 1057)
+  return launch_wnorm_fwd(c.w(wb.u2), c.prm(r.g2), nullptr, 0, ACT_SILU, in, c.w(wb.out), B, Cm, RT, P, c.s);
+}
+
+// d(out) is complete in the twin of wb.out; din (B, Cm, P) receives the gradient of the block input (plain store)
+int wide_res_bwd(const Ctx& c, const ResP& r, const WideResBuf& wb, const float* in, float* din) {
+  const int B = c.B, RT = c.RT, P = c.ar.P, Cm = r.cout;
+  const int64_t t = (int64_t)B * Cm * P;
+  float* xcol = c.w(c.ar.w_xcol);
+  float* dxcol = c.g(c.ar.w_xcol);
+  float* st = c.w(c.ar.w_stats);
+  const float* dout = c.g(wb.out);
+  // block2: out = silu(norm(u2)) + in ; u2 = W2 col(a1) + b2
+  DQ_TRY(launch_wnorm_bwd(c.w(wb.u2), dout, c.prm(r.g2), nullptr, 0, ACT_SILU, c.g(wb.u2), c.dprm(r.g2), nullptr, c.dprm(r.c2.b), st, B, Cm,
+                          RT, P, c.s));
+  DQ_TRY(launch_im2col3(c.w(wb.a1), xcol, B, Cm, RT, P, c.s));
+  DQ_TRY(wide_wgrad(c, c.g(wb.u2), xcol, c.dprm(r.c2.w), Cm, 3 * Cm));
+  DQ_TRY(wide_gemm(c, c.prm(r.c2.w), 0, 3 * Cm, c.g(wb.u2), Cm, dxcol, 3 * Cm, 3 * Cm, RT, Cm, nullptr, 0));
+  DQ_TRY(launch_col2im3(dxcol, c.g(wb.a1), B, Cm, RT, P, 0, c.s));
+  // block1: a1 = silu(norm(u1) (scale + 1) + shift) ; u1 = W1 col(in) + b1
+  DQ_TRY(launch_wnorm_bwd(c.w(wb.u1), c.g(wb.a1), c.prm(r.g1), c.w(c.ar.ss) + r.ss_off, c.p.ss_total, ACT_SILU, c.g(wb.u1), c.dprm(r.g1),
+                          c.g(c.ar.ss) + r.ss_off, c.dprm(r.c1.b), st, B, Cm, RT, P, c.s));
+  DQ_TRY(launch_im2col3(in, xcol, B, Cm, RT, P, c.s));
+  DQ_TRY(wide_wgrad(c, c.g(wb.u1), xcol, c.dprm(r.c1.w), Cm, 3 * Cm));
+  DQ_TRY(wide_gemm(c, c.prm(r.c1.w), 0, 3 * Cm, c.g(wb.u1), Cm, dxcol, 3 * Cm, 3 * Cm, RT, Cm, nullptr, 0));
+  DQ_TRY(launch_col2im3(dxcol, din, B, Cm, RT, P, 0, c.s));
+  return launch_axpy(din, dout, t, c.s);  // identity residual
+}
+
+int mid_forward_wide(const Ctx& c, const float* rope, const float* cur) {
+  const Plan& p = c.p;
+  const Arena& a = c.ar;
+  const int B = c.B, RT = c.RT, P = a.P, Cm = p.mid_c;
+  const int64_t t = (int64_t)B * Cm * P;
+  DQ_TRY(launch_fold(cur, c.w(a.w_mid_in), B, RT, Cm, 1, 0, c.s, P));
+  DQ_TRY(wide_res_fwd(c, p.mid1, a.wmid1, c.w(a.w_mid_in)));
+  // Residual(PreNorm(Attention(use_xattn))) (unet1d.py:552-567): q | v from the normed state, k from the MS1 features
+  DQ_TRY(launch_wnorm_fwd(c.w(a.wmid1.out), c.prm(p.ag), nullptr, 0, ACT_NONE, nullptr, c.w(a.w_xn), B, Cm, RT, P, c.s));
+  DQ_TRY(wide_gemm(c, c.prm(p.qv_w), 1, Cm, c.w(a.w_xn), Cm, c.w(a.w_qv), 2 * HID, 2 * HID, RT, Cm, nullptr, 0));
+  DQ_TRY(launch_repitch(c.w(a.qv), RT, c.w(a.w_qv), P, (int64_t)B * 2 * HID, RT, c.s));  // the attention kernels read rows of RT floats
+  DQ_TRY(conv_plain_fwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.w(a.kk), B, RT, RT));
+  if (rope) {
+    DQ_TRY(launch_rope(c.w(a.qv), rope, B, (int64_t)2 * HID * RT, RT, 1.f, c.s));
+    DQ_TRY(launch_rope(c.w(a.kk), rope, B, (int64_t)HID * RT, RT, 1.f, c.s));
+  }
+  const int64_t qvbs = (int64_t)2 * HID * RT, kbs = (int64_t)HID * RT;
+  DQ_TRY(launch_attn_fwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.w(a.lse), B, RT, c.s));
+  DQ_TRY(launch_repitch(c.w(a.w_o), P, c.w(a.o), RT, (int64_t)B * HID, RT, c.s));
+  DQ_TRY(launch_copy(c.w(a.w_attn_out), c.w(a.wmid1.out), t, c.s));  // the residual; attn_out += Wo o + b
+  DQ_TRY(wide_gemm(c, c.prm(p.ao_w), 1, HID, c.w(a.w_o), HID, c.w(a.w_attn_out), Cm, Cm, RT, HID, c.prm(p.ao_b), 1));
+  DQ_TRY(wide_res_fwd(c, p.mid2, a.wmid2, c.w(a.w_attn_out)));
+  return launch_fold(c.w(a.wmid2.out), c.w(a.mid_back), B, RT, Cm, 0, 0, c.s, P);
+}
+
+// d(mid_back) is complete; leaves d(downs[L-1].rs) (plain store) and all bottleneck parameter gradients (+=)
+int mid_backward_wide(const Ctx& c, const float* rope) {
+  const Plan& p = c.p;
+  const Arena& a = c.ar;
+  const int B = c.B, RT = c.RT, P = a.P, Cm = p.mid_c, L = p.levels;
+  const int64_t t = (int64_t)B * Cm * P;
+  float* st = c.w(a.w_stats);
+  DQ_TRY(launch_fold(c.g(a.mid_back), c.g(a.wmid2.out), B, RT, Cm, 1, 0, c.s, P));
+  DQ_TRY(wide_res_bwd(c, p.mid2, a.wmid2, c.w(a.w_attn_out), c.g(a.w_attn_out)));
+  // attn_out = mid1.out + Wo o + b
+  float* dao = c.g(a.w_attn_out);
+  DQ_TRY(wide_wgrad(c, dao, c.w(a.w_o), c.dprm(p.ao_w), Cm, HID));
+  DQ_TRY(launch_rowsum(dao, (int64_t)B * Cm, RT, P, st, c.s));
+  DQ_TRY(launch_sum_b(st, B, Cm, c.dprm(p.ao_b), c.s));
+  DQ_TRY(wide_gemm(c, c.prm(p.ao_w), 0, HID, dao, Cm, c.g(a.w_o), HID, HID, RT, Cm, nullptr, 0));
+  DQ_TRY(launch_repitch(c.g(a.o), RT, c.g(a.w_o), P, (int64_t)B * HID, RT, c.s));
+  DQ_TRY(launch_copy(c.g(a.wmid1.out), dao, t, c.s));  // the residual branch: first writer of d(mid1.out)
+  const int64_t qvbs = (int64_t)2 * HID * RT, kbs = (int64_t)HID * RT;
+  DQ_TRY(launch_attn_bwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.g(a.o), c.w(a.lse), c.w(a.delta), c.g(a.qv),
+                         qvbs, c.g(a.kk), kbs, c.g(a.qv) + kbs, qvbs, B, RT, c.s));
+  if (rope) {
+    DQ_TRY(launch_rope(c.g(a.qv), rope, B, (int64_t)2 * HID * RT, RT, -1.f, c.s));
+    DQ_TRY(launch_rope(c.g(a.kk), rope, B, (int64_t)HID * RT, RT, -1.f, c.s));
+  }
+  DQ_TRY(conv_plain_bwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.g(a.kk), c.g(a.ms1f), B, RT, RT, 0));
+  DQ_TRY(launch_repitch(c.g(a.w_qv), P, c.g(a.qv), RT, (int64_t)B * 2 * HID, RT, c.s));
+  DQ_TRY(wide_wgrad(c, c.g(a.w_qv), c.w(a.w_xn), c.dprm(p.qv_w), 2 * HID, Cm));
+  DQ_TRY(wide_gemm(c, c.prm(p.qv_w), 0, Cm, c.g(a.w_qv), 2 * HID, c.g(a.w_xn), Cm, Cm, RT, 2 * HID, nullptr, 0));
+  // PreNorm backward (no scale/shift, no activation), in place on d(xn); then into d(mid1.out)
+  DQ_TRY(launch_wnorm_bwd(c.w(a.wmid1.out), c.g(a.w_xn), c.prm(p.ag), nullptr, 0, ACT_NONE, c.g(a.w_xn), c.dprm(p.ag), nullptr, nullptr, st, B,
+                          Cm, RT, P, c.s));
+  DQ_TRY(launch_axpy(c.g(a.wmid1.out), c.g(a.w_xn), t, c.s));
+  DQ_TRY(wide_res_bwd(c, p.mid1, a.wmid1, c.w(a.w_mid_in), c.g(a.w_mid_in)));
+  return launch_fold(c.g(a.w_mid_in), c.g(a.downs[L - 1].rs), B, RT, Cm, 0, 0, c.s, P);
+}
+
 int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t* t, int t_scalar, const float* init_cond,
                  const float* attn_cond, float cm, float ca, const DevTables& dt, float* out, const int* step_tab = nullptr,
                  const int* step_ptr = nullptr) {
@@ -456,38 +608,42 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     cur = c.w(b.rs);
   }
   // bottleneck (unet1d.py:1144-1148)
-  DQ_TRY(launch_fold(cur, c.w(a.mid_in), B, RT, p.mid_c, 1, 0, c.s));
-  DQ_TRY(res_fwd(c, p.mid1, a.mid1, c.w(a.mid_in), p.mid_c, nullptr, 0, B, RT, 1));
-  {
-    // Residual(PreNorm(Attention(use_xattn))) (unet1d.py:552-567)
-    DQ_TRY(launch_rmsnorm_fwd(c.w(a.mid1.out), c.prm(p.ag), c.w(a.xn), p.mid_c, B, RT, c.s));
-    DQ_TRY(conv_plain_fwd(c, proj(p.qv_w, 2 * HID, p.mid_c), CONV_S1, c.w(a.xn), c.w(a.qv), B, RT, RT, prep_ok ? 0 : -1));
-    DQ_TRY(conv_plain_fwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.w(a.kk), B, RT, RT, prep_ok ? 1 : -1));
-    if (rope) {
-      DQ_TRY(launch_rope(c.w(a.qv), rope, B, (int64_t)2 * HID * RT, RT, 1.f, c.s));  // q = first 128 channels of each sample's 256
-      DQ_TRY(launch_rope(c.w(a.kk), rope, B, (int64_t)HID * RT, RT, 1.f, c.s));
+  if (p.wide_mid) {
+    DQ_TRY(mid_forward_wide(c, rope, cur));
+  } else {
+    DQ_TRY(launch_fold(cur, c.w(a.mid_in), B, RT, p.mid_c, 1, 0, c.s));
+    DQ_TRY(res_fwd(c, p.mid1, a.mid1, c.w(a.mid_in), p.mid_c, nullptr, 0, B, RT, 1));
+    {
+      // Residual(PreNorm(Attention(use_xattn))) (unet1d.py:552-567)
+      DQ_TRY(launch_rmsnorm_fwd(c.w(a.mid1.out), c.prm(p.ag), c.w(a.xn), p.mid_c, B, RT, c.s));
+      DQ_TRY(conv_plain_fwd(c, proj(p.qv_w, 2 * HID, p.mid_c), CONV_S1, c.w(a.xn), c.w(a.qv), B, RT, RT, prep_ok ? 0 : -1));
+      DQ_TRY(conv_plain_fwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.w(a.kk), B, RT, RT, prep_ok ? 1 : -1));
+      if (rope) {
+        DQ_TRY(launch_rope(c.w(a.qv), rope, B, (int64_t)2 * HID * RT, RT, 1.f, c.s));  // q = first 128 channels of each sample's 256
+        DQ_TRY(launch_rope(c.w(a.kk), rope, B, (int64_t)HID * RT, RT, 1.f, c.s));
+      }
+      const int64_t qvbs = (int64_t)2 * HID * RT, kbs = (int64_t)HID * RT;
+      DQ_TRY(launch_attn_fwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.w(a.lse), B, RT, c.s));
+      const ConvP ao = proj(p.ao_w, p.mid_c, HID);
+      if (conv_is_gemm(c, ao, CONV_S1, RT, RT) && (prep_ok || ((uintptr_t)c.prm(ao.w) & 15) == 0)) {
+        // to_out (1x1 conv, 128 -> mid_c channels, with bias) + the residual: attn_out = x ; attn_out += W o + b as a GEMM per sample
+        DQ_TRY(launch_copy(c.w(a.attn_out), c.w(a.mid1.out), (int64_t)B * p.mid_c * RT, c.s));
+        Gemm g;
+        DQ_TRY(gemm_weight(c, ao, &g.A, 2));
+        g.lda = HID; g.B = c.w(a.o); g.b_kmajor = 0; g.ldb = RT; g.C = c.w(a.attn_out); g.ldc = RT; g.M = p.mid_c; g.N = RT; g.K = HID;
+        g.batch = B; g.sBo = (int64_t)HID * RT; g.sCo = (int64_t)p.mid_c * RT; g.bias_m = c.prm(p.ao_b); g.accumulate = 1;
+        DQ_TRY(launch_gemm(g, c.s));
+      } else {
+        ConvFwd f;
+        f.inA = c.w(a.o); f.cinA = HID; f.w = c.prm(p.ao_w); f.bias = c.prm(p.ao_b); f.cout = p.mid_c; f.K = 1;
+        f.rows = B; f.n_in = RT; f.n_out = RT; f.y_out = c.w(a.attn_out);
+        f.resA = c.w(a.mid1.out); f.rcinA = p.mid_c;
+        DQ_TRY(launch_conv_fwd(f, c.s));
+      }
     }
-    const int64_t qvbs = (int64_t)2 * HID * RT, kbs = (int64_t)HID * RT;
-    DQ_TRY(launch_attn_fwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.w(a.lse), B, RT, c.s));
-    const ConvP ao = proj(p.ao_w, p.mid_c, HID);
-    if (conv_is_gemm(c, ao, CONV_S1, RT, RT) && (prep_ok || ((uintptr_t)c.prm(ao.w) & 15) == 0)) {
-      // to_out (1x1 conv, 128 -> mid_c channels, with bias) + the residual: attn_out = x ; attn_out += W o + b as a GEMM per sample
-      DQ_TRY(launch_copy(c.w(a.attn_out), c.w(a.mid1.out), (int64_t)B * p.mid_c * RT, c.s));
-      Gemm g;
-      DQ_TRY(gemm_weight(c, ao, &g.A, 2));
-      g.lda = HID; g.B = c.w(a.o); g.b_kmajor = 0; g.ldb = RT; g.C = c.w(a.attn_out); g.ldc = RT; g.M = p.mid_c; g.N = RT; g.K = HID;
-      g.batch = B; g.sBo = (int64_t)HID * RT; g.sCo = (int64_t)p.mid_c * RT; g.bias_m = c.prm(p.ao_b); g.accumulate = 1;
-      DQ_TRY(launch_gemm(g, c.s));
-    } else {
-      ConvFwd f;
-      f.inA = c.w(a.o); f.cinA = HID; f.w = c.prm(p.ao_w); f.bias = c.prm(p.ao_b); f.cout = p.mid_c; f.K = 1;
-      f.rows = B; f.n_in = RT; f.n_out = RT; f.y_out = c.w(a.attn_out);
-      f.resA = c.w(a.mid1.out); f.rcinA = p.mid_c;
-      DQ_TRY(launch_conv_fwd(f, c.s));
-    }
+    DQ_TRY(res_fwd(c, p.mid2, a.mid2, c.w(a.attn_out), p.mid_c, nullptr, 0, B, RT, 1));
+    DQ_TRY(launch_fold(c.w(a.mid2.out), c.w(a.mid_back), B, RT, p.mid_c, 0, 0, c.s));
   }
-  DQ_TRY(res_fwd(c, p.mid2, a.mid2, c.w(a.attn_out), p.mid_c, nullptr, 0, B, RT, 1));
-  DQ_TRY(launch_fold(c.w(a.mid2.out), c.w(a.mid_back), B, RT, p.mid_c, 0, 0, c.s));
   // up path (unet1d.py:1150-1158): first pop = post-attention skip, second pop = post-block1 skip
   cur = c.w(a.mid_back);
   for (int ui = 0; ui < L; ++ui) {
@@ -537,34 +693,38 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     DQ_TRY(side_flush(c));  // this level's resample-conv and two ResnetBlock weight gradients behind one event
   }
   // bottleneck
-  DQ_TRY(launch_fold(c.g(a.mid_back), c.g(a.mid2.out), B, RT, p.mid_c, 1, 1, c.s));
-  DQ_TRY(res_bwd(c, p.mid2, a.mid2, c.w(a.attn_out), c.g(a.attn_out), p.mid_c, nullptr, nullptr, 0, B, RT, 1));
-  {
-    const int64_t qvbs = (int64_t)2 * HID * RT, kbs = (int64_t)HID * RT;
-    // to_out (1x1 + bias) and the residual
-    ConvP ao = proj(p.ao_w, p.mid_c, HID);
-    ao.b = p.ao_b;
-    DQ_TRY(conv_plain_bwd(c, ao, CONV_S1, c.w(a.o), c.g(a.attn_out), c.g(a.o), B, RT, RT, 0));
-    DQ_TRY(launch_axpy(c.g(a.mid1.out), c.g(a.attn_out), (int64_t)R * p.mid_c, c.s));
-    DQ_TRY(launch_attn_bwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.g(a.o), c.w(a.lse), c.w(a.delta),
-                           c.g(a.qv), qvbs, c.g(a.kk), kbs, c.g(a.qv) + kbs, qvbs, B, RT, c.s));
-    if (rope) {
-      DQ_TRY(launch_rope(c.g(a.qv), rope, B, (int64_t)2 * HID * RT, RT, -1.f, c.s));
-      DQ_TRY(launch_rope(c.g(a.kk), rope, B, (int64_t)HID * RT, RT, -1.f, c.s));
+  if (p.wide_mid) {
+    DQ_TRY(mid_backward_wide(c, rope));
+  } else {
+    DQ_TRY(launch_fold(c.g(a.mid_back), c.g(a.mid2.out), B, RT, p.mid_c, 1, 1, c.s));
+    DQ_TRY(res_bwd(c, p.mid2, a.mid2, c.w(a.attn_out), c.g(a.attn_out), p.mid_c, nullptr, nullptr, 0, B, RT, 1));
+    {
+      const int64_t qvbs = (int64_t)2 * HID * RT, kbs = (int64_t)HID * RT;
+      // to_out (1x1 + bias) and the residual
+      ConvP ao = proj(p.ao_w, p.mid_c, HID);
+      ao.b = p.ao_b;
+      DQ_TRY(conv_plain_bwd(c, ao, CONV_S1, c.w(a.o), c.g(a.attn_out), c.g(a.o), B, RT, RT, 0));
+      DQ_TRY(launch_axpy(c.g(a.mid1.out), c.g(a.attn_out), (int64_t)R * p.mid_c, c.s));
+      DQ_TRY(launch_attn_bwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.g(a.o), c.w(a.lse), c.w(a.delta),
+                             c.g(a.qv), qvbs, c.g(a.kk), kbs, c.g(a.qv) + kbs, qvbs, B, RT, c.s));
+      if (rope) {
+        DQ_TRY(launch_rope(c.g(a.qv), rope, B, (int64_t)2 * HID * RT, RT, -1.f, c.s));
+        DQ_TRY(launch_rope(c.g(a.kk), rope, B, (int64_t)HID * RT, RT, -1.f, c.s));
+      }
+      const int ws_ok = (int)(p.downs.size() + p.ups.size()) <= LA_PREP_MAX ? 0 : -2;  // slots as the forward of this step filled them
+      DQ_TRY(conv_plain_bwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.g(a.kk), c.g(a.ms1f), B, RT, RT, 0, ws_ok + 1));
+      DQ_TRY(conv_plain_bwd(c, proj(p.qv_w, 2 * HID, p.mid_c), CONV_S1, c.w(a.xn), c.g(a.qv), c.g(a.xn), B, RT, RT, 0, ws_ok));
+      // PreNorm backward: xn = rmsnorm(mid1.out) * g  (pointwise kernel, no scale/shift, no activation)
+      BlockBwd nb;
+      nb.u = c.w(a.mid1.out); nb.dy = c.g(a.xn); nb.du = c.g(a.xn); nb.C = p.mid_c; nb.rows = B; nb.n = RT; nb.rows_per_sample = 1;
+      nb.g = c.prm(p.ag); nb.dg = c.dprm(p.ag);
+      nb.part = c.w(a.bb_part); nb.part_floats = a.bb_part_floats;
+      DQ_TRY(launch_block_bwd(nb, c.s));
+      DQ_TRY(launch_axpy(c.g(a.mid1.out), c.g(a.xn), (int64_t)R * p.mid_c, c.s));
     }
-    const int ws_ok = (int)(p.downs.size() + p.ups.size()) <= LA_PREP_MAX ? 0 : -2;  // slots as the forward of this step filled them
-    DQ_TRY(conv_plain_bwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.g(a.kk), c.g(a.ms1f), B, RT, RT, 0, ws_ok + 1));
-    DQ_TRY(conv_plain_bwd(c, proj(p.qv_w, 2 * HID, p.mid_c), CONV_S1, c.w(a.xn), c.g(a.qv), c.g(a.xn), B, RT, RT, 0, ws_ok));
-    // PreNorm backward: xn = rmsnorm(mid1.out) * g  (pointwise kernel, no scale/shift, no activation)
-    BlockBwd nb;
-    nb.u = c.w(a.mid1.out); nb.dy = c.g(a.xn); nb.du = c.g(a.xn); nb.C = p.mid_c; nb.rows = B; nb.n = RT; nb.rows_per_sample = 1;
-    nb.g = c.prm(p.ag); nb.dg = c.dprm(p.ag);
-    nb.part = c.w(a.bb_part); nb.part_floats = a.bb_part_floats;
-    DQ_TRY(launch_block_bwd(nb, c.s));
-    DQ_TRY(launch_axpy(c.g(a.mid1.out), c.g(a.xn), (int64_t)R * p.mid_c, c.s));
+    DQ_TRY(res_bwd(c, p.mid1, a.mid1, c.w(a.mid_in), c.g(a.mid_in), p.mid_c, nullptr, nullptr, 0, B, RT, 1));
+    DQ_TRY(launch_fold(c.g(a.mid_in), c.g(a.downs[L - 1].rs), B, RT, p.mid_c, 0, 0, c.s));  // first and only writer: store
   }
-  DQ_TRY(res_bwd(c, p.mid1, a.mid1, c.w(a.mid_in), c.g(a.mid_in), p.mid_c, nullptr, nullptr, 0, B, RT, 1));
-  DQ_TRY(launch_fold(c.g(a.mid_in), c.g(a.downs[L - 1].rs), B, RT, p.mid_c, 0, 0, c.s));  // first and only writer: store
   // down path, reversed
   for (int lv = L - 1; lv >= 0; --lv) {
     const LevelP& l = p.downs[lv];

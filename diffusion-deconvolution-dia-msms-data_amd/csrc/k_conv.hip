@@ -838,32 +838,34 @@ int launch_rmsnorm_fwd(const float* x, const float* g, float* y, int C, int rows
   return 0;
 }
 
-// in: to_mid ? (B*RT, cn) rows : (B, cn, RT).  Tiny tensor (B*RT*cn floats); plain index transpose.
+// in: to_mid ? (B*RT, cn) rows : (B, cn, P).  Small tensor (B*RT*cn floats); plain index transpose.
 __global__ void __launch_bounds__(256) k_fold(const float* __restrict__ in, float* __restrict__ out, int B, int RT, int cn, int to_mid,
-                                              int add) {
+                                              int add, int P) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const int64_t total = (int64_t)B * RT * cn;
-  if (i >= total) return;
-  // i indexes the OUTPUT contiguously
-  int64_t src;
-  if (to_mid) {  // out (B, cn, RT)
-    const int rt = (int)(i % RT);
-    const int c = (int)((i / RT) % cn);
-    const int b = (int)(i / ((int64_t)RT * cn));
-    src = ((int64_t)b * RT + rt) * cn + c;
+  // i indexes the OUTPUT contiguously; the (B, cn, .) side has row pitch P >= RT
+  if (to_mid) {  // out (B, cn, P)
+    if (i >= (int64_t)B * P * cn) return;
+    const int rt = (int)(i % P);
+    const int c = (int)((i / P) % cn);
+    const int b = (int)(i / ((int64_t)P * cn));
+    if (rt >= RT) { out[i] = 0.f; return; }  // pad column
+    const int64_t src = ((int64_t)b * RT + rt) * cn + c;
+    out[i] = add ? out[i] + in[src] : in[src];
   } else {  // out (B*RT, cn)
+    if (i >= (int64_t)B * RT * cn) return;
     const int c = (int)(i % cn);
     const int rt = (int)((i / cn) % RT);
     const int b = (int)(i / ((int64_t)RT * cn));
-    src = ((int64_t)b * cn + c) * RT + rt;
+    const int64_t src = ((int64_t)b * cn + c) * P + rt;
+    out[i] = add ? out[i] + in[src] : in[src];
   }
-  out[i] = add ? out[i] + in[src] : in[src];
 }
 
-int launch_fold(const float* in, float* out, int B, int RT, int cn, int to_mid, int add, hipStream_t s) {
-  const int64_t total = (int64_t)B * RT * cn;
+int launch_fold(const float* in, float* out, int B, int RT, int cn, int to_mid, int add, hipStream_t s, int pitch) {
+  const int P = pitch > 0 ? pitch : RT;
+  const int64_t total = (int64_t)B * (to_mid ? P : RT) * cn;
   if (total == 0) return 0;
-  hipLaunchKernelGGL(k_fold, dim3(cdiv(total, 256)), dim3(256), 0, s, in, out, B, RT, cn, to_mid, add);
+  hipLaunchKernelGGL(k_fold, dim3(cdiv(total, 256)), dim3(256), 0, s, in, out, B, RT, cn, to_mid, add, P);
   DQ_LAUNCH_CHECK();
   return 0;
 }

@@ -88,8 +88,13 @@ __device__ __forceinline__ float half_sum(float v) {
   return (threadIdx.x & 32) ? hi : lo;
 }
 
+// Two waves per SIMD (a 256-register budget, enforced through the launch bounds) where the spills that costs stay small: C = 4, and
+// C = 8 with rows of 32 / 8 positions (measured with tools/probe/la_bwd_time.hip, 12,800 rows: <8,32> 316 -> 260 us, <8,8> 126 -> 119 us;
+// <8,16> needs 172 B of scratch per lane at 256 registers and gains nothing, so it keeps its 340 registers and one wave per SIMD, as do
+// C = 12 / 16).  The partner wave covers the latencies the one-unit-ahead prefetch was there for, so those variants run without it.
+constexpr bool la_two_waves(int C, int N) { return C == 4 || (C == 8 && (N == 32 || N == 8)); }
 template <int C, int N>
-__global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBwdK a) {  // C = 4: <= 256 registers, two waves per SIMD
+__global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_bwd(LinAttnBwdK a) {
   constexpr int NB = N >= 32 ? N / 32 : 1;
   constexpr int RW = N >= 32 ? 1 : 32 / N;
   constexpr int NJ = C <= 8 ? 4 : 8;
@@ -97,7 +102,7 @@ __global__ void __launch_bounds__(256, (C == 4 ? 2 : 1)) k_linattn_bwd(LinAttnBw
   constexpr bool PARTNER = N >= 8;
   // C = 4 runs two waves per SIMD instead (the partner wave hides the latency); C = 16 and the 64-position C = 12 variant have
   // no registers to spare
-  constexpr bool PREFETCH = C == 8 || (C == 12 && N < 64);
+  constexpr bool PREFETCH = (C == 8 && !la_two_waves(C, N)) || (C == 12 && N < 64);
   constexpr int CG = C / 4;      // channel groups of 4 (one 4x4x1 MFMA chain each)
   constexpr int NP = NB * 32;    // positions (lanes x blocks) of one unit
   static_assert(NB <= 2, "rows longer than 64 are not built");
@@ -848,7 +853,7 @@ static int linattn_bwd_n(const LinAttnBwdK& k, int n, const LinAttnBwd& g, hipSt
     constexpr int RW = NN >= 32 ? 1 : 32 / NN;                                                     \
     const int units = cdiv(k.rows, RW);                                                            \
     LinAttnBwdK kk = k;                                                                            \
-    const int max_waves = std::min((C == 4 ? 2048 : 1024), (int)(k_part_floats / la_slot(C)));      \
+    const int max_waves = std::min(la_two_waves(C, NN) ? 2048 : 1024, (int)(k_part_floats / la_slot(C)));  \
     kk.units_per_wave = std::max(1, cdiv(units, max_waves));                                       \
     const int waves = cdiv(units, kk.units_per_wave);                                              \
     launch_one<C, NN>(kk, waves, s);                                                               \
@@ -869,7 +874,7 @@ static int linattn_bwd_n(const LinAttnBwdK& k, int n, const LinAttnBwd& g, hipSt
   return 0;
 }
 
-int64_t la_part_reserve(int C) { return (int64_t)(C == 4 ? 2048 : 1024) * la_slot(C); }
+int64_t la_part_reserve(int C) { return (int64_t)(C <= 8 ? 2048 : 1024) * la_slot(C); }  // one slot per wave of a resident round
 int launch_linattn_dw_reduce_multi(const LaReduceItem* items, int count, hipStream_t s) {
   if (count == 0) return 0;
   DQ_REQUIRE(count <= LA_REDUCE_MAX, "linattn dw reduce: too many deferred layers");
@@ -894,13 +899,13 @@ int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s) {
              "linattn_bwd: missing operand");
   if (a.f.rows == 0) return 0;
   const int C = a.f.C, rows = a.f.rows, n = a.f.n;
-  const bool deferred = a.defer_reduce && a.waves_out && n <= 64;
+  const bool deferred = a.defer_reduce && a.waves_out && n <= 64 && (n & (n - 1)) == 0;
   if (a.waves_out) *a.waves_out = 0;
   DQ_REQUIRE(a.part && a.part_floats >= (deferred ? la_part_reserve(C) : (int64_t)LA_MAX_WAVES * 512 * C),
              "linattn_bwd: partial-sum scratch missing or too small");
   static_assert((int64_t)LA_MAX_WAVES * 512 >= 1024 * (int64_t)la_slot(1), "slot scratch: 1024 waves x 515*C floats must fit");
   static const bool long_all = [] { const char* e = std::getenv("DQ_LA_BWD_LONG"); return e && e[0] == '1'; }();
-  if (n > 64 || (long_all && n >= 32 && C <= 8)) {
+  if (n > 64 || (n & (n - 1)) != 0 || (long_all && n >= 32 && C <= 8)) {
     // rows of 128 / 256 positions: the sweep kernel between two pointwise norm-backward launches
     // (these launches accumulate into dx: a caller that asked for a plain store gets a cleared dx first)
     if (a.dx_store)

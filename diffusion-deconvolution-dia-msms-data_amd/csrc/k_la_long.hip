@@ -10,6 +10,10 @@
 //             sweep 3 = k side (dK^T = xh^T dM, softmax backward with sum_n dK K = sum_c dM M in-lane, dWk, Wk^T and K^T paths
 //             of dXh).  dXh is accumulated in global memory per block (head 0's first touch initialises).
 // The post-norm / pre-norm backward and the residual stay in k_block_bwd for these rows (launch_linattn_bwd).
+// Row length: a compile-time N (128 / 256: the BASELINE configurations) or N = 0 = "read it from the launch" -- any length >= 1,
+// e.g. the 40000 -> 625 positions of the reference's shipped configuration (dquartic_train_config.json:35, unet1d.py:1027) or the
+// 5 .. 320 of an odd test shape.  With a run-time length the last 32-block may be ragged: its missing positions load as zeros
+// (so xh, dYpre and with them every gradient contribution vanish there), their k-softmax logits are -inf, and nothing is stored.
 #include "dq_common.h"
 #include "dq_kernels.h"
 #include "dq_mfma.h"
@@ -33,8 +37,16 @@ __device__ __forceinline__ void load_block(const float* __restrict__ src, int64_
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int c = rmap(j, half);
-    out[j] = c < C ? src[(row * C + c) * N + pos] : 0.f;
+    out[j] = (c < C && pos < N) ? src[(row * C + c) * N + pos] : 0.f;  // (pos >= N: the ragged tail of a run-time row length)
   }
+}
+
+// k-softmax logits (rows n = rmap(r, half) of the block starting at p0, col d): positions beyond the row are -inf
+__device__ __forceinline__ f32x16 mask_tail(f32x16 kT, int p0, int N, int half) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if (p0 + rmap(r, half) >= N) kT[r] = -INFINITY;
+  return kT;
 }
 
 template <int C, int NJ>
@@ -148,12 +160,15 @@ struct LinAttnBwdLongK {
   const float* w_qkv; const float* w_out; const float* g_pre;
   float* part;
   int rows; int units_per_wave;
+  int n;  // row length when the kernel is instantiated with N = 0
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int C, int N>
+template <int C, int NT>
 __global__ void __launch_bounds__(256) k_linattn_fwd_long(LinAttn a) {
-  constexpr int NB = N / 32;
+  const int N = NT ? NT : a.n;
+  const int NB = (N + 31) / 32;
+  constexpr bool RAGGED = NT == 0;
   constexpr int NJ = C <= 8 ? 4 : 8;
   constexpr int CG = C / 4;
   __shared__ __attribute__((aligned(16))) float w2_lds[4 * C * C];
@@ -194,7 +209,11 @@ __global__ void __launch_bounds__(256) k_linattn_fwd_long(LinAttn a) {
       stage_cn<C, NJ>(xs, xh, col, half);
       lfence();
 #pragma unroll
-      for (int hd = 0; hd < 4; ++hd) online_m<CG>(proj_a<NJ>(xh, wk[hd]), xs, m[hd], ssum[hd], mt[hd], lane, half);
+      for (int hd = 0; hd < 4; ++hd) {
+        f32x16 kT = proj_a<NJ>(xh, wk[hd]);
+        if (RAGGED) kT = mask_tail(kT, b * 32, N, half);
+        online_m<CG>(kT, xs, m[hd], ssum[hd], mt[hd], lane, half);
+      }
     }
 #pragma unroll
     for (int hd = 0; hd < 4; ++hd) {
@@ -269,7 +288,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd_long(LinAttn a) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int c = rmap(j, half);
-      if (c < C) {
+      if (c < C && pos < N) {
         const int64_t off = (row * C + c) * N + pos;
         if (a.ypre) a.ypre[off] = yv[j];
         a.y[off] = fmaf(yv[j] * go[j], inv, x[j]);
@@ -279,9 +298,11 @@ __global__ void __launch_bounds__(256) k_linattn_fwd_long(LinAttn a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int C, int N>
+template <int C, int NT>
 __global__ void __launch_bounds__(256, 2) k_linattn_bwd_long(LinAttnBwdLongK a) {  // <= 256 registers: two waves per SIMD
-  constexpr int NB = N / 32;
+  const int N = NT ? NT : a.n;
+  const int NB = (N + 31) / 32;
+  constexpr bool RAGGED = NT == 0;
   constexpr int NJ = C <= 8 ? 4 : 8;
   constexpr int CG = C / 4;
   __shared__ __attribute__((aligned(16))) float wp_lds[2 * 4 * 2 * C * 16];  // [q|k][head][half][c][r]
@@ -331,7 +352,7 @@ __global__ void __launch_bounds__(256, 2) k_linattn_bwd_long(LinAttnBwdLongK a) 
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int c = rmap(j, half);
-      if (c < C) {
+      if (c < C && pos < N) {
         float* dst = a.dxh + (row * C + c) * N + pos;
         const float val = own_of<C>(full, j, half);
         *dst = first ? val : *dst + val;
@@ -374,7 +395,9 @@ __global__ void __launch_bounds__(256, 2) k_linattn_bwd_long(LinAttnBwdLongK a) 
           lfence();
           stage_cn<C, NJ>(xs, xh, col, half);
           lfence();
-          online_m<CG>(proj_a<NJ>(xh, wk), xs, m, ssum, mt, lane, half);
+          f32x16 kT = proj_a<NJ>(xh, wk);
+          if (RAGGED) kT = mask_tail(kT, b * 32, N, half);
+          online_m<CG>(kT, xs, m, ssum, mt, lane, half);
         }
         ssum += swap_half(ssum);
         const float rs = 1.0f / ssum;
@@ -494,6 +517,7 @@ __global__ void __launch_bounds__(256, 2) k_linattn_bwd_long(LinAttnBwdLongK a) 
         stage_cn<C, NJ>(xs, xh, col, half);
         lfence();
         f32x16 kT = proj_a<NJ>(xh, wk);
+        if (RAGGED) kT = mask_tail(kT, b * 32, N, half);  // exp2(-inf) = 0: no key beyond the row
 #pragma unroll
         for (int r = 0; r < 16; ++r) kT[r] = __builtin_amdgcn_exp2f(kT[r] - m) * rs;  // normalised K^T
         f32x16 dkT = {0};
@@ -573,14 +597,22 @@ int launch_linattn_fwd_long(const LinAttn& a, hipStream_t s) {
   }
   DQ_LF(4, 128) DQ_LF(4, 256) DQ_LF(8, 128) DQ_LF(8, 256) DQ_LF(12, 128) DQ_LF(16, 128)
 #undef DQ_LF
-  set_error("linattn_fwd: (C, n) = (" + std::to_string(a.C) + ", " + std::to_string(a.n) + ") is not built");
-  return 2;
+  // any other row length: the same kernel with the length read from the launch (ragged last block masked)
+  switch (a.C) {
+    case 4: hipLaunchKernelGGL((k_linattn_fwd_long<4, 0>), grid, block, 0, s, a); break;
+    case 8: hipLaunchKernelGGL((k_linattn_fwd_long<8, 0>), grid, block, 0, s, a); break;
+    case 12: hipLaunchKernelGGL((k_linattn_fwd_long<12, 0>), grid, block, 0, s, a); break;
+    case 16: hipLaunchKernelGGL((k_linattn_fwd_long<16, 0>), grid, block, 0, s, a); break;
+    default: set_error("linattn_fwd: channel count " + std::to_string(a.C) + " is not built (4, 8, 12, 16)"); return 2;
+  }
+  DQ_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_linattn_bwd_long(const float* x, const float* dyp, float* dxh, const float* w_qkv, const float* w_out, const float* g_pre,
                             float* part, int C, int rows, int n, int* waves_out, hipStream_t s) {
   // two waves per SIMD are resident (<= 256 registers): 2048 waves = one resident round, and <= LA_MAX_WAVES partial slots
-  LinAttnBwdLongK k{x, dyp, dxh, w_qkv, w_out, g_pre, part, rows, std::max(1, cdiv(rows, 2048))};
+  LinAttnBwdLongK k{x, dyp, dxh, w_qkv, w_out, g_pre, part, rows, std::max(1, cdiv(rows, 2048)), n};
   const int waves = cdiv(rows, k.units_per_wave);
   *waves_out = waves;
   dim3 grid(cdiv(waves, 4)), block(256);
@@ -593,8 +625,15 @@ int launch_linattn_bwd_long(const float* x, const float* dyp, float* dxh, const 
   DQ_LBL(4, 128) DQ_LBL(4, 256) DQ_LBL(8, 128) DQ_LBL(8, 256) DQ_LBL(12, 128) DQ_LBL(16, 128)
   DQ_LBL(4, 64) DQ_LBL(4, 32) DQ_LBL(8, 32) DQ_LBL(8, 64)
 #undef DQ_LBL
-  set_error("linattn_bwd: (C, n) = (" + std::to_string(C) + ", " + std::to_string(n) + ") is not built");
-  return 2;
+  switch (C) {  // any other row length (see launch_linattn_fwd_long)
+    case 4: hipLaunchKernelGGL((k_linattn_bwd_long<4, 0>), grid, block, 0, s, k); break;
+    case 8: hipLaunchKernelGGL((k_linattn_bwd_long<8, 0>), grid, block, 0, s, k); break;
+    case 12: hipLaunchKernelGGL((k_linattn_bwd_long<12, 0>), grid, block, 0, s, k); break;
+    case 16: hipLaunchKernelGGL((k_linattn_bwd_long<16, 0>), grid, block, 0, s, k); break;
+    default: set_error("linattn_bwd: channel count " + std::to_string(C) + " is not built (4, 8, 12, 16)"); return 2;
+  }
+  DQ_LAUNCH_CHECK();
+  return 0;
 }
 
 }  // namespace dq

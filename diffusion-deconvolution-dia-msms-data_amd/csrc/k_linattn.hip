@@ -413,7 +413,7 @@ int launch_linattn_prepare(const LaPrepItem* items, int count, hipStream_t s, co
 int launch_linattn_fwd(const LinAttn& a, hipStream_t s) {
   DQ_REQUIRE(a.x && a.y && a.w_qkv && a.w_out && a.b_out && a.g_pre && a.g_out, "linattn_fwd: missing operand");
   if (a.rows == 0) return 0;
-  if (a.n > 64) return launch_linattn_fwd_long(a, s);
+  if (a.n > 64 || (a.n & (a.n - 1)) != 0) return launch_linattn_fwd_long(a, s);  // long rows, and lengths that are not a power of two
   switch (a.C) {
     case 4: return linattn_fwd_n<4>(a, s);
     case 8: return linattn_fwd_n<8>(a, s);

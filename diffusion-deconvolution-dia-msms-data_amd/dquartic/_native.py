@@ -90,6 +90,22 @@ def lib():
     return _lib
 
 
+def build_id() -> str:
+    """Identity of the native sources this tree was built from (sha256 over csrc/, include/dq_hip.h and the Makefile, 16 hex
+    digits).  Profiles under profiles/ record it, and bench.py only quotes a counter-derived figure whose build id matches."""
+    import hashlib
+
+    root = os.path.dirname(_HERE)
+    files = sorted(os.path.join(root, "csrc", f) for f in os.listdir(os.path.join(root, "csrc")) if f.endswith((".hip", ".h", ".cpp")))
+    files += [os.path.join(root, "Makefile"), os.path.join(os.path.dirname(root), "include", "dq_hip.h")]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def check(rc, what):
     if rc != 0:
         msg = lib().dq_last_error()

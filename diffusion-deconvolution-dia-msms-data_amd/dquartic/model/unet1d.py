@@ -9,7 +9,9 @@ fallback: on a CPU tensor or without the library ``forward`` raises.
 Differences from the reference, all documented in DESIGN.md:
   * batches work (the reference only runs at B = 1, SURVEY F1): sample b's time embedding is applied to its own rows;
   * only the working configuration family is built: simple=True, conditional=True, channels=1, init_cond_channels=1,
-    attn_cond_channels=1, 4 heads x 32, dim*mult <= 16 -- anything else raises at construction;
+    attn_cond_channels=1, 4 heads x 32, dim = 4, dim*mult <= 16, downsample_dim divisible by 2**(len(dim_mults)-1) -- which
+    includes the reference's shipped configuration (downsample_dim 40000: m/z rows of 40000 .. 625 positions and a
+    10,000-channel bottleneck) -- anything else raises at construction;
   * all trainable tensors are views of ONE flat fp32 buffer (``flat_params``), gradients of one flat ``flat_grads``.
 """
 import ctypes
@@ -166,7 +168,7 @@ class UNet1d(nn.Module):
                     ok = False
                     break
         if not ok:
-            flat = torch.empty(self._flat.numel(), dtype=torch.float32, device=dev)
+            flat = torch.zeros(self._flat.numel(), dtype=torch.float32, device=dev)  # (zeros: a wide bottleneck's layout has alignment gaps)
             for pname, o, shape in self._layout:
                 p = self._by_name[pname]
                 flat[o:o + p.numel()].copy_(p.detach().reshape(-1).to(torch.float32))

@@ -27,7 +27,11 @@ def N():
 
 
 @pytest.mark.parametrize("C,n,rows", [(4, 64, 37), (4, 32, 9), (8, 32, 70), (8, 16, 13), (8, 8, 22), (12, 8, 5), (12, 4, 50), (12, 2, 33),
-                                      (16, 2, 16), (16, 1, 77), (4, 64, 1300), (4, 128, 21), (4, 256, 9), (8, 128, 6)])
+                                      (16, 2, 16), (16, 1, 77), (4, 64, 1300), (4, 128, 21), (4, 256, 9), (8, 128, 6),
+                                      # run-time row lengths (k_la_long.hip with N = 0): ragged last block, rows shorter than a block,
+                                      # and the lengths of the reference's shipped downsample_dim 40000 (625 = 19 blocks + 17)
+                                      (4, 320, 5), (4, 160, 3), (8, 80, 4), (8, 40, 6), (12, 20, 7), (12, 10, 5), (16, 5, 9), (16, 625, 2),
+                                      (4, 1000, 2), (8, 96, 3), (12, 3, 4)])
 def test_linattn_bwd_vs_autograd(N, C, n, rows):
     from oracle import dq_oracle as O
 

@@ -11,6 +11,7 @@ namespace dq {
 void set_error(const std::string& m) { fprintf(stderr, "error: %s\n", m.c_str()); }
 int launch_axpy(float*, const float*, int64_t, hipStream_t) { return 1; }
 int launch_block_bwd(const BlockBwd&, hipStream_t) { return 1; }
+int launch_zero(float*, int64_t, hipStream_t) { return 1; }
 int launch_linattn_bwd_long(const float*, const float*, float*, const float*, const float*, const float*, float*, int, int, int, int*,
                             hipStream_t) { return 1; }
 void launch_linattn_bwd_big(const LinAttnBwdK&, int, int, hipStream_t) {}
@@ -58,7 +59,12 @@ static void run(int rows, int max_waves) {
   CK(hipMemcpy(h.data(), probe, h.size() * 8, hipMemcpyDeviceToHost));
   unsigned long long t0 = ~0ull;
   for (int w = 0; w < waves; ++w) t0 = std::min(t0, h[(size_t)w * 16]);
-  printf("C=%d N=%d rows=%d waves=%d units/wave=%d : %.1f us/launch\n", C, N, rows, waves, k.units_per_wave, 1e3 * ms / reps);
+  int occ = 0;
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_linattn_bwd<C, N>, 256, 0));
+  hipFuncAttributes fa;
+  CK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_linattn_bwd<C, N>)));
+  printf("C=%d N=%d rows=%d waves=%d units/wave=%d : %.1f us/launch  [occupancy %d blocks/CU, regs %d, lds %zu, scratch %zu]\n", C, N, rows, waves,
+         k.units_per_wave, 1e3 * ms / reps, occ, fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes);
   // stamps are s_memtime ticks (100 MHz on gfx9 "REALTIME"? clock64 = s_memtime: shader clock); report raw ticks, median / max over waves
   const char* names[13] = {"start", "staged", "h0 loop", "h0 flush", "h1 loop", "h1 flush", "h2 loop", "h2 flush", "h3 loop", "h3 flush", "h1 qk st", "h1 w2 red", "h1 dWvo"};
   for (int i = 0; i < 13; ++i) {
@@ -72,10 +78,16 @@ static void run(int rows, int max_waves) {
 }
 
 int main() {
-  const int rows = 12800;
-  run<16, 1>(32, 1024);
-  run<12, 4>(32, 1024);
-  run<8, 16>(32, 1024);
-  run<4, 64>(32, 2048);
+  const int rows = 12800;  // batch 32 x 400 RT: the bench's train step
+#ifdef PROBE_C8
+  run<8, 8>(rows, PROBE_C8);
+  run<8, 16>(rows, PROBE_C8);
+  run<8, 32>(rows, PROBE_C8);
+#else
+  run<16, 2>(rows, 1024);
+  run<12, 4>(rows, 1024);
+  run<8, 16>(rows, 1024);
+  run<4, 64>(rows, 2048);
+#endif
   return 0;
 }
