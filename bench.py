@@ -29,6 +29,7 @@ TRAIN_BATCH = 32
 SAMPLE_BATCH = 512
 SAMPLE_STEPS = 50
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 (v_mfma_f32_32x32x16_bf16 at 32 cycles)
 HBM_PEAK_GBS = 8000.0         # same guide: HBM3E 8 TB/s spec (6.3 TB/s achievable with a float4 copy)
 # algorithmic work per window at 400 x 64 (torch.utils.flop_counter on the reference, 2*MAC, conv/matmul only)
 FLOPS_FWD, FLOPS_TRAIN = 2_549_672_128, 7_648_971_456
@@ -258,19 +259,30 @@ def transformer_leg(device, with_cpu):
     dm._set_optimizer(1e-5)
     out = {"config": {"workload": "CustomTransformer(40000, 1024, 8 heads, 8 layers), windows 34 RT x 40000 m/z, MS1 (34,) as x_cond, fp32",
                       "params": int(net.transformer.flat_params.numel())}}
-    for B in (1, 32):
-        x0, c2, c1 = torch.rand(B, TFM_RT, D, device=device), torch.rand(B, TFM_RT, D, device=device), torch.rand(B, TFM_RT, device=device)
-        for _ in range(2):
-            dm._train_one_batch(x0, ms2_cond=c2, ms1_cond=c1, sync=False)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        steps = 10
-        for _ in range(steps):
-            loss = dm._train_one_batch(x0, ms2_cond=c2, ms1_cond=c1, sync=False)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        out[f"train_b{B}"] = {"value": round(B / dt, 2), "unit": "MS2 windows/s", "ms_per_step": round(dt * 1e3, 3), "loss": round(float(loss), 5)}
-        del x0, c2, c1
+
+    def train_rates(tag):
+        res = {}
+        for B in (1, 32):
+            x0, c2, c1 = torch.rand(B, TFM_RT, D, device=device), torch.rand(B, TFM_RT, D, device=device), torch.rand(B, TFM_RT, device=device)
+            for _ in range(2):
+                dm._train_one_batch(x0, ms2_cond=c2, ms1_cond=c1, sync=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            steps = 10
+            for _ in range(steps):
+                loss = dm._train_one_batch(x0, ms2_cond=c2, ms1_cond=c1, sync=False)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            res[f"train_b{B}"] = {"value": round(B / dt, 2), "unit": "MS2 windows/s", "ms_per_step": round(dt * 1e3, 3), "loss": round(float(loss), 5)}
+            del x0, c2, c1
+        return res
+
+    out.update(train_rates("fp32"))
+    # the same steps with the dense products in the bf16x3 precision mode (three bf16 matrix-core passes over hi/lo-split operands;
+    # NOT the fp32 arithmetic the headline is stated in: its own tolerance, tests/test_tfm.py)
+    net.transformer.set_precision("bf16x3")
+    out["bf16x3"] = {"dtype": "bf16x3 (split-bf16, 3 MFMA passes, fp32 accumulate)", **train_rates("bf16x3")}
+    net.transformer.set_precision("fp32")
     # roofline of the GEMM on the output projection's forward shape at batch 32
     lib = N.lib()
     M, Nn, K = 32 * TFM_RT, D, H
@@ -284,6 +296,13 @@ def transformer_leg(device, with_cpu):
                        "frac": round(fl / sec / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                        "traffic": None,  # not re-measured on this build (round 1, profiles/r01_pmc_gemm.md: 704.1 MB per launch)
                        "flops_per_launch": fl, "us_per_launch": round(sec * 1e6, 1)}
+    sec3 = time_kernel(lambda: N.check(lib.dq_gemm_bf16x3(N.ptr(A), N.ptr(Bm), N.ptr(C), None, M, Nn, K, K, K, Nn, 1, 1, 0, 0, N.ptr(scr), scr.numel(),
+                                                          N.stream_ptr()), "dq_gemm_bf16x3"), iters=10)
+    out["bf16x3"]["roofline"] = {"bound": "mfma", "kernel": "k_gemm_s3<A k-major, B k-major, 128x128x32> on the same product",
+                                 "achieved": round(fl / sec3 / 1e12, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 # three bf16 passes per product: executed FLOPs = 3 x algorithmic
+                                 "frac": round(3 * fl / sec3 / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4), "frac_basis": "executed FLOPs (3 passes)",
+                                 "flops_per_launch": fl, "us_per_launch": round(sec3 * 1e6, 1), "speedup_vs_fp32": round(sec / sec3, 2)}
     del net, dm, A, Bm, C
     torch.cuda.empty_cache()
     if with_cpu:

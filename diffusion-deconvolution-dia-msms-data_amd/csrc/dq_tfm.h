@@ -15,6 +15,8 @@ namespace dq {
 // C(m, n) = C[m * ldc + n].  Batched over z = zo * inner + zi with element offsets zo * s?o + zi * s?i per operand
 // (attention: zo = sample, zi = head).  K beyond the split / M, N beyond the tile are zero-filled / masked.
 // Requirements (checked): lda, ldb, K multiples of 4 and 16-byte aligned bases (vector loads along the contiguous axis).
+// arithmetic of a product: exact fp32 on v_mfma_f32_32x32x2_f32, or three bf16 passes over split operands (k_gemm.hip: k_gemm_s3)
+enum GemmPrecision { GEMM_FP32 = 0, GEMM_BF16X3 = 1 };
 struct Gemm {
   const float* A = nullptr; const float* B = nullptr; float* C = nullptr;
   int M = 0, N = 0, K = 0;
@@ -29,8 +31,10 @@ struct Gemm {
   // split-K: the reduction is cut into `splits` ranges whose partial products go to `partial` ([split][z][M][N] floats) and
   // are summed in a fixed order by a second kernel (deterministic, no atomics).  splits = 0: chosen by the launcher.
   int splits = 0; float* partial = nullptr; int64_t partial_floats = 0;
+  int precision = -1;  // GemmPrecision, or -1 = the calling thread's default (set_gemm_precision; GEMM_FP32 unless changed)
 };
 int launch_gemm(const Gemm& g, hipStream_t s);
+int set_gemm_precision(int precision);  // thread-local default of launch_gemm; returns the previous one
 int64_t gemm_partial_floats(int M, int N, int K, int batch);  // upper bound of what launch_gemm will ask of `partial`
 
 // ---- k_tfm.hip: the pointwise / row-wise kernels around the GEMMs

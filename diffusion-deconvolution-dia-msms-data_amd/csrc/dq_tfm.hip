@@ -27,6 +27,7 @@ struct dq_tfm {
   // what the last dq_tfm_fwd(save_for_bwd) left in the workspace
   int saved_B = 0, saved_S1 = 0, saved_S2 = 0;
   const void* saved_ws = nullptr;
+  int precision = dq::GEMM_FP32;  // arithmetic of the dense products (dq_tfm_set_precision)
 };
 
 namespace dq {
@@ -153,6 +154,13 @@ int attn_gemm(int which, const AttnDims& d, const float* q, const float* kv, flo
   return launch_gemm(g, s);
 }
 
+// the handle's precision as the thread's GEMM default for the duration of one call
+struct PrecisionScope {
+  int old;
+  explicit PrecisionScope(int p) : old(set_gemm_precision(p)) {}
+  ~PrecisionScope() { set_gemm_precision(old); }
+};
+
 int check_shapes(const dq_tfm* p, int B, int S1, int S2) {
   DQ_REQUIRE(p, "tfm: null handle");
   DQ_REQUIRE(B > 0 && S1 > 0 && S2 > 0, "tfm: batch and both sequence lengths must be positive");
@@ -173,6 +181,22 @@ int dq_gemm(const float* A, const float* B, float* C, const float* bias, int M, 
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.a_kmajor = a_kmajor; g.b_kmajor = b_kmajor; g.accumulate = accumulate; g.splits = splits; g.partial = scratch; g.partial_floats = scratch_floats;
   return launch_gemm(g, (hipStream_t)stream);
+}
+
+int dq_gemm_bf16x3(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                   int a_kmajor, int b_kmajor, int accumulate, int splits, float* scratch, int64_t scratch_floats, void* stream) {
+  Gemm g;
+  g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.a_kmajor = a_kmajor; g.b_kmajor = b_kmajor; g.accumulate = accumulate; g.splits = splits; g.partial = scratch; g.partial_floats = scratch_floats;
+  g.precision = GEMM_BF16X3;
+  return launch_gemm(g, (hipStream_t)stream);
+}
+
+int dq_tfm_set_precision(dq_tfm* tfm, int precision) {
+  DQ_REQUIRE(tfm, "dq_tfm_set_precision: null handle");
+  DQ_REQUIRE(precision == DQ_PRECISION_FP32 || precision == DQ_PRECISION_BF16X3, "dq_tfm_set_precision: precision must be DQ_PRECISION_FP32 or DQ_PRECISION_BF16X3");
+  tfm->precision = precision == DQ_PRECISION_BF16X3 ? GEMM_BF16X3 : GEMM_FP32;
+  return 0;
 }
 
 dq_tfm* dq_tfm_create(int input_dim, int hidden_dim, int num_heads, int num_layers) {
@@ -227,6 +251,7 @@ int dq_tfm_fwd(dq_tfm* p, const float* params, const float* rope_sin, const floa
   if (int rc = check_shapes(p, B, S1, S2)) return rc;
   DQ_REQUIRE(params && rope_sin && rope_cos && time_freqs && x_t && t && x_cond && out && workspace, "dq_tfm_fwd: missing operand");
   DQ_REQUIRE(((uintptr_t)params & 15) == 0 && ((uintptr_t)workspace & 15) == 0 && ((uintptr_t)x_t & 15) == 0, "dq_tfm_fwd: params, x_t and workspace must be 16-byte aligned");
+  PrecisionScope prec(p->precision);
   const bool training = save_for_bwd != 0;
   Ws w = carve(*p, (float*)workspace, B, S1, S2, training);
   DQ_REQUIRE(workspace_bytes >= w.floats * (int64_t)sizeof(float), "dq_tfm_fwd: workspace too small (dq_tfm_workspace_bytes)");
@@ -276,6 +301,7 @@ int dq_tfm_bwd(dq_tfm* p, const float* params, const float* rope_sin, const floa
   DQ_REQUIRE(p->saved_ws == workspace && p->saved_B == B && p->saved_S1 == S1 && p->saved_S2 == S2,
              "dq_tfm_bwd: no matching dq_tfm_fwd(save_for_bwd = 1) on this workspace");
   DQ_REQUIRE(((uintptr_t)grads & 15) == 0 && ((uintptr_t)dout & 15) == 0, "dq_tfm_bwd: grads and dout must be 16-byte aligned");
+  PrecisionScope prec(p->precision);
   Ws w = carve(*p, (float*)workspace, B, S1, S2, true);
   DQ_REQUIRE(workspace_bytes >= w.floats * (int64_t)sizeof(float), "dq_tfm_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;

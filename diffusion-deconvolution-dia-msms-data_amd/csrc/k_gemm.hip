@@ -95,6 +95,48 @@ struct TileIO {
   }
 };
 
+// the accumulator tiles of one wave -> C (or the split's partial tile).  Register r of lane (col, half) holds
+// C[row = rmap(r, half)][col] of its 32x32 tile.
+template <int TM, int TN, int BM, int BN>
+__device__ __forceinline__ void gemm_epilogue(const GemmK& g, f32x16 (&acc)[TM][TN], int tile_local, int m0, int n0, int wm0, int wn0, int z,
+                                              int zo, int zi, int sp, int col, int half) {
+  if (g.splits > 1) {  // partial tile of this split, tile-local layout [split][z][tile of the launch][BM][BN]
+    float* P = g.partial + (((int64_t)sp * g.batch + z) * gridDim.x + tile_local) * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) P[(wm0 + 32 * i + rmap(r, half)) * BN + wn0 + 32 * jn + col] = acc[i][jn][r];
+    return;
+  }
+  float* C = g.C + zo * g.sCo + zi * g.sCi;
+  const int64_t ldc = g.ldc;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+      const int n = n0 + wn0 + 32 * jn + col;
+      if (n >= g.N) continue;
+      const float bias = g.bias ? g.bias[n] : 0.f;
+      const bool rmw = g.accumulate != 0;
+      // all 16 reads of a += tile are issued before the first store (a load behind a store to a pointer the compiler cannot
+      // tell apart would wait for it: 64 serial round trips per lane)
+      float old[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + 32 * i + rmap(r, half);
+        old[r] = (rmw && m < g.M) ? C[(int64_t)m * ldc + n] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + 32 * i + rmap(r, half);
+        if (m >= g.M) continue;
+        C[(int64_t)m * ldc + n] = old[r] + (g.alpha * acc[i][jn][r] + bias + (g.bias_m ? g.bias_m[m] : 0.f));
+      }
+    }
+}
+
 template <bool A_K, bool B_K, int TM, int TN, int WM, int WN>
 __global__ void __launch_bounds__(WM * WN * 64) k_gemm(GemmK g) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
@@ -181,42 +223,155 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm(GemmK g) {
     __syncthreads();
   }
 
-  // register r of lane (col, half) holds C[row = rmap(r, half)][col] of its 32x32 tile
-  if (g.splits > 1) {  // partial tile of this split, tile-local layout [split][z][tile of the launch][BM][BN]
-    float* P = g.partial + (((int64_t)sp * g.batch + z) * gridDim.x + tile_local) * (BM * BN);
+  gemm_epilogue<TM, TN, BM, BN>(g, acc, tile_local, m0, n0, wm0, wn0, z, zo, zi, sp, col, half);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same product on the bf16 matrix path, THREE passes over split operands ("bf16x3"): every fp32 operand value x is split into
+// hi = bf16(x) and lo = bf16(x - hi) as its tile is written to LDS, and a (32 x 32 x 16) step runs hi.hi + hi.lo + lo.hi on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation (lo.lo, ~2^-16 of a term, is dropped).  An operand keeps ~16 mantissa bits
+// instead of fp32's 24, so a product term carries a relative error of ~1e-5 -- NOT the exact-fp32 arithmetic of k_gemm: this is a
+// separate precision mode with its own stated tolerance, selected per transformer handle
+// (dq_tfm_set_precision) or through dq_gemm_bf16x3.  Cost per 32-deep step and 32 x 32 tile: 6 MFMAs of 32 cycles against 16 of 64.
+// LDS: both operands as [row][k] bf16 planes (hi and lo) whatever their layout in memory, row pitch 40 bf16 = 80 B, so that a
+// lane's fragment (8 consecutive k of its row: A[row r][8h + j], B[8h + j][col r]) is ONE ds_read_b128 per plane.
+// ---------------------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int BKP = BK + 8;
+
+// One (R rows x 32 k) operand tile of the split kernel: global -> registers -> the two bf16 planes [row][k].  A thread always ends up
+// with FOUR CONSECUTIVE k of ONE row (8-byte plane stores): from one float4 when the rows are contiguous along k, from four dword
+// loads (each coalesced over the wave: consecutive lanes = consecutive rows) when memory runs along the rows instead -- so the
+// transposition of such an operand costs narrower global loads, not 2-byte scattered LDS stores.  (Measured against float4 loads +
+// a 4 x 4 DPP transpose inside each lane quad: the transformer's batch-32 train step 15.4 ms this way, 16.7 ms with the DPP form.)
+template <bool KMAJOR, int R, int NT>
+struct SplitIO {
+  static constexpr int U = R * Q4 / NT;  // (row, k-quad) units per thread
+  static_assert(R * Q4 % NT == 0, "tile does not divide over the block");
+  float4 v[U];
+  // unit u -> (row, k quad): k-major: rows of Q4 quads ; otherwise: quads of R rows (consecutive threads = consecutive rows)
+  static __device__ __forceinline__ int row_of(int u) { return KMAJOR ? u / Q4 : u % R; }
+  static __device__ __forceinline__ int quad_of(int u) { return KMAJOR ? u % Q4 : u / R; }
+  __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int r0, int rmax, int k0, int kend, int tid) {
+    const bool interior = r0 + R <= rmax && k0 + BK <= kend;  // block-uniform
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int jn = 0; jn < TN; ++jn)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) P[(wm0 + 32 * i + rmap(r, half)) * BN + wn0 + 32 * jn + col] = acc[i][jn][r];
-    return;
+    for (int i = 0; i < U; ++i) {
+      const int u = tid + NT * i;
+      const int row = r0 + row_of(u), k = k0 + 4 * quad_of(u);
+      float4 x = {0.f, 0.f, 0.f, 0.f};
+      if (KMAJOR) {
+        const float* p = base + (int64_t)row * ld + k;
+        if (interior || (row < rmax && k + 3 < kend)) x = *reinterpret_cast<const float4*>(p);
+        else if (row < rmax) {
+          if (k < kend) x.x = p[0];
+          if (k + 1 < kend) x.y = p[1];
+          if (k + 2 < kend) x.z = p[2];
+        }
+      } else {
+        const float* p = base + (int64_t)k * ld + row;
+        if (interior) { x.x = p[0]; x.y = p[ld]; x.z = p[2 * ld]; x.w = p[3 * ld]; }
+        else if (row < rmax) {
+          if (k < kend) x.x = p[0];
+          if (k + 1 < kend) x.y = p[ld];
+          if (k + 2 < kend) x.z = p[2 * ld];
+          if (k + 3 < kend) x.w = p[3 * ld];
+        }
+      }
+      v[i] = x;
+    }
   }
-  float* C = g.C + zo * g.sCo + zi * g.sCi;
-  const int64_t ldc = g.ldc;
+  __device__ __forceinline__ void store(__bf16* __restrict__ hi, __bf16* __restrict__ lo, int tid) const {
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      const int u = tid + NT * i;
+      const float x[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+      __bf16 h[4], l[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        h[q] = (__bf16)x[q];
+        l[q] = (__bf16)(x[q] - (float)h[q]);
+      }
+      const int o = row_of(u) * BKP + 4 * quad_of(u);
+      *reinterpret_cast<bf16x4*>(hi + o) = bf16x4{h[0], h[1], h[2], h[3]};
+      *reinterpret_cast<bf16x4*>(lo + o) = bf16x4{l[0], l[1], l[2], l[3]};
+    }
+  }
+};
+
+template <bool A_K, bool B_K, int TM, int TN, int WM, int WN>
+__global__ void __launch_bounds__(WM * WN * 64) k_gemm_s3(GemmK g) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
+  __shared__ __attribute__((aligned(16))) __bf16 ah[2][BM * BKP], al[2][BM * BKP], bh[2][BN * BKP], bl[2][BN * BKP];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, half = lane >> 5;
+  const int wm0 = (wv / WN) * TM * 32, wn0 = (wv % WN) * TN * 32;
+  int tile_local = blockIdx.x;
+  {
+    const int T = gridDim.x, per = T >> 3;
+    if (tile_local < per * 8) tile_local = (tile_local & 7) * per + (tile_local >> 3);
+  }
+  const int tile_id = g.tile_base + tile_local;
+  const int m0 = (tile_id % g.mt) * BM, n0 = (tile_id / g.mt) * BN;
+  const int z = blockIdx.y % g.batch, sp = blockIdx.y / g.batch;
+  const int zo = z / g.inner, zi = z % g.inner;
+  const float* A = g.A + zo * g.sAo + zi * g.sAi;
+  const float* B = g.B + zo * g.sBo + zi * g.sBi;
+  const int kbeg = sp * g.k_per_split, kend = min(g.K, kbeg + g.k_per_split);
+  const int nkt = (kend - kbeg + BK - 1) / BK;
+
+  f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-      const int n = n0 + wn0 + 32 * jn + col;
-      if (n >= g.N) continue;
-      const float bias = g.bias ? g.bias[n] : 0.f;
-      const bool rmw = g.accumulate != 0;
-      // all 16 reads of a += tile are issued before the first store (a load behind a store to a pointer the compiler cannot
-      // tell apart would wait for it: 64 serial round trips per lane)
-      float old[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm0 + 32 * i + rmap(r, half);
-        old[r] = (rmw && m < g.M) ? C[(int64_t)m * ldc + n] : 0.f;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm0 + 32 * i + rmap(r, half);
-        if (m >= g.M) continue;
-        C[(int64_t)m * ldc + n] = old[r] + (g.alpha * acc[i][jn][r] + bias + (g.bias_m ? g.bias_m[m] : 0.f));
-      }
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x16{0};
+
+  SplitIO<A_K, BM, NT> ta;
+  SplitIO<B_K, BN, NT> tb;
+  if (nkt > 0) {
+    ta.load(A, g.lda, m0, g.M, kbeg, kend, tid);
+    tb.load(B, g.ldb, n0, g.N, kbeg, kend, tid);
+    ta.store(ah[0], al[0], tid);
+    tb.store(bh[0], bl[0], tid);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const bool more = kt + 1 < nkt;
+    if (more) {
+      ta.load(A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend, tid);
+      tb.load(B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend, tid);
     }
+    const int cur = kt & 1;
+#pragma unroll
+    for (int jj = 0; jj < BK / 16; ++jj) {
+      bf16x8 a_h[TM], a_l[TM], b_h[TN], b_l[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int o = (wm0 + 32 * i + col) * BKP + 16 * jj + 8 * half;
+        a_h[i] = *reinterpret_cast<const bf16x8*>(ah[cur] + o);
+        a_l[i] = *reinterpret_cast<const bf16x8*>(al[cur] + o);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int o = (wn0 + 32 * j + col) * BKP + 16 * jj + 8 * half;
+        b_h[j] = *reinterpret_cast<const bf16x8*>(bh[cur] + o);
+        b_l[j] = *reinterpret_cast<const bf16x8*>(bl[cur] + o);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l[i], b_h[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h[i], b_l[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h[i], b_h[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (more) {
+      ta.store(ah[(kt + 1) & 1], al[(kt + 1) & 1], tid);
+      tb.store(bh[(kt + 1) & 1], bl[(kt + 1) & 1], tid);
+    }
+    __syncthreads();
+  }
+  gemm_epilogue<TM, TN, BM, BN>(g, acc, tile_local, m0, n0, wm0, wn0, z, zo, zi, sp, col, half);
 }
 
 // C tile = alpha * (sum over the splits, in order) + bias (+ C); one block per (tile of the launch, z)
@@ -300,11 +455,15 @@ Shape choose(int M, int N, int K, int batch, int forced_splits) {
 }
 
 template <bool A_K, bool B_K>
-int launch_part(GemmK k, const Part& p, int bm, hipStream_t s) {
+int launch_part(GemmK k, const Part& p, int bm, hipStream_t s, int precision) {
   if (p.ntiles == 0) return 0;
   k.tile_base = p.tile_base; k.splits = p.splits; k.k_per_split = p.k_per_split;
   const dim3 grid(p.ntiles, k.batch * p.splits);
-  if (bm == 32) hipLaunchKernelGGL((k_gemm<A_K, B_K, 1, 1, 1, 4>), grid, dim3(256), 0, s, k);
+  if (precision == GEMM_BF16X3) {
+    if (bm == 32) hipLaunchKernelGGL((k_gemm_s3<A_K, B_K, 1, 1, 1, 4>), grid, dim3(256), 0, s, k);
+    else if (bm == 64) hipLaunchKernelGGL((k_gemm_s3<A_K, B_K, 1, 2, 2, 2>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((k_gemm_s3<A_K, B_K, 1, 2, 4, 2>), grid, dim3(512), 0, s, k);
+  } else if (bm == 32) hipLaunchKernelGGL((k_gemm<A_K, B_K, 1, 1, 1, 4>), grid, dim3(256), 0, s, k);
   else if (bm == 64) hipLaunchKernelGGL((k_gemm<A_K, B_K, 1, 2, 2, 2>), grid, dim3(256), 0, s, k);
   // 128 x 128 on EIGHT waves (32 x 64 each): two waves per SIMD from one block cover each other's LDS / barrier waits, which a
   // lone 4-wave block per CU (a round of 256 tiles) cannot -- 3-6 % over the 4-wave form on every shape measured
@@ -324,8 +483,16 @@ int64_t gemm_partial_floats(int M, int N, int K, int batch) {
   return std::max(part_scratch(sh.full, sh.bm, batch), part_scratch(sh.rest, sh.bm, batch));
 }
 
+static thread_local int g_default_precision = GEMM_FP32;
+int set_gemm_precision(int precision) {
+  const int old = g_default_precision;
+  g_default_precision = precision == GEMM_BF16X3 ? GEMM_BF16X3 : GEMM_FP32;
+  return old;
+}
+
 int launch_gemm(const Gemm& g, hipStream_t s) {
   DQ_REQUIRE(g.A && g.B && g.C, "gemm: missing operand");
+  const int precision = g.precision >= 0 ? g.precision : g_default_precision;
   if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return 0;
   DQ_REQUIRE(g.K > 0 && g.inner > 0, "gemm: bad reduction length / batch split");
   DQ_REQUIRE(g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm: leading dimensions of A and B must be multiples of 4 floats");
@@ -342,9 +509,9 @@ int launch_gemm(const Gemm& g, hipStream_t s) {
   DQ_REQUIRE((int64_t)k.batch * std::max(sh.full.splits, sh.rest.splits) <= 65535, "gemm: batch x splits exceeds the grid");
   for (const Part* p : {&sh.full, &sh.rest}) {
     int rc;
-    if (g.a_kmajor && g.b_kmajor) rc = launch_part<true, true>(k, *p, sh.bm, s);
-    else if (g.a_kmajor && !g.b_kmajor) rc = launch_part<true, false>(k, *p, sh.bm, s);
-    else if (!g.a_kmajor && !g.b_kmajor) rc = launch_part<false, false>(k, *p, sh.bm, s);
+    if (g.a_kmajor && g.b_kmajor) rc = launch_part<true, true>(k, *p, sh.bm, s, precision);
+    else if (g.a_kmajor && !g.b_kmajor) rc = launch_part<true, false>(k, *p, sh.bm, s, precision);
+    else if (!g.a_kmajor && !g.b_kmajor) rc = launch_part<false, false>(k, *p, sh.bm, s, precision);
     else { set_error("gemm: the (A transposed, B k-major) layout is not built"); return 2; }
     if (rc) return rc;
   }

@@ -10,6 +10,7 @@ LIB_PATH = os.environ.get("DQ_HIP_LIB", os.path.join(os.path.dirname(_HERE), "li
 _lib = None
 ABI_VERSION = 5  # DQ_ABI_VERSION of include/dq_hip.h this table was written against
 PRED_TYPES = {"eps": 0, "x0": 1}  # DQ_PRED_EPS / DQ_PRED_X0
+PRECISIONS = {"fp32": 0, "bf16x3": 1}  # DQ_PRECISION_FP32 / DQ_PRECISION_BF16X3
 
 # name -> (restype, argtypes); this table is checked against include/dq_hip.h by tests/test_abi.py
 PROTOTYPES = {
@@ -55,6 +56,9 @@ PROTOTYPES = {
     "dq_gemm_scratch_floats": (c_int64, [c_int, c_int, c_int]),
     "dq_gemm": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int64,
                         c_void_p]),
+    "dq_gemm_bf16x3": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int64,
+                               c_void_p]),
+    "dq_tfm_set_precision": (c_int, [c_void_p, c_int]),
     "dq_linattn_fwd": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p]),
     "dq_linattn_bwd": (c_int, [c_void_p] * 15 + [c_int, c_int, c_int, c_void_p]),
     "dq_rmsnorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

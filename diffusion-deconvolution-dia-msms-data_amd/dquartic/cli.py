@@ -80,6 +80,15 @@ def train(config_path, parquet_directory, ms2_data_path, ms1_data_path, batch_si
         from .utils.data_loader import ResidentPairLoader
 
         loader = ResidentPairLoader(dataset, per_rank, device=device, drop_last=len(dataset) // world > per_rank, rank=rank, world_size=world)
+    elif world > 1 and not syn:
+        # data-parallel over a file-backed dataset: rank r draws the indices i with i % world == r of a per-epoch permutation
+        # (SURVEY 8e).  (DIAMSDataset ignores the index and returns a random pair, data_loader.py:60-69, so this fixes the number
+        # of batches per rank and epoch rather than the windows a rank sees; the synthetic dataset shards its window pool itself.)
+        from torch.utils.data.distributed import DistributedSampler
+
+        sampler = DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True, drop_last=False)
+        loader = DataLoader(dataset, batch_size=per_rank, sampler=sampler, num_workers=int(config["threads"]),
+                            drop_last=len(dataset) // world > per_rank)
     else:
         loader = DataLoader(dataset, batch_size=per_rank, shuffle=True, num_workers=int(config["threads"]), drop_last=len(dataset) > per_rank)
     if m["use_model"] == "UNet1d":

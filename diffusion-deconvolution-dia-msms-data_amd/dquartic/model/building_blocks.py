@@ -61,6 +61,7 @@ class CustomTransformer(nn.Module):
             self._by_name[pname] = p
             _attach(self, pname, p)
         self._reset_parameters()
+        self.precision = "fp32"
         self._ws = {}
         self._ws_pool = {}  # training workspaces of the autograd bridge: one per forward that still awaits its backward
         self._tables = {}
@@ -142,6 +143,16 @@ class CustomTransformer(nn.Module):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             self._ws[key] = ws
         return ws
+
+    def set_precision(self, precision: str):
+        """Arithmetic of the dense products: "fp32" (default; exact fp32 on the matrix cores -- the precision parity is stated in) or
+        "bf16x3" (three bf16 matrix-core passes over hi/lo-split operands, fp32 accumulation: ~1e-5 relative per product term, a
+        separate and faster mode with its own tolerance)."""
+        if precision not in N.PRECISIONS:
+            raise ValueError(f"CustomTransformer: precision must be one of {sorted(N.PRECISIONS)}")
+        N.check(N.lib().dq_tfm_set_precision(self._tfm, N.PRECISIONS[precision]), "dq_tfm_set_precision")
+        self.precision = precision
+        return self
 
     def checkout_train_workspace(self, B, S1, S2):
         """A training workspace owned by ONE forward of the autograd bridge until its backward returns it (see UNet1d)."""

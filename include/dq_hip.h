@@ -42,7 +42,8 @@ const char* dq_last_error(void);
  * dq_mse_loss_weighted_fwd_bwd, dq_pair_batch.  3: dq_tfm_* (CustomTransformer), dq_gemm.
  * 4: dq_tfm_bwd takes an accumulate flag.  5: dq_ddim_sample takes num_timesteps (the plan no longer fixes T); stand-alone
  * building blocks (dq_rmsnorm_fwd, dq_time_mlp_fwd, dq_scale_shift_fwd, dq_prep_inputs_fwd, dq_conv_fwd, dq_resblock_*,
- * dq_rope, dq_attn_*); dq_train_step takes ms1_loss_weight, dq_ms1_loss_fwd_bwd. */
+ * dq_rope, dq_attn_*); dq_train_step takes ms1_loss_weight, dq_ms1_loss_fwd_bwd;
+ * dq_tfm_set_precision, dq_gemm_bf16x3. */
 int dq_abi_version(void);
 #define DQ_ABI_VERSION 5
 
@@ -191,6 +192,12 @@ int dq_tfm_fwd(dq_tfm* tfm, const float* params, const float* rope_sin, const fl
 int dq_tfm_bwd(dq_tfm* tfm, const float* params, const float* rope_sin, const float* rope_cos, const float* x_t,
                const float* x_cond, const float* dout, float* grads, int accumulate, float* dx_t, float* dx_cond,
                void* workspace, int64_t workspace_bytes, int B, int S1, int S2, void* stream);
+/* Arithmetic of the transformer's dense products: DQ_PRECISION_FP32 (default) = exact fp32 on v_mfma_f32_32x32x2_f32, the precision
+ * every parity statement of this library is made in; DQ_PRECISION_BF16X3 = three bf16 matrix-core passes over operands split into
+ * hi + lo bf16 halves with fp32 accumulation (~16 mantissa bits per operand, relative error ~1e-5 per product term): a separate,
+ * faster mode with its own stated tolerance, never the default. */
+enum { DQ_PRECISION_FP32 = 0, DQ_PRECISION_BF16X3 = 1 };
+int dq_tfm_set_precision(dq_tfm* tfm, int precision);
 /* The fp32 matrix-core GEMM underneath (exported for the parity tests and the roofline measurement):
  * C (M,N; ldc) = A B (+ bias[n]) with A(m,k) = a_kmajor ? A[m*lda+k] : A[k*lda+m] and B(k,n) = b_kmajor ? B[n*ldb+k] :
  * B[k*ldb+n]; splits = 0 lets the library choose a split-K factor; scratch: dq_gemm_scratch_floats(M,N,K) floats. */
@@ -198,6 +205,10 @@ int64_t dq_gemm_scratch_floats(int M, int N, int K);
 int dq_gemm(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int64_t lda, int64_t ldb,
             int64_t ldc, int a_kmajor, int b_kmajor, int accumulate, int splits, float* scratch, int64_t scratch_floats,
             void* stream);
+/* The same product in the DQ_PRECISION_BF16X3 arithmetic. */
+int dq_gemm_bf16x3(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int64_t lda, int64_t ldb,
+                   int64_t ldc, int a_kmajor, int b_kmajor, int accumulate, int splits, float* scratch, int64_t scratch_floats,
+                   void* stream);
 
 /* ---- building blocks exported for the per-block parity tests (tests/test_blocks_gpu.py) ------------------------
  * Each runs the SAME kernels / dispatch the network uses, on caller-supplied tensors, so that the reference's per-block

@@ -104,9 +104,9 @@ def test_whole_net_grads_golden(golden, tag, use_rope):
         if e > worst[1]:
             worst = (k, e)
     assert n == 395
-    # fp32 sums over up to 1024 positions with cancellation, accumulated in a different (and for the float-atomic
-    # reductions run-to-run varying) order than the reference's: observed worst cases 1e-4 .. 4e-4 of the tensor's scale
-    assert worst[1] < 1e-3, worst
+    # fp32 sums over up to 1024 positions with cancellation, accumulated in a different (fixed) order than the reference's
+    print("whole-net gradients vs the reference:", tag, worst)
+    assert worst[1] < 2e-4, worst
 
 
 def _tiny_dm(g):
@@ -254,7 +254,7 @@ def test_default_net_grads_multiblock_attention(RT):
     for k in keys:
         ref = po[k].grad
         err = float((named[k].grad.cpu() - ref).abs().max())
-        assert err <= 1e-3 * max(float(ref.abs().max()), 1e-4 * gmax), (k, err)
+        assert err <= 2e-4 * max(float(ref.abs().max()), 1e-4 * gmax), (k, err)
 
 
 def test_two_forwards_before_backward_keep_their_own_activations(golden):

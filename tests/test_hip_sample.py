@@ -59,8 +59,9 @@ def test_sample_trajectory_golden(golden, ns):
     dm = _tiny(g)
     x_T, c2, c1 = (T(g[k]).cuda() for k in ("p/x_t", "ms2_cond", "ms1_cond"))
     s, pn, tx, te = dm.sample(x_T, c2, c1, num_steps=ns, return_trajectory=True)
-    # per-step eps: 1e-4 relative (first step amplifies eps error ~31.6x into x, SURVEY 3.2, hence 5e-4 on x)
-    assert rel_err(te, g[f"s{ns}/traj_eps"]) < 2e-4
+    # per-step eps: 1e-4 relative, the tolerance north_star states (first step amplifies eps error ~31.6x into x, SURVEY 3.2,
+    # hence 5e-4 on x)
+    assert rel_err(te, g[f"s{ns}/traj_eps"]) < 1e-4
     assert rel_err(tx, g[f"s{ns}/traj_x"]) < 5e-4
     assert rel_err(s, g[f"s{ns}/sample"]) < 5e-4
     assert rel_err(pn, g[f"s{ns}/pred_noise"]) < 5e-4
@@ -103,7 +104,7 @@ def test_sample_full_size_vs_oracle(golden):
     with torch.no_grad():
         so, po = O.Diffusion(p, O.UNetConfig(downsample_dim=64)).sample(xT, c2, c1, 5, trace=tr)
     s, pn, tx, te = dm.sample(xT.cuda(), c2.cuda(), c1.cuda(), num_steps=5, return_trajectory=True)
-    assert rel_err(te, torch.stack([e for _, _, e in tr])) < 2e-4
+    assert rel_err(te, torch.stack([e for _, _, e in tr])) < 1e-4
     assert rel_err(s, so) < 1e-3
     assert float(((s.cpu() - so) ** 2).mean()) < 1e-8
 

@@ -337,3 +337,89 @@ def test_checkpoint_roundtrip_with_the_adapter(tmp_path):
     assert (ep, best) == (2, 0.5)
     assert torch.equal(dm2.model.flat_params, dm.model.flat_params)
     assert torch.equal(dm2.optimizer._m, dm.optimizer._m) and torch.equal(dm2.optimizer._v, dm.optimizer._v) and dm2.optimizer._step == 5
+
+
+# ------------------------------------------------------------------------------------------------ bf16x3 precision mode (GPU)
+def _gemm_bf16x3(A, B, M, N, K, a_k, b_k, bias=None, C0=None, splits=0):
+    from dquartic import _native as N_
+
+    lib = N_.lib()
+    C = torch.zeros(M, N, device="cuda") if C0 is None else C0.clone()
+    n_s = max(int(lib.dq_gemm_scratch_floats(M, N, K)), splits * (M + 256) * (N + 128) if splits else 4)
+    scratch = torch.empty(n_s, device="cuda")
+    N_.check(lib.dq_gemm_bf16x3(N_.ptr(A), N_.ptr(B), N_.ptr(C), N_.ptr(bias), M, N, K, A.shape[1], B.shape[1], N, int(a_k), int(b_k),
+                                0 if C0 is None else 1, splits, N_.ptr(scratch), scratch.numel(), N_.stream_ptr()), "dq_gemm_bf16x3")
+    return C
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(5, 16, 24), (34, 1024, 4000), (130, 260, 68), (257, 129, 36), (64, 128, 32), (1, 4, 4), (300, 40, 7),
+                                   (1088, 1024, 1024)])
+@pytest.mark.parametrize("layout", ["kk", "kn", "mn"])
+def test_gemm_bf16x3_against_float64(M, N, K, layout):
+    """The split-bf16 three-pass product (DQ_PRECISION_BF16X3): ~16 mantissa bits per operand.  STATED TOLERANCE of this mode:
+    |C - C_exact| <= 2e-5 * sqrt(K) * max|A| * max|B| per element (a random-sign sum of K terms, each off by <= ~2^-16 relative) --
+    about 10x the exact-fp32 kernel's; bitwise repeatable; same tails / layouts / split-K / += handling as the fp32 kernel."""
+    torch.manual_seed(M * 7 + N)
+    pad = lambda v: (v + 3) // 4 * 4
+    a_k, b_k = layout[0] == "k", layout[1] == "k"
+    A = torch.randn((M, pad(K)) if a_k else (K, pad(M)), device="cuda")
+    B = torch.randn((N, pad(K)) if b_k else (K, pad(N)), device="cuda")
+    Am = (A[:, :K] if a_k else A[:, :M].t()).double()
+    Bm = (B[:, :K].t() if b_k else B[:, :N]).double()
+    bias = torch.randn(N, device="cuda")
+    ref = Am @ Bm + bias.double()
+    got = _gemm_bf16x3(A, B, M, N, K, a_k, b_k, bias=bias)
+    tol = 2e-5 * K ** 0.5 * float(Am.abs().max() * Bm.abs().max())
+    err = float((got.double() - ref).abs().max())
+    assert err < tol, (err, tol)
+    exact = _gemm(A, B, M, N, K, a_k, b_k, bias=bias)
+    assert float((exact.double() - ref).abs().max()) <= err + 1e-6 * float(ref.abs().max())  # (the fp32 kernel is at least as close)
+    C0 = torch.randn(M, N, device="cuda")
+    got2 = _gemm_bf16x3(A, B, M, N, K, a_k, b_k, C0=C0, splits=3 if K >= 64 else 0)
+    assert float((got2.double() - (Am @ Bm + C0.double())).abs().max()) < tol
+    assert torch.equal(_gemm_bf16x3(A, B, M, N, K, a_k, b_k, bias=bias), got)
+
+
+@pytest.mark.gpu
+def test_transformer_bf16x3_mode_within_its_stated_tolerance():
+    """CustomTransformer with set_precision("bf16x3"): output within 1e-4 and parameter / input gradients within 5e-4 of the oracle
+    (relative to each tensor's largest entry; observed on MI355X: 1.2e-5 / 3.4e-5) -- the tolerance of this mode; the default fp32
+    mode on the same inputs stays within the 2e-5 / 1e-4 of the fp32 tests (observed 1.1e-6 / 1.8e-6), and switching back restores
+    it bit for bit."""
+    from dquartic.model.building_blocks import CustomTransformer
+
+    D, H, heads, layers, B, S1, S2 = 1000, 256, 8, 3, 3, 21, 17
+    params = OT.init_params(D, H, layers, seed=D + H)
+    net = CustomTransformer(input_dim=D, hidden_dim=H, num_heads=heads, num_layers=layers)
+    net.load_state_dict(params)
+    net = net.cuda()
+    g = torch.Generator().manual_seed(5)
+    x, c = torch.randn(B, S1, D, generator=g), torch.randn(B, S2, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    probe = torch.randn(B, S1, D, generator=g)
+    p = {k: v.clone().requires_grad_() for k, v in params.items()}
+    xr, cr = x.clone().requires_grad_(), c.clone().requires_grad_()
+    ref = OT.forward(p, xr, t, cr, heads)
+    (ref * probe).sum().backward()
+
+    def run():
+        for q in net.parameters():
+            q.grad = None
+        xg, cg = x.cuda().requires_grad_(), c.cuda().requires_grad_()
+        y = net(xg, t.cuda(), cg)
+        (y * probe.cuda()).sum().backward()
+        worst = max(_rel(q.grad.cpu(), p[k].grad) for k, q in net.named_parameters())
+        return y.detach().clone(), _rel(y.detach().cpu(), ref.detach()), max(worst, _rel(xg.grad.cpu(), xr.grad), _rel(cg.grad.cpu(), cr.grad))
+
+    y32, e32, g32 = run()
+    assert e32 < 2e-5 and g32 < 1e-4
+    net.set_precision("bf16x3")
+    y16, e16, g16 = run()
+    print("bf16x3 mode: output rel err", e16, "worst gradient rel err", g16, "(fp32 mode:", e32, g32, ")")
+    assert e16 < 1e-4 and g16 < 5e-4
+    assert not torch.equal(y16, y32)  # the mode really ran
+    net.set_precision("fp32")
+    assert torch.equal(run()[0], y32)
+    with pytest.raises(ValueError):
+        net.set_precision("fp8")
