@@ -12,6 +12,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ constexpr int rmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+// Which channel x-register j of a lane of half `half` holds in the LinearAttention kernels, and how many such registers a lane
+// has.  C = 8 / 16: the accumulator row map (8 / 16 channel slots, all used).  C = 4: c = 2 * half + j over TWO registers, C = 12:
+// c = 6 * half + j over SIX -- with the row map the lanes of half 1 would hold channels 4..7 (C = 4) resp. four of the sixteen slots
+// would be empty (C = 12), i.e. part of every K = 2 slice of a 32x32x2 product would be zero padding: four MFMAs per K = 4
+// projection instead of two, eight per K = 12 projection instead of six.
+__host__ __device__ __forceinline__ constexpr int la_nj(int C) { return C == 4 ? 2 : (C == 12 ? 6 : (C <= 8 ? 4 : 8)); }
+__device__ __forceinline__ constexpr int la_chan(int C, int j, int half) {
+  return C == 4 ? 2 * half + j : (C == 12 ? 6 * half + j : rmap(j, half));
+}
 // value of lane ^ 32 (ds_bpermute).  gfx950's v_permlane32_swap_b32 (tools/probe/permlane32.hip) was tried here: with the
 // two register copies and the select it needs it is four VALU instructions, and the VALU-bound forward kernel got 4 % slower
 // (the LDS pipe that serves ds_bpermute is otherwise idle there); the latency-bound backward did not change.

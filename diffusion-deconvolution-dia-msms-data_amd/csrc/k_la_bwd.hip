@@ -97,7 +97,7 @@ template <int C, int N>
 __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_bwd(LinAttnBwdK a) {
   constexpr int NB = N >= 32 ? N / 32 : 1;
   constexpr int RW = N >= 32 ? 1 : 32 / N;
-  constexpr int NJ = C <= 8 ? 4 : 8;
+  constexpr int NJ = la_nj(C);  // x registers per lane; register j holds channel la_chan(C, j, half)
   constexpr int SEG = N >= 32 ? 16 : (N >= 8 ? N / 2 : N);
   constexpr bool PARTNER = N >= 8;
   // C = 4 runs two waves per SIMD instead (the partner wave hides the latency); C = 16 and the 64-position C = 12 variant have
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
   float gpre[NJ], gout[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int c = rmap(j, half);
+    const int c = la_chan(C, j, half);
     gpre[j] = c < C ? a.g_pre[c] : 0.f;
     gout[j] = c < C ? a.g_out[c] : 0.f;
   }
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
     float wq[NJ], wk[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int c = rmap(j, half);
+      const int c = la_chan(C, j, half);
       const bool ok = c < C;
       wq[j] = ok ? a.w_qkv[(hd * 32 + col) * C + c] * LOG2E : 0.f;   // log2(e) folded in: the softmaxes use exp2 like the forward
       wk[j] = ok ? a.w_qkv[(128 + hd * 32 + col) * C + c] * LOG2E : 0.f;
@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
         const int pos = N >= 32 ? b * 32 + col : col % N;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const int c = rmap(j, half);
+          const int c = la_chan(C, j, half);
           const bool ok = row_ok && c < C;
           const int64_t off = ((int64_t)row * C + c) * N + pos;
           px[b][j] = ok ? a.x[off] : 0.f;
@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
       for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const int c = rmap(j, half);
+          const int c = la_chan(C, j, half);
           const int64_t off = ((int64_t)row * C + c) * N + (N >= 32 ? b * 32 + col : col % N);
           const bool ok = row_ok && c < C;
           pdxh[b][j] = (PREFETCH && ok && !first) ? a.dxh[off] : 0.f;
@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
       for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const int c = rmap(j, half);
+          const int c = la_chan(C, j, half);
           if (c < C) {
             xs[c * NP + b * 32 + col] = Xh[b][j];
             dys[c * NP + b * 32 + col] = DY[b][j];
@@ -332,10 +332,10 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
           }
         }
       };
-      // this lane's operand slice of a per-position / per-d channel vector: v[c = rmap(j, half)] (zero beyond C)
+      // this lane's operand slice of a per-position / per-d channel vector: v[c = la_chan(C, j, half)] (zero beyond C)
       auto own = [&](const float (&v)[C], int j) {
-        const int c0 = rmap(j, 0);
-        const float lo = c0 < C ? v[c0 < C ? c0 : 0] : 0.f, hi = c0 + 4 < C ? v[c0 + 4 < C ? c0 + 4 : 0] : 0.f;
+        const int c0 = la_chan(C, j, 0), c1 = la_chan(C, j, 1);
+        const float lo = c0 < C ? v[c0 < C ? c0 : 0] : 0.f, hi = c1 < C ? v[c1 < C ? c1 : 0] : 0.f;
         return half ? hi : lo;
       };
 
@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
         for (int b = 0; b < NB; ++b)
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
-            const int c = rmap(j, half);
+            const int c = la_chan(C, j, half);
             const int64_t off = ((int64_t)row * C + c) * N + (N >= 32 ? b * 32 + col : col % N);
             const bool ok = row_ok && c < C;
             pdxh[b][j] = (ok && !first) ? a.dxh[off] : 0.f;
@@ -615,7 +615,7 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
         for (int c = 0; c < C; ++c) full[c] = part[b][c >> 2][c & 3] + swp32(part[b][c >> 2][c & 3]);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const int c = rmap(j, half);
+          const int c = la_chan(C, j, half);
           const float val = own(full, j);
           float lo = 0.f;  // this lane's total dXh of channel c (heads 0..3), only formed in the last head's pass
           if (row_ok && c < C) {
@@ -628,7 +628,7 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
           tot[j] = lo;
         }
         if (last) {
-          // ---- residual + pre-norm backward on the completed dXh (own channels c = rmap(j, half)); dx += dy + d/dx
+          // ---- residual + pre-norm backward on the completed dXh (own channels c = la_chan(C, j, half)); dx += dy + d/dx
           float xv[NJ];
           float ssq = 0.f;
 #pragma unroll
@@ -654,7 +654,7 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
           const bool clamped = nrm < RMS_EPS;
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
-            const int c = rmap(j, half);
+            const int c = la_chan(C, j, half);
             if (row_ok && c < C) {
               const int64_t off = ((int64_t)row * C + c) * N + pos;
               const float du = clamped ? tot[j] * inv : inv * (tot[j] - xv[j] * dot);
@@ -744,7 +744,7 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
     if (hd == 0 || (hd == 3 && N != 1)) {  // norm gains / bias: sum over the 32 positions-lanes of this half, one lane stores
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int c = rmap(j, half);
+        const int c = la_chan(C, j, half);
         const float s0 = half_sum(nacc0[j]), s1 = half_sum(nacc1[j]), s2 = N == 1 ? half_sum(nacc2[j]) : 0.f;
         if (col == 0 && c < C) {
           if (hd == 0) {

@@ -36,7 +36,7 @@ template <int C, int NJ>
 __device__ __forceinline__ void load_block(const float* __restrict__ src, int64_t row, int N, int pos, int half, float* out) {
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int c = rmap(j, half);
+    const int c = la_chan(C, j, half);
     out[j] = (c < C && pos < N) ? src[(row * C + c) * N + pos] : 0.f;  // (pos >= N: the ragged tail of a run-time row length)
   }
 }
@@ -65,7 +65,7 @@ template <int C, int NJ>
 __device__ __forceinline__ void stage_cn(float* dst, const float* v, int col, int half) {
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int c = rmap(j, half);
+    const int c = la_chan(C, j, half);
     if (c < C) dst[c * 32 + col] = v[j];
   }
 }
@@ -137,8 +137,8 @@ __device__ __forceinline__ f32x16 q_exp(f32x16 q, float& qs) {  // un-normalised
 
 template <int C>
 __device__ __forceinline__ float own_of(const float (&v)[C], int j, int half) {
-  const int c0 = rmap(j, 0);
-  const float lo = c0 < C ? v[c0 < C ? c0 : 0] : 0.f, hi = c0 + 4 < C ? v[c0 + 4 < C ? c0 + 4 : 0] : 0.f;
+  const int c0 = la_chan(C, j, 0), c1 = la_chan(C, j, 1);
+  const float lo = c0 < C ? v[c0 < C ? c0 : 0] : 0.f, hi = c1 < C ? v[c1 < C ? c1 : 0] : 0.f;
   return half ? hi : lo;
 }
 
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd_long(LinAttn a) {
   const int N = NT ? NT : a.n;
   const int NB = (N + 31) / 32;
   constexpr bool RAGGED = NT == 0;
-  constexpr int NJ = C <= 8 ? 4 : 8;
+  constexpr int NJ = la_nj(C);
   constexpr int CG = C / 4;
   __shared__ __attribute__((aligned(16))) float w2_lds[4 * C * C];
   __shared__ __attribute__((aligned(16))) float xs_lds[4][C * 32];
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd_long(LinAttn a) {
   if (row >= a.rows) return;
   float gpre[NJ];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) gpre[j] = rmap(j, half) < C ? a.g_pre[rmap(j, half)] : 0.f;
+  for (int j = 0; j < NJ; ++j) gpre[j] = la_chan(C, j, half) < C ? a.g_pre[la_chan(C, j, half)] : 0.f;
 
   // ---- sweep 1: M of the four heads, online softmax over the blocks
   {
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd_long(LinAttn a) {
       for (int g = 0; g < CG; ++g) mt[hd][g] = lf32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int c = rmap(j, half);
+        const int c = la_chan(C, j, half);
         wk[hd][j] = c < C ? a.w_qkv[(128 + hd * 32 + col) * C + c] * L_LOG2E : 0.f;
       }
     }
@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd_long(LinAttn a) {
   for (int hd = 0; hd < 4; ++hd)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int c = rmap(j, half);
+      const int c = la_chan(C, j, half);
       wq[hd][j] = c < C ? a.w_qkv[(hd * 32 + col) * C + c] * L_LOG2E : 0.f;
     }
 #pragma unroll 1
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd_long(LinAttn a) {
       }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int cp = rmap(j, half);
+        const int cp = la_chan(C, j, half);
         if (cp < C) {
           const float* w = w2_lds + (hd * C + cp) * C;
           float s = 0.f;
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd_long(LinAttn a) {
     float ssq = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int c = rmap(j, half);
+      const int c = la_chan(C, j, half);
       yv[j] = c < C ? yown[j] + a.b_out[c] : 0.f;
       ssq = fmaf(yv[j], yv[j], ssq);
     }
@@ -284,10 +284,10 @@ __global__ void __launch_bounds__(256) k_linattn_fwd_long(LinAttn a) {
     const float inv = sqrtf((float)C) / fmaxf(sqrtf(ssq), RMS_EPS);
     float go[NJ];  // gains read before the first store of this position (a load behind a store waits for it)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) go[j] = rmap(j, half) < C ? a.g_out[rmap(j, half)] : 0.f;
+    for (int j = 0; j < NJ; ++j) go[j] = la_chan(C, j, half) < C ? a.g_out[la_chan(C, j, half)] : 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int c = rmap(j, half);
+      const int c = la_chan(C, j, half);
       if (c < C && pos < N) {
         const int64_t off = (row * C + c) * N + pos;
         if (a.ypre) a.ypre[off] = yv[j];
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(256, 2) k_linattn_bwd_long(LinAttnBwdLongK a) 
   const int N = NT ? NT : a.n;
   const int NB = (N + 31) / 32;
   constexpr bool RAGGED = NT == 0;
-  constexpr int NJ = C <= 8 ? 4 : 8;
+  constexpr int NJ = la_nj(C);
   constexpr int CG = C / 4;
   __shared__ __attribute__((aligned(16))) float wp_lds[2 * 4 * 2 * C * 16];  // [q|k][head][half][c][r]
   __shared__ __attribute__((aligned(16))) float w2_lds[4 * C * C];
@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(256, 2) k_linattn_bwd_long(LinAttnBwdLongK a) 
   const int u1 = min(a.rows, u0 + a.units_per_wave);
   float gpre[NJ];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) gpre[j] = rmap(j, half) < C ? a.g_pre[rmap(j, half)] : 0.f;
+  for (int j = 0; j < NJ; ++j) gpre[j] = la_chan(C, j, half) < C ? a.g_pre[la_chan(C, j, half)] : 0.f;
 
   auto chainw = [&](int m, int hd, int g, const f32x16& t) {  // A = wp_lds[m][hd][half][c = 4*g + (lane&3)][r]
     const float* wr = wp_lds + (((m * 4 + hd) * 2 + half) * C + g * 4 + (lane & 3)) * 16;
@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(256, 2) k_linattn_bwd_long(LinAttnBwdLongK a) 
     for (int c = 0; c < C; ++c) full[c] = part[c >> 2][c & 3] + swap_half(part[c >> 2][c & 3]);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int c = rmap(j, half);
+      const int c = la_chan(C, j, half);
       if (c < C && pos < N) {
         float* dst = a.dxh + (row * C + c) * N + pos;
         const float val = own_of<C>(full, j, half);
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(256, 2) k_linattn_bwd_long(LinAttnBwdLongK a) 
     float wq[NJ], wk[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int c = rmap(j, half);
+      const int c = la_chan(C, j, half);
       wq[j] = c < C ? a.w_qkv[(hd * 32 + col) * C + c] * L_LOG2E : 0.f;
       wk[j] = c < C ? a.w_qkv[(128 + hd * 32 + col) * C + c] * L_LOG2E : 0.f;
     }

@@ -30,6 +30,7 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __
 // block = lane >> 2; a lane supplies A_blk[i = lane & 3] and B_blk[j = lane & 3]; register i of lane (blk, j) += A_blk[i] * B_blk[j]
 __device__ __forceinline__ f32x4 mfma4f(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ constexpr int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+// (channel map of a lane's x registers: la_nj / la_chan, dq_mfma.h)
 __device__ __forceinline__ float swap32(float v) { return swap_half(v); }  // v_permlane32_swap (dq_mfma.h)
 __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -40,7 +41,7 @@ template <int C, int N>
 __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   constexpr int NB = N >= 32 ? N / 32 : 1;    // 32-position blocks per row
   constexpr int RW = N >= 32 ? 1 : 32 / N;    // rows per wave
-  constexpr int NJ = C <= 8 ? 4 : 8;          // x registers per lane (channel = rowmap(j, half))
+  constexpr int NJ = la_nj(C);                // x registers per lane (channel = la_chan(C, j, half))
   constexpr int SEG = N >= 32 ? 16 : (N >= 8 ? N / 2 : N);  // registers of one row inside a lane
   constexpr bool PARTNER = N >= 8;            // does lane^32 hold positions of the same row?
   constexpr int CG = C / 4;                   // channel groups of 4 (one 4x4x1 MFMA chain each)
@@ -78,7 +79,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
     } else {
       for (int i = threadIdx.x; i < WQ; i += blockDim.x) {
         const int cc = i & 31, hh = (i >> 5) & 1, j = (i >> 6) % NJ, hd = (i / (64 * NJ)) & 3, m = i / (256 * NJ);
-        const int c = rowmap(j, hh);
+        const int c = la_chan(C, j, hh);
         wqk_lds[i] = c < C ? a.w_qkv[(m * 128 + hd * 32 + cc) * C + c] * 1.4426950408889634f : 0.f;
       }
     }
@@ -105,7 +106,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
     float ssq = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int c = rowmap(j, half);
+      const int c = la_chan(C, j, half);
       X[blk][j] = (row_ok && c < C) ? a.x[((int64_t)row * C + c) * N + pos] : 0.f;
       ssq = fmaf(X[blk][j], X[blk][j], ssq);
     }
@@ -113,24 +114,24 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
     const float inv = sqC / fmaxf(sqrtf(ssq), RMS_EPS);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int c = rowmap(j, half);
+      const int c = la_chan(C, j, half);
       Xh[blk][j] = X[blk][j] * inv * (c < C ? a.g_pre[c] : 0.f);
       if (c < C) xs[c * NP + blk * 32 + col] = Xh[blk][j];
     }
   }
   wave_fence();
 
-  float yown[NB][NJ];  // (Wo out) of this lane's channels c' = rowmap(j, half)
+  float yown[NB][NJ];  // (Wo out) of this lane's channels c' = la_chan(C, j, half)
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) yown[blk][j] = 0.f;
 
-  // yown[blk][j] += f * sum_c W2[hd][c' = rowmap(j, half)][c] * p[c]
+  // yown[blk][j] += f * sum_c W2[hd][c' = la_chan(C, j, half)][c] * p[c]
   auto add_w2 = [&](int hd, int blk, const float (&p)[C], float f) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int cp = rowmap(j, half);
+      const int cp = la_chan(C, j, half);
       if (cp < C) {
         const float* w = w2_lds + (hd * C + cp) * C;
         float s = 0.f;
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
       add_w2(hd, 0, xf, scale);
       continue;
     }
-    // weight operands of this head: lane (col, half) supplies W[o_base + col][rowmap(j, half)]
+    // weight operands of this head: lane (col, half) supplies W[o_base + col][la_chan(C, j, half)]
     float wq[NJ], wk[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -316,12 +317,12 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
     }
   }
 
-  // ---- bias, post-norm, residual, store (this lane's channels c = rowmap(j, half)).  The gains and biases are read before the
+  // ---- bias, post-norm, residual, store (this lane's channels c = la_chan(C, j, half)).  The gains and biases are read before the
   // first store: a load issued after a store waits for it, and the loop below would be 2 NJ serial round trips per block
   float gout_r[NJ], bout_r[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int c = rowmap(j, half);
+    const int c = la_chan(C, j, half);
     gout_r[j] = c < C ? a.g_out[c] : 0.f;
     bout_r[j] = c < C ? a.b_out[c] : 0.f;
   }
@@ -332,7 +333,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
     float ssq = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int c = rowmap(j, half);
+      const int c = la_chan(C, j, half);
       yv[j] = c < C ? yown[blk][j] + bout_r[j] : 0.f;
       ssq = fmaf(yv[j], yv[j], ssq);
     }
@@ -340,7 +341,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
     const float inv = sqC / fmaxf(sqrtf(ssq), RMS_EPS);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int c = rowmap(j, half);
+      const int c = la_chan(C, j, half);
       if (row_ok && c < C) {
         const int64_t off = ((int64_t)row * C + c) * N + pos;
         if (a.ypre) a.ypre[off] = yv[j];
@@ -380,7 +381,7 @@ __global__ void __launch_bounds__(256) k_linattn_prepare(LaPrepMulti m) {
     return;
   }
   const LaPrepItem& it = m.it[blockIdx.x];
-  const int C = it.C, NJ = C <= 8 ? 4 : 8;
+  const int C = it.C, NJ = la_nj(C);
   for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) {
     const int c = i % C, cp = (i / C) % C, hd = i / (C * C);
     float s = 0.f;
@@ -391,7 +392,7 @@ __global__ void __launch_bounds__(256) k_linattn_prepare(LaPrepMulti m) {
   const int WQ = 2 * 4 * NJ * 2 * 32;
   for (int i = threadIdx.x; i < WQ; i += blockDim.x) {
     const int cc = i & 31, hh = (i >> 5) & 1, j = (i >> 6) % NJ, hd = (i / (64 * NJ)) & 3, mm = i / (256 * NJ);
-    const int c = rowmap(j, hh);
+    const int c = la_chan(C, j, hh);
     it.prep[1024 + i] = c < C ? it.w_qkv[(mm * 128 + hd * 32 + cc) * C + c] * 1.4426950408889634f : 0.f;
   }
 }
