@@ -209,6 +209,7 @@ struct LinAttnBwd {
   // launch reduced them itself: the long-row path); the caller sums them later with launch_linattn_dw_reduce_multi, and then
   // part_floats only needs la_part_reserve(C)
   int defer_reduce = 0; int* waves_out = nullptr;
+  float** w2sum_out = nullptr;  // deferred: receives the address of the 4 C C floats (inside `part`) the reduce leaves the summed dW2 in
   float* dw_qkv = nullptr; float* dw_out = nullptr; float* db_out = nullptr; float* dg_pre = nullptr; float* dg_out = nullptr;
 };
 // rows of 128 / 256 positions (k_la_long.hip)
@@ -218,7 +219,12 @@ int launch_linattn_bwd_long(const float* x, const float* dyp, float* dxh, const 
 constexpr int LA_MAX_WAVES = 2048;  // the backward grid is one resident round: <= 1024 waves, one partial slot each
 int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s);
 // the deferred slot reductions of up to LA_REDUCE_MAX LinearAttention backwards in ONE launch (grad += ordered slot sums)
-struct LaReduceItem { const float* part; int nslots, C; float* dw_qkv; float* dw_out; float* dg_out; float* db_out; float* dg_pre; };
+// w2sum: 4 C C floats of scratch (the summed dW2 of the four heads; the launcher places it right behind the layer's slots);
+// w_qkv / w_out: the layer's weights (dWv = Wo^T dW2, dWo = dW2 Wv^T are formed from the sum)
+struct LaReduceItem {
+  const float* part; int nslots, C; float* dw_qkv; float* dw_out; float* dg_out; float* db_out; float* dg_pre;
+  float* w2sum; const float* w_qkv; const float* w_out;
+};
 constexpr int LA_REDUCE_MAX = 16;
 int64_t la_part_reserve(int C);  // floats of slot scratch one deferred launch with C channels can use
 int launch_linattn_dw_reduce_multi(const LaReduceItem* items, int count, hipStream_t s);

@@ -380,11 +380,12 @@ int la_bwd(const Ctx& c, const LAP& l, const LevelBuf& b, const float* x, const 
   const int64_t need = la_short_row(n) ? la_part_reserve(l.C) : c.ar.la_part_floats;
   if (d->count == LA_REDUCE_MAX || d->cursor + need > c.ar.la_part_floats) DQ_TRY(la_flush(c));  // (long rows use the whole buffer)
   int waves = 0;
+  float* w2sum = nullptr;  // where the launcher put this layer's summed-dW2 scratch (behind its slots)
   a.part = c.w(c.ar.la_part) + d->cursor; a.part_floats = c.ar.la_part_floats - d->cursor;
-  a.defer_reduce = 1; a.waves_out = &waves;
+  a.defer_reduce = 1; a.waves_out = &waves; a.w2sum_out = &w2sum;
   DQ_TRY(launch_linattn_bwd(a, c.s));
   if (waves > 0) {
-    d->items[d->count++] = LaReduceItem{a.part, waves, l.C, a.dw_qkv, a.dw_out, a.dg_out, a.db_out, a.dg_pre};
+    d->items[d->count++] = LaReduceItem{a.part, waves, l.C, a.dw_qkv, a.dw_out, a.dg_out, a.db_out, a.dg_pre, w2sum, a.f.w_qkv, a.f.w_out};
     d->cursor += need;
   }
   return 0;

@@ -51,7 +51,7 @@ struct LinAttnBwdK {
   float* dx;                                            // += d loss / d x (incl. the residual)
   float* dxh;                                           // scratch (rows, C, n): dXh accumulated over heads 0..2
   const float* w_qkv; const float* w_out; const float* g_pre; const float* g_out;
-  float* part;  // per-wave partial slots: [wave][LA_SLOT(C)] = dWqkv (384C) | dWo (128C) | d g_out | d b_out | d g_pre
+  float* part;  // per-wave partial slots: [wave][la_slot(C)] = dWq | dWk (256 C) | dW2 per head (4 C C) | d g_out | d b_out | d g_pre
   int rows; int units_per_wave;
   const float* prep;  // nullable: W2 (4 C C floats) prepared by launch_linattn_prepare
   int dx_store;       // dx is written, not accumulated into (its old contents are not read)
@@ -64,7 +64,7 @@ struct LinAttnBwdK {
 #else
 #define DQ_STAMP(i) do {} while (0)
 #endif
-constexpr int la_slot(int C) { return 515 * C; }
+constexpr int la_slot(int C) { return 256 * C + 4 * C * C + 3 * C; }  // dWq | dWk (256 C) | dW2 of the four heads (4 C C) | d g_out | d b_out | d g_pre
 
 // v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 outer products.  Block = lane >> 2; a lane supplies A_blk[i = lane & 3] and
 // B_blk[j = lane & 3]; register i of lane (blk, j) receives A_blk[i] * B_blk[j] (mapping measured: tools/probe/mfma4x4.hip).
@@ -682,17 +682,13 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
         }
       }
     if (hd == 1) DQ_STAMP(10);
-    // dW2 of this head: sum the 16 position blocks (lanes with equal lane & 3), publish [c'][c], then
-    // dWv[e][c] = sum_c' Wo[c'][e] dW2[c'][c] and dWo[c'][e] = sum_c dW2[c'][c] Wv[e][c] for this lane's e = col
+    // dW2 of this head: sum the 16 position blocks (lanes with equal lane & 3) and publish [c'][c] to the slot.  dWv = Wo^T dW2 and
+    // dWo = dW2 Wv^T are linear in dW2, so they are formed ONCE per layer from the slot SUM (k_linattn_dwvo, after the ordered
+    // reduce) instead of once per (wave, head) here: that was 2 C loads + C^2 FMAs + 2 C stores per lane and head (3-5 k of a
+    // 7-12 k cycle flush at 12 / 16 channels, tools/probe/la_bwd_time.hip) and 256 C of the 515 C floats of a slot.
     // Inside a row of 16 lanes: two DPP rotations (by 4 and by 8 lanes) leave every lane with the sum of its (lane & 3) class;
     // across the four rows: through the wave-private tile (4 x 16 C^2 / 4 floats <= 1024).  The four-step ds_bpermute butterfly
     // this replaces was 4 C^2 dependent LDS round trips per head: 8 us of a 25 us head at 16 channels (tools/probe/la_bwd_time.hip).
-    float wvr[C], wor[C];  // Wv[hd*32 + col][c], Wo[c'][hd*32 + col]: requested here, used after the reduction below
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      wvr[c] = a.w_qkv[(256 + hd * 32 + col) * C + c];
-      wor[c] = a.w_out[c * 128 + hd * 32 + col];
-    }
     constexpr int NV4 = CG * CG * 16;  // floats one row contributes: [value vi = (g1 * CG + g2) * 4 + i][j = lane & 3]
     wfence();
     if (walk) {  // (1-position rows: dW2 is the same for every head and stays in w2g from the hd = 0 pass)
@@ -715,32 +711,14 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
         const float v = (tile[e] + tile[NV4 + e]) + (tile[2 * NV4 + e] + tile[3 * NV4 + e]);
         const int vi = e >> 2, j = e & 3, i = vi & 3, g2 = (vi >> 2) % CG, g1 = (vi >> 2) / CG;
         w2g[(4 * g1 + i) * C + 4 * g2 + j] = v;
-        w2g[C * C + (4 * g2 + j) * C + 4 * g1 + i] = v;  // transposed copy: both halves below read along their reduction index
       }
     }
     }
     wfence();
     if (hd == 1) DQ_STAMP(11);
-    {
-      // lane half 0: dWv[e][c] = sum_c' Wo[c'][e] dW2[c'][c] (reads the transposed copy along c'); half 1: dWo[c][e] =
-      // sum_k dW2[c][k] Wv[e][k] -- one instruction stream, C^2 FMAs per lane instead of 2 C^2 on half of the lanes
-      const float* mx = half ? w2g : w2g + C * C;
-      float av[C];
-#pragma unroll
-      for (int k = 0; k < C; ++k) av[k] = half ? wvr[k] : wor[k];
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int k4 = 0; k4 < C; k4 += 4) {
-          const float4 m4 = *reinterpret_cast<const float4*>(mx + c * C + k4);
-          sacc = fmaf(av[k4], m4.x, sacc); sacc = fmaf(av[k4 + 1], m4.y, sacc);
-          sacc = fmaf(av[k4 + 2], m4.z, sacc); sacc = fmaf(av[k4 + 3], m4.w, sacc);
-        }
-        slot[half ? 384 * C + c * 128 + hd * 32 + col : (256 + hd * 32 + col) * C + c] = sacc;
-      }
-    }
+    for (int i = lane; i < C * C; i += 64) slot[256 * C + hd * C * C + i] = w2g[i];
     if (hd == 1) DQ_STAMP(12);
+    constexpr int GB = 256 * C + 4 * C * C;  // [d g_out | d b_out | d g_pre]
     if (hd == 0 || (hd == 3 && N != 1)) {  // norm gains / bias: sum over the 32 positions-lanes of this half, one lane stores
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
@@ -748,10 +726,10 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
         const float s0 = half_sum(nacc0[j]), s1 = half_sum(nacc1[j]), s2 = N == 1 ? half_sum(nacc2[j]) : 0.f;
         if (col == 0 && c < C) {
           if (hd == 0) {
-            slot[512 * C + c] = s0; slot[513 * C + c] = s1;
-            if (N == 1) slot[514 * C + c] = s2;
+            slot[GB + c] = s0; slot[GB + C + c] = s1;
+            if (N == 1) slot[GB + 2 * C + c] = s2;
           }
-          else slot[514 * C + c] = s0;
+          else slot[GB + 2 * C + c] = s0;
         }
       }
     }
@@ -793,7 +771,9 @@ __global__ void __launch_bounds__(256) k_linattn_dw_reduce(const float* __restri
     else dg_pre[e - 514 * C] += s;
   }
 }
-// the same reduction for several LinearAttention layers at once: block -> (item, 16-element group) through a prefix table
+// The slot reduction of the register-resident backward (slot layout la_slot(C)), for several LinearAttention layers at once: block ->
+// (item, 16-element group) through a prefix table.  dWq | dWk and the gains go to the gradient buffers (+=); the summed dW2 of the four
+// heads goes to the item's w2sum scratch, from which k_linattn_dwvo forms dWv and dWo.
 struct LaReduceMulti { LaReduceItem it[LA_REDUCE_MAX]; int first_block[LA_REDUCE_MAX + 1]; int count; };
 __global__ void __launch_bounds__(256) k_linattn_dw_reduce_multi(LaReduceMulti m) {
   int i = 0;
@@ -819,11 +799,29 @@ __global__ void __launch_bounds__(256) k_linattn_dw_reduce_multi(LaReduceMulti m
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) s += red[k][el];
-    if (e < 384 * C) it.dw_qkv[e] += s;
-    else if (e < 512 * C) it.dw_out[e - 384 * C] += s;
-    else if (e < 513 * C) it.dg_out[e - 512 * C] += s;
-    else if (e < 514 * C) it.db_out[e - 513 * C] += s;
-    else it.dg_pre[e - 514 * C] += s;
+    const int w2b = 256 * C, gb = w2b + 4 * C * C;
+    if (e < w2b) it.dw_qkv[e] += s;                 // rows 0..255 of to_qkv: q | k
+    else if (e < gb) it.w2sum[e - w2b] = s;         // dW2[head][c'][c]
+    else if (e < gb + C) it.dg_out[e - gb] += s;
+    else if (e < gb + 2 * C) it.db_out[e - gb - C] += s;
+    else it.dg_pre[e - gb - 2 * C] += s;
+  }
+}
+// dWv[e][c] += sum_c' Wo[c'][e] dW2[h(e)][c'][c] ; dWo[c'][e] += sum_c dW2[h(e)][c'][c] Wv[e][c]   (e = head * 32 + d: the 128 value /
+// output channels; W2_h = Wo_h Wv_h).  One block per layer.
+__global__ void __launch_bounds__(256) k_linattn_dwvo(LaReduceMulti m) {
+  const LaReduceItem& it = m.it[blockIdx.x];
+  const int C = it.C;
+  for (int idx = threadIdx.x; idx < 128 * C; idx += blockDim.x) {
+    const int e = idx / C, c = idx - e * C;
+    const float* w2 = it.w2sum + (e >> 5) * C * C;
+    float sv = 0.f, so = 0.f;
+    for (int k = 0; k < C; ++k) {
+      sv = fmaf(it.w_out[k * 128 + e], w2[k * C + c], sv);            // k = c'
+      so = fmaf(w2[c * C + k], it.w_qkv[(256 + e) * C + k], so);      // row c' = c of dW2, k = c
+    }
+    it.dw_qkv[(256 + e) * C + c] += sv;
+    it.dw_out[c * 128 + e] += so;
   }
 }
 #endif  // !DQ_LA_BIG_TU
@@ -853,14 +851,19 @@ static int linattn_bwd_n(const LinAttnBwdK& k, int n, const LinAttnBwd& g, hipSt
     constexpr int RW = NN >= 32 ? 1 : 32 / NN;                                                     \
     const int units = cdiv(k.rows, RW);                                                            \
     LinAttnBwdK kk = k;                                                                            \
-    const int max_waves = std::min(la_two_waves(C, NN) ? 2048 : 1024, (int)(k_part_floats / la_slot(C)));  \
+    /* (4 C C floats behind the slots hold the summed dW2 between the reduce and k_linattn_dwvo) */ \
+    const int max_waves = std::min(la_two_waves(C, NN) ? 2048 : 1024, (int)((k_part_floats - 4 * C * C) / la_slot(C)));  \
     kk.units_per_wave = std::max(1, cdiv(units, max_waves));                                       \
     const int waves = cdiv(units, kk.units_per_wave);                                              \
     launch_one<C, NN>(kk, waves, s);                                                               \
-    if (g.defer_reduce) *g.waves_out = waves;                                                      \
-    else                                                                                           \
-      hipLaunchKernelGGL(k_linattn_dw_reduce, dim3(cdiv(la_slot(C), 16)), dim3(256), 0, s, kk.part, waves, C, la_slot(C), g.dw_qkv, \
-                         g.dw_out, g.dg_out, g.db_out, g.dg_pre);                                  \
+    if (g.defer_reduce) {                                                                          \
+      *g.waves_out = waves;                                                                        \
+      if (g.w2sum_out) *g.w2sum_out = kk.part + (int64_t)waves * la_slot(C);                       \
+    } else {                                                                                       \
+      const LaReduceItem it{kk.part, waves, C, g.dw_qkv, g.dw_out, g.dg_out, g.db_out, g.dg_pre, kk.part + (int64_t)waves * la_slot(C), \
+                            k.w_qkv, k.w_out};                                                     \
+      if (int rc = launch_linattn_dw_reduce_multi(&it, 1, s)) return rc;                           \
+    }                                                                                              \
     break;                                                                                         \
   }
   switch (n) {
@@ -874,7 +877,8 @@ static int linattn_bwd_n(const LinAttnBwdK& k, int n, const LinAttnBwd& g, hipSt
   return 0;
 }
 
-int64_t la_part_reserve(int C) { return (int64_t)(C <= 8 ? 2048 : 1024) * la_slot(C); }  // one slot per wave of a resident round
+// one slot per wave of a resident round + the summed dW2
+int64_t la_part_reserve(int C) { return ((int64_t)(C <= 8 ? 2048 : 1024) * la_slot(C) + 4 * C * C + 63) / 64 * 64; }
 int launch_linattn_dw_reduce_multi(const LaReduceItem* items, int count, hipStream_t s) {
   if (count == 0) return 0;
   DQ_REQUIRE(count <= LA_REDUCE_MAX, "linattn dw reduce: too many deferred layers");
@@ -888,6 +892,8 @@ int launch_linattn_dw_reduce_multi(const LaReduceItem* items, int count, hipStre
   }
   m.first_block[count] = blocks;
   hipLaunchKernelGGL(k_linattn_dw_reduce_multi, dim3(blocks), dim3(256), 0, s, m);
+  DQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_linattn_dwvo, dim3(count), dim3(256), 0, s, m);
   DQ_LAUNCH_CHECK();
   return 0;
 }
@@ -903,7 +909,7 @@ int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s) {
   if (a.waves_out) *a.waves_out = 0;
   DQ_REQUIRE(a.part && a.part_floats >= (deferred ? la_part_reserve(C) : (int64_t)LA_MAX_WAVES * 512 * C),
              "linattn_bwd: partial-sum scratch missing or too small");
-  static_assert((int64_t)LA_MAX_WAVES * 512 >= 1024 * (int64_t)la_slot(1), "slot scratch: 1024 waves x 515*C floats must fit");
+  static_assert((int64_t)LA_MAX_WAVES * 512 * 4 >= 2048 * (int64_t)la_slot(4) + 64, "slot scratch: a resident round of slots must fit");
   static const bool long_all = [] { const char* e = std::getenv("DQ_LA_BWD_LONG"); return e && e[0] == '1'; }();
   if (n > 64 || (n & (n - 1)) != 0 || (long_all && n >= 32 && C <= 8)) {
     // rows of 128 / 256 positions: the sweep kernel between two pointwise norm-backward launches
