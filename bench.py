@@ -361,8 +361,8 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=10)  # a fresh box needs ~50 ms of work before its clocks settle
+    ap.add_argument("--steps", type=int, default=200)  # ~1.1 s of timed train steps: long enough for an outside observer to see the GPU busy
+    ap.add_argument("--warmup", type=int, default=20)  # a fresh box needs ~50 ms of work before its clocks settle
     ap.add_argument("--no-sample", action="store_true", help="skip the sampling leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-transformer", action="store_true", help="skip the CustomTransformer leg (rank 0, single-GPU runs only)")

@@ -83,6 +83,8 @@ def lib():
             raise RuntimeError(
                 f"libdq_hip.so not found at {LIB_PATH}: build it with `make -C diffusion-deconvolution-dia-msms-data_amd` "
                 "(or python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
+        import torch  # noqa: F401  (PyTorch's HIP runtime first: the library's libamdhip64 dependency must resolve to that same copy)
+
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)
