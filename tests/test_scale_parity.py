@@ -141,17 +141,18 @@ def test_sample_batch512_graph_vs_oracle_and_batch_independence():
         dm.use_graph = True
     assert torch.equal(s2, s2e)
     assert torch.equal(s[:2], s2) and torch.equal(pn[:2], pn2)
-    # windows 0..1 against the oracle: per-step eps (<= 1e-4 of the step's eps scale) and the denoised window
+    # window 0 against the oracle (50 CPU steps per window: one is enough, window 1 is tied to it by the batch-independence
+    # checks above): per-step eps (<= 1e-4 of the step's eps scale) and the denoised window
     tr = []
     with torch.no_grad():
-        so, _ = O.Diffusion(params, O.UNetConfig(downsample_dim=64)).sample(xT[:2], c2[:2], c1[:2], NS, trace=tr)
+        so, _ = O.Diffusion(params, O.UNetConfig(downsample_dim=64)).sample(xT[:1], c2[:1], c1[:1], NS, trace=tr)
     worst = 0.0
     for i, (_, _, e) in enumerate(tr):
-        worst = max(worst, float((te[i].cpu() - e).abs().max() / e.abs().max()))
-    print("50-step sampling: worst per-step eps rel err", worst, "final MSE", float(((s[:2].cpu() - so) ** 2).mean()))
+        worst = max(worst, float((te[i][:1].cpu() - e).abs().max() / e.abs().max()))
+    print("50-step sampling: worst per-step eps rel err", worst, "final MSE", float(((s[:1].cpu() - so) ** 2).mean()))
     assert worst < EPS_TOL, worst
-    assert float(((s[:2].cpu() - so) ** 2).mean()) < 1e-8                    # denoised-MS2 MSE
-    assert float((s[:2].cpu() - so).abs().max() / so.abs().max()) < 5e-4
+    assert float(((s[:1].cpu() - so) ** 2).mean()) < 1e-8                    # denoised-MS2 MSE
+    assert float((s[:1].cpu() - so).abs().max() / so.abs().max()) < 5e-4
 
 
 def test_large_window_2000x256_vs_oracle():
