@@ -388,6 +388,7 @@ def main():
 
     net, dm = build_model(device)
     dm._set_optimizer(1e-5)
+    dm._sync_replicas()  # data-parallel runs: every rank starts from rank 0's weights (the ranks seed their RNGs differently)
     log("building synthetic batches")
     batches = make_batches(4, TRAIN_BATCH, rank, world, device)
     log("train leg")
