@@ -756,8 +756,11 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     DQ_HIP_OK(hipMemcpy2DAsync(grad_x, sizeof(float) * p.mz, c.g(a.cat0) + p.mz, sizeof(float) * 2 * p.mz, sizeof(float) * p.mz, R,
                                hipMemcpyDeviceToDevice, c.s));
   }
-  DQ_TRY(la_flush(c));
+  // the last weight-gradient launches go to the side stream BEFORE the LinearAttention slot reduce is queued on the main stream: the
+  // side stream waits for an event recorded here, and recorded behind the reduce it made those launches (init_conv, the MS1 convs:
+  // ~80 us) start only when the ~100 us reduce had finished -- an exposed tail in front of the join
   DQ_TRY(side_flush(c));
+  DQ_TRY(la_flush(c));
   DQ_TRY(join_side(c));
   // time embedding: all scale/shift heads + the MLP -- after the join: the per-sample d(scale, shift) of the fused ResnetBlocks are
   // summed on the side stream
@@ -779,7 +782,8 @@ int wgrad_async(const Ctx& c, const ConvWgrad& w) {
     // the weight-gradient kernels behind the main chain (measured: 15.7 vs 13.0 ms/step under torch.distributed.run).
     int prio_least = 0, prio_greatest = 0;
     DQ_HIP_OK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    DQ_HIP_OK(hipStreamCreateWithPriority(&pl->side_stream, hipStreamNonBlocking, prio_greatest));
+    static const bool low = [] { const char* e = std::getenv("DQ_SIDE_PRIO"); return e && e[0] == 'l'; }();  // A-B switch
+    DQ_HIP_OK(hipStreamCreateWithPriority(&pl->side_stream, hipStreamNonBlocking, low ? prio_least : prio_greatest));
     for (auto& e : pl->events) DQ_HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   hipEvent_t ev = pl->events[pl->ev_next++ % dq_plan::NUM_EVENTS];

@@ -10,6 +10,7 @@
 // wave-uniform addresses (scalar loads).  No LDS.
 #include "dq_common.h"
 #include "dq_kernels.h"
+#include <cstdlib>
 
 namespace dq {
 
@@ -726,6 +727,12 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce_multi(WgradMulti m) {
   }
 }
 
+// blocks in flight per conv of a weight-gradient launch (A-B switch DQ_WGRAD_BLOCKS)
+static int wgrad_blocks() {
+  static const int v = [] { const char* e = std::getenv("DQ_WGRAD_BLOCKS"); return e ? std::max(64, std::atoi(e)) : 2048; }();
+  return v;
+}
+
 // count <= 3 stride-1 convs with identical (rows, n_in == n_out); each descriptor carries its own scratch region
 int launch_conv_wgrad_multi(const ConvWgrad* w, int count, hipStream_t s) {
   DQ_REQUIRE(count >= 1 && count <= 3, "conv_wgrad_multi: 1..3 convs");
@@ -734,6 +741,9 @@ int launch_conv_wgrad_multi(const ConvWgrad* w, int count, hipStream_t s) {
   const int64_t total = (int64_t)w[0].rows * w[0].n_out;
   if (total == 0) return 0;
   DQ_REQUIRE(total < (1ll << 31), "conv_wgrad: rows*n must be below 2^31");
+  for (int i = 0; i < count; ++i)
+    DQ_REQUIRE(w[i].du && w[i].inA && w[i].dw && w[i].scratch && w[i].cout > 0 && w[i].cinA > 0 && w[i].rows == w[0].rows &&
+               w[i].n_in == w[i].n_out && w[i].n_out == w[0].n_out, "conv_wgrad_multi: missing operand / different rows");
   const bool vec4 = w[0].n_out % 4 == 0;
   for (int i = 0; i < count; ++i) {
     const ConvWgrad& a = w[i];
@@ -746,7 +756,7 @@ int launch_conv_wgrad_multi(const ConvWgrad* w, int count, hipStream_t s) {
     m.n_cib[i] = n_cib;
     m.nelem_w[i] = a.cout * cin * a.K;
     m.tiles[i] = n_cob * n_cib;
-    m.gx[i] = std::max(1, std::min({cdiv(total, 256 * (vec4 ? 8 : 4)), WGRAD_MAX_PARTS, std::max(1, 2048 / m.tiles[i])}));
+    m.gx[i] = std::max(1, std::min({cdiv(total, 256 * (vec4 ? 8 : 4)), WGRAD_MAX_PARTS, std::max(1, wgrad_blocks() / m.tiles[i])}));
     DQ_REQUIRE((int64_t)m.gx[i] * (m.nelem_w[i] + a.cout) <= a.scratch_floats, "conv_wgrad_multi: scratch too small");
     gx_max = std::max(gx_max, m.gx[i]); tiles_max = std::max(tiles_max, m.tiles[i]);
     nelem_max = std::max(nelem_max, m.nelem_w[i] + a.cout);
@@ -772,7 +782,7 @@ int launch_conv_wgrad(const ConvWgrad& a, hipStream_t s) {
   const int nelem_w = a.cout * cin * a.K;
   // <= WGRAD_MAX_PARTS partial blocks per element; ~4 items per thread, ~2048 blocks in flight where the problem allows it
   const bool vec4 = a.mode == CONV_S1 && (a.K == 1 || a.K == 3) && a.n_out % 4 == 0 && a.n_in == a.n_out;
-  const int gx = std::max(1, std::min({cdiv(total, 256 * (vec4 ? 8 : 4)), WGRAD_MAX_PARTS, std::max(1, 2048 / (n_cob * n_cib))}));
+  const int gx = std::max(1, std::min({cdiv(total, 256 * (vec4 ? 8 : 4)), WGRAD_MAX_PARTS, std::max(1, wgrad_blocks() / (n_cob * n_cib))}));
   DQ_REQUIRE((int64_t)gx * (nelem_w + a.cout) <= a.scratch_floats, "conv_wgrad: scratch too small");
   dim3 grid(gx, n_cob * n_cib), block(256);
   if (vec4) {
