@@ -3,23 +3,30 @@
 // k_linattn.hip (per head: M[d][c] = sum_n K[d][n] xh[c][n], P[c][n] = sum_d M[d][c] Q[d][n], ypre = sum_h W2_h P_h + b with
 // W2_h = Wo_h Wv_h), differentiated in that form -- no 32x32 context / value tiles exist in either direction.
 //
-// One launch does the whole block (rows of up to 64 positions; longer rows: k_la_long.hip + two k_block_bwd):
-//   (1) post-norm backward, recomputed per head from the saved pre-norm output (per position, over channels: in-lane
-//       + one swap with lane^32)                                                   -> dYpre ; d g_out, d b_out (head 0 only)
-//   (2) per head, recomputing the forward in registers:
+// One launch does the whole block (rows of up to 64 positions; longer rows: k_la_long.hip + two k_block_bwd).  A workgroup is FOUR
+// waves = the FOUR heads of the same units (a unit = one row of 32 / 64 positions, or 32 / n rows of n < 32 positions): every wave
+//   (1) does the post-norm backward from the saved pre-norm output (per position, over channels: in-lane + one swap with lane^32;
+//       the four waves load the same x / ypre / dy at the same time: HBM sees them once)      -> dYpre ; d g_out, d b_out (head 0's wave)
+//   (2) for ITS head, recomputing the forward in registers:
 //         dP[c][n] = sum_c' W2[c'][c] dYpre[c'][n]                  VALU, C x C per position
 //         dW2[c'][c] += sum_n dYpre[c'][n] P[c][n]                  4x4x1 MFMA, both operands staged [c][n] in LDS
 //         dQ[d][n] = sum_c M[d][c] dP[c][n]   ; dK^T[n][d] = sum_c xh[c][n] dM[d][c]      32x32x2 MFMA with K = C
 //         dM^T[c][d] = sum_n dP[c][n] Q[d][n]                       4x4x1 MFMA (B = Q^T tile)
 //         softmax backward of q (over d, in-lane) and k (over n, in-lane in the K^T orientation)
-//         dXh += Wq^T dq_raw + Wk^T dk_raw + sum_d K[d][n] dM[d][c]                        4x4x1 MFMA
+//         dXh_h = Wq^T dq_raw + Wk^T dk_raw + sum_d K[d][n] dM[d][c]                       4x4x1 MFMA
 //         dWq += xh dq_raw^T, dWk += xh dk_raw^T                     4x4x1 MFMA
 //       Short rows (n < 32, 32/n rows per wave): the masked quadratic form S^T[n'][n] = sum_d K[d][n'] Q[d][n],
 //       R[c][n] = sum_n' xh[c][n'] S^T[n'][n] in place of M / P.
-//   (3) in the last head's pass: residual + pre-norm backward on the completed dXh -> dx += dy + d/dx ; d g_pre
-// dWv and dWo follow from dW2 once per (wave, head): dWo_h = dW2_h Wv_h^T, dWv_h = Wo_h^T dW2_h.
-// All parameter gradients go to this wave's partial slot (plain stores) and are summed by k_linattn_dw_reduce in a fixed
-// order: no atomics, bitwise repeatable.  Orientation changes (q -> q^T etc.) go through a wave-private 32x33 LDS tile.
+//   (3) publishes dXh_h to an LDS exchange buffer; behind ONE workgroup barrier per unit the last head's wave sums the four heads (in
+//       head order) and does the residual + pre-norm backward -> dx (+)= dy + d/dx ; d g_pre.  dXh never goes through HBM.
+// (Until round 2 every wave walked its units once per head: x / ypre / dy were loaded and normalised four times by different waves at
+// different times, dXh was read-modified-written through HBM per head, and a wave flushed its weight-gradient registers four times --
+// 25-40 % of a wave's life at 12 / 16 channels.  Heads across the waves of a block: one flush per wave, a slot per BLOCK instead of per
+// wave (4x less slot traffic for the reduce), 10-25 % per launch, tools/probe/la_bwd_time.hip.)
+// dWv and dWo follow from the summed dW2 once per layer (k_linattn_dwvo): dWo_h = dW2_h Wv_h^T, dWv_h = Wo_h^T dW2_h.
+// All parameter gradients go to the block's partial slot (plain stores, each head's wave its own sections) and are summed by
+// k_linattn_dw_reduce_multi in a fixed order: no atomics, bitwise repeatable.  Orientation changes (q -> q^T etc.) go through a
+// wave-private 32x33 LDS tile.  Rows of ONE position have a closed form: k_linattn_bwd1.
 #include "dq_common.h"
 #include "dq_kernels.h"
 #include "dq_mfma.h"
@@ -49,10 +56,9 @@ __device__ __forceinline__ f32x16 tr32(f32x16 a, float* tile, int col, int half)
 struct LinAttnBwdK {
   const float* x; const float* ypre; const float* dy;  // (rows, C, n): block input, saved pre-norm output, d loss / d y
   float* dx;                                            // += d loss / d x (incl. the residual)
-  float* dxh;                                           // scratch (rows, C, n): dXh accumulated over heads 0..2
   const float* w_qkv; const float* w_out; const float* g_pre; const float* g_out;
-  float* part;  // per-wave partial slots: [wave][la_slot(C)] = dWq | dWk (256 C) | dW2 per head (4 C C) | d g_out | d b_out | d g_pre
-  int rows; int units_per_wave;
+  float* part;  // partial slots (per block; per wave for rows of one position): [slot][la_slot(C)] = dWq | dWk (256 C) | dW2 per head (4 C C) | d g_out | d b_out | d g_pre
+  int rows; int units_per_wave;  // units per BLOCK in k_linattn_bwd (its four waves share them), per wave in k_linattn_bwd1
   const float* prep;  // nullable: W2 (4 C C floats) prepared by launch_linattn_prepare
   int dx_store;       // dx is written, not accumulated into (its old contents are not read)
 #ifdef DQ_LA_PROBE
@@ -95,6 +101,7 @@ __device__ __forceinline__ float half_sum(float v) {
 constexpr bool la_two_waves(int C, int N) { return C == 4 || (C == 8 && (N == 32 || N == 8)); }
 template <int C, int N>
 __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_bwd(LinAttnBwdK a) {
+  static_assert(N >= 2, "rows of one position: k_linattn_bwd1");
   constexpr int NB = N >= 32 ? N / 32 : 1;
   constexpr int RW = N >= 32 ? 1 : 32 / N;
   constexpr int NJ = la_nj(C);  // x registers per lane; register j holds channel la_chan(C, j, half)
@@ -113,6 +120,11 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
   __shared__ float tiles[4][32 * 33];
   // per wave: xh | dYpre | P (normalised) | dP as [c][n] ; M | dM as [c][d] ; dW2 of the head being flushed [c'][c] and [c][c']
   __shared__ __attribute__((aligned(16))) float stage[4][4 * C * NP + 2 * C * 32 + 2 * C * C];
+  // d xh of the four heads of one unit, [parity of the unit][head][c][n]: double-buffered so that ONE barrier per unit is enough (a
+  // wave that runs ahead writes the other parity; it cannot reach this parity again before the barrier of the unit in between).
+  // The 64-position C >= 12 variants have no LDS left for the second buffer and pay a second barrier instead.
+  constexpr bool EX2 = !(C >= 12 && N == 64);
+  __shared__ float exch[(EX2 ? 2 : 1) * 4 * C * NP];
   DQ_STAMP(0);
   for (int i = threadIdx.x; i < 2 * 4 * 2 * C * 16; i += blockDim.x) {
     const int r = i & 15, c = (i >> 4) % C, hh = (i / (16 * C)) & 1, hd = (i / (32 * C)) & 3, m = i / (128 * C);
@@ -130,11 +142,6 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
     }
   }
   __syncthreads();
-  if (N == 1) {  // rows of one position use sum_h W2_h only (closed form below): fold the heads into slot 0
-    for (int i = threadIdx.x; i < C * C; i += blockDim.x)
-      w2_lds[i] = ((w2_lds[i] + w2_lds[C * C + i]) + w2_lds[2 * C * C + i]) + w2_lds[3 * C * C + i];
-    __syncthreads();
-  }
   DQ_STAMP(1);
 
   const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wv = threadIdx.x >> 6;
@@ -146,10 +153,9 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
   float* ms = dps + C * NP;
   float* dms = ms + C * 32;
   float* w2g = dms + C * 32;
-  const int wave_id = blockIdx.x * (blockDim.x >> 6) + wv;
   const int n_units = (a.rows + RW - 1) / RW;
-  const int u0 = wave_id * a.units_per_wave;
-  if (u0 >= n_units) return;
+  const int u0 = blockIdx.x * a.units_per_wave;  // (units per BLOCK here: its four waves walk the same units, one head each)
+  if (u0 >= n_units) return;                     // (the whole block)
   const int u1 = min(n_units, u0 + a.units_per_wave);
   const float sqC = sqrtf((float)C);
   const float scale = 0.17677669529663687f;
@@ -191,12 +197,9 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
     return t0 + t1;
   };
 
-#pragma unroll 1
-  for (int hd = 0; hd < 4; ++hd) {
-    // rows of ONE position: every head contributes the same closed form (see below), so the rows are walked once (in the
-    // hd = 0 pass, which then is the first AND the last head's pass) and the passes hd = 1..3 only flush their dWv / dWo
-    const bool first = N == 1 || hd == 0, last = N == 1 || hd == 3;
-    const bool walk = N != 1 || hd == 0;
+  {
+    const int hd = wv;  // this wave's head
+    const bool first = hd == 0, last = hd == 3;
     float wq[NJ], wk[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -215,10 +218,9 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
 #pragma unroll
       for (int g2 = 0; g2 < CG; ++g2) gw2[g][g2] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    float nacc0[NJ], nacc1[NJ];  // norm-gain / bias gradient partials: head 0: (d g_out, d b_out); head 3: (d g_pre, -)
-    float nacc2[NJ];
+    float nacc0[NJ], nacc1[NJ];  // norm-gain / bias gradient partials: head 0's wave: (d g_out, d b_out); head 3's: (d g_pre, -)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) nacc0[j] = nacc1[j] = nacc2[j] = 0.f;
+    for (int j = 0; j < NJ; ++j) nacc0[j] = nacc1[j] = 0.f;
 
     // raw operands of one unit (row block): loaded one unit AHEAD when the registers allow it (C <= 8), so that the global
     // latency hides behind the previous unit's MFMAs -- with one wave per SIMD nothing else would cover it
@@ -243,7 +245,7 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
     if (PREFETCH) load_unit(u0);
 
 #pragma unroll 1
-    for (int u = u0; u < (walk ? u1 : u0); ++u) {
+    for (int u = u0; u < u1; ++u) {
       const int row = u * RW + rl;
       const bool row_ok = row < a.rows;
       // ---- x, ypre, dy; pre-norm recompute; post-norm backward (same arithmetic as k_block_bwd) -> DY = dYpre
@@ -255,18 +257,16 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
 #pragma unroll
         for (int j = 0; j < NJ; ++j) { cx[b][j] = px[b][j]; cu[b][j] = pu[b][j]; cd[b][j] = pd[b][j]; }
       if (PREFETCH && u + 1 < u1) load_unit(u + 1);
-      // what the tail of this iteration reads back -- dXh of the earlier heads, and dx in the last head's pass -- is requested
-      // now, so that its latency hides behind the MFMA work instead of stalling the read-modify-write at the end
-      float pdxh[NB][NJ], pdx[NB][NJ];
+      // what the tail of this iteration reads back -- dx, in the last head's wave when it accumulates -- is requested now, so that
+      // its latency hides behind the MFMA work instead of stalling the read-modify-write at the end
+      float pdx[NB][NJ];
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const int c = la_chan(C, j, half);
           const int64_t off = ((int64_t)row * C + c) * N + (N >= 32 ? b * 32 + col : col % N);
-          const bool ok = row_ok && c < C;
-          pdxh[b][j] = (PREFETCH && ok && !first) ? a.dxh[off] : 0.f;
-          pdx[b][j] = (PREFETCH && ok && last && !a.dx_store) ? a.dx[off] : 0.f;
+          pdx[b][j] = (PREFETCH && row_ok && c < C && last && !a.dx_store) ? a.dx[off] : 0.f;
         }
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
@@ -433,23 +433,7 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
         return o;
       };
 
-      if (N == 1) {
-        // ================= rows of ONE position: closed form =================
-        // softmax over a single position is 1 and the q softmax sums to 1: S = 32^-0.5 whatever Wq, Wk are, so
-        // R = 32^-0.5 xh, dWq = dWk = 0, dXh = 32^-0.5 W2^T dYpre and dW2 += dYpre (32^-0.5 xh)^T for every head
-        float dR[C];
-        make_dp(0, dR);
-        if (half == 0) {
-#pragma unroll
-          for (int c = 0; c < C; ++c) ps[c * NP + col] = scale * xs[c * NP + col];
-        }
-#pragma unroll
-        for (int g = 0; g < CG; ++g)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) part[0][g][i] = half == 0 ? scale * dR[g * 4 + i] : 0.f;  // (the halves are added below)
-        wfence();
-        add_dw2();
-      } else if (N >= 32) {
+      if (N >= 32) {
         // ================= one row per wave: M / P form =================
         // M[d = col][c] (both lane halves hold the total) and its [c][d] image for the P chains
         float Mr[C];
@@ -592,42 +576,37 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
         add_dxh(0, 1, tr32(dk_rawT, tile, col, half));
       }
 
-      // ---- d xh of this head: both halves' partial sums, then each lane keeps its own channels
-      if (!PREFETCH) {
-        // no registers to hold these across the MFMA work: requested here, but all of them before the first store below (a
-        // load placed after a store to the same array waits for it -- 8 serial round trips per unit and head otherwise)
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            const int c = la_chan(C, j, half);
-            const int64_t off = ((int64_t)row * C + c) * N + (N >= 32 ? b * 32 + col : col % N);
-            const bool ok = row_ok && c < C;
-            pdxh[b][j] = (ok && !first) ? a.dxh[off] : 0.f;
-            pdx[b][j] = (ok && last && !a.dx_store) ? a.dx[off] : 0.f;
-          }
-      }
+      // ---- d xh of this head: both halves' partial sums; each lane publishes its own channels to the block's exchange buffer, and
+      // the last head's wave sums the four heads (in head order) behind the barrier.  Nothing of d xh goes through HBM.
+      float* ex = exch + ((EX2 ? ((u - u0) & 1) : 0) * 4 + hd) * (C * NP);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        const int pos = N >= 32 ? b * 32 + col : col % N;
-        float full[C], tot[NJ];
+        float full[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) full[c] = part[b][c >> 2][c & 3] + swp32(part[b][c >> 2][c & 3]);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const int c = la_chan(C, j, half);
-          const float val = own(full, j);
-          float lo = 0.f;  // this lane's total dXh of channel c (heads 0..3), only formed in the last head's pass
-          if (row_ok && c < C) {
-            float* dst = a.dxh + ((int64_t)row * C + c) * N + pos;
-            // head 0 initialises, heads 1, 2 accumulate (same lane, same address); C > 8 has no registers for the prefetch
-            const float prev = pdxh[b][j];
-            if (!last) *dst = prev + val;
-            else lo = prev + val;
-          }
-          tot[j] = lo;
+          if (c < C) ex[c * NP + b * 32 + col] = own(full, j);
+          // (no registers to hold dx across the MFMA work in these variants: requested here, in front of the barrier)
+          if (!PREFETCH && row_ok && c < C && last && !a.dx_store)
+            pdx[b][j] = a.dx[((int64_t)row * C + c) * N + (N >= 32 ? b * 32 + col : col % N)];
         }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int pos = N >= 32 ? b * 32 + col : col % N;
+        float tot[NJ];
         if (last) {
+          const float* e0 = exch + (EX2 ? ((u - u0) & 1) : 0) * 4 * (C * NP);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int c = la_chan(C, j, half);
+            const int e = (c < C ? c : 0) * NP + b * 32 + col;
+            const float v = ((e0[e] + e0[C * NP + e]) + e0[2 * C * NP + e]) + e0[3 * C * NP + e];
+            tot[j] = (row_ok && c < C) ? v : 0.f;
+          }
           // ---- residual + pre-norm backward on the completed dXh (own channels c = la_chan(C, j, half)); dx += dy + d/dx
           float xv[NJ];
           float ssq = 0.f;
@@ -643,8 +622,7 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
             const float uh = xv[j] * inv;
-            if (N == 1) nacc2[j] = fmaf(tot[j], uh * sqC, nacc2[j]);  // d g_pre (its own accumulator when one pass is first and last)
-            else nacc0[j] = fmaf(tot[j], uh * sqC, nacc0[j]);
+            nacc0[j] = fmaf(tot[j], uh * sqC, nacc0[j]);  // d g_pre (this wave's nacc0: d g_out lives in head 0's wave)
             const float gd = tot[j] * gpre[j] * sqC;
             xv[j] = uh;
             tot[j] = gd;
@@ -663,11 +641,13 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
           }
         }
       }
+      if (!EX2) __syncthreads();  // (single exchange buffer: nobody overwrites it before the last head's wave has read it)
     }
 
-    DQ_STAMP(2 + 2 * hd);
-    // ---- flush this head's gradients to this wave's partial slot (plain stores; the ordered reduce kernel sums the slots)
-    float* slot = a.part + (int64_t)wave_id * la_slot(C);
+    DQ_STAMP(2);
+    // ---- flush this head's gradients to its sections of the BLOCK's partial slot (plain stores; the ordered reduce kernel sums the
+    // slots): once per wave -- with the heads walked one after the other by every wave this was four flushes per wave
+    float* slot = a.part + (int64_t)blockIdx.x * la_slot(C);
 #pragma unroll
     for (int g = 0; g < CG; ++g)
 #pragma unroll
@@ -681,7 +661,7 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
           slot[(128 + hd * 32 + col) * C + c] = vk;
         }
       }
-    if (hd == 1) DQ_STAMP(10);
+    DQ_STAMP(10);
     // dW2 of this head: sum the 16 position blocks (lanes with equal lane & 3) and publish [c'][c] to the slot.  dWv = Wo^T dW2 and
     // dWo = dW2 Wv^T are linear in dW2, so they are formed ONCE per layer from the slot SUM (k_linattn_dwvo, after the ordered
     // reduce) instead of once per (wave, head) here: that was 2 C loads + C^2 FMAs + 2 C stores per lane and head (3-5 k of a
@@ -691,7 +671,6 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
     // this replaces was 4 C^2 dependent LDS round trips per head: 8 us of a 25 us head at 16 channels (tools/probe/la_bwd_time.hip).
     constexpr int NV4 = CG * CG * 16;  // floats one row contributes: [value vi = (g1 * CG + g2) * 4 + i][j = lane & 3]
     wfence();
-    if (walk) {  // (1-position rows: dW2 is the same for every head and stays in w2g from the hd = 0 pass)
 #pragma unroll
     for (int g1 = 0; g1 < CG; ++g1)
 #pragma unroll
@@ -713,27 +692,221 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
         w2g[(4 * g1 + i) * C + 4 * g2 + j] = v;
       }
     }
-    }
     wfence();
-    if (hd == 1) DQ_STAMP(11);
+    DQ_STAMP(11);
     for (int i = lane; i < C * C; i += 64) slot[256 * C + hd * C * C + i] = w2g[i];
-    if (hd == 1) DQ_STAMP(12);
     constexpr int GB = 256 * C + 4 * C * C;  // [d g_out | d b_out | d g_pre]
-    if (hd == 0 || (hd == 3 && N != 1)) {  // norm gains / bias: sum over the 32 positions-lanes of this half, one lane stores
+    if (first || last) {  // norm gains / bias: sum over the 32 positions-lanes of this half, one lane stores
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int c = la_chan(C, j, half);
-        const float s0 = half_sum(nacc0[j]), s1 = half_sum(nacc1[j]), s2 = N == 1 ? half_sum(nacc2[j]) : 0.f;
+        const float s0 = half_sum(nacc0[j]), s1 = half_sum(nacc1[j]);
         if (col == 0 && c < C) {
-          if (hd == 0) {
-            slot[GB + c] = s0; slot[GB + C + c] = s1;
-            if (N == 1) slot[GB + 2 * C + c] = s2;
-          }
-          else slot[GB + 2 * C + c] = s0;
+          if (first) { slot[GB + c] = s0; slot[GB + C + c] = s1; }  // d g_out, d b_out
+          else slot[GB + 2 * C + c] = s0;                          // d g_pre
         }
       }
     }
-    DQ_STAMP(3 + 2 * hd);
+    DQ_STAMP(3);
+  }
+}
+
+// Rows of ONE position (the deepest level of the default U-Net): a closed form.  The softmax over a single position is 1 and the q
+// softmax sums to 1, so S = 32^-0.5 whatever Wq and Wk are: R = 32^-0.5 xh, dWq = dWk = 0, dXh = 32^-0.5 (sum_h W2_h)^T dYpre and
+// dW2_h = dYpre (32^-0.5 xh)^T for every head.  One wave per 32 rows (lane = (row, channel half)), per-WAVE slots in the layout of
+// k_linattn_bwd (the q / k sections are written as zeros, the dW2 section four times).
+template <int C>
+__global__ void __launch_bounds__(256) k_linattn_bwd1(LinAttnBwdK a) {
+  constexpr int NJ = la_nj(C), CG = C / 4, NP = 32;
+  __shared__ __attribute__((aligned(16))) float w2_lds[4 * C * C];
+  __shared__ float tiles[4][32 * 33];
+  __shared__ __attribute__((aligned(16))) float stage[4][3 * C * NP + C * C];  // per wave: xh | dYpre | 32^-0.5 xh as [c][row] ; dW2
+  if (a.prep) {
+    for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) w2_lds[i] = a.prep[i];
+  } else {
+    for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) {
+      const int c = i % C, cp = (i / C) % C, hd = i / (C * C);
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) s = fmaf(a.w_out[cp * 128 + hd * 32 + e], a.w_qkv[(256 + hd * 32 + e) * C + c], s);
+      w2_lds[i] = s;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * C; i += blockDim.x)  // sum_h W2_h into slot 0
+    w2_lds[i] = ((w2_lds[i] + w2_lds[C * C + i]) + w2_lds[2 * C * C + i]) + w2_lds[3 * C * C + i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wv = threadIdx.x >> 6;
+  float* tile = tiles[wv];
+  float* xs = stage[wv];
+  float* dys = xs + C * NP;
+  float* ps = dys + C * NP;
+  float* w2g = ps + C * NP;
+  const int wave_id = blockIdx.x * (blockDim.x >> 6) + wv;
+  const int n_units = (a.rows + 31) / 32;
+  const int u0 = wave_id * a.units_per_wave;
+  if (u0 >= n_units) return;
+  const int u1 = min(n_units, u0 + a.units_per_wave);
+  const float sqC = sqrtf((float)C);
+  const float scale = 0.17677669529663687f;
+  float gpre[NJ], gout[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = la_chan(C, j, half);
+    gpre[j] = c < C ? a.g_pre[c] : 0.f;
+    gout[j] = c < C ? a.g_out[c] : 0.f;
+  }
+  f32x4 gw2[CG][CG];  // dW2[c' = 4*g1 + i][c = 4*g2 + (lane&3)], partial over the rows of this 4-lane block
+#pragma unroll
+  for (int g = 0; g < CG; ++g)
+#pragma unroll
+    for (int g2 = 0; g2 < CG; ++g2) gw2[g][g2] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float nacc0[NJ], nacc1[NJ], nacc2[NJ];  // d g_out, d b_out, d g_pre
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) nacc0[j] = nacc1[j] = nacc2[j] = 0.f;
+
+#pragma unroll 1
+  for (int u = u0; u < u1; ++u) {
+    const int row = u * 32 + col;
+    const bool row_ok = row < a.rows;
+    float xv[NJ], uv[NJ], dv_[NJ], Xh[NJ], DY[NJ], pdx[NJ];
+    float ssq = 0.f, usq = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = la_chan(C, j, half);
+      const bool ok = row_ok && c < C;
+      const int64_t off = (int64_t)row * C + c;
+      xv[j] = ok ? a.x[off] : 0.f;
+      uv[j] = ok ? a.ypre[off] : 0.f;
+      dv_[j] = ok ? a.dy[off] : 0.f;
+      pdx[j] = (ok && !a.dx_store) ? a.dx[off] : 0.f;
+      ssq = fmaf(xv[j], xv[j], ssq);
+      usq = fmaf(uv[j], uv[j], usq);
+    }
+    // ---- pre-norm recompute; post-norm backward (same arithmetic as k_block_bwd) -> DY = dYpre
+    ssq += swp32(ssq);
+    usq += swp32(usq);
+    const float nrm = sqrtf(ssq);
+    const float inv = sqC / fmaxf(nrm, RMS_EPS);
+    const float unrm = sqrtf(usq);
+    const float uinv = 1.0f / fmaxf(unrm, RMS_EPS);
+    float dot = 0.f;
+    float gdv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      Xh[j] = xv[j] * inv * gpre[j];
+      const float uh = uv[j] * uinv;
+      nacc0[j] = fmaf(dv_[j], uh * sqC, nacc0[j]);  // d g_out
+      gdv[j] = dv_[j] * gout[j] * sqC;
+      uv[j] = uh;
+      dot = fmaf(gdv[j], uh, dot);
+    }
+    dot += swp32(dot);
+    const bool uclamped = unrm < RMS_EPS;  // F.normalize clamps the norm: below eps the map is linear
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      DY[j] = uclamped ? gdv[j] * uinv : uinv * (gdv[j] - uv[j] * dot);
+      nacc1[j] += DY[j];  // d b_out (bias of to_out)
+    }
+    // stage xh, 32^-0.5 xh and dYpre as [c][row]: 4x4x1 operands, and every lane needs ALL channels of dYpre of its row
+    wfence();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = la_chan(C, j, half);
+      if (c < C) {
+        xs[c * NP + col] = Xh[j];
+        ps[c * NP + col] = scale * Xh[j];
+        dys[c * NP + col] = DY[j];
+      }
+    }
+    wfence();
+    // dR[c] = sum_c' (sum_h W2_h)[c'][c] dYpre[c'] ; dXh = 32^-0.5 dR
+    float dR[C];
+    {
+      float dya[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) { dya[c] = dys[c * NP + col]; dR[c] = 0.f; }
+#pragma unroll
+      for (int cp = 0; cp < C; ++cp)
+#pragma unroll
+        for (int c = 0; c < C; ++c) dR[c] = fmaf(w2_lds[cp * C + c], dya[cp], dR[c]);
+    }
+    // dW2[c'][c] += sum_rows dYpre[c'][row] (32^-0.5 xh)[c][row]: row = 16 * s + (lane >> 2)
+#pragma unroll
+    for (int s = 0; s < NP / 16; ++s) {
+      const int n = 16 * s + (lane >> 2);
+#pragma unroll
+      for (int g1 = 0; g1 < CG; ++g1) {
+        const float av = dys[(4 * g1 + (lane & 3)) * NP + n];
+#pragma unroll
+        for (int g2 = 0; g2 < CG; ++g2) gw2[g1][g2] = mfma4(av, ps[(4 * g2 + (lane & 3)) * NP + n], gw2[g1][g2]);
+      }
+    }
+    // ---- residual + pre-norm backward on dXh (own channels); dx += dy + d/dx
+    const float pinv = 1.0f / fmaxf(nrm, RMS_EPS);
+    float tot[NJ], uh2[NJ];
+    float dot2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c0 = la_chan(C, j, 0), c1 = la_chan(C, j, 1);
+      const float lo = c0 < C ? dR[c0 < C ? c0 : 0] : 0.f, hi = c1 < C ? dR[c1 < C ? c1 : 0] : 0.f;
+      const float dxh = row_ok ? scale * (half ? hi : lo) : 0.f;
+      uh2[j] = xv[j] * pinv;
+      nacc2[j] = fmaf(dxh, uh2[j] * sqC, nacc2[j]);  // d g_pre
+      tot[j] = dxh * gpre[j] * sqC;
+      dot2 = fmaf(tot[j], uh2[j], dot2);
+    }
+    dot2 += swp32(dot2);
+    const bool clamped = nrm < RMS_EPS;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = la_chan(C, j, half);
+      if (row_ok && c < C) {
+        const float du = clamped ? tot[j] * pinv : pinv * (tot[j] - uh2[j] * dot2);
+        a.dx[(int64_t)row * C + c] = (pdx[j] + dv_[j]) + du;
+      }
+    }
+  }
+
+  // ---- flush: zeros for dWq | dWk, the block sum of dW2 for each of the four heads, the gains
+  float* slot = a.part + (int64_t)wave_id * la_slot(C);
+  for (int i = lane; i < 256 * C; i += 64) slot[i] = 0.f;
+  constexpr int NV4 = CG * CG * 16;
+  wfence();
+#pragma unroll
+  for (int g1 = 0; g1 < CG; ++g1)
+#pragma unroll
+    for (int g2 = 0; g2 < CG; ++g2)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = gw2[g1][g2][i];
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, false));  // row_ror:4
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));  // row_ror:8
+        if ((lane & 15) < 4) tile[(lane >> 4) * NV4 + ((g1 * CG + g2) * 4 + i) * 4 + (lane & 3)] = v;
+      }
+  wfence();
+#pragma unroll
+  for (int t = 0; t < (NV4 + 63) / 64; ++t) {
+    const int e = lane + 64 * t;
+    if (e < NV4) {
+      const float v = (tile[e] + tile[NV4 + e]) + (tile[2 * NV4 + e] + tile[3 * NV4 + e]);
+      const int vi = e >> 2, j = e & 3, i = vi & 3, g2 = (vi >> 2) % CG, g1 = (vi >> 2) / CG;
+      w2g[(4 * g1 + i) * C + 4 * g2 + j] = v;
+    }
+  }
+  wfence();
+  for (int i = lane; i < C * C; i += 64) {
+    const float v = w2g[i];
+#pragma unroll
+    for (int hd = 0; hd < 4; ++hd) slot[256 * C + hd * C * C + i] = v;
+  }
+  constexpr int GB = 256 * C + 4 * C * C;  // [d g_out | d b_out | d g_pre]
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = la_chan(C, j, half);
+    const float s0 = half_sum(nacc0[j]), s1 = half_sum(nacc1[j]), s2 = half_sum(nacc2[j]);
+    if (col == 0 && c < C) { slot[GB + c] = s0; slot[GB + C + c] = s1; slot[GB + 2 * C + c] = s2; }
   }
 }
 
@@ -845,36 +1018,46 @@ static void launch_one(const LinAttnBwdK& kk, int waves, hipStream_t s) {
 
 template <int C>
 static int linattn_bwd_n(const LinAttnBwdK& k, int n, const LinAttnBwd& g, hipStream_t s) {
-  const int64_t k_part_floats = g.part_floats;  // one resident round: 1 wave per SIMD (2 at C = 4), and a partial slot each
+  // one resident round: 1 block of four waves (= the four heads) per CU, 2 where the kernel runs two waves per SIMD; a partial slot
+  // per block.  Rows of one position: a wave per 32 rows, a slot per wave.
+  const int64_t k_part_floats = g.part_floats;
+  const int slots_max = (int)((k_part_floats - 4 * C * C) / la_slot(C));
+  LinAttnBwdK kk = k;
+  int slots = 0;
 #define DQ_LB(NN)                                                                                  \
   case NN: {                                                                                       \
     constexpr int RW = NN >= 32 ? 1 : 32 / NN;                                                     \
     const int units = cdiv(k.rows, RW);                                                            \
-    LinAttnBwdK kk = k;                                                                            \
-    /* (4 C C floats behind the slots hold the summed dW2 between the reduce and k_linattn_dwvo) */ \
-    const int max_waves = std::min(la_two_waves(C, NN) ? 2048 : 1024, (int)((k_part_floats - 4 * C * C) / la_slot(C)));  \
-    kk.units_per_wave = std::max(1, cdiv(units, max_waves));                                       \
-    const int waves = cdiv(units, kk.units_per_wave);                                              \
-    launch_one<C, NN>(kk, waves, s);                                                               \
-    if (g.defer_reduce) {                                                                          \
-      *g.waves_out = waves;                                                                        \
-      if (g.w2sum_out) *g.w2sum_out = kk.part + (int64_t)waves * la_slot(C);                       \
-    } else {                                                                                       \
-      const LaReduceItem it{kk.part, waves, C, g.dw_qkv, g.dw_out, g.dg_out, g.db_out, g.dg_pre, kk.part + (int64_t)waves * la_slot(C), \
-                            k.w_qkv, k.w_out};                                                     \
-      if (int rc = launch_linattn_dw_reduce_multi(&it, 1, s)) return rc;                           \
-    }                                                                                              \
+    const int max_blocks = std::min(la_two_waves(C, NN) ? 512 : 256, slots_max);                   \
+    kk.units_per_wave = std::max(1, cdiv(units, max_blocks));                                      \
+    slots = cdiv(units, kk.units_per_wave);                                                        \
+    launch_one<C, NN>(kk, 4 * slots, s);                                                           \
     break;                                                                                         \
   }
   switch (n) {
-    DQ_LB(1) DQ_LB(2) DQ_LB(4) DQ_LB(8) DQ_LB(16) DQ_LB(32) DQ_LB(64)
+    case 1: {
+      const int units = cdiv(k.rows, 32);
+      kk.units_per_wave = std::max(1, cdiv(units, std::min(1024, slots_max)));
+      slots = cdiv(units, kk.units_per_wave);
+      hipLaunchKernelGGL((k_linattn_bwd1<C>), dim3(cdiv(slots, 4)), dim3(256), 0, s, kk);
+      break;
+    }
+    DQ_LB(2) DQ_LB(4) DQ_LB(8) DQ_LB(16) DQ_LB(32) DQ_LB(64)
     default:
       set_error("linattn_bwd: m/z length " + std::to_string(n) + " is not built (powers of two up to 64)");
       return 2;
   }
 #undef DQ_LB
   DQ_LAUNCH_CHECK();
-  return 0;
+  /* (4 C C floats behind the slots hold the summed dW2 between the reduce and k_linattn_dwvo) */
+  if (g.defer_reduce) {
+    *g.waves_out = slots;
+    if (g.w2sum_out) *g.w2sum_out = kk.part + (int64_t)slots * la_slot(C);
+    return 0;
+  }
+  const LaReduceItem it{kk.part, slots, C, g.dw_qkv, g.dw_out, g.dg_out, g.db_out, g.dg_pre, kk.part + (int64_t)slots * la_slot(C),
+                        k.w_qkv, k.w_out};
+  return launch_linattn_dw_reduce_multi(&it, 1, s);
 }
 
 // one slot per wave of a resident round + the summed dW2
@@ -935,7 +1118,7 @@ int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s) {
     return launch_block_bwd(b1, s);
   }
   LinAttnBwdK k;
-  k.x = a.f.x; k.ypre = a.ypre; k.dy = a.dy; k.dx = a.dx; k.dxh = a.dxh; k.w_qkv = a.f.w_qkv; k.w_out = a.f.w_out;
+  k.x = a.f.x; k.ypre = a.ypre; k.dy = a.dy; k.dx = a.dx; k.w_qkv = a.f.w_qkv; k.w_out = a.f.w_out;
   k.g_pre = a.f.g_pre; k.g_out = a.f.g_out; k.part = a.part; k.rows = rows; k.units_per_wave = 1;
   k.prep = a.f.prep; k.dx_store = a.dx_store;
   switch (C) {
