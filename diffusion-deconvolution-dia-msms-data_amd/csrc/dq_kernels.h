@@ -130,7 +130,7 @@ struct ResBwd {
   float* gpart = nullptr; int64_t gpart_floats = 0; int* gblocks = nullptr;
   int C = 0, rows = 0, n = 0, rows_per_sample = 1;
 };
-bool res_fusable(int n, int C);
+bool res_fusable(int n, int C, int rows_per_sample);  // rows_per_sample == 1: the bottleneck (one RT row per sample, <= 512 positions)
 // k_res_cp.hip: channel-parallel variant for the deep levels (n <= 8, C = 12 / 16); launch_res_fwd / _bwd dispatch to it
 bool res_cp_usable(int n, int C, int cinA, int cinB);
 int launch_res_fwd_cp(const ResFwd& a, hipStream_t s);

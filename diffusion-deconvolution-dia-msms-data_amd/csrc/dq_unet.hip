@@ -176,7 +176,7 @@ int side_flush(const Ctx& c);
 // ResnetBlock forward (unet1d.py:302-323): input = cat(A, B)
 int res_fwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, int cinA, const float* inB, int cinB, int rows, int n,
             int rows_per_sample) {
-  if (rows_per_sample > 1 && res_fusable(n, r.cout)) {  // m/z levels: one fused launch
+  if (res_fusable(n, r.cout, rows_per_sample)) {  // m/z levels, and a bottleneck of up to 512 RT positions: one fused launch
     ResFwd k;
     k.inA = inA; k.inB = inB; k.cinA = cinA; k.cinB = cinB;
     k.w1 = c.prm(r.c1.w); k.b1 = c.prm(r.c1.b); k.g1 = c.prm(r.g1);
@@ -215,8 +215,8 @@ int res_fwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, int 
 int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, float* dA, int cinA, const float* inB, float* dB, int cinB,
             int rows, int n, int rows_per_sample, int storeA = 0, int storeB = 0) {
   const float* dout = c.g(b.out);
-  if (rows_per_sample > 1 && res_fusable(n, r.cout)) {
-    // m/z levels: the whole data path in one launch, then the three weight-gradient launches
+  if (res_fusable(n, r.cout, rows_per_sample)) {
+    // m/z levels (and a bottleneck of up to 512 RT positions): the whole data path in one launch, then the three weight-gradient launches
     ResBwd k;
     k.dout = dout; k.u1 = c.w(b.u1); k.u2 = c.w(b.u2);
     k.w1 = c.prm(r.c1.w); k.w2 = c.prm(r.c2.w); k.wr = r.res.cout ? c.prm(r.res.w) : nullptr;
@@ -303,7 +303,6 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
   if (r.res.cout) {
     ConvWgrad wr;
     wr.scratch = c.w(c.ar.wg); wr.scratch_floats = c.ar.wg_floats;
-  wr.scratch = c.w(c.ar.wg); wr.scratch_floats = c.ar.wg_floats;
     wr.du = dout; wr.inA = inA; wr.inB = inB; wr.cinA = cinA; wr.cinB = cinB; wr.cout = r.cout; wr.K = 1; wr.mode = CONV_S1;
     wr.rows = rows; wr.n_in = n; wr.n_out = n; wr.dw = c.dprm(r.res.w); wr.dbias = c.dprm(r.res.b);
     DQ_TRY(wgrad_async(c, wr));

@@ -95,10 +95,10 @@ __device__ __forceinline__ float half_sum(float v) {
 }
 
 // Two waves per SIMD (a 256-register budget, enforced through the launch bounds) where the spills that costs stay small: C = 4, and
-// C = 8 with rows of 32 / 8 positions (measured with tools/probe/la_bwd_time.hip, 12,800 rows: <8,32> 316 -> 260 us, <8,8> 126 -> 119 us;
-// <8,16> needs 172 B of scratch per lane at 256 registers and gains nothing, so it keeps its 340 registers and one wave per SIMD, as do
-// C = 12 / 16).  The partner wave covers the latencies the one-unit-ahead prefetch was there for, so those variants run without it.
-constexpr bool la_two_waves(int C, int N) { return C == 4 || (C == 8 && (N == 32 || N == 8)); }
+// C = 8 with rows of 32 / 16 / 8 positions (measured with tools/probe/la_bwd_time.hip, 12,800 rows: <8,16> 183 -> 161 us with 44 B of
+// scratch per lane; C = 12 / 16 need 386 / 466 registers and keep one wave per SIMD).  The partner wave covers the latencies the
+// one-unit-ahead prefetch was there for, so those variants run without it.
+constexpr bool la_two_waves(int C, int N) { return C == 4 || (C == 8 && (N == 32 || N == 16 || N == 8)); }
 template <int C, int N>
 __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_bwd(LinAttnBwdK a) {
   static_assert(N >= 2, "rows of one position: k_linattn_bwd1");
@@ -1016,10 +1016,25 @@ static void launch_one(const LinAttnBwdK& kk, int waves, hipStream_t s) {
   else hipLaunchKernelGGL((k_linattn_bwd<C, NN>), dim3(cdiv(waves, 4)), dim3(256), 0, s, kk);
 }
 
+// workgroups of k_linattn_bwd<C, NN> one resident round holds on this device
+template <int C, int NN>
+static int la_resident_blocks() {
+  if constexpr (C >= 12 && NN == 64) return 256;  // (the second translation unit's kernels: one wave per SIMD)
+  else {
+    static const int v = [] {
+      int occ = 1, dev = 0, cus = 256;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_linattn_bwd<C, NN>, 256, 0) != hipSuccess) occ = 1;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+      return std::max(1, occ) * std::max(1, cus);
+    }();
+    return v;
+  }
+}
+
 template <int C>
 static int linattn_bwd_n(const LinAttnBwdK& k, int n, const LinAttnBwd& g, hipStream_t s) {
-  // one resident round: 1 block of four waves (= the four heads) per CU, 2 where the kernel runs two waves per SIMD; a partial slot
-  // per block.  Rows of one position: a wave per 32 rows, a slot per wave.
+  // one resident round of blocks of four waves (= the four heads): 1-3 per CU, as the kernel's registers / LDS allow; a partial slot per
+  // block.  Rows of one position: a wave per 32 rows, a slot per wave.
   const int64_t k_part_floats = g.part_floats;
   const int slots_max = (int)((k_part_floats - 4 * C * C) / la_slot(C));
   LinAttnBwdK kk = k;
@@ -1028,7 +1043,7 @@ static int linattn_bwd_n(const LinAttnBwdK& k, int n, const LinAttnBwd& g, hipSt
   case NN: {                                                                                       \
     constexpr int RW = NN >= 32 ? 1 : 32 / NN;                                                     \
     const int units = cdiv(k.rows, RW);                                                            \
-    const int max_blocks = std::min(la_two_waves(C, NN) ? 512 : 256, slots_max);                   \
+    const int max_blocks = std::min(la_resident_blocks<C, NN>(), slots_max);                       \
     kk.units_per_wave = std::max(1, cdiv(units, max_blocks));                                      \
     slots = cdiv(units, kk.units_per_wave);                                                        \
     launch_one<C, NN>(kk, 4 * slots, s);                                                           \

@@ -27,13 +27,13 @@ __device__ __forceinline__ void exch_sync(bool wave_local) {
 }
 }
 
-template <int C>
-__global__ void __launch_bounds__(256) k_res_fwd(ResFwd a) {
-  __shared__ float sh[C][256 + 2];
+template <int C, int BS>
+__global__ void __launch_bounds__(BS) k_res_fwd(ResFwd a) {
+  __shared__ float sh[C][BS + 2];
   const int b = blockIdx.y;
   const int per_sample = a.rows_per_sample * a.n;
   const bool wave_local = a.n <= 64 && (64 % a.n) == 0;
-  const int it = blockIdx.x * 256 + threadIdx.x;
+  const int it = blockIdx.x * BS + threadIdx.x;
   const bool live = it < per_sample;
   const int row = b * a.rows_per_sample + (live ? it / a.n : 0), p = live ? it % a.n : 0;
   const int cin = a.cinA + a.cinB;
@@ -148,23 +148,33 @@ __global__ void __launch_bounds__(256) k_res_fwd(ResFwd a) {
   for (int co = 0; co < C; ++co) a.out[obase + (int64_t)co * a.n] = o[co];
 }
 
-bool res_fusable(int n, int C) { return n >= 1 && n <= 256 && (256 % n) == 0 && (C == 4 || C == 8 || C == 12 || C == 16); }
+// m/z levels: many rows per sample, the row length divides the block's 256 positions.  Bottleneck: ONE row per sample (its RT axis) of
+// up to 512 positions = one block per sample, whatever the length (no row can straddle a block then).
+bool res_fusable(int n, int C, int rows_per_sample) {
+  if (!(C == 4 || C == 8 || C == 12 || C == 16) || n < 1) return false;
+  return rows_per_sample == 1 ? n <= 512 : (n <= 256 && (256 % n) == 0);
+}
+namespace {
+int res_block_size(int n, int rows_per_sample) { return rows_per_sample == 1 && n > 256 ? 512 : 256; }
+}
 
 int launch_res_fwd(const ResFwd& a, hipStream_t s) {
-  DQ_REQUIRE(res_fusable(a.n, a.C), "res_fwd: row length must divide 256 and C be 4/8/12/16");
+  DQ_REQUIRE(res_fusable(a.n, a.C, a.rows_per_sample), "res_fwd: row length must divide 256 (or one row of <= 512 per sample) and C be 4/8/12/16");
   DQ_REQUIRE(a.rows % a.rows_per_sample == 0, "res_fwd: rows must be a multiple of rows_per_sample");
   DQ_REQUIRE(a.wr || (a.cinA == a.C && a.cinB == 0), "res_fwd: identity residual needs C input channels");
-  if (res_cp_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_fwd_cp(a, s);
-  if (res_v4_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_fwd_v4(a, s);
+  if (a.rows_per_sample > 1 && res_cp_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_fwd_cp(a, s);
+  if (a.rows_per_sample > 1 && res_v4_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_fwd_v4(a, s);
   DQ_REQUIRE(a.cinA == a.C && a.cinB <= a.C && (a.cinB == 0 || a.inB), "res_fwd: input must be C channels (+ at most C skip channels)");
   const int B = a.rows / a.rows_per_sample;
-  dim3 grid(cdiv((int64_t)a.rows_per_sample * a.n, 256), B), block(256);
-  switch (a.C) {
-    case 4: hipLaunchKernelGGL((k_res_fwd<4>), grid, block, 0, s, a); break;
-    case 8: hipLaunchKernelGGL((k_res_fwd<8>), grid, block, 0, s, a); break;
-    case 12: hipLaunchKernelGGL((k_res_fwd<12>), grid, block, 0, s, a); break;
-    case 16: hipLaunchKernelGGL((k_res_fwd<16>), grid, block, 0, s, a); break;
-  }
+  const int BS = res_block_size(a.n, a.rows_per_sample);
+  dim3 grid(cdiv((int64_t)a.rows_per_sample * a.n, BS), B), block(BS);
+#define DQ_RF(CC)                                                                \
+  case CC:                                                                       \
+    if (BS == 512) hipLaunchKernelGGL((k_res_fwd<CC, 512>), grid, block, 0, s, a); \
+    else hipLaunchKernelGGL((k_res_fwd<CC, 256>), grid, block, 0, s, a);          \
+    break;
+  switch (a.C) { DQ_RF(4) DQ_RF(8) DQ_RF(12) DQ_RF(16) }
+#undef DQ_RF
   DQ_LAUNCH_CHECK();
   return 0;
 }
@@ -203,10 +213,10 @@ __device__ __forceinline__ void norm_act_bwd(const float* u, float* d, const flo
 }
 }  // namespace
 
-template <int C>
-__global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
-  __shared__ float sh[C][256 + 2];
-  __shared__ float red[4][4 * C];
+template <int C, int BS>
+__global__ void __launch_bounds__(BS) k_res_bwd(ResBwd a) {
+  __shared__ float sh[C][BS + 2];
+  __shared__ float red[BS / 64][4 * C];
   // the block's weights in LDS: read from memory inside the channel loops they are scalar loads that nothing overlaps
   __shared__ float w2s[C * C * 3], w1s[C * 2 * C * 3], wrs[C * 2 * C];
   {
@@ -220,7 +230,7 @@ __global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
   const int b = blockIdx.y;
   const int per_sample = a.rows_per_sample * a.n;
   const bool wave_local = a.n <= 64 && (64 % a.n) == 0;
-  const int it = blockIdx.x * 256 + threadIdx.x;
+  const int it = blockIdx.x * BS + threadIdx.x;
   const bool live = it < per_sample;
   const int row = b * a.rows_per_sample + (live ? it / a.n : 0), p = live ? it % a.n : 0;
   const int cin = a.cinA + a.cinB;
@@ -337,28 +347,33 @@ __global__ void __launch_bounds__(256) k_res_bwd(ResBwd a) {
   __syncthreads();
   // every block leaves its four sums [dg2 | dg1 | dscale | dshift] in its own slot of gpart; launch_part_reduce adds them up in
   // block order (repeatable to the bit: no float atomics)
-  for (int i = threadIdx.x; i < 4 * C; i += blockDim.x)
-    a.gpart[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (4 * C) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+  for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) {
+    float v = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    if (BS == 512) v += (red[4][i] + red[5][i]) + (red[6][i] + red[7][i]);
+    a.gpart[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (4 * C) + i] = v;
+  }
 }
 
 int launch_res_bwd(const ResBwd& a, hipStream_t s) {
-  DQ_REQUIRE(res_fusable(a.n, a.C), "res_bwd: row length must divide 256 and C be 4/8/12/16");
+  DQ_REQUIRE(res_fusable(a.n, a.C, a.rows_per_sample), "res_bwd: row length must divide 256 (or one row of <= 512 per sample) and C be 4/8/12/16");
   DQ_REQUIRE(a.rows % a.rows_per_sample == 0, "res_bwd: rows must be a multiple of rows_per_sample");
   DQ_REQUIRE(a.wr || (a.cinA == a.C && a.cinB == 0), "res_bwd: identity residual needs C input channels");
   DQ_REQUIRE(a.cinA + a.cinB <= 2 * a.C, "res_bwd: a block input wider than two C-channel tensors is not built");
   if (a.gblocks) *a.gblocks = 0;
-  if (res_cp_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_bwd_cp(a, s);
+  if (a.rows_per_sample > 1 && res_cp_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_bwd_cp(a, s);
   const int B = a.rows / a.rows_per_sample;
-  dim3 grid(cdiv((int64_t)a.rows_per_sample * a.n, 256), B), block(256);
+  const int BS = res_block_size(a.n, a.rows_per_sample);
+  dim3 grid(cdiv((int64_t)a.rows_per_sample * a.n, BS), B), block(BS);
   ResBwd k = a;
   DQ_REQUIRE(k.gpart && k.gblocks && k.gpart_floats >= (int64_t)grid.x * grid.y * 4 * a.C, "res_bwd: partial-sum slot missing or too small");
   *k.gblocks = (int)grid.x;  // blocks per sample
-  switch (a.C) {
-    case 4: hipLaunchKernelGGL((k_res_bwd<4>), grid, block, 0, s, k); break;
-    case 8: hipLaunchKernelGGL((k_res_bwd<8>), grid, block, 0, s, k); break;
-    case 12: hipLaunchKernelGGL((k_res_bwd<12>), grid, block, 0, s, k); break;
-    case 16: hipLaunchKernelGGL((k_res_bwd<16>), grid, block, 0, s, k); break;
-  }
+#define DQ_RB(CC)                                                                \
+  case CC:                                                                       \
+    if (BS == 512) hipLaunchKernelGGL((k_res_bwd<CC, 512>), grid, block, 0, s, k); \
+    else hipLaunchKernelGGL((k_res_bwd<CC, 256>), grid, block, 0, s, k);          \
+    break;
+  switch (a.C) { DQ_RB(4) DQ_RB(8) DQ_RB(12) DQ_RB(16) }
+#undef DQ_RB
   DQ_LAUNCH_CHECK();
   return 0;
 }

@@ -38,7 +38,9 @@ static void run(int rows) {
   k.w_qkv = dev_rand(384 * C, 0.3f, 6); k.w_out = dev_rand(128 * C, 0.3f, 7); k.g_pre = dev_rand(C, 1.f, 8); k.g_out = dev_rand(C, 1.f, 9);
   // the launcher's grid (linattn_bwd_n): a block of four waves (= heads) per unit range, one resident round; N = 1: a wave per range
   const int units = cdiv(rows, RW);
-  const int max_slots = N == 1 ? 1024 : (la_two_waves(C, N) ? 512 : 256);
+  int occ0 = 1;
+  if constexpr (N != 1) CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ0, k_linattn_bwd<C, N>, 256, 0));
+  const int max_slots = N == 1 ? 1024 : 256 * occ0;
   k.units_per_wave = std::max(1, cdiv(units, max_slots));
   const int slots = cdiv(units, k.units_per_wave);
   const int blocks = N == 1 ? cdiv(slots, 4) : slots, waves = 4 * blocks;
