@@ -408,6 +408,7 @@ def main():
     for i in range(args.steps):
         x0, c2, c1 = batches[i % len(batches)]
         loss = dm._train_one_batch(x0, ms2_cond=c2, ms1_cond=c1, sync=False)
+    host_issue_ms = (time.perf_counter() - t0) * 1e3 / max(1, args.steps)  # the host's share: all launches queued, nothing waited for
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -469,6 +470,7 @@ def main():
                                    "windows 400 RT x 64 m/z, batch 32 per GPU, fp32", "global_batch": world * TRAIN_BATCH,
                        "window": [RT, MZ], "parallelism": f"dp{world}"},
             "last_loss": round(last_loss, 6),
+            "host_issue_ms_per_step": round(host_issue_ms, 3),
             "build_id": __import__("dquartic._native", fromlist=["x"]).build_id(),
             # whole-step fractions per GPU: algorithmic FLOPs of fwd + bwd against the f32 matrix peak; compulsory bytes against HBM
             "whole_step": {"flop_frac": round(train_wps / world * FLOPS_TRAIN / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),

@@ -734,6 +734,9 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     DQ_TRY(conv_plain_bwd(c, l.resample, l.last ? CONV_S1 : CONV_DOWN, c.w(b.la), c.g(b.rs), c.g(b.la), R, l.n, l.n_next, 1));
     DQ_TRY(la_bwd(c, l.la, b, c.w(b.r1.out), c.g(b.la), c.g(b.r1.out), R, l.n, lv));
     DQ_TRY(res_bwd(c, l.r1, b.r1, c.w(b.r0.out), c.g(b.r0.out), C, nullptr, nullptr, 0, R, l.n, RT));
+    // (the last level's weight gradients are the tail of the side stream, in front of the join: hand them over block by block, so that
+    // r1's run under r0's data path instead of behind it)
+    if (lv == 0) DQ_TRY(side_flush(c));
     DQ_TRY(res_bwd(c, l.r0, b.r0, c.w(in_off), c.g(in_off), C, nullptr, nullptr, 0, R, l.n, RT, lv > 0 ? 1 : 0, 0));  // (d h0 has the final block's part already)
     DQ_TRY(side_flush(c));
   }

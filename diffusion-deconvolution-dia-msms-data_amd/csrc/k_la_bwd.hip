@@ -981,17 +981,24 @@ __global__ void __launch_bounds__(256) k_linattn_dw_reduce_multi(LaReduceMulti m
   }
 }
 // dWv[e][c] += sum_c' Wo[c'][e] dW2[h(e)][c'][c] ; dWo[c'][e] += sum_c dW2[h(e)][c'][c] Wv[e][c]   (e = head * 32 + d: the 128 value /
-// output channels; W2_h = Wo_h Wv_h).  One block per layer.
+// output channels; W2_h = Wo_h Wv_h).  One block per (layer, head); the head's dW2 and weight slices in LDS (as
+// one block per layer with every operand read from memory in a runtime-length loop this was 42 us at the end of the backward).
 __global__ void __launch_bounds__(256) k_linattn_dwvo(LaReduceMulti m) {
   const LaReduceItem& it = m.it[blockIdx.x];
-  const int C = it.C;
-  for (int idx = threadIdx.x; idx < 128 * C; idx += blockDim.x) {
-    const int e = idx / C, c = idx - e * C;
-    const float* w2 = it.w2sum + (e >> 5) * C * C;
+  const int C = it.C, hd = blockIdx.y;
+  __shared__ float w2[16 * 16], wo[16 * 32], wv[32 * 16];  // dW2_h [c'][c] ; Wo[c'][e = hd*32 + d] as [c'][d] ; Wv[e][c] as [d][c]
+  for (int i = threadIdx.x; i < C * C; i += blockDim.x) w2[i] = it.w2sum[hd * C * C + i];
+  for (int i = threadIdx.x; i < 32 * C; i += blockDim.x) {
+    wo[i] = it.w_out[(i >> 5) * 128 + hd * 32 + (i & 31)];
+    wv[i] = it.w_qkv[(256 + hd * 32) * C + i];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 32 * C; idx += blockDim.x) {
+    const int d = idx / C, c = idx - d * C, e = hd * 32 + d;
     float sv = 0.f, so = 0.f;
     for (int k = 0; k < C; ++k) {
-      sv = fmaf(it.w_out[k * 128 + e], w2[k * C + c], sv);            // k = c'
-      so = fmaf(w2[c * C + k], it.w_qkv[(256 + e) * C + k], so);      // row c' = c of dW2, k = c
+      sv = fmaf(wo[k * 32 + d], w2[k * C + c], sv);   // k = c'
+      so = fmaf(w2[c * C + k], wv[d * C + k], so);    // row c' = c of dW2, k = c
     }
     it.dw_qkv[(256 + e) * C + c] += sv;
     it.dw_out[c * 128 + e] += so;
@@ -1091,7 +1098,7 @@ int launch_linattn_dw_reduce_multi(const LaReduceItem* items, int count, hipStre
   m.first_block[count] = blocks;
   hipLaunchKernelGGL(k_linattn_dw_reduce_multi, dim3(blocks), dim3(256), 0, s, m);
   DQ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_linattn_dwvo, dim3(count), dim3(256), 0, s, m);
+  hipLaunchKernelGGL(k_linattn_dwvo, dim3(count, 4), dim3(256), 0, s, m);
   DQ_LAUNCH_CHECK();
   return 0;
 }

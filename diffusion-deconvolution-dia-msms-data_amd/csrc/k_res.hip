@@ -4,9 +4,10 @@
 //             d(scale)/d(shift)                                                                                 (one launch)
 // instead of 2 and 5-6 launches of the generic kernels in k_conv.hip.  Thread = (row, position), all channels in
 // registers; the +-1 neighbours a k=3 conv needs of an intermediate (a1 forward; dU2, dU1 backward) are exchanged through
-// LDS inside the 256-thread block.  A block covers 256 consecutive positions of ONE sample (grid = (blocks per sample, B)),
-// rows never straddle blocks because the row length divides 256 -- the launcher refuses anything else (the bottleneck's
-// RT-long rows keep the unfused path).  Weight gradients stay in k_conv_wgrad (they read dU1 / dU2 written here).
+// LDS inside the block.  A block covers 256 consecutive positions of ONE sample (grid = (blocks per sample, B)); rows never
+// straddle blocks because the row length divides 256 -- or, at the bottleneck, because a sample IS one row (its RT axis, up to 512
+// positions) and gets one block of 256 / 512 threads; the launcher refuses anything else (longer RT axes keep the unfused path).
+// Weight gradients stay in k_conv_wgrad (they read dU1 / dU2 written here).
 #include "dq_common.h"
 #include "dq_kernels.h"
 
@@ -30,13 +31,21 @@ __device__ __forceinline__ void exch_sync(bool wave_local) {
 template <int C, int BS>
 __global__ void __launch_bounds__(BS) k_res_fwd(ResFwd a) {
   __shared__ float sh[C][BS + 2];
+  // the block's weights in LDS (broadcast reads): as scalar loads from memory inside the channel loops nothing overlapped their latency
+  // -- 33 us for the bottleneck's 16-channel block, one workgroup per sample
+  __shared__ float w2s[C * C * 3], w1s[C * 2 * C * 3], wrs[C * 2 * C];
+  const int cin = a.cinA + a.cinB;  // <= 2 C (checked by the launcher)
+  for (int i = threadIdx.x; i < C * C * 3; i += blockDim.x) w2s[i] = a.w2[i];
+  for (int i = threadIdx.x; i < C * cin * 3; i += blockDim.x) w1s[i] = a.w1[i];
+  if (a.wr)
+    for (int i = threadIdx.x; i < C * cin; i += blockDim.x) wrs[i] = a.wr[i];
+  __syncthreads();
   const int b = blockIdx.y;
   const int per_sample = a.rows_per_sample * a.n;
   const bool wave_local = a.n <= 64 && (64 % a.n) == 0;
   const int it = blockIdx.x * BS + threadIdx.x;
   const bool live = it < per_sample;
   const int row = b * a.rows_per_sample + (live ? it / a.n : 0), p = live ? it % a.n : 0;
-  const int cin = a.cinA + a.cinB;
   const float sqC = sqrtf((float)C);
   float acc[C];
   // ---- conv1 (k3, zero padding) over cat(A, B)
@@ -64,7 +73,7 @@ __global__ void __launch_bounds__(BS) k_res_fwd(ResFwd a) {
   for (int ci = 0; ci < C; ++ci)
 #pragma unroll
     for (int co = 0; co < C; ++co) {
-      const float* w = a.w1 + ((int64_t)co * cin + ci) * 3;
+      const float* w = w1s + (co * cin + ci) * 3;
       acc[co] = fmaf(w[0], xa[ci][0], fmaf(w[1], xa[ci][1], fmaf(w[2], xa[ci][2], acc[co])));
     }
   if (a.cinB) {
@@ -73,7 +82,7 @@ __global__ void __launch_bounds__(BS) k_res_fwd(ResFwd a) {
       if (ci < a.cinB) {
 #pragma unroll
         for (int co = 0; co < C; ++co) {
-          const float* w = a.w1 + ((int64_t)co * cin + C + ci) * 3;
+          const float* w = w1s + (co * cin + C + ci) * 3;
           acc[co] = fmaf(w[0], xb[ci][0], fmaf(w[1], xb[ci][1], fmaf(w[2], xb[ci][2], acc[co])));
         }
       }
@@ -108,7 +117,7 @@ __global__ void __launch_bounds__(BS) k_res_fwd(ResFwd a) {
 #pragma unroll 1
   for (int ci = 0; ci < C; ++ci) {  // not unrolled: C*C*3 weights would not fit in registers
     const float x0 = hasL ? sh[ci][threadIdx.x] : 0.f, x1 = sh[ci][threadIdx.x + 1], x2 = hasR ? sh[ci][threadIdx.x + 2] : 0.f;
-    const float* w = a.w2 + (int64_t)ci * 3;
+    const float* w = w2s + ci * 3;
 #pragma unroll
     for (int co = 0; co < C; ++co) o[co] = fmaf(w[co * C * 3 + 0], x0, fmaf(w[co * C * 3 + 1], x1, fmaf(w[co * C * 3 + 2], x2, o[co])));
   }
@@ -132,12 +141,12 @@ __global__ void __launch_bounds__(BS) k_res_fwd(ResFwd a) {
 #pragma unroll
     for (int ci = 0; ci < C; ++ci)
 #pragma unroll
-      for (int co = 0; co < C; ++co) o[co] = fmaf(a.wr[(int64_t)co * cin + ci], xa[ci][1], o[co]);
+      for (int co = 0; co < C; ++co) o[co] = fmaf(wrs[co * cin + ci], xa[ci][1], o[co]);
 #pragma unroll
     for (int ci = 0; ci < C; ++ci) {
       if (ci < a.cinB) {
 #pragma unroll
-        for (int co = 0; co < C; ++co) o[co] = fmaf(a.wr[(int64_t)co * cin + C + ci], xb[ci][1], o[co]);
+        for (int co = 0; co < C; ++co) o[co] = fmaf(wrs[co * cin + C + ci], xb[ci][1], o[co]);
       }
     }
   } else {
