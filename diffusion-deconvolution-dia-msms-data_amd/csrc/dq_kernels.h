@@ -191,8 +191,9 @@ struct LinAttn {
   const float* prep = nullptr;
 };
 int launch_linattn_fwd(const LinAttn& a, hipStream_t s);
-constexpr int LA_PREP_FLOATS = 1024 + 4096;  // [w2: 4 * 16 * 16][wqk: 2 * 4 * 8 * 2 * 32]
-struct LaPrepItem { const float* w_qkv; const float* w_out; int C; float* prep; };
+constexpr int LA_PREP_BOUNDED = 1024 + 4096;          // 1.0f when the layer's softmax logits are bounded by 64 for every input (k_linattn_prepare)
+constexpr int LA_PREP_FLOATS = 1024 + 4096 + 8;       // [w2: 4 * 16 * 16][wqk: 2 * 4 * 8 * 2 * 32][bounded, 7 unused]
+struct LaPrepItem { const float* w_qkv; const float* w_out; int C; float* prep; const float* g_pre; };
 constexpr int LA_PREP_MAX = 16;
 struct PrepCopy { const float* src; float* dst; int n; };  // plain copies riding in the same launch (aligned weight slots)
 constexpr int PREP_COPY_MAX = 4;

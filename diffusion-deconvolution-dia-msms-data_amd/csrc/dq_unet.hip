@@ -336,7 +336,7 @@ int la_prepare_all(const Ctx& c) {
   LaPrepItem items[LA_PREP_MAX];
   int count = 0;
   auto add = [&](const LAP& l) {
-    items[count] = LaPrepItem{c.prm(l.qkv_w), c.prm(l.out_w), l.C, c.w(c.ar.la_prep) + (int64_t)count * LA_PREP_FLOATS};
+    items[count] = LaPrepItem{c.prm(l.qkv_w), c.prm(l.out_w), l.C, c.w(c.ar.la_prep) + (int64_t)count * LA_PREP_FLOATS, c.prm(l.g_pre)};
     ++count;
   };
   if ((int)(p.downs.size() + p.ups.size()) > LA_PREP_MAX) return 0;  // (callers then pass slot -1)

@@ -59,7 +59,7 @@ struct LinAttnBwdK {
   const float* w_qkv; const float* w_out; const float* g_pre; const float* g_out;
   float* part;  // partial slots (per block; per wave for rows of one position): [slot][la_slot(C)] = dWq | dWk (256 C) | dW2 per head (4 C C) | d g_out | d b_out | d g_pre
   int rows; int units_per_wave;  // units per BLOCK in k_linattn_bwd (its four waves share them), per wave in k_linattn_bwd1
-  const float* prep;  // nullable: W2 (4 C C floats) prepared by launch_linattn_prepare
+  const float* prep;  // nullable: this layer's LA_PREP_FLOATS prepared by launch_linattn_prepare (W2 = 4 C C floats, the bounded-logit flag)
   int dx_store;       // dx is written, not accumulated into (its old contents are not read)
 #ifdef DQ_LA_PROBE
   unsigned long long* probe;  // tools/probe/la_bwd_time.hip: [wave][16] shader-clock stamps
@@ -160,6 +160,7 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
   const float sqC = sqrtf((float)C);
   const float scale = 0.17677669529663687f;
   const float LOG2E = 1.4426950408889634f;
+  const bool bounded = a.prep && a.prep[LA_PREP_BOUNDED] != 0.f;  // (wave-uniform)
   const int rl = N >= 32 ? 0 : col / N;
   // norm gains of this lane's channels, once per wave (a load inside the row loop cannot be hoisted past the loop's stores
   // by the compiler and would sit on the critical path of every row)
@@ -379,21 +380,32 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
       }
 #pragma unroll
       for (int s0 = 0; s0 < 16; s0 += SEG) {
-        float m = -INFINITY;
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-          for (int r = s0; r < s0 + SEG; ++r) m = fmaxf(m, kT[b][r]);
-        if (PARTNER) m = fmaxf(m, swp32(m));
         float ssum = 0.f;
+        if (bounded) {  // |logit| <= 64 for every input (LA_PREP_BOUNDED, k_linattn_prepare): no shift by the row maximum, as in the forward
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+          for (int b = 0; b < NB; ++b)
 #pragma unroll
-          for (int r = s0; r < s0 + SEG; ++r) {
-            const float e = __builtin_amdgcn_exp2f(kT[b][r] - m);
-            kT[b][r] = e;
-            ssum += e;
-          }
+            for (int r = s0; r < s0 + SEG; ++r) {
+              const float e = __builtin_amdgcn_exp2f(kT[b][r]);
+              kT[b][r] = e;
+              ssum += e;
+            }
+        } else {
+          float m = -INFINITY;
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = s0; r < s0 + SEG; ++r) m = fmaxf(m, kT[b][r]);
+          if (PARTNER) m = fmaxf(m, swp32(m));
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = s0; r < s0 + SEG; ++r) {
+              const float e = __builtin_amdgcn_exp2f(kT[b][r] - m);
+              kT[b][r] = e;
+              ssum += e;
+            }
+        }
         if (PARTNER) ssum += swp32(ssum);
         const float rs = 1.0f / ssum;
 #pragma unroll
@@ -406,15 +418,23 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
         f32x16 q = {0};
 #pragma unroll
         for (int j = 0; j < NJ; ++j) q = mfma32b(wq[j], Xh[b][j], q);
-        float m = q[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) m = fmaxf(m, q[r]);
-        m = fmaxf(m, swp32(m));
         float ssum = 0.f;
+        if (bounded) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          q[r] = __builtin_amdgcn_exp2f(q[r] - m);
-          ssum += q[r];
+          for (int r = 0; r < 16; ++r) {
+            q[r] = __builtin_amdgcn_exp2f(q[r]);
+            ssum += q[r];
+          }
+        } else {
+          float m = q[0];
+#pragma unroll
+          for (int r = 1; r < 16; ++r) m = fmaxf(m, q[r]);
+          m = fmaxf(m, swp32(m));
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            q[r] = __builtin_amdgcn_exp2f(q[r] - m);
+            ssum += q[r];
+          }
         }
         ssum += swp32(ssum);
         const float qs = scale / ssum;

@@ -22,6 +22,7 @@
 #include "dq_common.h"
 #include "dq_kernels.h"
 #include "dq_mfma.h"
+#include <algorithm>
 
 namespace dq {
 
@@ -89,14 +90,17 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wv = threadIdx.x >> 6;
   float* xs = xs_lds[wv];
   float* ms = ms_lds[wv];
-  const int unit = blockIdx.x * (blockDim.x >> 6) + wv;
-  const int row0 = unit * RW;
-  if (row0 >= a.rows) return;
   const int rl = N >= 32 ? 0 : col / N;
-  const int row = row0 + rl;
-  const bool row_ok = row < a.rows;
   const float sqC = sqrtf((float)C);
   const float scale = 0.17677669529663687f;  // 32^-0.5
+  const bool bounded = a.prep && a.prep[LA_PREP_BOUNDED] != 0.f;  // (wave-uniform: a scalar load)
+  // ONE unit per wave.  (A wave walking several units of a resident grid, so that the weight staging above is paid once per resident
+  // block instead of once per four units, was measured: the sampling leg went from 879 back to 842 windows/s -- the many short
+  // blocks are what hides this kernel's latencies.)
+  const int unit = blockIdx.x * (blockDim.x >> 6) + wv;
+  if (unit * RW >= a.rows) return;
+  const int row = unit * RW + rl;
+  const bool row_ok = row < a.rows;
 
   // ---- load x, pre-norm; stage xh as [c][n] for the 4x4x1 A operands
   float X[NB][NJ], Xh[NB][NJ];
@@ -189,21 +193,32 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
     for (int s = 0; s < 16 / SEG; ++s) krs_seg[s] = 1.f;
 #pragma unroll
     for (int s0 = 0; s0 < 16; s0 += SEG) {
-      float m = -INFINITY;
-#pragma unroll
-      for (int blk = 0; blk < NB; ++blk)
-#pragma unroll
-        for (int r = s0; r < s0 + SEG; ++r) m = fmaxf(m, kT[blk][r]);
-      if (PARTNER) m = fmaxf(m, swap32(m));
       float ssum = 0.f;
+      if (bounded) {  // |logit| <= 64 whatever the input (see LA_PREP_BOUNDED): 2^logit needs no shift by the row maximum
 #pragma unroll
-      for (int blk = 0; blk < NB; ++blk)
+        for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
-        for (int r = s0; r < s0 + SEG; ++r) {
-          const float e = __builtin_amdgcn_exp2f(kT[blk][r] - m);  // k rows are pre-scaled by log2(e)
-          kT[blk][r] = e;
-          ssum += e;
-        }
+          for (int r = s0; r < s0 + SEG; ++r) {
+            const float e = __builtin_amdgcn_exp2f(kT[blk][r]);  // k rows are pre-scaled by log2(e)
+            kT[blk][r] = e;
+            ssum += e;
+          }
+      } else {
+        float m = -INFINITY;
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+          for (int r = s0; r < s0 + SEG; ++r) m = fmaxf(m, kT[blk][r]);
+        if (PARTNER) m = fmaxf(m, swap32(m));
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+          for (int r = s0; r < s0 + SEG; ++r) {
+            const float e = __builtin_amdgcn_exp2f(kT[blk][r] - m);
+            kT[blk][r] = e;
+            ssum += e;
+          }
+      }
       if (PARTNER) ssum += swap32(ssum);
       const float rs = 1.0f / ssum;
       if (N >= 32) krs = rs;
@@ -218,15 +233,23 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
       f32x16 q = {0};
 #pragma unroll
       for (int j = 0; j < NJ; ++j) q = mfma32(wq[j], Xh[blk][j], q);
-      float m = q[0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) m = fmaxf(m, q[r]);
-      m = fmaxf(m, swap32(m));
       float ssum = 0.f;
+      if (bounded) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        q[r] = __builtin_amdgcn_exp2f(q[r] - m);  // q rows are pre-scaled by log2(e)
-        ssum += q[r];
+        for (int r = 0; r < 16; ++r) {
+          q[r] = __builtin_amdgcn_exp2f(q[r]);  // q rows are pre-scaled by log2(e)
+          ssum += q[r];
+        }
+      } else {
+        float m = q[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m = fmaxf(m, q[r]);
+        m = fmaxf(m, swap32(m));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          q[r] = __builtin_amdgcn_exp2f(q[r] - m);
+          ssum += q[r];
+        }
       }
       ssum += swap32(ssum);
       qs = scale / ssum;
@@ -394,6 +417,27 @@ __global__ void __launch_bounds__(256) k_linattn_prepare(LaPrepMulti m) {
     const int cc = i & 31, hh = (i >> 5) & 1, j = (i >> 6) % NJ, hd = (i / (64 * NJ)) & 3, mm = i / (256 * NJ);
     const int c = la_chan(C, j, hh);
     it.prep[1024 + i] = c < C ? it.w_qkv[(mm * 128 + hd * 32 + cc) * C + c] * 1.4426950408889634f : 0.f;
+  }
+  // LA_PREP_BOUNDED: are the softmax logits bounded for EVERY input?  xh = x / max(|x|, eps) * sqrt(C) * g_pre has |xh| <= sqrt(C)
+  // max|g_pre|, so a logit (row r of Wq | Wk, in the log2 domain) is at most log2(e) |W_r| sqrt(C) max|g_pre| in magnitude.  Below 64
+  // the kernels evaluate softmax as 2^x / sum 2^x without the shift by the row maximum: the same function (fp32 keeps its relative
+  // precision over that range, the sums of <= 64 terms stay below 2^70), ~1/3 fewer VALU instructions per softmax.  Thread t = row t.
+  __shared__ float red[256];
+  {
+    float n2 = 0.f;
+    for (int c = 0; c < C; ++c) { const float w = it.w_qkv[threadIdx.x * C + c]; n2 = fmaf(w, w, n2); }
+    red[threadIdx.x] = n2;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if ((int)threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      float gm = 0.f;
+      for (int c = 0; c < C; ++c) gm = fmaxf(gm, fabsf(it.g_pre[c]));
+      const float bound = 1.4426950408889634f * sqrtf(red[0]) * sqrtf((float)C) * gm;
+      it.prep[LA_PREP_BOUNDED] = (bound <= 64.f) ? 1.f : 0.f;  // (a NaN anywhere compares false: the shifted form)
+    }
   }
 }
 int launch_linattn_prepare(const LaPrepItem* items, int count, hipStream_t s, const PrepCopy* copies, int n_copies) {

@@ -257,6 +257,62 @@ def test_default_net_grads_multiblock_attention(RT):
         assert err <= 2e-4 * max(float(ref.abs().max()), 1e-4 * gmax), (k, err)
 
 
+@pytest.mark.parametrize("qk_scale,gtol", [(1.0, 2e-4), (30.0, 1e-2)])
+def test_linattn_softmax_forms_through_the_whole_net(qk_scale, gtol):
+    """The LinearAttention kernels evaluate softmax without the shift by the row maximum when the layer's logits are bounded for
+    every input (log2(e) |W_row| sqrt(C) max|g_pre| <= 64, decided per layer by k_linattn_prepare) and with it otherwise.  Default
+    initialisation takes the first form; to_qkv rows scaled 30x push every layer into the second.  Same function: loss and all
+    parameter gradients vs the oracle's autograd in both.  (With logits of +-100 the softmaxes are nearly one-hot and the gradient is
+    ill-conditioned in fp32: the fp32 oracle itself is 5e-3 away from its float64 evaluation there, hence the 1e-2 for that case.)"""
+    from oracle import dq_oracle as O
+    from dquartic.model.model import DDIMDiffusionModel
+    from dquartic.model.unet1d import UNet1d
+
+    torch.manual_seed(21)
+    net = UNet1d(dim=4, channels=1, dim_mults=(1, 2, 2, 3, 3, 4, 4), conditional=True, init_cond_channels=1,
+                 attn_cond_channels=1, downsample_dim=64, simple=True)
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            p.add_(0.05 * torch.randn_like(p))
+        sd = net.state_dict()
+        n_scaled = 0
+        for k in sd:
+            if k.endswith("to_qkv.weight") and sd[k].shape[0] == 384:  # LinearAttention: q | k | v rows; scale q and k
+                sd[k][:256] *= qk_scale
+                n_scaled += 1
+        net.load_state_dict(sd)
+    assert n_scaled == 14
+    # the kernel's criterion, restated: which form does each layer take?
+    sd = net.state_dict()
+    for k in sd:
+        if k.endswith("to_qkv.weight") and sd[k].shape[0] == 384:
+            C = sd[k].shape[1]
+            g = sd[k.replace("fn.to_qkv.weight", "norm.g")].abs().max()
+            bound = 1.4426950408889634 * float(sd[k][:256, :, 0].norm(dim=1).max()) * C ** 0.5 * float(g)
+            assert (bound <= 64.0) == (qk_scale == 1.0), (k, bound)
+    po = {k: v.detach().clone().cpu() for k, v in net.state_dict().items()}
+    dm = DDIMDiffusionModel(model_class=net.cuda(), device="cuda")
+    od = O.Diffusion(po, O.UNetConfig(downsample_dim=64))
+    B, RT, MZ = 2, 24, 64
+    gen = torch.Generator().manual_seed(5)
+    x0, c2, c1 = torch.rand(B, RT, MZ, generator=gen), torch.rand(B, RT, MZ, generator=gen), torch.rand(B, RT, generator=gen)
+    t, nz = torch.tensor([3, 911]), torch.randn(B, RT, MZ, generator=gen)
+    keys = O.trainable_keys(po)
+    for k in keys:
+        po[k].requires_grad_(True)
+    lo, _ = od.train_loss(x0, c2, c1, t, nz)
+    lo.backward()
+    net.train()
+    loss = dm.train_step_fused(x0.cuda(), c2.cuda(), c1.cuda(), t=t.cuda(), noise=nz.cuda())
+    assert abs(float(loss.detach()) - float(lo.detach())) < 2e-5 * abs(float(lo.detach()))
+    gmax = max(float(po[k].grad.abs().max()) for k in keys)
+    named = dict(net.named_parameters())
+    for k in keys:
+        ref = po[k].grad
+        err = float((named[k].grad.cpu() - ref).abs().max())
+        assert err <= gtol * max(float(ref.abs().max()), 1e-4 * gmax), (k, err)
+
+
 def test_two_forwards_before_backward_keep_their_own_activations(golden):
     """two evaluations with grad enabled before one backward (micro-batches whose losses are summed) -- each forward
     owns its training workspace until its backward ran, so the summed gradient equals the sum of the separate gradients."""
