@@ -408,7 +408,9 @@ def main():
     for i in range(args.steps):
         x0, c2, c1 = batches[i % len(batches)]
         loss = dm._train_one_batch(x0, ms2_cond=c2, ms1_cond=c1, sync=False)
-    host_issue_ms = (time.perf_counter() - t0) * 1e3 / max(1, args.steps)  # the host's share: all launches queued, nothing waited for
+    # the host's share (all launches queued, nothing waited for); with many steps it includes the back-pressure of a full queue,
+    # i.e. it approaches ms_per_step from below -- the host's own cost is what a short run shows (~2.3 ms at --steps 20)
+    host_issue_ms = (time.perf_counter() - t0) * 1e3 / max(1, args.steps)
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], device=device, dtype=torch.float64)

@@ -1180,6 +1180,16 @@ int dq_linattn_bwd(const float* x, const float* ypre, const float* dy, float* dx
   a.ypre = ypre; a.dyp = scratch; a.dxh = scratch + (int64_t)rows * C * n;
   a.part = scratch + 2 * (int64_t)rows * C * n; a.part_floats = (int64_t)LA_MAX_WAVES * 512 * C;
   a.dy = dy; a.dx = dx; a.dw_qkv = dw_qkv; a.dw_out = dw_out; a.db_out = db_out; a.dg_pre = dg_pre; a.dg_out = dg_out;
+  if (la_short_row(n) && C % 4 == 0 && C <= 16) {
+    // the prepared weights of the network path (W2, the bounded-logit flag: k_linattn_prepare), so that this entry point runs the very
+    // kernel code a train step runs: carved from the tail of the slot scratch, of which short rows use a few per cent
+    constexpr int64_t PREP = (LA_PREP_FLOATS + 63) / 64 * 64;
+    a.part_floats -= PREP;
+    float* prep = a.part + a.part_floats;
+    const LaPrepItem it{w_qkv, w_out, C, prep, g_pre};
+    DQ_TRY(launch_linattn_prepare(&it, 1, (hipStream_t)stream));
+    a.f.prep = prep;
+  }
   return launch_linattn_bwd(a, (hipStream_t)stream);
 }
 

@@ -217,7 +217,7 @@ int dq_gemm_bf16x3(const float* A, const float* B, float* C, const float* bias, 
 int dq_linattn_fwd(const float* x, float* y, float* ypre /* nullable: pre-norm output saved for the backward */,
                    const float* w_qkv, const float* w_out, const float* b_out, const float* g_pre, const float* g_out, int C,
                    int rows, int n, void* stream);
-/* Backward: dx += d/dx, parameter gradients +=.  ypre from the forward; scratch: 2*rows*C*n + 1024*512*C floats. */
+/* Backward: dx += d/dx, parameter gradients +=.  ypre from the forward; scratch: 2*rows*C*n + 2048*512*C floats. */
 int dq_linattn_bwd(const float* x, const float* ypre, const float* dy, float* dx, const float* w_qkv, const float* w_out,
                    const float* b_out, const float* g_pre, const float* g_out, float* dw_qkv, float* dw_out, float* db_out,
                    float* dg_pre, float* dg_out, float* scratch, int C, int rows, int n, void* stream);
