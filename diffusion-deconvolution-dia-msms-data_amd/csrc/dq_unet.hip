@@ -732,6 +732,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     const int C = l.r0.cin;
     const int64_t in_off = lv == 0 ? a.h0 : a.downs[lv - 1].rs;
     DQ_TRY(conv_plain_bwd(c, l.resample, l.last ? CONV_S1 : CONV_DOWN, c.w(b.la), c.g(b.rs), c.g(b.la), R, l.n, l.n_next, 1));
+    if (lv == 0) DQ_TRY(side_flush(c));  // (last level: the resample conv's weight gradient under the LinearAttention backward, not in the tail)
     DQ_TRY(la_bwd(c, l.la, b, c.w(b.r1.out), c.g(b.la), c.g(b.r1.out), R, l.n, lv));
     DQ_TRY(res_bwd(c, l.r1, b.r1, c.w(b.r0.out), c.g(b.r0.out), C, nullptr, nullptr, 0, R, l.n, RT));
     // (the last level's weight gradients are the tail of the side stream, in front of the join: hand them over block by block, so that
