@@ -30,16 +30,38 @@ __device__ __forceinline__ void axpy4_pk(float (&acc)[4], const float (&x)[6], f
   acc[0] = a0.x; acc[1] = a0.y; acc[2] = a1.x; acc[3] = a1.y;
 }
 
-template <int C>
+// HASB: the input is cat(A, B) (up path); without it (down path) the second input's 6 C window registers do not exist and the
+// kernel fits one more wave per SIMD
+template <int C, bool HASB>
 __global__ void __launch_bounds__(256) k_res_fwd_v4(ResFwd a) {
   __shared__ float eL[C][256], eR[C][256];
+  // The block's weights in LDS, one 16-byte entry per (input channel, output channel): {w[k=0], w[k=1], w[k=2], res_conv weight} for
+  // conv1 over cat(A, B) (input channels 0..2C-1, absent ones zero) and {w0, w1, w2, -} for conv2.  As wave-uniform scalar loads
+  // straight from memory (fully unrolled: 600-800 of them at C = 8, in batches the 104 SGPRs can hold) their latency was exposed
+  // batch after batch with two waves per SIMD: 1.4 TB/s and 15 TFLOP/s at sampling batch sizes, bound by neither.
+  __shared__ __attribute__((aligned(16))) float w1q[2 * C][C][4], w2q[C][C][4];
+  {
+    const int cin_ = a.cinA + a.cinB;
+    for (int i = threadIdx.x; i < 2 * C * C; i += blockDim.x) {
+      const int co = i % C, ci = i / C;
+      const bool ok = ci < cin_;
+      const float* w = a.w1 + ((int64_t)co * cin_ + (ok ? ci : 0)) * 3;
+      w1q[ci][co][0] = ok ? w[0] : 0.f; w1q[ci][co][1] = ok ? w[1] : 0.f; w1q[ci][co][2] = ok ? w[2] : 0.f;
+      w1q[ci][co][3] = (ok && a.wr) ? a.wr[(int64_t)co * cin_ + ci] : 0.f;
+    }
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
+      const int co = i % C, ci = i / C;
+      const float* w = a.w2 + ((int64_t)co * C + ci) * 3;
+      w2q[ci][co][0] = w[0]; w2q[ci][co][1] = w[1]; w2q[ci][co][2] = w[2]; w2q[ci][co][3] = 0.f;
+    }
+    __syncthreads();
+  }
   const int b = blockIdx.y;
   const int n = a.n, n4 = n >> 2;
   const int per_sample4 = a.rows_per_sample * n4;
   const int it = blockIdx.x * 256 + threadIdx.x;
   const bool live = it < per_sample4;
   const int row = b * a.rows_per_sample + (live ? it / n4 : 0), q4 = live ? it % n4 : 0, p0 = q4 * 4;
-  const int cin = a.cinA + a.cinB;
   const float sqC = sqrtf((float)C);
   const bool hasL = live && q4 > 0, hasR = live && q4 + 1 < n4;
 
@@ -54,7 +76,7 @@ __global__ void __launch_bounds__(256) k_res_fwd_v4(ResFwd a) {
     xa[ci][5] = hasR ? src[4] : 0.f;
   }
 #pragma unroll
-  for (int ci = 0; ci < C; ++ci) {
+  for (int ci = 0; ci < (HASB ? C : 0); ++ci) {
     const bool ok = ci < a.cinB;
     const float* src = a.inB + ((int64_t)row * a.cinB + ci) * n + p0;
     const float4 v = (ok && live) ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -75,19 +97,17 @@ __global__ void __launch_bounds__(256) k_res_fwd_v4(ResFwd a) {
   for (int ci = 0; ci < C; ++ci)
 #pragma unroll
     for (int co = 0; co < C; ++co) {
-      const float* w = a.w1 + ((int64_t)co * cin + ci) * 3;
-      const float w0 = w[0], w1 = w[1], w2 = w[2];
-      conv3_pk(acc[co], xa[ci], w0, w1, w2);
+      const float4 w = *reinterpret_cast<const float4*>(w1q[ci][co]);
+      conv3_pk(acc[co], xa[ci], w.x, w.y, w.z);
     }
-  if (a.cinB) {
+  if (HASB) {
 #pragma unroll
     for (int ci = 0; ci < C; ++ci) {
       if (ci < a.cinB) {
 #pragma unroll
         for (int co = 0; co < C; ++co) {
-          const float* w = a.w1 + ((int64_t)co * cin + C + ci) * 3;
-          const float w0 = w[0], w1 = w[1], w2 = w[2];
-          conv3_pk(acc[co], xb[ci], w0, w1, w2);
+          const float4 w = *reinterpret_cast<const float4*>(w1q[C + ci][co]);
+          conv3_pk(acc[co], xb[ci], w.x, w.y, w.z);
         }
       }
     }
@@ -136,9 +156,8 @@ __global__ void __launch_bounds__(256) k_res_fwd_v4(ResFwd a) {
     win[5] = hasR ? eL[ci][threadIdx.x + 1] : 0.f;
 #pragma unroll
     for (int co = 0; co < C; ++co) {
-      const float* w = a.w2 + ((int64_t)co * C + ci) * 3;
-      const float w0 = w[0], w1 = w[1], w2 = w[2];
-      conv3_pk(o[co], win, w0, w1, w2);
+      const float4 w = *reinterpret_cast<const float4*>(w2q[ci][co]);
+      conv3_pk(o[co], win, w.x, w.y, w.z);
     }
   }
   if (!live) return;
@@ -167,18 +186,12 @@ __global__ void __launch_bounds__(256) k_res_fwd_v4(ResFwd a) {
 #pragma unroll
     for (int ci = 0; ci < C; ++ci)
 #pragma unroll
-      for (int co = 0; co < C; ++co) {
-        const float w = a.wr[(int64_t)co * cin + ci];
-        axpy4_pk(o[co], xa[ci], w);
-      }
+      for (int co = 0; co < C; ++co) axpy4_pk(o[co], xa[ci], w1q[ci][co][3]);
 #pragma unroll
-    for (int ci = 0; ci < C; ++ci) {
+    for (int ci = 0; ci < (HASB ? C : 0); ++ci) {
       if (ci < a.cinB) {
 #pragma unroll
-        for (int co = 0; co < C; ++co) {
-          const float w = a.wr[(int64_t)co * cin + C + ci];
-          axpy4_pk(o[co], xb[ci], w);
-        }
+        for (int co = 0; co < C; ++co) axpy4_pk(o[co], xb[ci], w1q[C + ci][co][3]);
       }
     }
   } else {
@@ -199,8 +212,13 @@ bool res_v4_usable(int n, int C, int cinA, int cinB) {
 int launch_res_fwd_v4(const ResFwd& a, hipStream_t s) {
   const int B = a.rows / a.rows_per_sample;
   dim3 grid(cdiv((int64_t)a.rows_per_sample * (a.n / 4), 256), B), block(256);
-  if (a.C == 4) hipLaunchKernelGGL((k_res_fwd_v4<4>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((k_res_fwd_v4<8>), grid, block, 0, s, a);
+  if (a.C == 4) {
+    if (a.cinB) hipLaunchKernelGGL((k_res_fwd_v4<4, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_res_fwd_v4<4, false>), grid, block, 0, s, a);
+  } else {
+    if (a.cinB) hipLaunchKernelGGL((k_res_fwd_v4<8, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_res_fwd_v4<8, false>), grid, block, 0, s, a);
+  }
   DQ_LAUNCH_CHECK();
   return 0;
 }
