@@ -106,6 +106,12 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
   constexpr int RW = N >= 32 ? 1 : 32 / N;
   constexpr int NJ = la_nj(C);  // x registers per lane; register j holds channel la_chan(C, j, half)
   constexpr int SEG = N >= 32 ? 16 : (N >= 8 ? N / 2 : N);
+  // rows of 16 positions in the M / P form per ROW (a row = register segment s of k^T), as in the forward.  (Rows of 8: measured slower
+  // than the masked quadratic form -- four rows per unit mean 2 x 4 C cross-half sums and four short chains per product: <8,8> 90 -> 98 us,
+  // <12,8> 132 -> 200 us per 12,800 rows; <8,16> 160 -> 141 us.)
+  constexpr bool SEGM = N == 16;
+  constexpr int MS_ROW = C * 32 + 8;        // one row's M as [c][d]; + 8 floats: the rows of a unit start in different LDS banks
+  constexpr int MS_FLOATS = SEGM ? (RW * MS_ROW > 2 * C * 32 ? RW * MS_ROW : 2 * C * 32) : 2 * C * 32;  // M | dM ; SEGM: M_s, then dM_s over them
   constexpr bool PARTNER = N >= 8;
   // C = 4 runs two waves per SIMD instead (the partner wave hides the latency); C = 16 and the 64-position C = 12 variant have
   // no registers to spare
@@ -119,7 +125,7 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
   __shared__ __attribute__((aligned(16))) float w2_lds[4 * C * C];           // [head][c'][c] = sum_e Wo[c'][head*32+e] Wv[head*32+e][c]
   __shared__ float tiles[4][32 * 33];
   // per wave: xh | dYpre | P (normalised) | dP as [c][n] ; M | dM as [c][d] ; dW2 of the head being flushed [c'][c] and [c][c']
-  __shared__ __attribute__((aligned(16))) float stage[4][4 * C * NP + 2 * C * 32 + 2 * C * C];
+  __shared__ __attribute__((aligned(16))) float stage[4][4 * C * NP + MS_FLOATS + 2 * C * C];
   // d xh of the four heads of one unit, [parity of the unit][head][c][n]: double-buffered so that ONE barrier per unit is enough (a
   // wave that runs ahead writes the other parity; it cannot reach this parity again before the barrier of the unit in between).
   // The 64-position C >= 12 variants have no LDS left for the second buffer and pay a second barrier instead.
@@ -151,8 +157,8 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
   float* ps = dys + C * NP;
   float* dps = ps + C * NP;
   float* ms = dps + C * NP;
-  float* dms = ms + C * 32;
-  float* w2g = dms + C * 32;
+  float* dms = SEGM ? ms : ms + C * 32;
+  float* w2g = ms + MS_FLOATS;
   const int n_units = (a.rows + RW - 1) / RW;
   const int u0 = blockIdx.x * a.units_per_wave;  // (units per BLOCK here: its four waves walk the same units, one head each)
   if (u0 >= n_units) return;                     // (the whole block)
@@ -534,6 +540,103 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
 #pragma unroll
           for (int g = 0; g < CG; ++g) part[b][g] += chain4(dms, 32, 0, g, Kd);  // dXh[c][n] += sum_d K[d][n] dM[d][c]
         }
+      } else if (SEGM) {
+        // ================= rows of 16 positions (two rows per unit): M / P form per ROW =================
+        // Row s of the unit is register segment s of k^T in both lane halves (the forward's mapping), so M_s / dM_s are the 4x4x1 chains
+        // restricted to that segment, and a position contracts with the M of its own row (a 4-lane block never straddles rows).  The
+        // products with K = C that mix rows -- dQ = M_row(n) dP, dK^T = xh dM_row(n) -- run once per row with the other rows' columns
+        // zeroed: 2 NJ + 2 RW NJ 32x32x2 MFMAs per unit instead of the 64 + 4 NJ of the masked S tiles, no S / dS tiles at all.
+        auto seg_chain = [&](const float* src, int g, int s, const f32x16& t) {  // sum over the registers of segment s
+          const float* ar = src + (g * 4 + (lane & 3)) * NP + 4 * half;
+          f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q4 = s * SEG / 4; q4 < (s + 1) * SEG / 4; ++q4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(ar + 8 * q4);
+            t0 = mfma4(a4.x, t[q4 * 4 + 0], t0); t1 = mfma4(a4.y, t[q4 * 4 + 1], t1);
+            t0 = mfma4(a4.z, t[q4 * 4 + 2], t0); t1 = mfma4(a4.w, t[q4 * 4 + 3], t1);
+          }
+          return t0 + t1;
+        };
+        // M_s[d = col][c] = sum_(n in row s) k[d][n] xh[c][n], staged [s][c][d]
+#pragma unroll
+        for (int s = 0; s < RW; ++s)
+#pragma unroll
+          for (int g = 0; g < CG; ++g) {
+            const f32x4 mt = seg_chain(xs, g, s, kT[0]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float v = mt[i] + swp32(mt[i]);
+              if (half == 0) ms[s * MS_ROW + (g * 4 + i) * 32 + col] = v;
+            }
+          }
+        wfence();
+        const f32x16 q = make_q(0);
+        float dP[C], P[C];
+        make_dp(0, dP);
+#pragma unroll
+        for (int g = 0; g < CG; ++g) {
+          const f32x4 pp = chain4(ms + rl * MS_ROW, 32, 0, g, q);  // P[c][n] = sum_d M_row(n)[d][c] q[d][n]
+#pragma unroll
+          for (int i = 0; i < 4; ++i) P[g * 4 + i] = pp[i] + swp32(pp[i]);
+        }
+        if (half == 0) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) { ps[c * NP + col] = P[c]; dps[c * NP + col] = dP[c]; }
+        }
+        // dQ[d][n] = sum_c M_row(n)[d][c] dP[c][n]: row by row, the columns of the other rows zeroed
+        f32x16 dq = {0};
+#pragma unroll
+        for (int s = 0; s < RW; ++s)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int c = la_chan(C, j, half);
+            const float mv = c < C ? ms[s * MS_ROW + (c < C ? c : 0) * 32 + col] : 0.f;
+            dq = mfma32b(mv, rl == s ? own(dP, j) : 0.f, dq);
+          }
+        const f32x16 dq_raw = q_softmax_bwd(q, dq);
+        add_dxh(0, 0, dq_raw);
+        add_dw(gq, 0, tr32(dq_raw, tile, col, half));
+        const f32x16 qT = tr32(q, tile, col, half);  // rows n, col d
+        wfence();  // ps / dps complete; every read of M_s is done (dM_s goes over it)
+        add_dw2();
+        // dM_s^T[c][d] = sum_(n in row s) dP[c][n] Q[d][n], staged [s][c][d] over M_s
+#pragma unroll
+        for (int s = 0; s < RW; ++s)
+#pragma unroll
+          for (int g = 0; g < CG; ++g) {
+            const f32x4 mt = seg_chain(dps, g, s, qT);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float v = mt[i] + swp32(mt[i]);
+              if (half == 0) dms[s * MS_ROW + (g * 4 + i) * 32 + col] = v;
+            }
+          }
+        wfence();
+        // dK^T[n][d] = sum_c xh[c][n] dM_row(n)[d][c]: row by row, the rows (positions) of the other rows zeroed
+        f32x16 dkT = {0};
+#pragma unroll
+        for (int s = 0; s < RW; ++s)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int c = la_chan(C, j, half);
+            const float dmv = c < C ? dms[s * MS_ROW + (c < C ? c : 0) * 32 + col] : 0.f;
+            dkT = mfma32b(rl == s ? Xh[0][j] : 0.f, dmv, dkT);
+          }
+        f32x16 dk_rawT;  // softmax over the positions of each row: a lane's own register segment (+ lane^32)
+#pragma unroll
+        for (int s0 = 0; s0 < 16; s0 += SEG) {
+          float dl = 0.f;
+#pragma unroll
+          for (int r = s0; r < s0 + SEG; ++r) dl = fmaf(dkT[r], kT[0][r], dl);
+          dl += swp32(dl);
+#pragma unroll
+          for (int r = s0; r < s0 + SEG; ++r) dk_rawT[r] = kT[0][r] * (dkT[r] - dl);
+        }
+        add_dw(gk, 0, dk_rawT);
+        add_dxh(0, 1, tr32(dk_rawT, tile, col, half));
+        const f32x16 Kd = tr32(kT[0], tile, col, half);  // rows d, col n
+#pragma unroll
+        for (int g = 0; g < CG; ++g) part[0][g] += chain4(dms + rl * MS_ROW, 32, 0, g, Kd);  // dXh[c][n] += sum_d K[d][n] dM_row(n)[d][c]
       } else {
         // ================= 32/N rows per wave, one block: masked quadratic form =================
         const f32x16 q = make_q(0);
@@ -1130,7 +1233,6 @@ int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s) {
              "linattn_bwd: missing operand");
   if (a.f.rows == 0) return 0;
   const int C = a.f.C, rows = a.f.rows, n = a.f.n;
-  const bool deferred = a.defer_reduce && a.waves_out && n <= 64 && (n & (n - 1)) == 0;
   if (a.waves_out) *a.waves_out = 0;
   const bool short_rows = n <= 64 && (n & (n - 1)) == 0;  // (a slot per block; the sweep kernel of longer rows: 512 C floats per wave)
   DQ_REQUIRE(a.part && a.part_floats >= (short_rows ? la_part_reserve(C) : (int64_t)LA_MAX_WAVES * 512 * C),
