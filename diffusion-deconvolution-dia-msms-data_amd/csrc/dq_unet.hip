@@ -166,6 +166,9 @@ int wgrad_async(const Ctx& c, const ConvWgrad& w);
 int wgrad_async_multi(const Ctx& c, ConvWgrad* w, int count);  // <= 3 stride-1 convs over the same rows: one launch + one reduce
 int join_side(const Ctx& c);
 int side_flush(const Ctx& c);
+// flush after every second level (measured, ms per step: every level 4.876, the three widest + every second deeper one 4.858, every
+// second 4.836, every third 4.90 -- the side stream then starts too late); level 0 always flushes
+static inline bool side_flush_here(int lv) { return (lv & 1) == 0; }
 
 #define DQ_TRY(expr)            \
   do {                          \
@@ -690,7 +693,9 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     // the up path is the first writer of its own tensors AND of the skip tensors (the down path accumulates into them later)
     DQ_TRY(res_bwd(c, l.r1, b.r1, c.w(b.r0.out), c.g(b.r0.out), cx, c.w(a.downs[lv].r0.out), c.g(a.downs[lv].r0.out), cs, R, l.n, RT, 1, 1));
     DQ_TRY(res_bwd(c, l.r0, b.r0, c.w(in_off), c.g(in_off), cx, c.w(a.downs[lv].la), c.g(a.downs[lv].la), cs, R, l.n, RT, 1, 1));
-    DQ_TRY(side_flush(c));  // this level's resample-conv and two ResnetBlock weight gradients behind one event
+    // the resample-conv and ResnetBlock weight gradients of two levels behind one event: an event record holds the main queue for ~6 us
+    // (kernel trace)
+    if (side_flush_here(lv)) DQ_TRY(side_flush(c));
   }
   // bottleneck
   if (p.wide_mid) {
@@ -739,7 +744,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     // r1's run under r0's data path instead of behind it)
     if (lv == 0) DQ_TRY(side_flush(c));
     DQ_TRY(res_bwd(c, l.r0, b.r0, c.w(in_off), c.g(in_off), C, nullptr, nullptr, 0, R, l.n, RT, lv > 0 ? 1 : 0, 0));  // (d h0 has the final block's part already)
-    DQ_TRY(side_flush(c));
+    if (side_flush_here(lv)) DQ_TRY(side_flush(c));
   }
   // MS1 feature path
   DQ_TRY(conv_plain_bwd(c, p.ms1_c1, CONV_S1, c.w(a.ms1_a), c.g(a.ms1f), c.g(a.ms1_a), B, RT, RT, 0));
