@@ -31,7 +31,11 @@ def N():
                                       # run-time row lengths (k_la_long.hip with N = 0): ragged last block, rows shorter than a block,
                                       # and the lengths of the reference's shipped downsample_dim 40000 (625 = 19 blocks + 17)
                                       (4, 320, 5), (4, 160, 3), (8, 80, 4), (8, 40, 6), (12, 20, 7), (12, 10, 5), (16, 5, 9), (16, 625, 2),
-                                      (4, 1000, 2), (8, 96, 3), (12, 3, 4)])
+                                      (4, 1000, 2), (8, 96, 3), (12, 3, 4),
+                                      # rows of 16 positions at every width (the per-row M / P form), rows of 8 / 4 at the others, more rows than one
+                                      # resident round of four-wave blocks, and one-position rows at every width (the closed form)
+                                      (4, 16, 11), (12, 16, 7), (16, 16, 5), (4, 8, 10), (16, 8, 9), (16, 4, 3), (8, 16, 9000), (4, 1, 40), (8, 1, 33),
+                                      (12, 1, 100)])
 def test_linattn_bwd_vs_autograd(N, C, n, rows):
     from oracle import dq_oracle as O
 
