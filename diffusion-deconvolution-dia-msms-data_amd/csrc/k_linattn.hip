@@ -85,6 +85,19 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
       }
     }
   }
+  // Without prepared weights (the stand-alone entry point) the block also decides by itself whether the logits are bounded
+  // (k_linattn_prepare's criterion, LA_PREP_BOUNDED): thread t = row t of Wq | Wk, the 256 row norms meet in LDS
+  __shared__ float bnd_lds[N > 1 ? 256 : 1];
+  if (N > 1 && !a.prep) {
+    float n2 = 0.f;
+    for (int c = 0; c < C; ++c) { const float w = a.w_qkv[threadIdx.x * C + c]; n2 = fmaf(w, w, n2); }
+    bnd_lds[threadIdx.x] = n2;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if ((int)threadIdx.x < st) bnd_lds[threadIdx.x] = fmaxf(bnd_lds[threadIdx.x], bnd_lds[threadIdx.x + st]);
+      __syncthreads();
+    }
+  }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wv = threadIdx.x >> 6;
@@ -93,7 +106,16 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   const int rl = N >= 32 ? 0 : col / N;
   const float sqC = sqrtf((float)C);
   const float scale = 0.17677669529663687f;  // 32^-0.5
-  const bool bounded = a.prep && a.prep[LA_PREP_BOUNDED] != 0.f;  // (wave-uniform: a scalar load)
+  bool bounded;  // (wave-uniform)
+  if (a.prep) {
+    bounded = a.prep[LA_PREP_BOUNDED] != 0.f;
+  } else if (N > 1) {
+    float gm = 0.f;
+    for (int c = 0; c < C; ++c) gm = fmaxf(gm, fabsf(a.g_pre[c]));
+    bounded = 1.4426950408889634f * sqrtf(bnd_lds[0]) * sqC * gm <= 64.f;
+  } else {
+    bounded = false;
+  }
   // ONE unit per wave.  (A wave walking several units of a resident grid, so that the weight staging above is paid once per resident
   // block instead of once per four units, was measured: the sampling leg went from 879 back to 842 windows/s -- the many short
   // blocks are what hides this kernel's latencies.)
