@@ -35,7 +35,9 @@ def N():
                                       # rows of 16 positions at every width (the per-row M / P form), rows of 8 / 4 at the others, more rows than one
                                       # resident round of four-wave blocks, and one-position rows at every width (the closed form)
                                       (4, 16, 11), (12, 16, 7), (16, 16, 5), (4, 8, 10), (16, 8, 9), (16, 4, 3), (8, 16, 9000), (4, 1, 40), (8, 1, 33),
-                                      (12, 1, 100)])
+                                      (12, 1, 100),
+                                      # the instantiations no level of the default network uses (the widest hold 110-160 KB of LDS per workgroup)
+                                      (8, 64, 5), (12, 32, 4), (16, 32, 3), (12, 64, 3), (16, 64, 2), (8, 4, 9), (8, 2, 17), (4, 4, 6), (4, 2, 40)])
 def test_linattn_bwd_vs_autograd(N, C, n, rows):
     from oracle import dq_oracle as O
 
