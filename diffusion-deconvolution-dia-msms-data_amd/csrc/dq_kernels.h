@@ -90,7 +90,7 @@ struct ConvBwdData {
 };
 int launch_conv_bwd_data(const ConvBwdData& a, hipStream_t s);
 
-// dW (+=, atomic) and dbias (+=, atomic; optional) of a conv
+// dW (+=) and dbias (+=; optional) of a conv: per-block partials + an ordered reduce (no atomics)
 struct ConvWgrad {
   const float* du = nullptr; const float* inA = nullptr; const float* inB = nullptr; int cinA = 0, cinB = 0;
   int cout = 0, K = 1, mode = CONV_S1, rows = 0, n_in = 0, n_out = 0;
@@ -138,8 +138,35 @@ int launch_res_bwd_cp(const ResBwd& a, hipStream_t s);
 // k_res_v4.hip: 4-positions-per-thread forward for the wide levels (C = 4 / 8, n >= 8)
 bool res_v4_usable(int n, int C, int cinA, int cinB);
 int launch_res_fwd_v4(const ResFwd& a, hipStream_t s);
+// k_res_mm.hip: forward with the convolutions on the 4x4x1 matrix pipe (rows of 1..64 positions, C = 4 / 8 / 12 / 16)
+bool res_mm_usable(int n, int C, int cinA, int cinB, int rows_per_sample, bool has_wr);
+int launch_res_fwd_mm(const ResFwd& a, hipStream_t s);
 int launch_res_fwd(const ResFwd& a, hipStream_t s);
 int launch_res_bwd(const ResBwd& a, hipStream_t s);
+// k_res_wg.hip: ResnetBlock backward of the wide levels (C = 4 / 8, rows of 8..256 positions) with the block's weight gradients formed
+// in the same launch on the 4x4x1 matrix pipe.  Every workgroup leaves [c1.w | c1.b | g1 | c2.w | c2.b | g2 | res.w | res.b | dscale |
+// dshift] in its own slot of `part`; launch_res_wg_reduce adds the slots up in block order into the flat gradient buffer (the
+// block's parameters are contiguous there, in this order) and into the per-sample d(scale, shift).
+struct ResBwdWg {
+  const float* dout = nullptr; const float* u1 = nullptr; const float* u2 = nullptr;
+  const float* inA = nullptr; const float* inB = nullptr; int cinA = 0, cinB = 0;   // the block's input (forward activations)
+  const float* w1 = nullptr; const float* w2 = nullptr; const float* wr = nullptr;
+  const float* g1 = nullptr; const float* g2 = nullptr; const float* ss = nullptr; int ss_stride = 0;
+  float* dA = nullptr; float* dB = nullptr; int dA_store = 0, dB_store = 0;         // as ResBwd
+  float* part = nullptr; int64_t part_floats = 0;                                   // >= res_wg_part_floats(...)
+  float* dparams = nullptr;   // gradient of block1.proj.weight in the flat gradient buffer (the slot's first tensor)
+  float* dss = nullptr;       // this block's [dscale | dshift] of sample 0 (stride ss_stride)
+  int C = 0, rows = 0, n = 0, rows_per_sample = 1;
+  int tiles_ps = 0, tpb = 0, nv = 0;  // (filled by the launcher)
+};
+struct ResWgReduce { const float* part; int B, gx, nv, nglob, C; float* dst; float* dss; int ss_stride; };
+constexpr int RES_WG_REDUCE_MAX = 32;
+struct ResWgReduceMulti { ResWgReduce it[RES_WG_REDUCE_MAX]; };
+bool res_wg_usable(int n, int C, int cinA, int cinB, int rows_per_sample);
+int64_t res_wg_part_floats(int C, int cin, bool wr, int B, int rows_per_sample, int n);
+// launches the backward; *red_out receives the descriptor of the slot reduction (launch_res_wg_reduce: right away or collected)
+int launch_res_bwd_wg(const ResBwdWg& a, hipStream_t s, ResWgReduce* red_out);
+int launch_res_wg_reduce(const ResWgReduce* items, int count, hipStream_t s);
 // the descriptor of a fused ResnetBlock backward's partial sums for launch_part_reduce
 inline PartReduce res_part_reduce(const float* gpart, int gx, int B, int C, float* dg2, float* dg1, float* dss, int ss_stride) {
   PartReduce r;

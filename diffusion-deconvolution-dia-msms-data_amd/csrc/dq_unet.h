@@ -24,7 +24,11 @@ int launch_time_embed_bwd(const Plan& p, const DevTables& dt, const float* param
 
 // Activation arena: offsets (in floats) of every tensor the forward produces for a given (B, RT).  The backward's
 // gradient of a tensor lives at the same offset in a second arena of the same size ("twin").
-struct ResBuf { int64_t u1, a1, u2, out; int64_t gpart = 0, gpart_floats = 0; };  // gpart: per-block norm-gain sums of the backward
+struct ResBuf {
+  int64_t u1, a1, u2, out;
+  int64_t gpart = 0, gpart_floats = 0;  // per-block norm-gain sums of the backward (k_res_bwd / k_res_bwd_cp / k_block_bwd)
+  int64_t wpart = 0, wpart_floats = 0;  // per-workgroup slots of the backward that forms its weight gradients itself (k_res_bwd_wg); 0: not that path
+};
 struct LevelBuf { ResBuf r0, r1; int64_t la, la_pre, la_tmp, rs; };
 struct WideResBuf { int64_t u1 = 0, a1 = 0, u2 = 0, out = 0; };  // (B, mid_c, P) each: a ResnetBlock of the wide bottleneck  // la_pre: saved pre-norm LA output; la_tmp: backward scratch (twin only)
 struct Arena {

@@ -37,9 +37,12 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
   // zero_out: the gradient of the block's output is accumulated into before anything stores to it (the bottleneck blocks'
   // step-by-step backward); everywhere else the first writer of a gradient tensor stores (unet_backward), so the twin of that
   // tensor needs no clearing -- the zero-fill per backward went from 452 MB to the few small tensors that are left in `take`
-  auto res = [&](int64_t rows, int c, int n, bool zero_out = false) {
+  auto res = [&](int64_t rows, int cin, int c, int n, bool zero_out = false) {
     ResBuf r;
-    r.u1 = take_nz(rows * c * n); r.a1 = take_nz(rows * c * n); r.u2 = take_nz(rows * c * n);
+    // (blocks whose backward forms the weight gradients itself recompute a1 from u1: no a1 tensor)
+    const bool wg = B > 0 && res_wg_usable(n, c, c, cin - c, (int)(rows / B));
+    r.u1 = take_nz(rows * c * n); r.a1 = wg ? r.u1 : take_nz(rows * c * n); r.u2 = take_nz(rows * c * n);
+    if (wg) { r.wpart_floats = res_wg_part_floats(c, cin, cin != c, B, (int)(rows / B), n); r.wpart = take_nz(r.wpart_floats); }
     r.out = zero_out ? take(rows * c * n) : take_nz(rows * c * n);
     // one slot per ResnetBlock (the ordered reduce runs on the side stream and may lag behind the next block's backward)
     // per-block partial sums [dg2 | dg1 | dscale | dshift]: k_res_bwd / k_res_bwd_cp grids, or the <= 64 blocks per sample of
@@ -57,7 +60,7 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
   for (int lv = 0; lv < p.levels; ++lv) {
     const LevelP& l = p.downs[lv];
     LevelBuf b;
-    b.r0 = res(R, l.r0.cout, l.n); b.r1 = res(R, l.r1.cout, l.n);
+    b.r0 = res(R, l.r0.cin, l.r0.cout, l.n); b.r1 = res(R, l.r1.cin, l.r1.cout, l.n);
     b.la = take_nz(R * l.la.C * l.n); b.la_pre = take_nz(R * l.la.C * l.n); b.la_tmp = take_nz(R * l.la.C * l.n);
     b.rs = take_nz(R * l.resample.cout * l.n_next);
     a.downs.push_back(b);
@@ -83,22 +86,22 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
     a.w_gemm_part = take_nz(gp + 64);
   }
   a.mid_in = take(R * (p.wide_mid ? 1 : p.mid_c));
-  a.mid1 = res(B, p.wide_mid ? 4 : p.mid_c, RT, true);
+  a.mid1 = res(B, p.wide_mid ? 4 : p.mid_c, p.wide_mid ? 4 : p.mid_c, RT, true);
   a.xn = take(R * (p.wide_mid ? 1 : p.mid_c));
   a.qv = take(R * 2 * HID); a.kk = take(R * HID); a.o = take(R * HID);
   a.lse = take(R * HEADS); a.delta = take(R * HEADS);
   a.attn_out = take(R * (p.wide_mid ? 1 : p.mid_c));
-  a.mid2 = res(B, p.wide_mid ? 4 : p.mid_c, RT, true);
+  a.mid2 = res(B, p.wide_mid ? 4 : p.mid_c, p.wide_mid ? 4 : p.mid_c, RT, true);
   a.mid_back = take(R * p.mid_c);
   for (int ui = 0; ui < p.levels; ++ui) {
     const LevelP& l = p.ups[ui];
     LevelBuf b;
-    b.r0 = res(R, l.r0.cout, l.n); b.r1 = res(R, l.r1.cout, l.n);
+    b.r0 = res(R, l.r0.cin, l.r0.cout, l.n); b.r1 = res(R, l.r1.cin, l.r1.cout, l.n);
     b.la = take_nz(R * l.la.C * l.n); b.la_pre = take_nz(R * l.la.C * l.n); b.la_tmp = take_nz(R * l.la.C * l.n);
     b.rs = take_nz(R * l.resample.cout * l.n_next);
     a.ups.push_back(b);
   }
-  a.fin = res(R, p.dim, p.mz);
+  a.fin = res(R, 2 * p.dim, p.dim, p.mz);
   a.eps = take(R * p.mz);
   a.xa = take_nz(R * p.mz);   // sampling ping-pong / train-step x_t
   a.xb = take_nz(R * p.mz);
@@ -154,6 +157,9 @@ struct Ctx {
   // of them were 0.13 ms per step); everything they read is final when it is queued and stays untouched until the join
   struct SideItem { int kind; ConvWgrad w[3]; int count; PartReduce red; };
   std::vector<SideItem>* side_defer = nullptr;
+  // set by unet_backward: the slot reductions of the ResnetBlock backwards that form their own weight gradients (k_res_bwd_wg),
+  // collected for ONE launch at the end of the pass (null: each is reduced right behind its launch)
+  std::vector<ResWgReduce>* wg_defer = nullptr;
   float* w(int64_t off) const { return W + off; }
   float* g(int64_t off) const { return G + off; }
   const float* prm(int64_t off) const { return P + off; }
@@ -186,7 +192,7 @@ int res_fwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, int 
     k.w2 = c.prm(r.c2.w); k.b2 = c.prm(r.c2.b); k.g2 = c.prm(r.g2);
     if (r.res.cout) { k.wr = c.prm(r.res.w); k.br = c.prm(r.res.b); }
     k.ss = c.w(c.ar.ss) + r.ss_off; k.ss_stride = c.p.ss_total;
-    if (c.save) { k.u1 = c.w(b.u1); k.a1 = c.w(b.a1); k.u2 = c.w(b.u2); }
+    if (c.save) { k.u1 = c.w(b.u1); k.a1 = b.wpart_floats ? nullptr : c.w(b.a1); k.u2 = c.w(b.u2); }  // (wpart: the backward recomputes a1)
     k.out = c.w(b.out);
     k.C = r.cout; k.rows = rows; k.n = n; k.rows_per_sample = rows_per_sample;
     return launch_res_fwd(k, c.s);
@@ -218,6 +224,25 @@ int res_fwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, int 
 int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, float* dA, int cinA, const float* inB, float* dB, int cinB,
             int rows, int n, int rows_per_sample, int storeA = 0, int storeB = 0) {
   const float* dout = c.g(b.out);
+  if (b.wpart_floats && res_wg_usable(n, r.cout, cinA, cinB, rows_per_sample)) {
+    // wide m/z levels: the data path AND the block's weight gradients in one launch; its slots are summed by one launch per pass
+    ResBwdWg k;
+    k.dout = dout; k.u1 = c.w(b.u1); k.u2 = c.w(b.u2); k.inA = inA; k.inB = inB; k.cinA = cinA; k.cinB = cinB;
+    k.w1 = c.prm(r.c1.w); k.w2 = c.prm(r.c2.w); k.wr = r.res.cout ? c.prm(r.res.w) : nullptr;
+    k.g1 = c.prm(r.g1); k.g2 = c.prm(r.g2); k.ss = c.w(c.ar.ss) + r.ss_off; k.ss_stride = c.p.ss_total;
+    k.dA = dA; k.dB = dB; k.dA_store = storeA; k.dB_store = storeB;
+    k.part = c.w(b.wpart); k.part_floats = b.wpart_floats;
+    // the slot order is the order of the block's tensors in the flat buffer (dq_plan.cpp, Builder::res)
+    const int64_t cw = (int64_t)r.cout * r.cin * 3, C = r.cout;
+    DQ_REQUIRE(r.c1.b == r.c1.w + cw && r.g1 == r.c1.b + C && r.c2.w == r.g1 + C && r.c2.b == r.c2.w + C * C * 3 && r.g2 == r.c2.b + C &&
+               (!r.res.cout || (r.res.w == r.g2 + C && r.res.b == r.res.w + C * r.cin)), "res_bwd: the block's parameters are not contiguous");
+    k.dparams = c.dprm(r.c1.w); k.dss = c.g(c.ar.ss) + r.ss_off;
+    k.C = r.cout; k.rows = rows; k.n = n; k.rows_per_sample = rows_per_sample;
+    ResWgReduce red;
+    DQ_TRY(launch_res_bwd_wg(k, c.s, &red));
+    if (c.wg_defer) { c.wg_defer->push_back(red); return 0; }
+    return launch_res_wg_reduce(&red, 1, c.s);
+  }
   if (res_fusable(n, r.cout, rows_per_sample)) {
     // m/z levels (and a bottleneck of up to 512 RT positions): the whole data path in one launch, then the three weight-gradient launches
     ResBwd k;
@@ -670,8 +695,10 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
                   const float* grad_out, float* grad_x) {
   Ctx::LaDefer la_defer;
   std::vector<Ctx::SideItem> side_items;
+  std::vector<ResWgReduce> wg_items;
   Ctx c = c_in;
   c.la_defer = &la_defer;
+  c.wg_defer = &wg_items;
   if (c.owner) c.side_defer = &side_items;
   const Plan& p = c.p;
   const Arena& a = c.ar;
@@ -769,6 +796,8 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
   // ~80 us) start only when the ~100 us reduce had finished -- an exposed tail in front of the join
   DQ_TRY(side_flush(c));
   DQ_TRY(la_flush(c));
+  for (size_t i = 0; i < wg_items.size(); i += RES_WG_REDUCE_MAX)  // (one launch for the network's <= 32 such blocks)
+    DQ_TRY(launch_res_wg_reduce(wg_items.data() + i, (int)std::min<size_t>(RES_WG_REDUCE_MAX, wg_items.size() - i), c.s));
   DQ_TRY(join_side(c));
   // time embedding: all scale/shift heads + the MLP -- after the join: the per-sample d(scale, shift) of the fused ResnetBlocks are
   // summed on the side stream
@@ -1250,6 +1279,10 @@ int block_ws(BlockWs& w, int cin, int cout, int rows, int n, int rows_per_sample
   const int64_t t = (int64_t)rows * cout * n;
   w.ar.ss = take((int64_t)w.B * w.plan.ss_total);
   w.rb.u1 = take(t); w.rb.a1 = take(t); w.rb.u2 = take(t); w.rb.out = take(t);
+  if (res_wg_usable(n, cout, cout, cin - cout, rows_per_sample)) {
+    w.rb.wpart_floats = res_wg_part_floats(cout, cin, cin != cout, w.B, rows_per_sample, n);
+    w.rb.wpart = take(w.rb.wpart_floats);
+  }
   w.rb.gpart_floats = (int64_t)w.B * std::max<int64_t>({((int64_t)rows_per_sample * n + 255) / 256, (rows_per_sample + 15) / 16, 64}) * 4 * cout;
   w.rb.gpart = take(w.rb.gpart_floats);
   w.ar.wg_floats = (int64_t)WGRAD_MAX_PARTS * ((int64_t)cout * std::max(cin, cout) * 3 + cout) * 3;

@@ -10,6 +10,8 @@
 // Weight gradients stay in k_conv_wgrad (they read dU1 / dU2 written here).
 #include "dq_common.h"
 #include "dq_kernels.h"
+#include "k_res_common.h"
+#include <cstdlib>
 
 namespace dq {
 
@@ -171,6 +173,9 @@ int launch_res_fwd(const ResFwd& a, hipStream_t s) {
   DQ_REQUIRE(res_fusable(a.n, a.C, a.rows_per_sample), "res_fwd: row length must divide 256 (or one row of <= 512 per sample) and C be 4/8/12/16");
   DQ_REQUIRE(a.rows % a.rows_per_sample == 0, "res_fwd: rows must be a multiple of rows_per_sample");
   DQ_REQUIRE(a.wr || (a.cinA == a.C && a.cinB == 0), "res_fwd: identity residual needs C input channels");
+  // m/z rows of up to 64 positions: the convolutions on the matrix pipe (k_res_mm.hip).  DQ_RES_FWD=old keeps the VALU kernels (A-B switch)
+  static const bool old_fwd = [] { const char* e = std::getenv("DQ_RES_FWD"); return e && e[0] == 'o'; }();
+  if (!old_fwd && res_mm_usable(a.n, a.C, a.cinA, a.cinB, a.rows_per_sample, a.wr != nullptr)) return launch_res_fwd_mm(a, s);
   if (a.rows_per_sample > 1 && res_cp_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_fwd_cp(a, s);
   if (a.rows_per_sample > 1 && res_v4_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_fwd_v4(a, s);
   DQ_REQUIRE(a.cinA == a.C && a.cinB <= a.C && (a.cinB == 0 || a.inB), "res_fwd: input must be C channels (+ at most C skip channels)");
@@ -191,37 +196,6 @@ int launch_res_fwd(const ResFwd& a, hipStream_t s) {
 // -----------------------------------------------------------------------------------------------------------------
 // backward data path
 // -----------------------------------------------------------------------------------------------------------------
-namespace {
-// pointwise backward of RMSNorm -> (scale+1, shift) -> SiLU at one position; returns dU in d[], accumulates dg / dsc / dsh
-template <int C, bool SS>
-__device__ __forceinline__ void norm_act_bwd(const float* u, float* d, const float* __restrict__ g, const float* __restrict__ ss,
-                                             float* dg, float* dsc, float* dsh) {
-  const float sqC = sqrtf((float)C);
-  float ssq = 0.f;
-#pragma unroll
-  for (int c = 0; c < C; ++c) ssq = fmaf(u[c], u[c], ssq);
-  const float nrm = fast_sqrt(ssq), inv = fast_rcp(fmaxf(nrm, RMS_EPS));
-  float uh[C];
-  float dot = 0.f;
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    uh[c] = u[c] * inv;
-    const float z = uh[c] * g[c] * sqC;
-    const float sc = SS ? ss[c] + 1.0f : 1.0f, sh = SS ? ss[C + c] : 0.f;
-    const float w = fmaf(z, sc, sh);
-    const float dw = d[c] * silu_grad_f(w);
-    if (SS) { dsh[c] += dw; dsc[c] = fmaf(dw, z, dsc[c]); }
-    const float dz = dw * sc;
-    dg[c] = fmaf(dz, uh[c] * sqC, dg[c]);
-    d[c] = dz * g[c] * sqC;
-    dot = fmaf(d[c], uh[c], dot);
-  }
-  const bool clamped = nrm < RMS_EPS;
-#pragma unroll
-  for (int c = 0; c < C; ++c) d[c] = clamped ? d[c] * inv : inv * (d[c] - uh[c] * dot);
-}
-}  // namespace
-
 template <int C, int BS>
 __global__ void __launch_bounds__(BS) k_res_bwd(ResBwd a) {
   __shared__ float sh[C][BS + 2];

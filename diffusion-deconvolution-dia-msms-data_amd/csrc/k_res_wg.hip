@@ -1,0 +1,493 @@
+// ResnetBlock backward for the wide m/z levels (4 / 8 channels, rows of 8..256 positions) WITH the block's weight gradients
+// formed in the same launch (reference dquartic/model/unet1d.py:271-323; autograd of it is what model_interface.py:1120 runs).
+//
+// k_res_bwd (k_res.hip) leaves dU2 / dU1 in memory and three weight-gradient launches (+ reduces) on the side stream re-read
+// them together with a1, x (twice) and d out: six tensor reads and two tensor writes per block, at a time when the main chain's
+// kernels want the same HBM.  Here the data path is the same (thread = (row, position), all channels in registers), but
+//   * every operand the weight gradients need is staged ONCE in LDS as a [position][channel] image (16-byte stores; the k = 3
+//     neighbour exchange of dU2 / dU1 reads the same images with 16-byte loads),
+//   * dW2 = dU2 (x) a1, dW1 = dU1 (x) x, dWr = d out (x) x and the three bias sums run on the matrix pipe, which this kernel
+//     otherwise leaves idle: v_mfma_f32_4x4x1 takes 16 positions per instruction as 16 independent (4 co) x (4 ci) outer
+//     products, lane (blk, i) supplying channel 4g + i of position 16 blk + s at step s -- a block of lanes walks a RUN of 16
+//     consecutive positions, so the operand of tap k - 1 / k + 1 is the centre operand of the previous / next step (one LDS read
+//     per step and input-channel quad serves three MFMAs); the (co quad, ci quad, tap) jobs are split over the four waves,
+//   * a1 = SiLU(norm(u1) (scale + 1) + shift) is recomputed from u1 (which the data path loads anyway): the forward stores one
+//     tensor less per block in training,
+//   * a workgroup walks several 256-position tiles of ONE sample with its accumulators (MFMA results, norm-gain and scale /
+//     shift sums) in registers and leaves them in its own slot [c1.w | c1.b | g1 | c2.w | c2.b | g2 | res.w | res.b | dscale |
+//     dshift] -- the order of the flat parameter buffer -- for k_res_wg_reduce to add up in block order: no atomics, bitwise
+//     repeatable.
+#include "dq_common.h"
+#include "dq_kernels.h"
+#include "k_res_common.h"
+#include <algorithm>
+#include <cstdlib>
+
+namespace dq {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
+constexpr int TILE = 256;
+constexpr int RUN = 16;  // consecutive positions a 4-lane block of the MFMA walks
+
+// LDS image of one C-channel operand over a tile: [position + 1 (one halo slot on either side)][channel], C = 8 padded to 12
+// floats per position (16-byte accesses of consecutive positions then fall into different 16-byte bank slots), and 4 floats of
+// padding after every 16 positions: the 8 lane blocks of a half-wave read positions 16 apart, whose distance in floats must be
+// an odd multiple of 4 modulo the 32 banks of a 4-byte LDS read.
+template <int C>
+struct Img {
+  static constexpr int ST = C == 4 ? 4 : C + 4;
+  static constexpr int FLOATS = (TILE + 2) * ST + ((TILE + 2) / RUN + 1) * 4;
+  __device__ static __forceinline__ int at(int q) { return q * ST + (q >> 4) * 4; }  // q = position in the tile + 1
+};
+// offset of step s of a run from the run's first position (the run's last position lies behind a padding slot)
+template <int ST>
+__device__ __forceinline__ constexpr int run_off(int s) { return s * ST + (s == RUN - 1 ? 4 : 0); }
+
+__device__ __forceinline__ float dpp_ror(float v, int ctrl4or8) {
+  const int x = __float_as_int(v);
+  return ctrl4or8 == 4 ? __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x124, 0xF, 0xF, false))
+                       : __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, false));
+}
+// sum of the 16 lane blocks' 4 x 4 results: afterwards lanes 0..3 (block 0, column j = lane) hold the total in every register
+__device__ __forceinline__ f32x4 blocks_sum(f32x4 v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float t = v[i];
+    t += dpp_ror(t, 4);
+    t += dpp_ror(t, 8);   // every lane: the 4 blocks of its 16-lane row
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    v[i] = t;
+  }
+  return v;
+}
+
+}  // namespace
+
+template <int C, bool WR>
+__global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
+  using I = Img<C>;
+  constexpr int ST = I::ST, CQ = C / 4;
+  __shared__ __attribute__((aligned(16))) float i_du2[I::FLOATS], i_du1[I::FLOATS], i_a1[I::FLOATS], i_xa[I::FLOATS];
+  __shared__ __attribute__((aligned(16))) float i_xb[WR ? I::FLOATS : 4], i_do[WR ? I::FLOATS : 4];
+  __shared__ float red[4][4 * C];
+  __shared__ float w2s[C * C * 3], w1s[C * 2 * C * 3], wrs[WR ? C * 2 * C : 1];
+  const int cin = a.cinA + a.cinB;  // C (identity residual) or C + cinB, cinB in {4, .., C} (checked by the launcher)
+  {
+    for (int i = threadIdx.x; i < C * C * 3; i += 256) w2s[i] = a.w2[i];
+    for (int i = threadIdx.x; i < C * cin * 3; i += 256) w1s[i] = a.w1[i];
+    if constexpr (WR)
+      for (int i = threadIdx.x; i < C * cin; i += 256) wrs[i] = a.wr[i];
+  }
+  const int b = blockIdx.y, n = a.n;
+  const int per_sample = a.rows_per_sample * n;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = tid + 1;                      // this thread's slot in the images
+  const int blk = lane >> 2, li = lane & 3;   // MFMA: 4-lane block and the lane's channel inside a quad
+  const int lb = I::at(blk * RUN + 1) + li;   // image offset of (first position of the block's run, channel li)
+  // rows never straddle a run of 16 unless they are 8 long (then every run is two rows); n is a power of two in 8..256
+  const bool n8 = n == 8;
+  const bool zl = ((blk * RUN) % n) == 0;            // the run starts a row: its tap k = 0 operand at step 0 is the zero padding
+  const bool zr = ((blk * RUN + RUN) % n) == 0;      // the run ends a row
+  // ---- which weight-gradient jobs this wave runs (wave-uniform)
+  //   C = 8: wave = (co quad g, half hs): dW2 (g, ci quad hs), dWr / dW1 (g, ci quads 2 hs, 2 hs + 1 of cat(A, B)) or dW1 (g, hs)
+  //          for the identity residual; the bias sums on the waves with hs = 0
+  //   C = 4: wave 0: dW2 + db2; wave 1: dWr + dbr; wave 2: dW1 (ci quad 0) + db1; wave 3: dW1 (ci quad 1)
+  const int cinq = cin >> 2;
+  const int g = C == 8 ? (wv & 1) : 0, hs = C == 8 ? (wv >> 1) : wv;
+  const bool doW2 = C == 8 ? true : wv == 0;
+  const int hW2 = C == 8 ? hs : 0;
+  const bool doB2 = C == 8 ? hs == 0 : wv == 0;
+  const bool doWr = WR && (C == 8 ? true : wv == 1);
+  const int hr0 = C == 8 ? 2 * hs : 0, hr1 = C == 8 ? 2 * hs + 1 : 1;
+  const bool doBr = WR && (C == 8 ? hs == 0 : wv == 1);
+  const bool doW1 = C == 8 ? true : (wv == 2 || (WR && wv == 3));
+  const int h10 = C == 8 ? (WR ? 2 * hs : hs) : (wv == 3 ? 1 : 0);
+  const int h11 = (C == 8 && WR) ? 2 * hs + 1 : -1;
+  const bool doB1 = C == 8 ? hs == 0 : wv == 2;
+  const bool v_r0 = doWr && hr0 < cinq, v_r1 = doWr && hr1 < cinq;
+  const bool v_10 = doW1 && h10 < cinq, v_11 = doW1 && h11 >= 0 && h11 < cinq;
+  auto ximg = [&](int h) -> const float* { return (h < CQ || !WR ? i_xa + 4 * (h < CQ ? h : 0) : i_xb + 4 * (h - CQ)) + lb; };
+
+  f32x4 aW2[3], aWr[2], aW1[2][3], aB2 = {0.f, 0.f, 0.f, 0.f}, aBr = aB2, aB1 = aB2;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { aW2[k] = aB2; aW1[0][k] = aB2; aW1[1][k] = aB2; }
+  aWr[0] = aB2; aWr[1] = aB2;
+  float dg2[C], dg1[C], dsc[C], dsh[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) dg2[c] = dg1[c] = dsc[c] = dsh[c] = 0.f;
+  const float sqC = sqrtf((float)C);
+  const float* ss = a.ss + (int64_t)b * a.ss_stride;
+
+  const int tile_end = min(a.tiles_ps, ((int)blockIdx.x + 1) * a.tpb);
+#pragma unroll 1
+  for (int tile = blockIdx.x * a.tpb; tile < tile_end; ++tile) {
+    const int it = tile * TILE + tid;
+    const bool live = it < per_sample;
+    const int row = b * a.rows_per_sample + (live ? it / n : 0), p = live ? it % n : 0;
+    const int64_t obase = ((int64_t)row * C) * n + p;
+    const bool hasL = live && p > 0, hasR = live && p + 1 < n;
+    // ---- every global read of the tile up front
+    float dout[C], d[C], u[C], u1v[C], dold[C], xa[C], xb[WR ? C : 1];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      dout[c] = live ? a.dout[obase + (int64_t)c * n] : 0.f;
+      u[c] = live ? a.u2[obase + (int64_t)c * n] : 1.f;
+      u1v[c] = live ? a.u1[obase + (int64_t)c * n] : 1.f;
+      xa[c] = live ? a.inA[obase + (int64_t)c * n] : 0.f;  // cinA == C
+      dold[c] = (live && !WR && a.dA && !a.dA_store) ? a.dA[obase + (int64_t)c * n] : 0.f;
+      d[c] = dout[c];
+    }
+    if constexpr (WR) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) xb[c] = (live && c < a.cinB) ? a.inB[((int64_t)row * a.cinB + c) * n + p] : 0.f;
+    }
+    // ---- block2: dU2; block1's activation a1 recomputed from u1 with the forward's expression
+    norm_act_bwd<C, false>(u, d, a.g2, nullptr, dg2, nullptr, nullptr);
+    float a1v[C];
+    {
+      float ssq = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) ssq = fmaf(u1v[c], u1v[c], ssq);
+      const float inv = rms_inv(ssq, sqC);
+#pragma unroll
+      for (int c = 0; c < C; ++c) a1v[c] = live ? silu_f(fmaf(u1v[c] * inv * a.g1[c], ss[c] + 1.0f, ss[C + c])) : 0.f;
+    }
+    __syncthreads();  // the previous tile's readers of the images are done (first tile: the staged weights are visible)
+    {
+      const int o = I::at(q);
+#pragma unroll
+      for (int c4 = 0; c4 < CQ; ++c4) {
+        const int c = 4 * c4;
+        *reinterpret_cast<float4*>(i_du2 + o + c) = live ? make_float4(d[c], d[c + 1], d[c + 2], d[c + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(i_a1 + o + c) = make_float4(a1v[c], a1v[c + 1], a1v[c + 2], a1v[c + 3]);
+        *reinterpret_cast<float4*>(i_xa + o + c) = make_float4(xa[c], xa[c + 1], xa[c + 2], xa[c + 3]);
+        if constexpr (WR) {
+          *reinterpret_cast<float4*>(i_xb + o + c) = make_float4(xb[c], xb[c + 1], xb[c + 2], xb[c + 3]);
+          *reinterpret_cast<float4*>(i_do + o + c) = make_float4(dout[c], dout[c + 1], dout[c + 2], dout[c + 3]);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- matrix pipe: dW2 (+ db2), dWr (+ dbr)
+#ifndef DQ_WG_V_NOMFMA
+    if (doW2) {
+      const float* A = i_du2 + lb + 4 * g;
+      const float* Bp = i_a1 + lb + 4 * hW2;
+      float bprev = zl ? 0.f : Bp[-ST], bcur = Bp[0];
+#pragma unroll
+      for (int s = 0; s < RUN; ++s) {
+        const float av = A[run_off<ST>(s)];
+        float bnext = s + 1 < RUN ? Bp[run_off<ST>(s + 1 < RUN ? s + 1 : s)] : (zr ? 0.f : Bp[RUN * ST + 4]);
+        float b0 = bprev, b2 = bnext;
+        if (s == 8) b0 = n8 ? 0.f : b0;
+        if (s == 7) b2 = n8 ? 0.f : b2;
+        aW2[0] = mfma4(av, b0, aW2[0]);
+        aW2[1] = mfma4(av, bcur, aW2[1]);
+        aW2[2] = mfma4(av, b2, aW2[2]);
+        if (doB2) aB2 = mfma4(av, 1.f, aB2);
+        bprev = bcur; bcur = bnext;
+      }
+    }
+    if constexpr (WR) {
+     if (doWr) {
+      const float* A = i_do + lb + 4 * g;
+      const float* X0 = ximg(hr0);
+      const float* X1 = ximg(v_r1 ? hr1 : hr0);
+#pragma unroll
+      for (int s = 0; s < RUN; ++s) {
+        const float av = A[run_off<ST>(s)];
+        if (v_r0) aWr[0] = mfma4(av, X0[run_off<ST>(s)], aWr[0]);
+        if (v_r1) aWr[1] = mfma4(av, X1[run_off<ST>(s)], aWr[1]);
+        if (doBr) aBr = mfma4(av, 1.f, aBr);
+      }
+     }
+    }
+#endif
+    // ---- d a1[ci][p] = sum_co sum_k W2[co][ci][k] dU2[co][p + 1 - k]
+    float da1[C];
+    {
+      float dl[C], dr[C];
+#pragma unroll
+      for (int c4 = 0; c4 < CQ; ++c4) {
+        const float4 l4 = *reinterpret_cast<const float4*>(i_du2 + I::at(q - 1) + 4 * c4);
+        const float4 r4 = *reinterpret_cast<const float4*>(i_du2 + I::at(q + 1) + 4 * c4);
+        dl[4 * c4] = hasL ? l4.x : 0.f; dl[4 * c4 + 1] = hasL ? l4.y : 0.f; dl[4 * c4 + 2] = hasL ? l4.z : 0.f; dl[4 * c4 + 3] = hasL ? l4.w : 0.f;
+        dr[4 * c4] = hasR ? r4.x : 0.f; dr[4 * c4 + 1] = hasR ? r4.y : 0.f; dr[4 * c4 + 2] = hasR ? r4.z : 0.f; dr[4 * c4 + 3] = hasR ? r4.w : 0.f;
+      }
+#pragma unroll
+      for (int ci = 0; ci < C; ++ci) da1[ci] = 0.f;
+#pragma unroll
+      for (int co = 0; co < C; ++co) {
+        const float dc = live ? d[co] : 0.f;
+        const float* w = w2s + co * C * 3;
+#pragma unroll
+        for (int ci = 0; ci < C; ++ci) da1[ci] = fmaf(w[ci * 3 + 0], dr[co], fmaf(w[ci * 3 + 1], dc, fmaf(w[ci * 3 + 2], dl[co], da1[ci])));
+      }
+    }
+    // ---- block1: dU1
+#pragma unroll
+    for (int c = 0; c < C; ++c) u[c] = u1v[c];
+    norm_act_bwd<C, true>(u, da1, a.g1, ss, dg1, dsc, dsh);
+    {
+      const int o = I::at(q);
+#pragma unroll
+      for (int c4 = 0; c4 < CQ; ++c4) {
+        const int c = 4 * c4;
+        *reinterpret_cast<float4*>(i_du1 + o + c) = live ? make_float4(da1[c], da1[c + 1], da1[c + 2], da1[c + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    __syncthreads();
+    // ---- matrix pipe: dW1 (+ db1)
+#ifndef DQ_WG_V_NOMFMA
+    if (doW1) {
+      const float* A = i_du1 + lb + 4 * g;
+      const float* X0 = ximg(v_10 ? h10 : 0);
+      const float* X1 = ximg(v_11 ? h11 : 0);
+      float p0 = zl ? 0.f : X0[-ST], c0 = X0[0], p1 = zl ? 0.f : X1[-ST], c1 = X1[0];
+#pragma unroll
+      for (int s = 0; s < RUN; ++s) {
+        const float av = A[run_off<ST>(s)];
+        float n0 = s + 1 < RUN ? X0[run_off<ST>(s + 1 < RUN ? s + 1 : s)] : (zr ? 0.f : X0[RUN * ST + 4]);
+        float n1 = s + 1 < RUN ? X1[run_off<ST>(s + 1 < RUN ? s + 1 : s)] : (zr ? 0.f : X1[RUN * ST + 4]);
+        float l0 = p0, r0 = n0, l1 = p1, r1 = n1;
+        if (s == 8) { l0 = n8 ? 0.f : l0; l1 = n8 ? 0.f : l1; }
+        if (s == 7) { r0 = n8 ? 0.f : r0; r1 = n8 ? 0.f : r1; }
+        if (v_10) {
+          aW1[0][0] = mfma4(av, l0, aW1[0][0]);
+          aW1[0][1] = mfma4(av, c0, aW1[0][1]);
+          aW1[0][2] = mfma4(av, r0, aW1[0][2]);
+        }
+        if (v_11) {
+          aW1[1][0] = mfma4(av, l1, aW1[1][0]);
+          aW1[1][1] = mfma4(av, c1, aW1[1][1]);
+          aW1[1][2] = mfma4(av, r1, aW1[1][2]);
+        }
+        if (doB1) aB1 = mfma4(av, 1.f, aB1);
+        p0 = c0; c0 = n0; p1 = c1; c1 = n1;
+      }
+    }
+#endif
+    // ---- d x[ci][p] = sum_co sum_k W1[co][ci][k] dU1[co][p + 1 - k]  (+ residual branch) into dA / dB
+    if (a.dA || a.dB) {
+      float dl[C], dr[C];
+#pragma unroll
+      for (int c4 = 0; c4 < CQ; ++c4) {
+        const float4 l4 = *reinterpret_cast<const float4*>(i_du1 + I::at(q - 1) + 4 * c4);
+        const float4 r4 = *reinterpret_cast<const float4*>(i_du1 + I::at(q + 1) + 4 * c4);
+        dl[4 * c4] = hasL ? l4.x : 0.f; dl[4 * c4 + 1] = hasL ? l4.y : 0.f; dl[4 * c4 + 2] = hasL ? l4.z : 0.f; dl[4 * c4 + 3] = hasL ? l4.w : 0.f;
+        dr[4 * c4] = hasR ? r4.x : 0.f; dr[4 * c4 + 1] = hasR ? r4.y : 0.f; dr[4 * c4 + 2] = hasR ? r4.z : 0.f; dr[4 * c4 + 3] = hasR ? r4.w : 0.f;
+      }
+      if constexpr (WR) {
+        // all input channels of this position at once; the old values of dA / dB are requested together before the first store
+        constexpr int CM = 2 * C;
+        float v[CM];
+#pragma unroll
+        for (int ci = 0; ci < CM; ++ci) v[ci] = 0.f;
+#pragma unroll
+        for (int co = 0; co < C; ++co) {
+          const float dc = da1[co], dco = dout[co];
+#pragma unroll
+          for (int ci = 0; ci < CM; ++ci) {
+            if (ci < cin) {
+              const float* w = w1s + (co * cin + ci) * 3;
+              v[ci] = fmaf(w[0], dr[co], fmaf(w[1], dc, fmaf(w[2], dl[co], v[ci])));
+              v[ci] = fmaf(wrs[co * cin + ci], dco, v[ci]);
+            }
+          }
+        }
+        if (live) {
+          float oldv[CM];
+#pragma unroll
+          for (int ci = 0; ci < CM; ++ci) {
+            float* dst = nullptr;
+            if (ci < a.cinA) { if (a.dA) dst = a.dA + ((int64_t)row * a.cinA + ci) * n + p; }
+            else if (ci < cin) { if (a.dB) dst = a.dB + ((int64_t)row * a.cinB + (ci - a.cinA)) * n + p; }
+            oldv[ci] = (dst && !(ci < a.cinA ? a.dA_store : a.dB_store)) ? *dst : 0.f;
+          }
+#pragma unroll
+          for (int ci = 0; ci < CM; ++ci) {
+            float* dst = nullptr;
+            if (ci < a.cinA) { if (a.dA) dst = a.dA + ((int64_t)row * a.cinA + ci) * n + p; }
+            else if (ci < cin) { if (a.dB) dst = a.dB + ((int64_t)row * a.cinB + (ci - a.cinA)) * n + p; }
+            if (dst) *dst = oldv[ci] + v[ci];
+          }
+        }
+      } else if (a.dA) {  // identity residual: cin == C, single input
+        float dx[C];
+#pragma unroll
+        for (int ci = 0; ci < C; ++ci) dx[ci] = dout[ci];
+#pragma unroll
+        for (int co = 0; co < C; ++co) {
+          const float dc = da1[co];
+          const float* w = w1s + co * C * 3;
+#pragma unroll
+          for (int ci = 0; ci < C; ++ci) dx[ci] = fmaf(w[ci * 3 + 0], dr[co], fmaf(w[ci * 3 + 1], dc, fmaf(w[ci * 3 + 2], dl[co], dx[ci])));
+        }
+        if (live) {
+#pragma unroll
+          for (int ci = 0; ci < C; ++ci) a.dA[obase + (int64_t)ci * n] = dold[ci] + dx[ci];
+        }
+      }
+    }
+  }  // tile
+
+  // ---- the block's slot: MFMA results (each job belongs to exactly one wave), then the VALU sums
+  float* part = a.part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * a.nv;
+  const int oC1W = 0, oC1B = C * cin * 3, oG1 = oC1B + C, oC2W = oG1 + C, oC2B = oC2W + C * C * 3, oG2 = oC2B + C, oRW = oG2 + C,
+            oRB = oRW + C * cin, nglob = WR ? oRB + C : oRW;
+  auto put_w = [&](f32x4 acc, int base, int h, int kdim, int k, int ld) {  // D[i][j] -> W[4 g + i][4 h + j][k]
+    const f32x4 t = blocks_sum(acc);
+    if (lane < 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) part[base + ((4 * g + i) * ld + 4 * h + lane) * kdim + k] = t[i];
+    }
+  };
+  auto put_b = [&](f32x4 acc, int base) {
+    const f32x4 t = blocks_sum(acc);
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) part[base + 4 * g + i] = t[i];
+    }
+  };
+  if (doW2) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) put_w(aW2[k], oC2W, hW2, 3, k, C);
+  }
+  if (doB2) put_b(aB2, oC2B);
+  if (v_r0) put_w(aWr[0], oRW, hr0, 1, 0, cin);
+  if (v_r1) put_w(aWr[1], oRW, hr1, 1, 0, cin);
+  if (doBr) put_b(aBr, oRB);
+  if (v_10) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) put_w(aW1[0][k], oC1W, h10, 3, k, cin);
+  }
+  if (v_11) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) put_w(aW1[1][k], oC1W, h11, 3, k, cin);
+  }
+  if (doB1) put_b(aB1, oC1B);
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float s0 = wave_sum(dg2[c]), s1 = wave_sum(dg1[c]), s2 = wave_sum(dsc[c]), s3 = wave_sum(dsh[c]);
+    if (lane == 0) { red[wv][c] = s0; red[wv][C + c] = s1; red[wv][2 * C + c] = s2; red[wv][3 * C + c] = s3; }
+  }
+  __syncthreads();
+  for (int i = tid; i < 4 * C; i += 256) {
+    const float v = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    const int what = i / C, c = i % C;
+    part[(what == 0 ? oG2 : what == 1 ? oG1 : what == 2 ? nglob : nglob + C) + c] = v;
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// ordered sums of the slots: dst[e] += sum over all blocks (e < nglob: the block's parameters are contiguous in the flat gradient
+// buffer, in slot order), dss[b][j] += sum over the sample's blocks (j < 2 C).  16 elements x 16 partial groups per workgroup.
+// -----------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_res_wg_reduce(ResWgReduceMulti m) {
+  const ResWgReduce& r = m.it[blockIdx.y];
+  const int twoC = 2 * r.C;
+  const int nelem = r.nglob + r.B * twoC;
+  if ((int)blockIdx.x * 16 >= nelem) return;  // uniform per block
+  __shared__ float red[16][17];
+  const int el = threadIdx.x & 15, gq = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + el;
+  float s0 = 0.f, s1 = 0.f;
+  if (e < nelem) {
+    const bool glob = e < r.nglob;
+    const int bs = glob ? 0 : (e - r.nglob) / twoC;
+    const float* src = r.part + (glob ? e : (int64_t)bs * r.gx * r.nv + r.nglob + (e - r.nglob) % twoC);
+    const int cnt = glob ? r.gx * r.B : r.gx;
+    int k = gq;
+    for (; k + 16 < cnt; k += 32) {
+      s0 += src[(int64_t)k * r.nv];
+      s1 += src[(int64_t)(k + 16) * r.nv];
+    }
+    if (k < cnt) s0 += src[(int64_t)k * r.nv];
+  }
+  red[gq][el] = s0 + s1;
+  __syncthreads();
+  if (gq == 0 && e < nelem) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][el];
+    if (e < r.nglob) r.dst[e] += s;
+    else r.dss[(int64_t)((e - r.nglob) / twoC) * r.ss_stride + (e - r.nglob) % twoC] += s;
+  }
+}
+
+bool res_wg_usable(int n, int C, int cinA, int cinB, int rows_per_sample) {
+  return (C == 4 || C == 8) && n >= 8 && n <= 256 && (n & (n - 1)) == 0 && rows_per_sample > 1 && cinA == C &&
+         (cinB == 0 || (cinB % 4 == 0 && cinB <= C));
+}
+
+// grid of a launch: a workgroup takes `tpb` consecutive tiles of one sample; about 1024 workgroups in all (one resident round at
+// 2-4 per CU).  A pure function of the shape, so that the arena (sized without a device) and the launcher agree.
+void res_wg_grid(int B, int rows_per_sample, int n, int* tiles_ps, int* tpb, int* gx) {
+  *tiles_ps = cdiv((int64_t)rows_per_sample * n, TILE);
+  const int64_t total = (int64_t)*tiles_ps * B;
+  *tpb = (int)std::max<int64_t>(1, (total + 1023) / 1024);
+  static const int tpb_min = [] { const char* e = std::getenv("DQ_WG_TPB"); return e ? std::atoi(e) : 0; }();  // A-B switch
+  if (tpb_min > 0) *tpb = std::max(*tpb, tpb_min);
+  if (tpb_min < 0) *tpb = 1;
+  *gx = cdiv(*tiles_ps, *tpb);
+}
+int res_wg_nv(int C, int cin, bool wr) { return C * cin * 3 + C + C + C * C * 3 + C + C + (wr ? C * cin + C : 0) + 2 * C; }
+int64_t res_wg_part_floats(int C, int cin, bool wr, int B, int rows_per_sample, int n) {
+  int tiles_ps, tpb, gx;
+  res_wg_grid(B, rows_per_sample, n, &tiles_ps, &tpb, &gx);
+  return (int64_t)gx * B * res_wg_nv(C, cin, wr);
+}
+
+int launch_res_bwd_wg(const ResBwdWg& a_in, hipStream_t s, ResWgReduce* red_out) {
+  ResBwdWg a = a_in;
+  DQ_REQUIRE(res_wg_usable(a.n, a.C, a.cinA, a.cinB, a.rows_per_sample), "res_bwd_wg: unsupported shape");
+  DQ_REQUIRE(a.rows % a.rows_per_sample == 0, "res_bwd_wg: rows must be a multiple of rows_per_sample");
+  DQ_REQUIRE(a.wr || a.cinB == 0, "res_bwd_wg: identity residual needs C input channels");
+  DQ_REQUIRE(a.dout && a.u1 && a.u2 && a.inA && (a.cinB == 0 || a.inB) && a.w1 && a.w2 && a.g1 && a.g2 && a.ss && a.part,
+             "res_bwd_wg: missing operand");
+  const int B = a.rows / a.rows_per_sample;
+  int gx;
+  res_wg_grid(B, a.rows_per_sample, a.n, &a.tiles_ps, &a.tpb, &gx);
+  const bool wr = a.wr != nullptr;
+  a.nv = res_wg_nv(a.C, a.cinA + a.cinB, wr);
+  DQ_REQUIRE(a.part_floats >= (int64_t)gx * B * a.nv, "res_bwd_wg: slot scratch too small");
+  dim3 grid(gx, B), block(256);
+  if (a.C == 4) {
+    if (wr) hipLaunchKernelGGL((k_res_bwd_wg<4, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_res_bwd_wg<4, false>), grid, block, 0, s, a);
+  } else {
+    if (wr) hipLaunchKernelGGL((k_res_bwd_wg<8, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_res_bwd_wg<8, false>), grid, block, 0, s, a);
+  }
+  DQ_LAUNCH_CHECK();
+  if (red_out) {
+    ResWgReduce r;
+    r.part = a.part; r.B = B; r.gx = gx; r.nv = a.nv; r.nglob = a.nv - 2 * a.C; r.C = a.C;
+    r.dst = a.dparams; r.dss = a.dss; r.ss_stride = a.ss_stride;
+    *red_out = r;
+  }
+  return 0;
+}
+
+int launch_res_wg_reduce(const ResWgReduce* items, int count, hipStream_t s) {
+  if (count == 0) return 0;
+  DQ_REQUIRE(count <= RES_WG_REDUCE_MAX, "res_wg_reduce: too many items");
+  ResWgReduceMulti m;
+  int nmax = 1;
+  for (int i = 0; i < count; ++i) {
+    m.it[i] = items[i];
+    DQ_REQUIRE(items[i].part && items[i].dst && items[i].dss, "res_wg_reduce: missing operand");
+    nmax = std::max(nmax, items[i].nglob + items[i].B * 2 * items[i].C);
+  }
+  hipLaunchKernelGGL(k_res_wg_reduce, dim3(cdiv(nmax, 16), count), dim3(256), 0, s, m);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace dq
