@@ -141,6 +141,21 @@ int launch_res_fwd_v4(const ResFwd& a, hipStream_t s);
 // k_res_mm.hip: forward with the convolutions on the 4x4x1 matrix pipe (rows of 1..64 positions, C = 4 / 8 / 12 / 16)
 bool res_mm_usable(int n, int C, int cinA, int cinB, int rows_per_sample, bool has_wr);
 int launch_res_fwd_mm(const ResFwd& a, hipStream_t s);
+// k_level.hip: [resample conv that produces the level's input] -> ResnetBlock (-> ResnetBlock) in ONE launch, convolutions on the
+// matrix pipe (rows of 1..64 positions).  blk[i].inA / cinA are unused (a block's first input is in registers); blk[i].out == null:
+// that block's output is not written (inference, up path); pre_out: where the input stage's result is kept (training) or null.
+enum LevelPre { LEVEL_PRE_NONE = 0, LEVEL_PRE_DOWN = 1, LEVEL_PRE_UP = 2, LEVEL_PRE_S1 = 3 };
+struct LevelFwd {
+  const float* in = nullptr; int cp = 0;                    // stage input (rows, cp, n_in); NONE: the first block's input (rows, C, n)
+  const float* pw = nullptr; const float* pb = nullptr;     // stage conv weight (C, cp, K) and bias (C)
+  const float* params = nullptr;                            // the flat parameter buffer every weight / bias / gain pointer points into
+  float* pre_out = nullptr;
+  int pre = LEVEL_PRE_NONE, nblocks = 1;
+  ResFwd blk[2];
+  int C = 0, rows = 0, n = 0, rows_per_sample = 1;
+};
+bool level_fwd_usable(int C, int n, int rows_per_sample, int pre_mode, int cp, int nblocks, const ResFwd* blk);
+int launch_level_fwd(const LevelFwd& a, hipStream_t s);
 int launch_res_fwd(const ResFwd& a, hipStream_t s);
 int launch_res_bwd(const ResBwd& a, hipStream_t s);
 // k_res_wg.hip: ResnetBlock backward of the wide levels (C = 4 / 8, rows of 8..256 positions) with the block's weight gradients formed

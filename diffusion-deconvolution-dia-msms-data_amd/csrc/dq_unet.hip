@@ -602,6 +602,47 @@ int mid_backward_wide(const Ctx& c, const float* rope) {
   return launch_fold(c.g(a.w_mid_in), c.g(a.downs[L - 1].rs), B, RT, Cm, 0, 0, c.s, P);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// one launch per level for [the resample conv that produces the level's input] + the level's ResnetBlocks (k_level.hip)
+// ---------------------------------------------------------------------------------------------------------------
+bool level_kernels_enabled() {
+  static const bool on = [] { const char* e = std::getenv("DQ_NO_LEVEL_FWD"); return !(e && e[0] == '1'); }();  // A-B switch
+  return on;
+}
+// a block of the level kernel: its second input (skip channels) and where its results go
+ResFwd level_block(const Ctx& c, const ResP& r, const ResBuf& b, const float* inB, int cinB, bool write_out) {
+  ResFwd k;
+  k.inB = cinB ? inB : nullptr; k.cinB = cinB;
+  k.w1 = c.prm(r.c1.w); k.b1 = c.prm(r.c1.b); k.g1 = c.prm(r.g1);
+  k.w2 = c.prm(r.c2.w); k.b2 = c.prm(r.c2.b); k.g2 = c.prm(r.g2);
+  if (r.res.cout) { k.wr = c.prm(r.res.w); k.br = c.prm(r.res.b); }
+  k.ss = c.w(c.ar.ss) + r.ss_off; k.ss_stride = c.p.ss_total;
+  if (c.save) { k.u1 = c.w(b.u1); k.a1 = b.wpart_floats ? nullptr : c.w(b.a1); k.u2 = c.w(b.u2); }
+  k.out = (write_out || c.save) ? c.w(b.out) : nullptr;
+  return k;
+}
+struct LevelCall {
+  int pre = LEVEL_PRE_NONE; const ConvP* pc = nullptr; const float* in = nullptr; float* pre_out = nullptr;
+  int C = 0, n = 0, nblocks = 0;
+  const ResP* r[2] = {nullptr, nullptr}; const ResBuf* rb[2] = {nullptr, nullptr};
+  const float* inB[2] = {nullptr, nullptr}; int cinB[2] = {0, 0}; bool write_out[2] = {true, true};
+};
+LevelFwd level_desc(const Ctx& c, const LevelCall& lc) {
+  LevelFwd f;
+  f.params = c.P; f.in = lc.in; f.pre = lc.pre; f.nblocks = lc.nblocks; f.C = lc.C; f.rows = c.B * c.RT; f.n = lc.n; f.rows_per_sample = c.RT;
+  if (lc.pc) { f.cp = lc.pc->cin; f.pw = c.prm(lc.pc->w); f.pb = lc.pc->b >= 0 ? c.prm(lc.pc->b) : nullptr; f.pre_out = c.save ? lc.pre_out : nullptr; }
+  for (int i = 0; i < lc.nblocks; ++i) f.blk[i] = level_block(c, *lc.r[i], *lc.rb[i], lc.inB[i], lc.cinB[i], lc.write_out[i]);
+  return f;
+}
+bool level_ok(const Ctx& c, const LevelCall& lc) {
+  if (!level_kernels_enabled()) return false;
+  for (int i = 0; i < lc.nblocks; ++i)
+    if (lc.r[i]->cout != lc.C || lc.r[i]->cin != lc.C + lc.cinB[i]) return false;
+  if (lc.pc && (lc.pc->cout != lc.C || lc.pc->b < 0)) return false;
+  const LevelFwd f = level_desc(c, lc);
+  return level_fwd_usable(f.C, f.n, f.rows_per_sample, f.pre, f.cp, f.nblocks, f.blk);
+}
+
 int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t* t, int t_scalar, const float* init_cond,
                  const float* attn_cond, float cm, float ca, const DevTables& dt, float* out, const int* step_tab = nullptr,
                  const int* step_ptr = nullptr) {
@@ -624,14 +665,31 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     DQ_TRY(conv_plain_fwd(c, p.ms1_c1, CONV_S1, c.w(a.ms1_a), c.w(a.ms1f), B, RT, RT));
   }
   // down path (unet1d.py:1134-1142)
+  // A level whose ResnetBlocks the level kernel takes also computes its own input from the previous level's LinearAttention
+  // output (Downsample, unet1d.py:1141): that conv is then not launched and, in inference, its result never exists in memory.
+  auto down_call = [&](int lv) {
+    LevelCall lc;
+    const LevelP& l = p.downs[lv];
+    lc.C = l.r0.cout; lc.n = l.n; lc.nblocks = 2;
+    lc.r[0] = &l.r0; lc.r[1] = &l.r1; lc.rb[0] = &a.downs[lv].r0; lc.rb[1] = &a.downs[lv].r1;
+    if (lv == 0) { lc.in = c.w(a.h0); }
+    else { lc.pre = LEVEL_PRE_DOWN; lc.pc = &p.downs[lv - 1].resample; lc.in = c.w(a.downs[lv - 1].la); lc.pre_out = c.w(a.downs[lv - 1].rs); }
+    return lc;
+  };
   const float* cur = c.w(a.h0);
   for (int lv = 0; lv < L; ++lv) {
     const LevelP& l = p.downs[lv];
     const LevelBuf& b = a.downs[lv];
     const int C = l.r0.cin;
-    DQ_TRY(res_fwd(c, l.r0, b.r0, cur, C, nullptr, 0, R, l.n, RT));
-    DQ_TRY(res_fwd(c, l.r1, b.r1, c.w(b.r0.out), C, nullptr, 0, R, l.n, RT));
+    const LevelCall lc = down_call(lv);
+    if (level_ok(c, lc)) {
+      DQ_TRY(launch_level_fwd(level_desc(c, lc), c.s));
+    } else {
+      DQ_TRY(res_fwd(c, l.r0, b.r0, cur, C, nullptr, 0, R, l.n, RT));
+      DQ_TRY(res_fwd(c, l.r1, b.r1, c.w(b.r0.out), C, nullptr, 0, R, l.n, RT));
+    }
     DQ_TRY(la_fwd(c, l.la, c.w(b.r1.out), c.w(b.la), c.save ? c.w(b.la_pre) : nullptr, R, l.n, prep_ok ? lv : -1));
+    if (lv + 1 < L && level_ok(c, down_call(lv + 1))) continue;  // the next level's launch applies this level's Downsample itself
     DQ_TRY(conv_plain_fwd(c, l.resample, l.last ? CONV_S1 : CONV_DOWN, c.w(b.la), c.w(b.rs), R, l.n, l.n_next));
     cur = c.w(b.rs);
   }
@@ -673,20 +731,47 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     DQ_TRY(launch_fold(c.w(a.mid2.out), c.w(a.mid_back), B, RT, p.mid_c, 0, 0, c.s));
   }
   // up path (unet1d.py:1150-1158): first pop = post-attention skip, second pop = post-block1 skip
+  auto up_call = [&](int ui) {  // ui == L: the final ResnetBlock behind the last level's k3 conv (unet1d.py:1160-1163)
+    LevelCall lc;
+    if (ui < L) {
+      const LevelP& l = p.ups[ui];
+      const int lv = L - 1 - ui, cs = l.r0.cin - l.r0.cout;
+      lc.C = l.r0.cout; lc.n = l.n; lc.nblocks = 2;
+      lc.r[0] = &l.r0; lc.r[1] = &l.r1; lc.rb[0] = &a.ups[ui].r0; lc.rb[1] = &a.ups[ui].r1;
+      lc.inB[0] = c.w(a.downs[lv].la); lc.inB[1] = c.w(a.downs[lv].r0.out); lc.cinB[0] = lc.cinB[1] = cs;
+      lc.write_out[0] = false;  // (inference: only the second block's output leaves the launch)
+    } else {
+      lc.C = p.fin.cout; lc.n = p.mz; lc.nblocks = 1;
+      lc.r[0] = &p.fin; lc.rb[0] = &a.fin; lc.inB[0] = c.w(a.h0); lc.cinB[0] = p.dim;
+    }
+    if (ui == 0) { lc.in = c.w(a.mid_back); }
+    else {
+      const LevelP& lp = p.ups[ui - 1];
+      lc.pre = lp.last ? LEVEL_PRE_S1 : LEVEL_PRE_UP; lc.pc = &lp.resample; lc.in = c.w(a.ups[ui - 1].la); lc.pre_out = c.w(a.ups[ui - 1].rs);
+    }
+    return lc;
+  };
   cur = c.w(a.mid_back);
   for (int ui = 0; ui < L; ++ui) {
     const LevelP& l = p.ups[ui];
     const LevelBuf& b = a.ups[ui];
     const int lv = L - 1 - ui;
     const int cx = l.r0.cout, cs = l.r0.cin - l.r0.cout;
-    DQ_TRY(res_fwd(c, l.r0, b.r0, cur, cx, c.w(a.downs[lv].la), cs, R, l.n, RT));
-    DQ_TRY(res_fwd(c, l.r1, b.r1, c.w(b.r0.out), cx, c.w(a.downs[lv].r0.out), cs, R, l.n, RT));
+    const LevelCall lc = up_call(ui);
+    if (level_ok(c, lc)) {
+      DQ_TRY(launch_level_fwd(level_desc(c, lc), c.s));
+    } else {
+      DQ_TRY(res_fwd(c, l.r0, b.r0, cur, cx, c.w(a.downs[lv].la), cs, R, l.n, RT));
+      DQ_TRY(res_fwd(c, l.r1, b.r1, c.w(b.r0.out), cx, c.w(a.downs[lv].r0.out), cs, R, l.n, RT));
+    }
     DQ_TRY(la_fwd(c, l.la, c.w(b.r1.out), c.w(b.la), c.save ? c.w(b.la_pre) : nullptr, R, l.n, prep_ok ? L + ui : -1));
+    if (level_ok(c, up_call(ui + 1))) continue;  // the next launch applies this level's Upsample / k3 conv itself
     DQ_TRY(conv_plain_fwd(c, l.resample, l.last ? CONV_S1 : CONV_UP, c.w(b.la), c.w(b.rs), R, l.n, l.n_next));
     cur = c.w(b.rs);
   }
   // head (unet1d.py:1160-1166)
-  DQ_TRY(res_fwd(c, p.fin, a.fin, cur, p.dim, c.w(a.h0), p.dim, R, p.mz, RT));
+  if (level_ok(c, up_call(L))) DQ_TRY(launch_level_fwd(level_desc(c, up_call(L)), c.s));
+  else DQ_TRY(res_fwd(c, p.fin, a.fin, cur, p.dim, c.w(a.h0), p.dim, R, p.mz, RT));
   DQ_TRY(conv_plain_fwd(c, p.final_conv, CONV_S1, c.w(a.fin.out), out, R, p.mz, p.mz));
   return 0;
 }

@@ -1,0 +1,466 @@
+// One launch for the convolutional part of a U-Net level (reference dquartic/model/unet1d.py:1134-1142, 1150-1158, 1160-1163):
+//   [ the resample conv that produces the level's input: Downsample k4 s2 | Upsample nearest x2 + k3 | k3 (last levels) ]
+//   -> ResnetBlock -> ResnetBlock
+// with every convolution on the 4x4x1 matrix pipe in the lane = position layout of k_res_mm.hip.  The level's input never goes
+// to memory in inference (the resampled tensor `rs` and, on the way down, the re-read of block 1's output disappear), and the four
+// launches of a level become two (this + the LinearAttention).
+//
+// Input stage, lane q = output position of the level (row length n):
+//   DOWN: out[q] = sum_k w[k] in[2 q - 1 + k]   -- the lane loads in[2 q], in[2 q + 1] (8 bytes); in[2 q - 1] is lane q - 1's second
+//         value and in[2 q + 2] lane q + 1's first (one DPP wave shift each)
+//   UP:   out[q] = sum_k w[k] up[q - 1 + k], up[j] = in[j / 2]  -- the lane loads in[q / 2] (= up[q]); its neighbours' values are up[q -+ 1]
+//   S1:   plain k3
+// Every global read of a tile (stage input, the skip channels of cat(x, skip), unet1d.py:1151, 1154) is requested before the first use.
+#include "dq_common.h"
+#include "dq_kernels.h"
+#include <algorithm>
+
+namespace dq {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float lane_m1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, false)); }
+__device__ __forceinline__ float lane_p1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, false)); }
+__host__ __device__ constexpr int pad4(int x) { return (x + 3) / 4 * 4; }
+
+// job offsets of the weight image: [stage][block 0: conv1 | conv2 | res][block 1: ...]; a job = one MFMA weight operand
+struct Jobs {
+  int pre, c1[2], c2[2], rs[2], total;
+};
+__host__ __device__ inline Jobs level_jobs(int C, int pre_mode, int cp, int nblocks, const int* cin, const bool* wr) {
+  Jobs j;
+  const int G = C / 4;
+  int o = 0;
+  j.pre = o;
+  if (pre_mode != LEVEL_PRE_NONE) o += pad4(G * cp * (pre_mode == LEVEL_PRE_DOWN ? 4 : 3));
+  for (int b = 0; b < 2; ++b) {
+    j.c1[b] = o;
+    if (b < nblocks) o += pad4(G * cin[b] * 3);
+    j.c2[b] = o;
+    if (b < nblocks) o += pad4(G * C * 3);
+    j.rs[b] = o;
+    if (b < nblocks && wr[b]) o += pad4(G * cin[b]);
+  }
+  j.total = o;
+  return j;
+}
+
+// What the kernel receives: parameter tensors as 32-bit offsets into the flat parameter buffer P (ONE `const float* __restrict__`
+// kernel argument: wave-uniform reads of biases / gains / weights become scalar loads, and a tensor costs one scalar register instead of
+// two -- with 26 pointers the kernel spilled scalar registers inside the tile loop), activations as pointers.
+struct LevelBlkK {
+  int w1, b1, g1, w2, b2, g2, wr, br;  // wr < 0: identity residual
+  int ss_off, cinB;
+  const float* inB; float* u1; float* a1; float* u2; float* out;
+};
+struct LevelFwdK {
+  const float* in; float* pre_out;
+  int pw, pb, nblocks, rows_per_sample, n, ss_stride;
+  LevelBlkK blk[2];
+};
+
+}  // namespace
+
+// CP: input channels of the stage (compile time: every global read of a tile is issued up front from statically indexed registers --
+// with the channel quads walked in a run-time load -> use loop a wave exposed one memory latency per quad and the launch ran at a
+// third of the rate its loads in flight allow)
+template <int C, int PRE, int CP>
+__global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __restrict__ P, const float* __restrict__ ssb, int tiles_ps, int total_tiles,
+                                                   int ln) {  // ssb: the per-sample scale / shift vectors; ln = log2(n)
+  constexpr int G = C / 4;
+  constexpr int KP = PRE == LEVEL_PRE_DOWN ? 4 : 3;
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [job / 4][lane & 3][job % 4]
+  const int cin_[2] = {C + a.blk[0].cinB, C + a.blk[1].cinB};
+  const bool wr_[2] = {a.blk[0].wr >= 0, a.blk[1].wr >= 0};
+  const Jobs J = level_jobs(C, PRE, CP, a.nblocks, cin_, wr_);
+  for (int idx = threadIdx.x; idx < J.total * 4; idx += 256) {
+    const int j = (idx >> 4) * 4 + (idx & 3), li = (idx >> 2) & 3;
+    float v = 0.f;
+    if (PRE != LEVEL_PRE_NONE && j < J.c1[0]) {  // stage: job = (c * G + g) * KP + k
+      const int jj = j - J.pre;
+      if (jj < G * CP * KP) {
+        const int k = jj % KP, g = (jj / KP) % G, c = jj / (KP * G);
+        v = P[a.pw + ((4 * g + li) * CP + c) * KP + k];
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        if (b >= a.nblocks) break;
+        const LevelBlkK& r = a.blk[b];
+        const int cin = cin_[b];
+        if (j >= J.c1[b] && j < J.c2[b]) {          // conv1: job = (c * G + g) * 3 + k
+          const int jj = j - J.c1[b];
+          if (jj < G * cin * 3) { const int k = jj % 3, g = (jj / 3) % G, c = jj / (3 * G); v = P[r.w1 + ((4 * g + li) * cin + c) * 3 + k]; }
+        } else if (j >= J.c2[b] && j < J.rs[b]) {   // conv2
+          const int jj = j - J.c2[b];
+          if (jj < G * C * 3) { const int k = jj % 3, g = (jj / 3) % G, c = jj / (3 * G); v = P[r.w2 + ((4 * g + li) * C + c) * 3 + k]; }
+        } else if (wr_[b] && j >= J.rs[b] && j < J.rs[b] + G * cin) {  // res_conv: job = c * G + g
+          const int jj = j - J.rs[b], g = jj % G, c = jj / G;
+          v = P[r.wr + (4 * g + li) * cin + c];
+        }
+      }
+    }
+    wl[idx] = v;
+  }
+  // Per-channel parameters and THIS SAMPLE's scale / shift vectors (a workgroup works on one sample, blockIdx.y), also in LDS:
+  // [stage bias C][per block: b1 | g1 | b2 | g2 | br | scale + 1 | shift] -- read back as 16-byte broadcasts.  Inside the tile loop a
+  // wave then waits on nothing but its own tile's loads and LDS reads (as scalar loads from memory, re-issued per tile under
+  // scalar-register pressure, they cost a full wait each: the launch time did not move with the instruction count).
+  float* prm = wl + J.total * 4;
+  {
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < C * 15; i += 256) {
+      const int what = i / C, c = i % C;
+      float v = 0.f;
+      if (what == 0) { v = (PRE != LEVEL_PRE_NONE) ? P[a.pb + c] : 0.f; }
+      else {
+        const int bi = (what - 1) / 7, k = (what - 1) % 7;
+        const LevelBlkK& r = a.blk[bi];
+        if (bi < a.nblocks) {
+          const float* ss = ssb + (int64_t)b * a.ss_stride + r.ss_off;
+          v = k == 0 ? P[r.b1 + c] : k == 1 ? P[r.g1 + c] : k == 2 ? P[r.b2 + c] : k == 3 ? P[r.g2 + c] : k == 4 ? (r.wr >= 0 ? P[r.br + c] : 0.f)
+            : k == 5 ? ss[c] + 1.0f : ss[C + c];
+        }
+      }
+      prm[i] = v;
+    }
+  }
+  __syncthreads();
+  auto prm4 = [&](int what, int g) -> float4 { return *reinterpret_cast<const float4*>(prm + what * C + 4 * g); };
+  const int lane = threadIdx.x & 63, li = lane & 3;
+  const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int b = blockIdx.y;
+  const int n = a.n;
+  const int per_sample = a.rows_per_sample * n;
+  const float sqC = sqrtf((float)C);
+  const float* wlane = wl + li * 4;
+  // weight operand of job (base + js): base is a multiple of 4 at run time, js a compile-time constant -> one 16-byte read per four jobs
+  auto wop = [&](int base, int js) -> float { return wlane[(base >> 2) * 16 + (js >> 2) * 16 + (js & 3)]; };
+
+  // the grid is ONE resident round (launcher); wave w takes the 64-position tiles w, w + nwaves, ... of the (sample, tile) list
+  // Index arithmetic per tile is kept off the critical path: n is a power of two (shifts), offsets are 32-bit element counts against
+  // wave-uniform channel base pointers (the launcher checks every tensor stays below 2^31 elements), and NO load is predicated -- the
+  // lanes beyond a sample's last position read its last position instead (their values reach no live lane: a sample ends at a row end)
+  // -- so the only control flow is one branch around each group of stores.
+#pragma unroll 1
+  for (int tile = wid; tile < tiles_ps; tile += nwaves) {  // the workgroups of a sample share its tiles; the grid is one resident round
+    const int it = tile * 64 + lane;
+    const bool live = it < per_sample;
+    const int itc = live ? it : per_sample - 1;
+    const int rr = itc >> ln, p = itc & (n - 1);
+    const unsigned row = (unsigned)(b * a.rows_per_sample + rr);
+    const bool hasL = p > 0, hasR = p + 1 < n;
+    const unsigned obase = (((row * C) << ln) + p) * 4u;  // BYTE offset of (row, channel 0, p) in a (rows, C, n) tensor
+    // tensor base + channel (wave-uniform, scalar registers) + the lane's 32-bit byte offset: one address register per lane
+    auto ld = [&](const float* base, int c, unsigned boff) -> float {
+      return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + ((size_t)c << ln)) + boff);
+    };
+    auto st = [&](float* base, int c, unsigned boff, float v) {
+      *reinterpret_cast<float*>(reinterpret_cast<char*>(base + ((size_t)c << ln)) + boff) = v;
+    };
+    float x[C];
+    // skip channels of the two blocks (cinB <= C): block 0's are requested with the stage's input, block 1's before block 0 computes
+    float xb[2][C];
+    auto load_skip = [&](int bi) {
+      const LevelBlkK& r = a.blk[bi];
+      const unsigned boff = (((row * r.cinB) << ln) + p) * 4u;
+#pragma unroll
+      for (int c = 0; c < C; ++c) xb[bi][c] = (bi < a.nblocks && c < r.cinB) ? ld(r.inB, c, boff) : 0.f;
+    };
+    // ---------------------------------------------------------------- input stage
+    if constexpr (PRE == LEVEL_PRE_NONE) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) x[c] = ld(a.in, c, obase);
+      load_skip(0);
+    } else {
+      f32x4 acc[G][KP];
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int k = 0; k < KP; ++k) acc[g][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int n_in = PRE == LEVEL_PRE_DOWN ? 2 * n : (PRE == LEVEL_PRE_UP ? n / 2 : n);
+      const int p_in = PRE == LEVEL_PRE_DOWN ? 2 * p : (PRE == LEVEL_PRE_UP ? p >> 1 : p);
+      const unsigned soff = (row * CP * n_in + p_in) * 4u;
+      float v0[CP], v1[PRE == LEVEL_PRE_DOWN ? CP : 1];
+#pragma unroll
+      for (int c = 0; c < CP; ++c) {
+        const float* s = a.in + (size_t)c * n_in;  // wave-uniform
+        if constexpr (PRE == LEVEL_PRE_DOWN) {
+          const float2 v = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(s) + soff);
+          v0[c] = v.x; v1[c] = v.y;
+        } else {
+          v0[c] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(s) + soff);
+        }
+      }
+      load_skip(0);  // block 0's skip channels: requested together with the stage's input
+#pragma unroll
+      for (int c = 0; c < CP; ++c) {
+        if constexpr (PRE == LEVEL_PRE_DOWN) {
+          const float tm = lane_m1(v1[c]), tp = lane_p1(v0[c]);
+          const float xm = hasL ? tm : 0.f, xp = hasR ? tp : 0.f;
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            const int js = (c * G + g) * 4;
+            acc[g][0] = mfma4(wop(J.pre, js + 0), xm, acc[g][0]);
+            acc[g][1] = mfma4(wop(J.pre, js + 1), v0[c], acc[g][1]);
+            acc[g][2] = mfma4(wop(J.pre, js + 2), v1[c], acc[g][2]);
+            acc[g][3] = mfma4(wop(J.pre, js + 3), xp, acc[g][3]);
+          }
+        } else {
+          const float tm = lane_m1(v0[c]), tp = lane_p1(v0[c]);
+          const float xm = hasL ? tm : 0.f, xp = hasR ? tp : 0.f;
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            const int js = (c * G + g) * 3;
+            acc[g][0] = mfma4(wop(J.pre, js + 0), xm, acc[g][0]);
+            acc[g][1] = mfma4(wop(J.pre, js + 1), v0[c], acc[g][1]);
+            acc[g][2] = mfma4(wop(J.pre, js + 2), xp, acc[g][2]);
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float4 pb4 = prm4(0, g);
+        const float pbv[4] = {pb4.x, pb4.y, pb4.z, pb4.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float s = (acc[g][0][i] + acc[g][1][i]) + acc[g][2][i];
+          if constexpr (KP == 4) s += acc[g][3][i];
+          x[4 * g + i] = s + pbv[i];
+        }
+      }
+      if (a.pre_out && live) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) st(a.pre_out, c, obase, x[c]);
+      }
+    }
+    // ---------------------------------------------------------------- the level's ResnetBlocks
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi) {
+      if (bi >= a.nblocks) break;
+      const LevelBlkK& r = a.blk[bi];
+      const bool wr = r.wr >= 0;
+      const int pq = 1 + 7 * bi;  // this block's rows of the parameter image: b1, g1, b2, g2, br, scale + 1, shift
+      f32x4 acc[G][3], ar[G][2];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[g][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ar[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ar[g][1] = ar[g][0];
+      }
+      // conv1 (and the 1x1 residual conv) over the block input held in registers ...
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float tm = lane_m1(x[c]), tp = lane_p1(x[c]);
+        const float xm = hasL ? tm : 0.f, xp = hasR ? tp : 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const int js = (c * G + g) * 3;
+          acc[g][0] = mfma4(wop(J.c1[bi], js + 0), xm, acc[g][0]);
+          acc[g][1] = mfma4(wop(J.c1[bi], js + 1), x[c], acc[g][1]);
+          acc[g][2] = mfma4(wop(J.c1[bi], js + 2), xp, acc[g][2]);
+        }
+      }
+      if (wr) {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+          for (int g = 0; g < G; ++g) ar[g][c & 1] = mfma4(wop(J.rs[bi], c * G + g), x[c], ar[g][c & 1]);
+      }
+      // ... and over the skip channels (a block with skip channels has a residual conv)
+      if (bi == 0 && a.nblocks > 1) load_skip(1);  // block 1's skip channels travel while block 0 computes
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        if (c < r.cinB) {  // wave-uniform
+          const float tm = lane_m1(xb[bi][c]), tp = lane_p1(xb[bi][c]);
+          const float xm = hasL ? tm : 0.f, xp = hasR ? tp : 0.f;
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            const int js = ((C + c) * G + g) * 3;
+            acc[g][0] = mfma4(wop(J.c1[bi], js + 0), xm, acc[g][0]);
+            acc[g][1] = mfma4(wop(J.c1[bi], js + 1), xb[bi][c], acc[g][1]);
+            acc[g][2] = mfma4(wop(J.c1[bi], js + 2), xp, acc[g][2]);
+            ar[g][c & 1] = mfma4(wop(J.rs[bi], (C + c) * G + g), xb[bi][c], ar[g][c & 1]);
+          }
+        }
+      }
+      float u[C];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float4 t = prm4(pq + 0, g);
+        const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[4 * g + i] = (acc[g][0][i] + acc[g][1][i]) + (acc[g][2][i] + tv[i]);
+      }
+      if (r.u1 && live) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) st(r.u1, c, obase, u[c]);
+      }
+      {
+        float ssq = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) ssq = fmaf(u[c], u[c], ssq);
+        const float inv = rms_inv(ssq, sqC);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float4 g4 = prm4(pq + 1, g), s4 = prm4(pq + 5, g), h4 = prm4(pq + 6, g);
+          const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w}, hv[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) u[4 * g + i] = silu_f(fmaf(u[4 * g + i] * inv * gv[i], sv[i], hv[i]));
+        }
+      }
+      if (r.a1 && live) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) st(r.a1, c, obase, u[c]);
+      }
+      // conv2 over the block-1 activation
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[g][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float tm = lane_m1(u[c]), tp = lane_p1(u[c]);
+        const float xm = hasL ? tm : 0.f, xp = hasR ? tp : 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const int js = (c * G + g) * 3;
+          acc[g][0] = mfma4(wop(J.c2[bi], js + 0), xm, acc[g][0]);
+          acc[g][1] = mfma4(wop(J.c2[bi], js + 1), u[c], acc[g][1]);
+          acc[g][2] = mfma4(wop(J.c2[bi], js + 2), xp, acc[g][2]);
+        }
+      }
+      float o[C];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float4 t = prm4(pq + 2, g);
+        const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[4 * g + i] = (acc[g][0][i] + acc[g][1][i]) + (acc[g][2][i] + tv[i]);
+      }
+      if (r.u2 && live) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) st(r.u2, c, obase, o[c]);
+      }
+      {
+        float ssq = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) ssq = fmaf(o[c], o[c], ssq);
+        const float inv = rms_inv(ssq, sqC);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float4 g4 = prm4(pq + 3, g);
+          const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[4 * g + i] = silu_f(o[4 * g + i] * inv * gv[i]);
+        }
+      }
+      if (wr) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float4 t = prm4(pq + 4, g);
+          const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[4 * g + i] += (ar[g][0][i] + ar[g][1][i]) + tv[i];
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) o[c] += x[c];
+      }
+      if (r.out && live) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) st(r.out, c, obase, o[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < C; ++c) x[c] = o[c];
+    }
+  }
+}
+
+// stage input widths that are instantiated: a Downsample from C - 4 or C channels, an Upsample / k3 conv from C or C + 4 (channel
+// widths that move by at most one step of 4 per level, as in the reference's configurations; anything else keeps the per-op path)
+static bool level_cp_built(int C, int pre, int cp) {
+  if (pre == LEVEL_PRE_NONE) return true;
+  if (pre == LEVEL_PRE_DOWN) return cp == C || (cp == C - 4 && cp >= 4);
+  return cp == C || (cp == C + 4 && cp <= 16);
+}
+
+static int num_cus() {
+  static const int v = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+  return v;
+}
+
+bool level_fwd_usable(int C, int n, int rows_per_sample, int pre_mode, int cp, int nblocks, const ResFwd* blk) {
+  if (!(C == 4 || C == 8 || C == 12 || C == 16) || n < 1 || n > 64 || (n & (n - 1)) != 0 || rows_per_sample <= 1) return false;
+  if (nblocks < 1 || nblocks > 2) return false;
+  if (!level_cp_built(C, pre_mode, cp)) return false;
+  if (pre_mode == LEVEL_PRE_UP && n < 2) return false;
+  for (int b = 0; b < nblocks; ++b) {
+    const ResFwd& r = blk[b];
+    if (r.cinB % 4 != 0 || r.cinB < 0 || r.cinB > C || (r.cinB > 0) != (r.wr != nullptr)) return false;
+  }
+  return true;
+}
+
+int launch_level_fwd(const LevelFwd& a, hipStream_t s) {
+  DQ_REQUIRE(level_fwd_usable(a.C, a.n, a.rows_per_sample, a.pre, a.cp, a.nblocks, a.blk), "level_fwd: unsupported shape");
+  DQ_REQUIRE(a.rows % a.rows_per_sample == 0 && a.in && a.params, "level_fwd: bad rows / missing input");
+  DQ_REQUIRE(a.pre == LEVEL_PRE_NONE || (a.pw && a.pb), "level_fwd: the input stage needs its conv weight and bias");
+  LevelFwdK k;
+  auto poff = [&](const float* ptr) -> int { return ptr ? (int)(ptr - a.params) : -1; };
+  k.in = a.in; k.pre_out = a.pre_out; k.pw = poff(a.pw); k.pb = poff(a.pb); k.nblocks = a.nblocks; k.rows_per_sample = a.rows_per_sample; k.n = a.n;
+  const float* ssb = a.blk[0].ss;
+  k.ss_stride = a.blk[0].ss_stride;
+  for (int b = 0; b < 2; ++b) {
+    const ResFwd& r = a.blk[b < a.nblocks ? b : 0];
+    DQ_REQUIRE(r.w1 && r.b1 && r.g1 && r.w2 && r.b2 && r.g2 && r.ss && (r.cinB == 0 || (r.inB && r.wr && r.br)), "level_fwd: missing block operand");
+    DQ_REQUIRE(r.ss_stride == k.ss_stride && r.ss >= ssb - (1 << 20) && r.ss <= ssb + (1 << 20), "level_fwd: the blocks' scale / shift vectors must share one buffer");
+    for (const float* q : {r.w1, r.b1, r.g1, r.w2, r.b2, r.g2, r.wr, r.br})
+      DQ_REQUIRE(!q || (q >= a.params && q - a.params < (1ll << 31)), "level_fwd: a parameter lies outside the flat parameter buffer");
+    LevelBlkK& d = k.blk[b];
+    d.w1 = poff(r.w1); d.b1 = poff(r.b1); d.g1 = poff(r.g1); d.w2 = poff(r.w2); d.b2 = poff(r.b2); d.g2 = poff(r.g2); d.wr = poff(r.wr); d.br = poff(r.br);
+    d.ss_off = (int)(r.ss - ssb); d.cinB = b < a.nblocks ? r.cinB : 0;
+    d.inB = r.inB; d.u1 = r.u1; d.a1 = r.a1; d.u2 = r.u2; d.out = r.out;
+  }
+  const int B = a.rows / a.rows_per_sample;
+  const int tiles_ps = cdiv((int64_t)a.rows_per_sample * a.n, 64);
+  const int64_t total = (int64_t)tiles_ps * B;
+  DQ_REQUIRE(total < (1ll << 31), "level_fwd: too many tiles");
+  DQ_REQUIRE((int64_t)a.rows * 2 * std::max(a.C, a.cp) * std::max(a.n, 2) < (1ll << 31), "level_fwd: tensors of 2^31 elements or more are not built (32-bit offsets)");
+  int ln = 0;
+  while ((1 << ln) < a.n) ++ln;
+  const int cin[2] = {a.C + a.blk[0].cinB, a.C + a.blk[1].cinB};
+  const bool wr[2] = {a.blk[0].wr != nullptr, a.blk[1].wr != nullptr};
+  const int cp = a.pre == LEVEL_PRE_NONE ? 4 : a.cp;
+  const size_t lds = (size_t)level_jobs(a.C, a.pre, cp, a.nblocks, cin, wr).total * 16 + (size_t)a.C * 15 * 4;
+  DQ_REQUIRE(lds <= 64 * 1024, "level_fwd: weight image too large");
+  // one resident round: blocks per CU from the occupancy query, capped at 6 (at this kernel's ~106 scalar registers the hardware admits six
+  // 256-thread blocks per CU where the query can say seven: MI355X_MICROARCH.md, Residency), never more blocks than tiles need
+#define DQ_LV(CC, PP, PC)                                                                                                     \
+  if (a.C == CC && a.pre == PP && cp == PC) {                                                                                 \
+    static int occ = 0;                                                                                                       \
+    if (!occ) {                                                                                                               \
+      int nb = 0;                                                                                                             \
+      DQ_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_level_fwd<CC, PP, PC>, 256, lds));                        \
+      occ = std::max(1, std::min(nb, 6));                                                                                     \
+    }                                                                                                                         \
+    const int gx = std::max(1, std::min(occ * num_cus() / B, (tiles_ps + 3) / 4));  /* workgroups per sample */                \
+    hipLaunchKernelGGL((k_level_fwd<CC, PP, PC>), dim3(gx, B), dim3(256), lds, s, k, a.params, ssb, tiles_ps, (int)total, ln);  \
+    DQ_LAUNCH_CHECK();                                                                                                        \
+    return 0;                                                                                                                 \
+  }
+  DQ_LV(4, LEVEL_PRE_NONE, 4) DQ_LV(8, LEVEL_PRE_NONE, 4) DQ_LV(12, LEVEL_PRE_NONE, 4) DQ_LV(16, LEVEL_PRE_NONE, 4)
+  DQ_LV(4, LEVEL_PRE_DOWN, 4) DQ_LV(8, LEVEL_PRE_DOWN, 4) DQ_LV(8, LEVEL_PRE_DOWN, 8) DQ_LV(12, LEVEL_PRE_DOWN, 8) DQ_LV(12, LEVEL_PRE_DOWN, 12)
+  DQ_LV(16, LEVEL_PRE_DOWN, 12) DQ_LV(16, LEVEL_PRE_DOWN, 16)
+  DQ_LV(4, LEVEL_PRE_UP, 4) DQ_LV(4, LEVEL_PRE_UP, 8) DQ_LV(8, LEVEL_PRE_UP, 8) DQ_LV(8, LEVEL_PRE_UP, 12) DQ_LV(12, LEVEL_PRE_UP, 12) DQ_LV(12, LEVEL_PRE_UP, 16)
+  DQ_LV(16, LEVEL_PRE_UP, 16)
+  DQ_LV(4, LEVEL_PRE_S1, 4) DQ_LV(4, LEVEL_PRE_S1, 8) DQ_LV(8, LEVEL_PRE_S1, 8) DQ_LV(8, LEVEL_PRE_S1, 12) DQ_LV(12, LEVEL_PRE_S1, 12) DQ_LV(12, LEVEL_PRE_S1, 16)
+  DQ_LV(16, LEVEL_PRE_S1, 16)
+#undef DQ_LV
+  set_error("level_fwd: unsupported (C, stage, stage input width)");
+  return 2;
+}
+
+}  // namespace dq

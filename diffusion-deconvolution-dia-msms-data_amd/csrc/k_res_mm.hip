@@ -36,7 +36,7 @@ constexpr int pad4(int x) { return (x + 3) / 4 * 4; }
 
 // CBQ: channel quads of the second input (cat(A, B), up path; then the residual is a 1x1 conv); 0: single input, identity residual
 template <int C, int CBQ>
-__global__ void __launch_bounds__(256) k_res_fwd_mm(ResFwd a, int tiles_ps, int tpw) {
+__global__ void __launch_bounds__(256) k_res_fwd_mm(ResFwd a, int tiles_ps, int total_tiles) {
   constexpr int G = C / 4, CB = 4 * CBQ, CIN = C + CB;
   constexpr bool WR = CBQ > 0;
   constexpr int J1 = G * CIN * 3, J2 = G * C * 3, JR = WR ? G * CIN : 0;   // jobs (one weight operand each)
@@ -59,18 +59,18 @@ __global__ void __launch_bounds__(256) k_res_fwd_mm(ResFwd a, int tiles_ps, int 
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, li = lane & 3;
-  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int b = blockIdx.y, n = a.n;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int n = a.n;
   const int per_sample = a.rows_per_sample * n;
   const float sqC = sqrtf((float)C);
-  const float* ss = a.ss + (int64_t)b * a.ss_stride;
   const float* wlane = wl + li * 4;
   auto wop = [&](int j) -> float { return wlane[(j >> 2) * 16 + (j & 3)]; };  // (the compiler merges the four jobs of a group into one 16-byte read)
 
+  // the grid is ONE resident round; wave w takes the 64-position tiles w, w + nwaves, ... of the (sample, tile) list
 #pragma unroll 1
-  for (int t = 0; t < tpw; ++t) {
-    const int tile = wid * tpw + t;
-    if (tile >= tiles_ps) break;  // wave-uniform
+  for (int gt = wid; gt < total_tiles; gt += nwaves) {
+    const int b = gt / tiles_ps, tile = gt - b * tiles_ps;  // wave-uniform
+    const float* ss = a.ss + (int64_t)b * a.ss_stride;
     const int it = tile * 64 + lane;
     const bool live = it < per_sample;
     const int rr = live ? it / n : 0, p = live ? it - rr * n : 0;
@@ -191,12 +191,25 @@ int launch_res_fwd_mm(const ResFwd& a, hipStream_t s) {
   DQ_REQUIRE(a.rows % a.rows_per_sample == 0, "res_fwd_mm: rows must be a multiple of rows_per_sample");
   const int B = a.rows / a.rows_per_sample;
   const int tiles_ps = cdiv((int64_t)a.rows_per_sample * a.n, 64);
-  // about 8192 waves in all (eight per SIMD at most); a wave walks tpw tiles of one sample with the weight image staged once per block
   const int64_t total = (int64_t)tiles_ps * B;
-  const int tpw = (int)std::max<int64_t>(1, (total + 8191) / 8192);
-  dim3 grid(cdiv(cdiv(tiles_ps, tpw), 4), B), block(256);
-#define DQ_MM(CC, QQ) \
-  if (a.C == CC && a.cinB == 4 * QQ) { hipLaunchKernelGGL((k_res_fwd_mm<CC, QQ>), grid, block, 0, s, a, tiles_ps, tpw); DQ_LAUNCH_CHECK(); return 0; }
+  DQ_REQUIRE(total < (1ll << 31), "res_fwd_mm: too many tiles");
+  int dev = 0;
+  hipDeviceProp_t pr;
+  static const int cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
+  // one resident round (blocks per CU from the occupancy query, at most 7: the scalar-register cap of MI355X_MICROARCH.md, Residency)
+#define DQ_MM(CC, QQ)                                                                                          \
+  if (a.C == CC && a.cinB == 4 * QQ) {                                                                         \
+    static int occ = 0;                                                                                        \
+    if (!occ) {                                                                                                \
+      int nb = 0;                                                                                              \
+      DQ_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_res_fwd_mm<CC, QQ>, 256, 0));              \
+      occ = std::max(1, std::min(nb, 7));                                                                      \
+    }                                                                                                          \
+    const int nblk = (int)std::min<int64_t>((int64_t)occ * cus, (total + 3) / 4);                              \
+    hipLaunchKernelGGL((k_res_fwd_mm<CC, QQ>), dim3(nblk), dim3(256), 0, s, a, tiles_ps, (int)total);          \
+    DQ_LAUNCH_CHECK();                                                                                         \
+    return 0;                                                                                                  \
+  }
   DQ_MM(4, 0) DQ_MM(4, 1) DQ_MM(8, 0) DQ_MM(8, 1) DQ_MM(8, 2) DQ_MM(12, 0) DQ_MM(12, 1) DQ_MM(12, 2) DQ_MM(12, 3)
   DQ_MM(16, 0) DQ_MM(16, 1) DQ_MM(16, 2) DQ_MM(16, 3) DQ_MM(16, 4)
 #undef DQ_MM

@@ -168,7 +168,7 @@ def sinusoidal_emb(t: torch.Tensor, dim: int, theta: float = 10000.0) -> torch.T
 
 def time_mlp(p: Params, t: torch.Tensor, cfg: UNetConfig) -> torch.Tensor:
     """unet1d.py:956-960: sinusoidal -> Linear(dim,4dim) -> exact GELU -> Linear.  Returns (B, time_dim)."""
-    e = sinusoidal_emb(t, cfg.dim, cfg.theta)
+    e = sinusoidal_emb(t, cfg.dim, cfg.theta).to(p["time_mlp.1.weight"].dtype)  # (float64 parameters: the yardstick runs of the tests)
     h = F.linear(e, p["time_mlp.1.weight"], p["time_mlp.1.bias"])
     h = F.gelu(h)
     return F.linear(h, p["time_mlp.3.weight"], p["time_mlp.3.bias"])

@@ -68,7 +68,7 @@ def test_linattn_bwd_vs_autograd(N, C, n, rows):
             "dq_linattn_bwd")
     torch.cuda.synchronize()
     assert rel_err(yd, y) < 1e-5
-    tol = 2e-5 if rows < 1000 else 1e-4  # atomics: summation order varies; long sums lose a little
+    tol = 2e-5 if rows < 1000 else 1e-4  # long fp32 sums (in a fixed order: no atomics) lose a little
     assert rel_err(dx, x.grad) < tol
     assert rel_err(dw, p["la.fn.fn.to_qkv.weight"].grad) < tol
     assert rel_err(dwo, p["la.fn.fn.to_out.0.weight"].grad) < tol
@@ -110,9 +110,29 @@ def test_whole_net_grads_golden(golden, tag, use_rope):
         if e > worst[1]:
             worst = (k, e)
     assert n == 395
-    # fp32 sums over up to 1024 positions with cancellation, accumulated in a different (fixed) order than the reference's
-    print("whole-net gradients vs the reference:", tag, worst)
-    assert worst[1] < 2e-4, worst
+    # The yardstick is the oracle evaluated in float64.  A few of these sums cancel heavily (the gain of a LinearAttention output norm:
+    # ups.5.2.fn.fn.to_out.1.g) and move by ~1e-4 of their value when one conv of the forward pass rounds differently: the REFERENCE's own
+    # fp32 result is 1.2e-4 off the float64 value on that tensor (5.7e-5 on the next one), the kernels' between 3e-5 and 1.2e-4 depending on
+    # which conv kernels ran.  So: within 2e-4 of the float64 value (the reference's own distance from it, with margin), and within 4e-4 of
+    # the reference's fp32 fixture (the two fp32 errors can add up).
+    from oracle import dq_oracle as O
+    p64 = {k: v.double().clone().requires_grad_(not k.endswith("freqs")) for k, v in sub(g, "w/").items()}
+    y64 = O.unet_forward(p64, O.UNetConfig(downsample_dim=64), T(g["x"]).double(), torch.as_tensor(np.asarray(g["t"])), T(g["init_cond"]).double(),
+                         T(g["attn_cond"]).double(), use_rope=use_rope)
+    (y64 * T(g["gout"]).double()).sum().backward()
+    worst64, ref64 = ("", 0.0), ("", 0.0)
+    for k, v in ref.items():
+        t64 = p64[k].grad
+        d = max(float(t64.abs().max()), floor)
+        e = float((named[k].grad.detach().cpu().double() - t64).abs().max()) / d
+        if e > worst64[1]:
+            worst64 = (k, e)
+        er = float((v.double() - t64).abs().max()) / d
+        if er > ref64[1]:
+            ref64 = (k, er)
+    print("whole-net gradients:", tag, "vs the reference's fp32", worst, "| vs float64", worst64, "| the reference's fp32 vs float64", ref64)
+    assert worst64[1] < 2e-4, worst64
+    assert worst[1] < 4e-4, worst
 
 
 def _tiny_dm(g):
