@@ -11,6 +11,11 @@
 //     products, lane (blk, i) supplying channel 4g + i of position 16 blk + s at step s -- a block of lanes walks a RUN of 16
 //     consecutive positions, so the operand of tap k - 1 / k + 1 is the centre operand of the previous / next step (one LDS read
 //     per step and input-channel quad serves three MFMAs); the (co quad, ci quad, tap) jobs are split over the four waves,
+//   * the data path's own (transposed) convolutions  d a1 = W2^T * dU2,  d x = W1^T * dU1 + Wr^T d out  run on the matrix pipe too, in the
+//     lane = position form of k_res_mm.hip: B operand = the register holding dU[co] (one DPP wave shift for the outer taps), A
+//     operand = W[co][4 g + (lane & 3)][k] from an LDS operand image, result = "channel 4 g + i of this lane's position in register i".
+//     (As VALU FMAs with the weights read from LDS as broadcasts -- one LDS instruction per FMA -- this kernel took 3-4x longer than
+//     the data path + the separate weight-gradient launches it replaces.)
 //   * a1 = SiLU(norm(u1) (scale + 1) + shift) is recomputed from u1 (which the data path loads anyway): the forward stores one
 //     tensor less per block in training,
 //   * a workgroup walks several 256-position tiles of ONE sample with its accumulators (MFMA results, norm-gain and scale /
@@ -29,6 +34,11 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
+// value of lane - 1 / lane + 1 (0 beyond the wave's ends); every lane takes part: never under control flow
+__device__ __forceinline__ float lane_m1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, false)); }
+__device__ __forceinline__ float lane_p1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, false)); }
+constexpr int pad4(int x) { return (x + 3) / 4 * 4; }
 
 constexpr int TILE = 256;
 constexpr int RUN = 16;  // consecutive positions a 4-lane block of the MFMA walks
@@ -75,14 +85,37 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
   __shared__ __attribute__((aligned(16))) float i_du2[I::FLOATS], i_du1[I::FLOATS], i_a1[I::FLOATS], i_xa[I::FLOATS];
   __shared__ __attribute__((aligned(16))) float i_xb[WR ? I::FLOATS : 4], i_do[WR ? I::FLOATS : 4];
   __shared__ float red[4][4 * C];
-  __shared__ float w2s[C * C * 3], w1s[C * 2 * C * 3], wrs[WR ? C * 2 * C : 1];
+  // operand image of the TRANSPOSED convolutions of the data path, [job / 4][lane & 3][job % 4]:
+  //   T2: job (co, g, k)  = W2[co][4 g + li][k]      (d a1: C output channels = input channels of conv2)
+  //   T1: job (co, gi, k) = W1[co][4 gi + li][k]     (d x: cin channels, gi < GI quads of cat(A, B))
+  //   TR: job (co, gi)    = Wr[co][4 gi + li]
+  constexpr int GI = WR ? 2 * CQ : CQ;
+  constexpr int JT2 = C * CQ * 3, JT1 = C * GI * 3, JTR = WR ? C * GI : 0;
+  constexpr int OT1 = pad4(JT2), OTR = OT1 + pad4(JT1), JTT = OTR + pad4(JTR);
+  __shared__ __attribute__((aligned(16))) float wl[JTT * 4];
+  __shared__ __attribute__((aligned(16))) float prm[4 * C];  // g2 | g1 | scale | shift (this sample's): no global reads of them inside the tile loop
   const int cin = a.cinA + a.cinB;  // C (identity residual) or C + cinB, cinB in {4, .., C} (checked by the launcher)
-  {
-    for (int i = threadIdx.x; i < C * C * 3; i += 256) w2s[i] = a.w2[i];
-    for (int i = threadIdx.x; i < C * cin * 3; i += 256) w1s[i] = a.w1[i];
-    if constexpr (WR)
-      for (int i = threadIdx.x; i < C * cin; i += 256) wrs[i] = a.wr[i];
+  for (int idx = threadIdx.x; idx < JTT * 4; idx += 256) {
+    const int j = (idx >> 4) * 4 + (idx & 3), l4 = (idx >> 2) & 3;
+    float v = 0.f;
+    if (j < JT2) {
+      const int k = j % 3, gg = (j / 3) % CQ, co = j / (3 * CQ);
+      v = a.w2[(co * C + 4 * gg + l4) * 3 + k];
+    } else if (j >= OT1 && j < OT1 + JT1) {
+      const int jj = j - OT1, k = jj % 3, gi = (jj / 3) % GI, co = jj / (3 * GI), ci = 4 * gi + l4;
+      if (ci < cin) v = a.w1[(co * cin + ci) * 3 + k];
+    } else if (WR && j >= OTR && j < OTR + JTR) {
+      const int jj = j - OTR, gi = jj % GI, co = jj / GI, ci = 4 * gi + l4;
+      if (ci < cin) v = a.wr[co * cin + ci];
+    }
+    wl[idx] = v;
   }
+  for (int i = threadIdx.x; i < 4 * C; i += 256) {
+    const int what = i / C, c = i % C;
+    const float* ssp = a.ss + (int64_t)blockIdx.y * a.ss_stride;
+    prm[i] = what == 0 ? a.g2[c] : what == 1 ? a.g1[c] : what == 2 ? ssp[c] : ssp[C + c];
+  }
+  __syncthreads();  // (the first tile reads prm before its first barrier)
   const int b = blockIdx.y, n = a.n;
   const int per_sample = a.rows_per_sample * n;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -90,7 +123,7 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
   const int q = tid + 1;                      // this thread's slot in the images
   const int blk = lane >> 2, li = lane & 3;   // MFMA: 4-lane block and the lane's channel inside a quad
   const int lb = I::at(blk * RUN + 1) + li;   // image offset of (first position of the block's run, channel li)
-  // rows never straddle a run of 16 unless they are 8 long (then every run is two rows); n is a power of two in 8..256
+  // rows never straddle a run of 16 unless they are 8 long (then every run is two rows); n is a power of two in 8..64
   const bool n8 = n == 8;
   const bool zl = ((blk * RUN) % n) == 0;            // the run starts a row: its tap k = 0 operand at step 0 is the zero padding
   const bool zr = ((blk * RUN + RUN) % n) == 0;      // the run ends a row
@@ -122,7 +155,8 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
 #pragma unroll
   for (int c = 0; c < C; ++c) dg2[c] = dg1[c] = dsc[c] = dsh[c] = 0.f;
   const float sqC = sqrtf((float)C);
-  const float* ss = a.ss + (int64_t)b * a.ss_stride;
+  const float* wlane = wl + li * 4;
+  auto wop = [&](int j) -> float { return wlane[(j >> 2) * 16 + (j & 3)]; };  // (four jobs of a group: one 16-byte read)
 
   const int tile_end = min(a.tiles_ps, ((int)blockIdx.x + 1) * a.tpb);
 #pragma unroll 1
@@ -133,14 +167,13 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
     const int64_t obase = ((int64_t)row * C) * n + p;
     const bool hasL = live && p > 0, hasR = live && p + 1 < n;
     // ---- every global read of the tile up front
-    float dout[C], d[C], u[C], u1v[C], dold[C], xa[C], xb[WR ? C : 1];
+    float dout[C], d[C], u[C], u1v[C], xa[C], xb[WR ? C : 1];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       dout[c] = live ? a.dout[obase + (int64_t)c * n] : 0.f;
       u[c] = live ? a.u2[obase + (int64_t)c * n] : 1.f;
       u1v[c] = live ? a.u1[obase + (int64_t)c * n] : 1.f;
       xa[c] = live ? a.inA[obase + (int64_t)c * n] : 0.f;  // cinA == C
-      dold[c] = (live && !WR && a.dA && !a.dA_store) ? a.dA[obase + (int64_t)c * n] : 0.f;
       d[c] = dout[c];
     }
     if constexpr (WR) {
@@ -148,7 +181,7 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
       for (int c = 0; c < C; ++c) xb[c] = (live && c < a.cinB) ? a.inB[((int64_t)row * a.cinB + c) * n + p] : 0.f;
     }
     // ---- block2: dU2; block1's activation a1 recomputed from u1 with the forward's expression
-    norm_act_bwd<C, false>(u, d, a.g2, nullptr, dg2, nullptr, nullptr);
+    norm_act_bwd<C, false>(u, d, prm, nullptr, dg2, nullptr, nullptr);
     float a1v[C];
     {
       float ssq = 0.f;
@@ -156,7 +189,7 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
       for (int c = 0; c < C; ++c) ssq = fmaf(u1v[c], u1v[c], ssq);
       const float inv = rms_inv(ssq, sqC);
 #pragma unroll
-      for (int c = 0; c < C; ++c) a1v[c] = live ? silu_f(fmaf(u1v[c] * inv * a.g1[c], ss[c] + 1.0f, ss[C + c])) : 0.f;
+      for (int c = 0; c < C; ++c) a1v[c] = live ? silu_f(fmaf(u1v[c] * inv * prm[C + c], prm[2 * C + c] + 1.0f, prm[3 * C + c])) : 0.f;
     }
     __syncthreads();  // the previous tile's readers of the images are done (first tile: the staged weights are visible)
     {
@@ -209,31 +242,36 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
      }
     }
 #endif
-    // ---- d a1[ci][p] = sum_co sum_k W2[co][ci][k] dU2[co][p + 1 - k]
+    // ---- d a1[ci][p] = sum_co sum_k W2[co][ci][k] dU2[co][p + 1 - k]  (matrix pipe; tap k reads position p + 1 - k)
     float da1[C];
     {
-      float dl[C], dr[C];
+      f32x4 acc[CQ][3];
 #pragma unroll
-      for (int c4 = 0; c4 < CQ; ++c4) {
-        const float4 l4 = *reinterpret_cast<const float4*>(i_du2 + I::at(q - 1) + 4 * c4);
-        const float4 r4 = *reinterpret_cast<const float4*>(i_du2 + I::at(q + 1) + 4 * c4);
-        dl[4 * c4] = hasL ? l4.x : 0.f; dl[4 * c4 + 1] = hasL ? l4.y : 0.f; dl[4 * c4 + 2] = hasL ? l4.z : 0.f; dl[4 * c4 + 3] = hasL ? l4.w : 0.f;
-        dr[4 * c4] = hasR ? r4.x : 0.f; dr[4 * c4 + 1] = hasR ? r4.y : 0.f; dr[4 * c4 + 2] = hasR ? r4.z : 0.f; dr[4 * c4 + 3] = hasR ? r4.w : 0.f;
-      }
+      for (int gg = 0; gg < CQ; ++gg)
 #pragma unroll
-      for (int ci = 0; ci < C; ++ci) da1[ci] = 0.f;
+        for (int k = 0; k < 3; ++k) acc[gg][k] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int co = 0; co < C; ++co) {
         const float dc = live ? d[co] : 0.f;
-        const float* w = w2s + co * C * 3;
+        const float tp = lane_p1(dc), tm = lane_m1(dc);
+        const float dr = hasR ? tp : 0.f, dl = hasL ? tm : 0.f;
 #pragma unroll
-        for (int ci = 0; ci < C; ++ci) da1[ci] = fmaf(w[ci * 3 + 0], dr[co], fmaf(w[ci * 3 + 1], dc, fmaf(w[ci * 3 + 2], dl[co], da1[ci])));
+        for (int gg = 0; gg < CQ; ++gg) {
+          const int j = (co * CQ + gg) * 3;
+          acc[gg][0] = mfma4(wop(j + 0), dr, acc[gg][0]);
+          acc[gg][1] = mfma4(wop(j + 1), dc, acc[gg][1]);
+          acc[gg][2] = mfma4(wop(j + 2), dl, acc[gg][2]);
+        }
       }
+#pragma unroll
+      for (int gg = 0; gg < CQ; ++gg)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) da1[4 * gg + i] = (acc[gg][0][i] + acc[gg][1][i]) + acc[gg][2][i];
     }
     // ---- block1: dU1
 #pragma unroll
     for (int c = 0; c < C; ++c) u[c] = u1v[c];
-    norm_act_bwd<C, true>(u, da1, a.g1, ss, dg1, dsc, dsh);
+    norm_act_bwd<C, true>(u, da1, prm + C, prm + 2 * C, dg1, dsc, dsh);
     {
       const int o = I::at(q);
 #pragma unroll
@@ -273,65 +311,53 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
       }
     }
 #endif
-    // ---- d x[ci][p] = sum_co sum_k W1[co][ci][k] dU1[co][p + 1 - k]  (+ residual branch) into dA / dB
+    // ---- d x[ci][p] = sum_co sum_k W1[co][ci][k] dU1[co][p + 1 - k]  (+ residual branch) into dA / dB  (matrix pipe)
     if (a.dA || a.dB) {
-      float dl[C], dr[C];
+      f32x4 acc[GI][3], ar[GI];
 #pragma unroll
-      for (int c4 = 0; c4 < CQ; ++c4) {
-        const float4 l4 = *reinterpret_cast<const float4*>(i_du1 + I::at(q - 1) + 4 * c4);
-        const float4 r4 = *reinterpret_cast<const float4*>(i_du1 + I::at(q + 1) + 4 * c4);
-        dl[4 * c4] = hasL ? l4.x : 0.f; dl[4 * c4 + 1] = hasL ? l4.y : 0.f; dl[4 * c4 + 2] = hasL ? l4.z : 0.f; dl[4 * c4 + 3] = hasL ? l4.w : 0.f;
-        dr[4 * c4] = hasR ? r4.x : 0.f; dr[4 * c4 + 1] = hasR ? r4.y : 0.f; dr[4 * c4 + 2] = hasR ? r4.z : 0.f; dr[4 * c4 + 3] = hasR ? r4.w : 0.f;
+      for (int gi = 0; gi < GI; ++gi) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[gi][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ar[gi] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      if constexpr (WR) {
-        // all input channels of this position at once; the old values of dA / dB are requested together before the first store
-        constexpr int CM = 2 * C;
-        float v[CM];
 #pragma unroll
-        for (int ci = 0; ci < CM; ++ci) v[ci] = 0.f;
+      for (int co = 0; co < C; ++co) {
+        const float dc = live ? da1[co] : 0.f;  // dU1
+        const float tp = lane_p1(dc), tm = lane_m1(dc);
+        const float dr = hasR ? tp : 0.f, dl = hasL ? tm : 0.f;
 #pragma unroll
-        for (int co = 0; co < C; ++co) {
-          const float dc = da1[co], dco = dout[co];
-#pragma unroll
-          for (int ci = 0; ci < CM; ++ci) {
-            if (ci < cin) {
-              const float* w = w1s + (co * cin + ci) * 3;
-              v[ci] = fmaf(w[0], dr[co], fmaf(w[1], dc, fmaf(w[2], dl[co], v[ci])));
-              v[ci] = fmaf(wrs[co * cin + ci], dco, v[ci]);
-            }
+        for (int gi = 0; gi < GI; ++gi) {
+          if (gi < cinq) {  // wave-uniform
+            const int j = OT1 + (co * GI + gi) * 3;
+            acc[gi][0] = mfma4(wop(j + 0), dr, acc[gi][0]);
+            acc[gi][1] = mfma4(wop(j + 1), dc, acc[gi][1]);
+            acc[gi][2] = mfma4(wop(j + 2), dl, acc[gi][2]);
+            if constexpr (WR) ar[gi] = mfma4(wop(OTR + co * GI + gi), dout[co], ar[gi]);
           }
         }
-        if (live) {
-          float oldv[CM];
+      }
+      if (live) {
+        // the old values of dA / dB (a gradient tensor this launch is not the first writer of) are requested together before the first store
+        float v[4 * GI], oldv[4 * GI];
 #pragma unroll
-          for (int ci = 0; ci < CM; ++ci) {
-            float* dst = nullptr;
-            if (ci < a.cinA) { if (a.dA) dst = a.dA + ((int64_t)row * a.cinA + ci) * n + p; }
-            else if (ci < cin) { if (a.dB) dst = a.dB + ((int64_t)row * a.cinB + (ci - a.cinA)) * n + p; }
-            oldv[ci] = (dst && !(ci < a.cinA ? a.dA_store : a.dB_store)) ? *dst : 0.f;
+        for (int gi = 0; gi < GI; ++gi)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[4 * gi + i] = (acc[gi][0][i] + acc[gi][1][i]) + (acc[gi][2][i] + (WR ? ar[gi][i] : dout[4 * gi + i]));
           }
 #pragma unroll
-          for (int ci = 0; ci < CM; ++ci) {
-            float* dst = nullptr;
-            if (ci < a.cinA) { if (a.dA) dst = a.dA + ((int64_t)row * a.cinA + ci) * n + p; }
-            else if (ci < cin) { if (a.dB) dst = a.dB + ((int64_t)row * a.cinB + (ci - a.cinA)) * n + p; }
-            if (dst) *dst = oldv[ci] + v[ci];
-          }
+        for (int ci = 0; ci < 4 * GI; ++ci) {
+          float* dst = nullptr;
+          if (ci < a.cinA) { if (a.dA) dst = a.dA + ((int64_t)row * a.cinA + ci) * n + p; }
+          else if (ci < cin) { if (a.dB) dst = a.dB + ((int64_t)row * a.cinB + (ci - a.cinA)) * n + p; }
+          oldv[ci] = (dst && !(ci < a.cinA ? a.dA_store : a.dB_store)) ? *dst : 0.f;
         }
-      } else if (a.dA) {  // identity residual: cin == C, single input
-        float dx[C];
 #pragma unroll
-        for (int ci = 0; ci < C; ++ci) dx[ci] = dout[ci];
-#pragma unroll
-        for (int co = 0; co < C; ++co) {
-          const float dc = da1[co];
-          const float* w = w1s + co * C * 3;
-#pragma unroll
-          for (int ci = 0; ci < C; ++ci) dx[ci] = fmaf(w[ci * 3 + 0], dr[co], fmaf(w[ci * 3 + 1], dc, fmaf(w[ci * 3 + 2], dl[co], dx[ci])));
-        }
-        if (live) {
-#pragma unroll
-          for (int ci = 0; ci < C; ++ci) a.dA[obase + (int64_t)ci * n] = dold[ci] + dx[ci];
+        for (int ci = 0; ci < 4 * GI; ++ci) {
+          float* dst = nullptr;
+          if (ci < a.cinA) { if (a.dA) dst = a.dA + ((int64_t)row * a.cinA + ci) * n + p; }
+          else if (ci < cin) { if (a.dB) dst = a.dB + ((int64_t)row * a.cinB + (ci - a.cinA)) * n + p; }
+          if (dst) *dst = oldv[ci] + v[ci];
         }
       }
     }
@@ -422,7 +448,8 @@ __global__ void __launch_bounds__(256) k_res_wg_reduce(ResWgReduceMulti m) {
 }
 
 bool res_wg_usable(int n, int C, int cinA, int cinB, int rows_per_sample) {
-  return (C == 4 || C == 8) && n >= 8 && n <= 256 && (n & (n - 1)) == 0 && rows_per_sample > 1 && cinA == C &&
+  // (rows of up to 64 positions: a row lives inside one wave, whose DPP shifts are the conv's neighbours)
+  return (C == 4 || C == 8) && n >= 8 && n <= 64 && (n & (n - 1)) == 0 && rows_per_sample > 1 && cinA == C &&
          (cinB == 0 || (cinB % 4 == 0 && cinB <= C));
 }
 
