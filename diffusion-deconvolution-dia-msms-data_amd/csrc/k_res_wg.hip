@@ -163,23 +163,26 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
   for (int tile = blockIdx.x * a.tpb; tile < tile_end; ++tile) {
     const int it = tile * TILE + tid;
     const bool live = it < per_sample;
-    const int row = b * a.rows_per_sample + (live ? it / n : 0), p = live ? it % n : 0;
+    // (no load is predicated: the threads beyond the sample's last position read its last position and contribute zeros -- d out := 0)
+    const int itc = live ? it : per_sample - 1;
+    const int row = b * a.rows_per_sample + itc / n, p = itc % n;
     const int64_t obase = ((int64_t)row * C) * n + p;
     const bool hasL = live && p > 0, hasR = live && p + 1 < n;
     // ---- every global read of the tile up front
     float dout[C], d[C], u[C], u1v[C], xa[C], xb[WR ? C : 1];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      dout[c] = live ? a.dout[obase + (int64_t)c * n] : 0.f;
-      u[c] = live ? a.u2[obase + (int64_t)c * n] : 1.f;
-      u1v[c] = live ? a.u1[obase + (int64_t)c * n] : 1.f;
-      xa[c] = live ? a.inA[obase + (int64_t)c * n] : 0.f;  // cinA == C
-      d[c] = dout[c];
+      dout[c] = a.dout[obase + (int64_t)c * n];
+      u[c] = a.u2[obase + (int64_t)c * n];
+      u1v[c] = a.u1[obase + (int64_t)c * n];
+      xa[c] = a.inA[obase + (int64_t)c * n];  // cinA == C
     }
     if constexpr (WR) {
 #pragma unroll
-      for (int c = 0; c < C; ++c) xb[c] = (live && c < a.cinB) ? a.inB[((int64_t)row * a.cinB + c) * n + p] : 0.f;
+      for (int c = 0; c < C; ++c) xb[c] = c < a.cinB ? a.inB[((int64_t)row * a.cinB + c) * n + p] : 0.f;
     }
+#pragma unroll
+    for (int c = 0; c < C; ++c) { dout[c] = live ? dout[c] : 0.f; d[c] = dout[c]; }
     // ---- block2: dU2; block1's activation a1 recomputed from u1 with the forward's expression
     norm_act_bwd<C, false>(u, d, prm, nullptr, dg2, nullptr, nullptr);
     float a1v[C];
@@ -189,7 +192,7 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
       for (int c = 0; c < C; ++c) ssq = fmaf(u1v[c], u1v[c], ssq);
       const float inv = rms_inv(ssq, sqC);
 #pragma unroll
-      for (int c = 0; c < C; ++c) a1v[c] = live ? silu_f(fmaf(u1v[c] * inv * prm[C + c], prm[2 * C + c] + 1.0f, prm[3 * C + c])) : 0.f;
+      for (int c = 0; c < C; ++c) a1v[c] = silu_f(fmaf(u1v[c] * inv * prm[C + c], prm[2 * C + c] + 1.0f, prm[3 * C + c]));
     }
     __syncthreads();  // the previous tile's readers of the images are done (first tile: the staged weights are visible)
     {
@@ -482,6 +485,26 @@ int launch_res_bwd_wg(const ResBwdWg& a_in, hipStream_t s, ResWgReduce* red_out)
   int gx;
   res_wg_grid(B, a.rows_per_sample, a.n, &a.tiles_ps, &a.tpb, &gx);
   const bool wr = a.wr != nullptr;
+  // ONE resident round: with more workgroups than the CUs hold (2-4 each: the LDS images), the few left over ran as a second round
+  // behind the first -- up to twice the time.  More tiles per workgroup instead (never fewer than the arena's slot count assumes).
+  {
+    static int occ[2][2] = {{0, 0}, {0, 0}};
+    int& o = occ[a.C == 8][wr];
+    if (!o) {
+      int nb = 0;
+      const void* fn = a.C == 4 ? (wr ? (const void*)k_res_bwd_wg<4, true> : (const void*)k_res_bwd_wg<4, false>)
+                                : (wr ? (const void*)k_res_bwd_wg<8, true> : (const void*)k_res_bwd_wg<8, false>);
+      DQ_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0));
+      o = std::max(1, std::min(nb, 6));
+    }
+    int dev = 0;
+    hipDeviceProp_t pr;
+    static const int cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
+    const int64_t resident = (int64_t)o * cus, total = (int64_t)a.tiles_ps * B;
+    a.tpb = std::max(a.tpb, (int)((total + resident - 1) / resident));
+    while (a.tpb < a.tiles_ps && (int64_t)cdiv(a.tiles_ps, a.tpb) * B > resident) ++a.tpb;  // (the per-sample rounding can still overshoot)
+    gx = cdiv(a.tiles_ps, a.tpb);
+  }
   a.nv = res_wg_nv(a.C, a.cinA + a.cinB, wr);
   DQ_REQUIRE(a.part_floats >= (int64_t)gx * B * a.nv, "res_bwd_wg: slot scratch too small");
   dim3 grid(gx, B), block(256);
