@@ -141,10 +141,10 @@ int launch_res_fwd_v4(const ResFwd& a, hipStream_t s);
 // k_res_mm.hip: forward with the convolutions on the 4x4x1 matrix pipe (rows of 1..64 positions, C = 4 / 8 / 12 / 16)
 bool res_mm_usable(int n, int C, int cinA, int cinB, int rows_per_sample, bool has_wr);
 int launch_res_fwd_mm(const ResFwd& a, hipStream_t s);
+enum LevelPre { LEVEL_PRE_NONE = 0, LEVEL_PRE_DOWN = 1, LEVEL_PRE_UP = 2, LEVEL_PRE_S1 = 3 };
 // k_level.hip: [resample conv that produces the level's input] -> ResnetBlock (-> ResnetBlock) in ONE launch, convolutions on the
 // matrix pipe (rows of 1..64 positions).  blk[i].inA / cinA are unused (a block's first input is in registers); blk[i].out == null:
 // that block's output is not written (inference, up path); pre_out: where the input stage's result is kept (training) or null.
-enum LevelPre { LEVEL_PRE_NONE = 0, LEVEL_PRE_DOWN = 1, LEVEL_PRE_UP = 2, LEVEL_PRE_S1 = 3 };
 struct LevelFwd {
   const float* in = nullptr; int cp = 0;                    // stage input (rows, cp, n_in); NONE: the first block's input (rows, C, n)
   const float* pw = nullptr; const float* pb = nullptr;     // stage conv weight (C, cp, K) and bias (C)
@@ -182,6 +182,21 @@ int64_t res_wg_part_floats(int C, int cin, bool wr, int B, int rows_per_sample, 
 // launches the backward; *red_out receives the descriptor of the slot reduction (launch_res_wg_reduce: right away or collected)
 int launch_res_bwd_wg(const ResBwdWg& a, hipStream_t s, ResWgReduce* red_out);
 int launch_res_wg_reduce(const ResWgReduce* items, int count, hipStream_t s);
+// k_conv_wg.hip: backward of a level's resample conv (data gradient + weight / bias gradient in one launch, matrix pipe).  `n` is the
+// conv's OUTPUT row length; pre = LEVEL_PRE_DOWN (k4 s2) / _UP (nearest x2 + k3) / _S1 (k3).  Slots [dW | dbias] -> launch_res_wg_reduce.
+struct ConvBwdWg {
+  const float* dy = nullptr;   // (rows, C, n) gradient of the conv output
+  const float* in = nullptr;   // (rows, cp, n_in) forward input
+  const float* w = nullptr;    // (C, cp, K)
+  float* din = nullptr; int accumulate = 0;   // (rows, cp, n_in): = or += ; null: not needed
+  float* part = nullptr; int64_t part_floats = 0;
+  float* dparams = nullptr;    // gradient of the conv weight in the flat gradient buffer (the bias gradient follows it)
+  int C = 0, pre = 0, cp = 0, rows = 0, n = 0, rows_per_sample = 1;
+  int tiles_ps = 0, tpb = 0, nv = 0;  // (filled by the launcher)
+};
+bool conv_wg_usable(int C, int pre, int cp, int n, int rows_per_sample);
+int64_t conv_wg_part_floats(int C, int pre, int cp, int B, int rows_per_sample, int n);
+int launch_conv_bwd_wg(const ConvBwdWg& a, hipStream_t s, ResWgReduce* red_out);
 // the descriptor of a fused ResnetBlock backward's partial sums for launch_part_reduce
 inline PartReduce res_part_reduce(const float* gpart, int gx, int B, int C, float* dg2, float* dg1, float* dss, int ss_stride) {
   PartReduce r;

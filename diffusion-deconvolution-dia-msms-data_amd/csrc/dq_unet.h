@@ -29,7 +29,10 @@ struct ResBuf {
   int64_t gpart = 0, gpart_floats = 0;  // per-block norm-gain sums of the backward (k_res_bwd / k_res_bwd_cp / k_block_bwd)
   int64_t wpart = 0, wpart_floats = 0;  // per-workgroup slots of the backward that forms its weight gradients itself (k_res_bwd_wg); 0: not that path
 };
-struct LevelBuf { ResBuf r0, r1; int64_t la, la_pre, la_tmp, rs; };
+struct LevelBuf {
+  ResBuf r0, r1; int64_t la, la_pre, la_tmp, rs;
+  int64_t cpart = 0, cpart_floats = 0;  // per-workgroup slots of the resample conv's backward (k_conv_bwd_wg); 0: not that path
+};
 struct WideResBuf { int64_t u1 = 0, a1 = 0, u2 = 0, out = 0; };  // (B, mid_c, P) each: a ResnetBlock of the wide bottleneck  // la_pre: saved pre-norm LA output; la_tmp: backward scratch (twin only)
 struct Arena {
   int B = 0, RT = 0;

@@ -63,6 +63,10 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
     b.r0 = res(R, l.r0.cin, l.r0.cout, l.n); b.r1 = res(R, l.r1.cin, l.r1.cout, l.n);
     b.la = take_nz(R * l.la.C * l.n); b.la_pre = take_nz(R * l.la.C * l.n); b.la_tmp = take_nz(R * l.la.C * l.n);
     b.rs = take_nz(R * l.resample.cout * l.n_next);
+    if (B > 0 && conv_wg_usable(l.resample.cout, l.last ? LEVEL_PRE_S1 : LEVEL_PRE_DOWN, l.resample.cin, l.n_next, RT)) {
+      b.cpart_floats = conv_wg_part_floats(l.resample.cout, l.last ? LEVEL_PRE_S1 : LEVEL_PRE_DOWN, l.resample.cin, B, RT, l.n_next);
+      b.cpart = take_nz(b.cpart_floats);
+    }
     a.downs.push_back(b);
   }
   if (p.wide_mid) {
@@ -99,6 +103,10 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
     b.r0 = res(R, l.r0.cin, l.r0.cout, l.n); b.r1 = res(R, l.r1.cin, l.r1.cout, l.n);
     b.la = take_nz(R * l.la.C * l.n); b.la_pre = take_nz(R * l.la.C * l.n); b.la_tmp = take_nz(R * l.la.C * l.n);
     b.rs = take_nz(R * l.resample.cout * l.n_next);
+    if (B > 0 && conv_wg_usable(l.resample.cout, l.last ? LEVEL_PRE_S1 : LEVEL_PRE_UP, l.resample.cin, l.n_next, RT)) {
+      b.cpart_floats = conv_wg_part_floats(l.resample.cout, l.last ? LEVEL_PRE_S1 : LEVEL_PRE_UP, l.resample.cin, B, RT, l.n_next);
+      b.cpart = take_nz(b.cpart_floats);
+    }
     a.ups.push_back(b);
   }
   a.fin = res(R, 2 * p.dim, p.dim, p.mz);
@@ -475,6 +483,23 @@ int conv_plain_bwd(const Ctx& c, const ConvP& cp, int mode, const float* in, con
   return 0;
 }
 
+// backward of a level's resample conv: one launch for the data and the weight / bias gradient when the shape allows it
+int resample_bwd(const Ctx& c, const ConvP& cp, int pre, const LevelBuf& b, int n_in, int n_out, int accumulate) {
+  static const bool off = [] { const char* e = std::getenv("DQ_NO_CONV_WG"); return e && e[0] == '1'; }();  // A-B switch
+  if (!off && b.cpart_floats && cp.b == cp.w + (int64_t)cp.cout * cp.cin * cp.k && conv_wg_usable(cp.cout, pre, cp.cin, n_out, c.RT)) {
+    ConvBwdWg k;
+    k.dy = c.g(b.rs); k.in = c.w(b.la); k.w = c.prm(cp.w); k.din = c.g(b.la); k.accumulate = accumulate;
+    k.part = c.w(b.cpart); k.part_floats = b.cpart_floats; k.dparams = c.dprm(cp.w);
+    k.C = cp.cout; k.pre = pre; k.cp = cp.cin; k.rows = c.B * c.RT; k.n = n_out; k.rows_per_sample = c.RT;
+    ResWgReduce red;
+    DQ_TRY(launch_conv_bwd_wg(k, c.s, &red));
+    if (c.wg_defer) { c.wg_defer->push_back(red); return 0; }
+    return launch_res_wg_reduce(&red, 1, c.s);
+  }
+  const int mode = pre == LEVEL_PRE_DOWN ? CONV_DOWN : (pre == LEVEL_PRE_UP ? CONV_UP : CONV_S1);
+  return conv_plain_bwd(c, cp, mode, c.w(b.la), c.g(b.rs), c.g(b.la), c.B * c.RT, n_in, n_out, accumulate);
+}
+
 ConvP proj(int64_t w, int cout, int cin) { ConvP c; c.w = w; c.b = -1; c.cout = cout; c.cin = cin; c.k = 1; return c; }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -800,7 +825,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     const int lv = L - 1 - ui;
     const int cx = l.r0.cout, cs = l.r0.cin - l.r0.cout;
     const int64_t in_off = ui == 0 ? a.mid_back : a.ups[ui - 1].rs;
-    DQ_TRY(conv_plain_bwd(c, l.resample, l.last ? CONV_S1 : CONV_UP, c.w(b.la), c.g(b.rs), c.g(b.la), R, l.n, l.n_next, 0));  // only writer of d la (up): store
+    DQ_TRY(resample_bwd(c, l.resample, l.last ? LEVEL_PRE_S1 : LEVEL_PRE_UP, b, l.n, l.n_next, 0));  // only writer of d la (up): store
     DQ_TRY(la_bwd(c, l.la, b, c.w(b.r1.out), c.g(b.la), c.g(b.r1.out), R, l.n, L + ui));
     // the up path is the first writer of its own tensors AND of the skip tensors (the down path accumulates into them later)
     DQ_TRY(res_bwd(c, l.r1, b.r1, c.w(b.r0.out), c.g(b.r0.out), cx, c.w(a.downs[lv].r0.out), c.g(a.downs[lv].r0.out), cs, R, l.n, RT, 1, 1));
@@ -848,7 +873,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     const LevelBuf& b = a.downs[lv];
     const int C = l.r0.cin;
     const int64_t in_off = lv == 0 ? a.h0 : a.downs[lv - 1].rs;
-    DQ_TRY(conv_plain_bwd(c, l.resample, l.last ? CONV_S1 : CONV_DOWN, c.w(b.la), c.g(b.rs), c.g(b.la), R, l.n, l.n_next, 1));
+    DQ_TRY(resample_bwd(c, l.resample, l.last ? LEVEL_PRE_S1 : LEVEL_PRE_DOWN, b, l.n, l.n_next, 1));
     if (lv == 0) DQ_TRY(side_flush(c));  // (last level: the resample conv's weight gradient under the LinearAttention backward, not in the tail)
     DQ_TRY(la_bwd(c, l.la, b, c.w(b.r1.out), c.g(b.la), c.g(b.r1.out), R, l.n, lv));
     DQ_TRY(res_bwd(c, l.r1, b.r1, c.w(b.r0.out), c.g(b.r0.out), C, nullptr, nullptr, 0, R, l.n, RT));

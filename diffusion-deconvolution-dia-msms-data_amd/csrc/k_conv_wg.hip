@@ -1,0 +1,316 @@
+// Backward of a level's resample conv -- Downsample (k4 s2 p1), Upsample (nearest x2 + k3 p1) or the k3 conv of the last levels
+// (reference dquartic/model/unet1d.py:82-110) -- data gradient AND weight / bias gradient in ONE launch, both on the 4x4x1 matrix
+// pipe.  Replaces k_conv_bwd_data (main stream) + k_conv_wgrad + k_wgrad_reduce (side stream), which read dY and the conv input
+// twice.
+//
+// Thread = output position q of the conv (a wave = 64 consecutive positions = whole rows, n <= 64):
+//   data gradient  : the transposed conv in the lane = position form of k_res_mm.hip (B operand = the register holding dY[co], one DPP
+//                    wave shift for the neighbours; A operand = W[co][4 gi + (lane & 3)][k] from an LDS operand image):
+//                      DOWN: d in[2 q] = sum_co W[.][.][1] dY[q] + W[.][.][3] dY[q - 1],  d in[2 q + 1] = sum_co W[.][.][2] dY[q] + W[.][.][0] dY[q + 1]
+//                            (stored as one 8-byte pair per channel)
+//                      UP:   d up[q] = sum_co sum_k W[.][.][k] dY[q + 1 - k],  d in[q / 2] = d up[q] + d up[q ^ 1]  (the even lane stores)
+//                      S1:   d in[q] = sum_co sum_k W[.][.][k] dY[q + 1 - k]
+//   weight gradient: dW[co][ci][k] = sum_q dY[co][q] tap_k[ci][q] with the taps the forward conv multiplies (DOWN: in[2 q - 1 .. 2 q + 2];
+//                    UP / S1: the (upsampled) input at q - 1, q, q + 1) -- dY and the K tap tensors are staged in LDS as [position][channel]
+//                    images, and the (co quad, ci quad, tap) jobs are split over the workgroup's four waves, exactly as in k_res_wg.hip.
+// A workgroup walks several 256-position tiles of one sample and leaves [dW | dbias] in its slot; k_res_wg_reduce sums the slots in
+// block order into the flat gradient buffer (a conv's weight and bias are adjacent there).  No atomics: bitwise repeatable.
+#include "dq_common.h"
+#include "dq_kernels.h"
+#include <algorithm>
+
+namespace dq {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float lane_m1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, false)); }
+__device__ __forceinline__ float lane_p1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, false)); }
+__device__ __forceinline__ float lane_x1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)); }  // lane ^ 1
+constexpr int pad4(int x) { return (x + 3) / 4 * 4; }
+constexpr int TILE = 256, RUN = 16;
+// [position + 1][channel] image (k_res_wg.hip): floats per position an odd number of 16-byte slots, 4 floats of padding per 16 positions
+constexpr int img_st(int c) { return c == 4 ? 4 : (c == 8 ? 12 : 20); }
+constexpr int img_floats(int c) { return (TILE + 2) * img_st(c) + ((TILE + 2) / RUN + 1) * 4; }
+__device__ __forceinline__ int img_at(int q, int st) { return q * st + (q >> 4) * 4; }
+
+__device__ __forceinline__ f32x4 blocks_sum(f32x4 v) {  // sum over the 16 lane blocks; lanes 0..3 hold the total
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float t = v[i];
+    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x124, 0xF, 0xF, false));  // row_ror:4
+    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xF, 0xF, false));  // row_ror:8
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    v[i] = t;
+  }
+  return v;
+}
+
+}  // namespace
+
+template <int C, int PRE, int CP>
+__global__ void __launch_bounds__(256) k_conv_bwd_wg(ConvBwdWg a) {
+  constexpr int K = PRE == LEVEL_PRE_DOWN ? 4 : 3;
+  constexpr int G = C / 4, H = CP / 4;
+  constexpr int STY = img_st(C), STX = img_st(CP);
+  constexpr int JW = (G * H * K + 3) / 4;  // weight-gradient jobs per wave
+  // operand image of the transposed conv: job (co, gi, k) = W[co][4 gi + li][k]
+  constexpr int JT = pad4(C * H * K);
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* wl = lds;                          // JT * 4
+  float* i_dy = wl + JT * 4;                // img_floats(C)
+  float* i_tap = i_dy + img_floats(C);      // K x img_floats(CP)
+  for (int idx = threadIdx.x; idx < JT * 4; idx += 256) {
+    const int j = (idx >> 4) * 4 + (idx & 3), l4 = (idx >> 2) & 3;
+    float v = 0.f;
+    if (j < C * H * K) {
+      const int k = j % K, gi = (j / K) % H, co = j / (K * H);
+      v = a.w[(co * CP + 4 * gi + l4) * K + k];
+    }
+    wl[idx] = v;
+  }
+  const int b = blockIdx.y, n = a.n;
+  const int per_sample = a.rows_per_sample * n;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q1 = tid + 1;
+  const int blk = lane >> 2, li = lane & 3;
+  const int lby = img_at(blk * RUN + 1, STY) + li, lbx = img_at(blk * RUN + 1, STX) + li;
+  const float* wlane = wl + li * 4;
+  auto wop = [&](int j) -> float { return wlane[(j >> 2) * 16 + (j & 3)]; };
+  // this wave's weight-gradient jobs j = wv * JW + jj = (g * H + h) * K + k, and the bias sum of channel quad g == wv
+  f32x4 aw[JW], ab = {0.f, 0.f, 0.f, 0.f};
+  const float* pa[JW]; const float* pb[JW];
+  bool jv[JW];
+#pragma unroll
+  for (int jj = 0; jj < JW; ++jj) {
+    aw[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int j = wv * JW + jj;
+    jv[jj] = j < G * H * K;
+    const int jc = jv[jj] ? j : 0;
+    const int k = jc % K, h = (jc / K) % H, g = jc / (K * H);
+    pa[jj] = i_dy + lby + 4 * g;
+    pb[jj] = i_tap + k * img_floats(CP) + lbx + 4 * h;
+  }
+  const bool do_bias = wv < G;
+  const int n_in = PRE == LEVEL_PRE_DOWN ? 2 * n : (PRE == LEVEL_PRE_UP ? n / 2 : n);
+
+  const int tile_end = min(a.tiles_ps, ((int)blockIdx.x + 1) * a.tpb);
+#pragma unroll 1
+  for (int tile = blockIdx.x * a.tpb; tile < tile_end; ++tile) {
+    const int it = tile * TILE + tid;
+    const bool live = it < per_sample;
+    const int itc = live ? it : per_sample - 1;   // (no load is predicated; the threads beyond the sample contribute dY = 0)
+    const int rr = itc / n, p = itc - rr * n;
+    const int row = b * a.rows_per_sample + rr;
+    const bool hasL = live && p > 0, hasR = live && p + 1 < n;
+    const int p_in = PRE == LEVEL_PRE_DOWN ? 2 * p : (PRE == LEVEL_PRE_UP ? p >> 1 : p);
+    float dy[C], v0[CP], v1[PRE == LEVEL_PRE_DOWN ? CP : 1];
+#pragma unroll
+    for (int c = 0; c < C; ++c) dy[c] = a.dy[((int64_t)row * C + c) * n + p];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      const float* s = a.in + ((int64_t)row * CP + c) * n_in + p_in;
+      if constexpr (PRE == LEVEL_PRE_DOWN) {
+        const float2 v = *reinterpret_cast<const float2*>(s);
+        v0[c] = v.x; v1[c] = v.y;
+      } else {
+        v0[c] = *s;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) dy[c] = live ? dy[c] : 0.f;
+    __syncthreads();  // the previous tile's readers of the images are done (first tile: the operand image is visible)
+    {
+      const int oy = img_at(q1, STY), ox = img_at(q1, STX);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        *reinterpret_cast<float4*>(i_dy + oy + 4 * g) = make_float4(dy[4 * g], dy[4 * g + 1], dy[4 * g + 2], dy[4 * g + 3]);
+      // the K taps the forward conv multiplied at this output position
+      float t[K][CP];
+#pragma unroll
+      for (int c = 0; c < CP; ++c) {
+        if constexpr (PRE == LEVEL_PRE_DOWN) {
+          const float tm = lane_m1(v1[c]), tp = lane_p1(v0[c]);
+          t[0][c] = hasL ? tm : 0.f; t[1][c] = v0[c]; t[2][c] = v1[c]; t[3][c] = hasR ? tp : 0.f;
+        } else {
+          const float tm = lane_m1(v0[c]), tp = lane_p1(v0[c]);
+          t[0][c] = hasL ? tm : 0.f; t[1][c] = v0[c]; t[2][c] = hasR ? tp : 0.f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+          *reinterpret_cast<float4*>(i_tap + k * img_floats(CP) + ox + 4 * h) = make_float4(t[k][4 * h], t[k][4 * h + 1], t[k][4 * h + 2], t[k][4 * h + 3]);
+    }
+    __syncthreads();
+    // ---- weight / bias gradient on the matrix pipe: lane block blk walks positions 16 blk .. 16 blk + 15 of the tile
+#pragma unroll 2  // (fully unrolled, the scheduler hoists all 2 x 16 x JW LDS reads and some instantiations need 390 registers)
+    for (int s = 0; s < RUN; ++s) {
+      const int oy = s * STY + (s == RUN - 1 ? 4 : 0), ox = s * STX + (s == RUN - 1 ? 4 : 0);
+#pragma unroll
+      for (int jj = 0; jj < JW; ++jj)
+        if (jv[jj]) aw[jj] = mfma4(pa[jj][oy], pb[jj][ox], aw[jj]);
+      if (do_bias) ab = mfma4(i_dy[lby + 4 * wv + oy], 1.f, ab);
+    }
+    // ---- data gradient (transposed conv, registers + DPP shifts)
+    if (a.din) {
+      if constexpr (PRE == LEVEL_PRE_DOWN) {
+        f32x4 e0[H], e1[H], o0[H], o1[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) e0[h] = e1[h] = o0[h] = o1[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int co = 0; co < C; ++co) {
+          const float tm = lane_m1(dy[co]), tp = lane_p1(dy[co]);
+          const float dl = hasL ? tm : 0.f, dr = hasR ? tp : 0.f;
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            const int j = (co * H + h) * 4;
+            e0[h] = mfma4(wop(j + 1), dy[co], e0[h]);
+            e1[h] = mfma4(wop(j + 3), dl, e1[h]);
+            o0[h] = mfma4(wop(j + 2), dy[co], o0[h]);
+            o1[h] = mfma4(wop(j + 0), dr, o1[h]);
+          }
+        }
+        if (live) {
+          float2* dst[CP];
+          float2 old[CP];
+#pragma unroll
+          for (int c = 0; c < CP; ++c) {
+            dst[c] = reinterpret_cast<float2*>(a.din + ((int64_t)row * CP + c) * n_in + p_in);
+            old[c] = a.accumulate ? *dst[c] : make_float2(0.f, 0.f);
+          }
+#pragma unroll
+          for (int c = 0; c < CP; ++c) {
+            const int h = c >> 2, i = c & 3;
+            *dst[c] = make_float2(old[c].x + (e0[h][i] + e1[h][i]), old[c].y + (o0[h][i] + o1[h][i]));
+          }
+        }
+      } else {
+        f32x4 acc[H][3];
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) acc[h][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int co = 0; co < C; ++co) {
+          const float tm = lane_m1(dy[co]), tp = lane_p1(dy[co]);
+          const float dl = hasL ? tm : 0.f, dr = hasR ? tp : 0.f;
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            const int j = (co * H + h) * 3;
+            acc[h][0] = mfma4(wop(j + 0), dr, acc[h][0]);     // tap k reads dY[q + 1 - k]
+            acc[h][1] = mfma4(wop(j + 1), dy[co], acc[h][1]);
+            acc[h][2] = mfma4(wop(j + 2), dl, acc[h][2]);
+          }
+        }
+        float v[CP];
+#pragma unroll
+        for (int c = 0; c < CP; ++c) v[c] = (acc[c >> 2][0][c & 3] + acc[c >> 2][1][c & 3]) + acc[c >> 2][2][c & 3];
+        if constexpr (PRE == LEVEL_PRE_UP) {  // d in[q / 2] = d up[q] + d up[q ^ 1]
+#pragma unroll
+          for (int c = 0; c < CP; ++c) v[c] += lane_x1(v[c]);
+        }
+        if (live && (PRE != LEVEL_PRE_UP || (lane & 1) == 0)) {
+          float* dst[CP];
+          float old[CP];
+#pragma unroll
+          for (int c = 0; c < CP; ++c) {
+            dst[c] = a.din + ((int64_t)row * CP + c) * n_in + p_in;
+            old[c] = a.accumulate ? *dst[c] : 0.f;
+          }
+#pragma unroll
+          for (int c = 0; c < CP; ++c) *dst[c] = old[c] + v[c];
+        }
+      }
+    }
+  }  // tile
+
+  // ---- the block's slot [dW (C x CP x K) | dbias (C)]
+  float* part = a.part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * a.nv;
+#pragma unroll
+  for (int jj = 0; jj < JW; ++jj) {
+    if (jv[jj]) {  // wave-uniform
+      const int j = wv * JW + jj;
+      const int k = j % K, h = (j / K) % H, g = j / (K * H);
+      const f32x4 t = blocks_sum(aw[jj]);
+      if (lane < 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[((4 * g + i) * CP + 4 * h + lane) * K + k] = t[i];
+      }
+    }
+  }
+  if (do_bias) {
+    const f32x4 t = blocks_sum(ab);
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) part[C * CP * K + 4 * wv + i] = t[i];
+    }
+  }
+}
+
+static bool conv_wg_built(int C, int pre, int cp) {
+  if (pre == LEVEL_PRE_DOWN) return cp == C || (cp == C - 4 && cp >= 4);
+  if (pre == LEVEL_PRE_UP || pre == LEVEL_PRE_S1) return cp == C || (cp == C + 4 && cp <= 16);
+  return false;
+}
+bool conv_wg_usable(int C, int pre, int cp, int n, int rows_per_sample) {
+  return (C == 4 || C == 8 || C == 12 || C == 16) && conv_wg_built(C, pre, cp) && n >= 1 && n <= 64 && (n & (n - 1)) == 0 && rows_per_sample > 1 &&
+         !(pre == LEVEL_PRE_UP && n < 2);
+}
+static void conv_wg_grid(int B, int rows_per_sample, int n, int* tiles_ps, int* tpb, int* gx) {
+  *tiles_ps = cdiv((int64_t)rows_per_sample * n, TILE);
+  const int64_t total = (int64_t)*tiles_ps * B;
+  *tpb = (int)std::max<int64_t>(1, (total + 511) / 512);  // (two workgroups per CU at most: the LDS images)
+  *gx = cdiv(*tiles_ps, *tpb);
+}
+int64_t conv_wg_part_floats(int C, int pre, int cp, int B, int rows_per_sample, int n) {
+  int tiles_ps, tpb, gx;
+  conv_wg_grid(B, rows_per_sample, n, &tiles_ps, &tpb, &gx);
+  return (int64_t)gx * B * (C * cp * (pre == LEVEL_PRE_DOWN ? 4 : 3) + C);
+}
+
+int launch_conv_bwd_wg(const ConvBwdWg& a_in, hipStream_t s, ResWgReduce* red_out) {
+  ConvBwdWg a = a_in;
+  DQ_REQUIRE(conv_wg_usable(a.C, a.pre, a.cp, a.n, a.rows_per_sample), "conv_bwd_wg: unsupported shape");
+  DQ_REQUIRE(a.dy && a.in && a.w && a.part && a.dparams && a.rows % a.rows_per_sample == 0, "conv_bwd_wg: missing operand");
+  const int B = a.rows / a.rows_per_sample;
+  const int K = a.pre == LEVEL_PRE_DOWN ? 4 : 3;
+  int gx;
+  conv_wg_grid(B, a.rows_per_sample, a.n, &a.tiles_ps, &a.tpb, &gx);
+  a.nv = a.C * a.cp * K + a.C;
+  DQ_REQUIRE(a.part_floats >= (int64_t)gx * B * a.nv, "conv_bwd_wg: slot scratch too small");
+  const size_t lds = sizeof(float) * ((size_t)pad4(a.C * (a.cp / 4) * K) * 4 + img_floats(a.C) + (size_t)K * img_floats(a.cp));
+  DQ_REQUIRE(lds <= 160 * 1024, "conv_bwd_wg: LDS images too large");
+  dim3 grid(gx, B), block(256);
+#define DQ_CW(CC, PP, PC)                                                                                              \
+  if (a.C == CC && a.pre == PP && a.cp == PC) {                                                                        \
+    static bool attr = false;                                                                                          \
+    if (!attr) {                                                                                                       \
+      DQ_HIP_OK(hipFuncSetAttribute((const void*)k_conv_bwd_wg<CC, PP, PC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      attr = true;                                                                                                     \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((k_conv_bwd_wg<CC, PP, PC>), grid, block, lds, s, a);                                           \
+    DQ_LAUNCH_CHECK();                                                                                                 \
+  } else
+  DQ_CW(4, LEVEL_PRE_DOWN, 4) DQ_CW(8, LEVEL_PRE_DOWN, 4) DQ_CW(8, LEVEL_PRE_DOWN, 8) DQ_CW(12, LEVEL_PRE_DOWN, 8) DQ_CW(12, LEVEL_PRE_DOWN, 12)
+  DQ_CW(16, LEVEL_PRE_DOWN, 12) DQ_CW(16, LEVEL_PRE_DOWN, 16)
+  DQ_CW(4, LEVEL_PRE_UP, 4) DQ_CW(4, LEVEL_PRE_UP, 8) DQ_CW(8, LEVEL_PRE_UP, 8) DQ_CW(8, LEVEL_PRE_UP, 12) DQ_CW(12, LEVEL_PRE_UP, 12) DQ_CW(12, LEVEL_PRE_UP, 16)
+  DQ_CW(16, LEVEL_PRE_UP, 16)
+  DQ_CW(4, LEVEL_PRE_S1, 4) DQ_CW(4, LEVEL_PRE_S1, 8) DQ_CW(8, LEVEL_PRE_S1, 8) DQ_CW(8, LEVEL_PRE_S1, 12) DQ_CW(12, LEVEL_PRE_S1, 12) DQ_CW(12, LEVEL_PRE_S1, 16)
+  DQ_CW(16, LEVEL_PRE_S1, 16)
+  { set_error("conv_bwd_wg: unsupported (C, stage, input width)"); return 2; }
+#undef DQ_CW
+  if (red_out) {
+    ResWgReduce r;
+    r.part = a.part; r.B = B; r.gx = gx; r.nv = a.nv; r.nglob = a.nv; r.C = 0;
+    r.dst = a.dparams; r.dss = a.dparams; r.ss_stride = 0;  // (no per-sample part)
+    *red_out = r;
+  }
+  return 0;
+}
+
+}  // namespace dq
