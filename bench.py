@@ -98,6 +98,86 @@ def pmc_traffic(kernel_prefix):
     return None, f"{kernel_prefix} not in profiles/pmc_linattn.json"
 
 
+def pmc_sq(kernel_prefix, launch_seconds):
+    """Matrix-pipe busy fraction of a kernel from the SQ counter pass of the same file (stale file: null): SQ_VALU_MFMA_BUSY_CYCLES (summed
+    over the SIMDs) / (launch duration x 2.4 GHz x 1,024 SIMDs)."""
+    from dquartic import _native as N
+
+    path = os.path.join(REPO, "profiles", "pmc_linattn.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        pmc = json.load(fh)
+    if pmc.get("build_id") != N.build_id():
+        return None
+    for name, v in pmc.get("sq", {}).items():
+        if name.startswith(kernel_prefix) and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
+            return round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (launch_seconds * 2.4e9 * 1024), 4)
+    return None
+
+
+def roofline_hbm_kernels(device):
+    """The top HBM-bound kernel of each leg, alone on the device, timed with HIP events on the launch stream:
+      train    -- k_res_bwd_wg<4, true> (+ its slot reduce): backward of an up-path ResnetBlock of level 0 (cat(4, 4) -> 4 channels, rows of 64
+                  positions, 12,800 rows) INCLUDING its weight gradients; algorithmic bytes = read d out, u1, u2, x (8 channels), write d x
+                  (8 channels) = 28 channel planes;
+      sampling -- k_level_fwd<4, 0, 4>: the two ResnetBlocks of down level 0 at batch 512 (204,800 rows of 64 positions, 4 channels) in one
+                  launch; algorithmic bytes = read x, write both block outputs (the skip and the LinearAttention input) = 12 channel planes.
+    `traffic` = HBM bytes per launch from the counter passes of THIS build (profiles/pmc_linattn.json; FETCH_SIZE scaled by the factor
+    measured on a kernel of the same access width, k_rmsnorm_fwd) or null."""
+    from dquartic import _native as N
+
+    L = N.lib()
+    out = {}
+    g = torch.Generator(device="cpu").manual_seed(0)
+    # ---- train: ResnetBlock backward with fused weight gradients
+    cin, cout, n, rows, B = 8, 4, 64, TRAIN_BATCH * RT, TRAIN_BATCH
+    nparam = 2 * cout * 16 + 2 * cout + cout * cin * 3 + 2 * cout + cout * cout * 3 + 2 * cout + cout * cin + cout
+    flat = (torch.randn(nparam, generator=g) * 0.3).to(device)
+    xA, xB = torch.randn(rows, cout, n, generator=g).to(device), torch.randn(rows, cin - cout, n, generator=g).to(device)
+    temb = torch.randn(B, 16, generator=g).to(device)
+    nws = L.dq_resblock_workspace_floats(cin, cout, rows, n, RT)
+    ws = torch.zeros(nws, device=device)
+    outb = torch.empty(rows, cout, n, device=device)
+    N.check(L.dq_resblock_fwd(N.ptr(flat), N.ptr(xA), cout, N.ptr(xB), cin - cout, N.ptr(temb), N.ptr(outb), cout, rows, n, RT, 1, N.ptr(ws), nws,
+                              N.stream_ptr()), "dq_resblock_fwd")
+    off = L.dq_resblock_dout_offset(cin, cout, rows, n, RT)
+    ws[off:off + rows * cout * n].copy_(torch.randn(rows * cout * n, generator=g).to(device))
+    dA, dB, grads = torch.empty_like(xA), torch.empty_like(xB), torch.zeros_like(flat)
+
+    def bwd():
+        N.check(L.dq_resblock_bwd(N.ptr(flat), N.ptr(xA), cout, N.ptr(xB), cin - cout, None, N.ptr(dA), N.ptr(dB), N.ptr(grads), None, cout, rows, n, RT,
+                                  N.ptr(ws), nws, N.stream_ptr()), "dq_resblock_bwd")
+
+    t = time_kernel(bwd)
+    by = 28 * n * 4 * rows
+    tr, src = pmc_traffic("k_res_bwd_wg<4, true>")
+    out["train"] = {"bound": "hbm", "kernel": "k_res_bwd_wg<4,true> (+ k_res_wg_reduce): ResnetBlock backward incl. its weight gradients, cat(4,4)->4 channels, n 64",
+                    "rows": rows, "launch_us": round(t * 1e6, 2), "achieved": round(by / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(by / t / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": by, "traffic": tr, "traffic_source": src}
+    del ws, xA, xB, dA, dB, outb
+    # ---- sampling: the level kernel on down level 0 at the sampling batch
+    C, rows = 4, SAMPLE_BATCH * RT
+    npar = L.dq_level_param_floats(0, C, C, 0, 2)
+    params = (torch.randn(npar, generator=g) * 0.3).to(device)
+    x = torch.randn(rows, C, n, generator=g).to(device)
+    temb = torch.randn(SAMPLE_BATCH, 16, generator=g).to(device)
+    o0, o1 = torch.empty_like(x), torch.empty_like(x)
+    wsl = torch.empty(2 * SAMPLE_BATCH * 2 * C, device=device)
+
+    def lvl():
+        N.check(L.dq_level_fwd(N.ptr(params), 0, N.ptr(x), C, None, None, 0, N.ptr(temb), N.ptr(o0), N.ptr(o1), C, 2, rows, n, RT, N.ptr(wsl), wsl.numel(),
+                               N.stream_ptr()), "dq_level_fwd")
+
+    t = time_kernel(lvl)  # (the two 3-us k_ss_heads launches of the entry point ride along)
+    by = 12 * n * 4 * rows
+    tr, src = pmc_traffic("k_level_fwd<4, 0, 4>")
+    out["sample"] = {"bound": "hbm", "kernel": "k_level_fwd<4,0,4>: both ResnetBlocks of down level 0 in one launch, batch 512", "rows": rows,
+                     "launch_us": round(t * 1e6, 2), "achieved": round(by / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(by / t / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": by, "traffic": tr, "traffic_source": src}
+    return out
+
+
 def roofline_linattn(device, rows=TRAIN_BATCH * RT, with_bwd=True):
     """Dominant kernels: k_linattn_bwd<4,64> (train step; level-0 LinearAttention backward over 32*400 rows) and
     k_linattn_fwd<4,64> (sampling leg at rows = 512*400).  Timed live with HIP events on the launch stream; `achieved` prices the
@@ -132,7 +212,9 @@ def roofline_linattn(device, rows=TRAIN_BATCH * RT, with_bwd=True):
     by_f = 8 * C * n * rows  # x in, y out (inference; training adds the 4*C*n pre-norm save)
     tr_f, src_f = pmc_traffic("k_linattn_fwd<4, 64>")
     fwd_obj = {"bound": "mfma", "kernel": "k_linattn_fwd<4,64>", "rows": rows, "launch_us": round(t_f * 1e6, 2),
-               "achieved": round(fl_f / t_f / 1e12, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+               "achieved": round(ex_f / t_f / 1e12, 3), "algorithmic_achieved": round(fl_f / t_f / 1e12, 3),
+               "algorithmic_frac": round(fl_f / t_f / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), "mfma_busy": pmc_sq("k_linattn_fwd<4, 64>", t_f) if rows == TRAIN_BATCH * RT else None,
+               "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                # the re-association removed work: the algorithmic rate can exceed the pipe's peak, so `frac` is stated on the FLOPs
                # the kernel executes; the algorithmic figure stays in `achieved`
                "frac": round(ex_f / t_f / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), "frac_basis": "executed FLOPs",
@@ -149,8 +231,13 @@ def roofline_linattn(device, rows=TRAIN_BATCH * RT, with_bwd=True):
     ex_b = 4 * (12 * 2 * 32 * C * n + 3 * 2 * C * C * n) * rows
     by_b = 20 * C * n * rows  # read x, ypre, dy, (dx) ; write dx
     tr_b, src_b = pmc_traffic("k_linattn_bwd<4, 64>")
-    return {"bound": "mfma", "kernel": "k_linattn_bwd<4,64>", "achieved": round(ach_b, 3), "peak": F32_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach_b / F32_MFMA_PEAK_TFLOPS, 4),
+    # ONE basis under `frac` for both LinearAttention kernels: the FLOPs the kernel EXECUTES (the re-association removed work, so the
+    # reference-count figure is not a fraction of the pipe: it stays under `algorithmic_frac`); `mfma_busy` is the matrix pipe's measured
+    # busy share (SQ pass of the same build)
+    return {"bound": "mfma", "kernel": "k_linattn_bwd<4,64>", "achieved": round(ex_b / t_b / 1e12, 3), "peak": F32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(ex_b / t_b / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), "frac_basis": "executed FLOPs",
+            "algorithmic_achieved": round(ach_b, 3), "algorithmic_frac": round(ach_b / F32_MFMA_PEAK_TFLOPS, 4),
+            "mfma_busy": pmc_sq("k_linattn_bwd<4, 64>", t_b),
             "traffic": tr_b, "traffic_source": src_b,
             "launch_us": round(t_b * 1e6, 2), "flops_per_launch": 2 * fl_f,
             "executed_flops_per_launch": ex_b, "executed_frac": round(ex_b / t_b / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
@@ -420,6 +507,57 @@ def main():
     train_wps = world * TRAIN_BATCH * args.steps / dt
     last_loss = float(loss)
 
+    # ------------------------------------------------------------------ the same step over >= 5 s (clock settle; whatever --steps was)
+    sustained = None
+    if not args.train_only:
+        n_sus = max(args.steps, int(5.0 / (dt / args.steps)) + 1)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(n_sus):
+            x0, c2, c1 = batches[i % len(batches)]
+            dm._train_one_batch(x0, ms2_cond=c2, ms1_cond=c1, sync=False)
+        barrier()
+        ts_ = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        if dist_on:
+            torch.distributed.all_reduce(ts_, op=torch.distributed.ReduceOp.MAX)
+        sustained = {"value": round(world * TRAIN_BATCH * n_sus / float(ts_), 2), "unit": "windows/s", "steps": n_sus, "seconds": round(float(ts_), 3),
+                     "ms_per_step": round(float(ts_) / n_sus * 1e3, 3)}
+    # ------------------------------------------------------------------ small batches: the reference trains at batch_size 1
+    # (dquartic_train_config.json:12), BASELINE configs[0] at 4 -- a dependency chain of ~250 short launches there
+    small = None
+    if rank == 0 and not args.train_only:
+        small = {}
+        for bsz in (1, 4):
+            x0, c2, c1 = (v[:bsz].contiguous() for v in batches[0])
+            for _ in range(5):
+                dm._train_one_batch(x0, ms2_cond=c2, ms1_cond=c1, sync=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                dm._train_one_batch(x0, ms2_cond=c2, ms1_cond=c1, sync=False)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 50 * 1e3
+            small[f"b{bsz}"] = {"ms_per_step": round(ms, 3), "windows_per_s": round(bsz / ms * 1e3, 1)}
+            # the same step as ONE captured hipGraph replay (ModelInterface.enable_train_graph)
+            try:
+                dm.enable_train_graph(True)
+                for _ in range(3):
+                    dm._train_one_batch(x0, ms2_cond=c2, ms1_cond=c1, sync=False)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(50):
+                    dm._train_one_batch(x0, ms2_cond=c2, ms1_cond=c1, sync=False)
+                torch.cuda.synchronize()
+                msg = (time.perf_counter() - t0) / 50 * 1e3
+                small[f"b{bsz}"].update({"graph_ms_per_step": round(msg, 3), "graph_windows_per_s": round(bsz / msg * 1e3, 1),
+                                         "graph_speedup": round(ms / msg, 2)})
+            except Exception as e:  # (a box whose runtime refuses the capture: the eager figures stand)
+                small[f"b{bsz}"]["graph_error"] = str(e)[:200]
+            finally:
+                dm.enable_train_graph(False)
+    if dist_on:
+        torch.distributed.barrier()
+
     # ------------------------------------------------------------------ sampling leg (no collective: batch shards)
     log(f"train: {train_wps:.1f} windows/s; sampling leg")
     sample = None
@@ -453,6 +591,7 @@ def main():
     log("roofline leg")
     roof = roofline_linattn(device) if (rank == 0 and not args.train_only) else None
     form = batch_formation(device) if (rank == 0 and not args.train_only) else None
+    hbm = roofline_hbm_kernels(device) if (rank == 0 and not args.train_only) else None
     log("cpu baseline leg")
     cpu = cpu_baseline(net) if (rank == 0 and world == 1 and not args.no_cpu) else None
     tfm = None
@@ -477,7 +616,8 @@ def main():
             # whole-step fractions per GPU: algorithmic FLOPs of fwd + bwd against the f32 matrix peak; compulsory bytes against HBM
             "whole_step": {"flop_frac": round(train_wps / world * FLOPS_TRAIN / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                            "hbm_frac": round(train_wps / world * BYTES_TRAIN(TRAIN_BATCH) / 1e9 / HBM_PEAK_GBS, 6)},
-            "sample": sample, "roofline": roof, "cpu_baseline": cpu, "batch_formation": form, "transformer": tfm,
+            "sustained": sustained, "small_batch": small,
+            "sample": sample, "roofline": roof, "roofline_hbm": hbm, "cpu_baseline": cpu, "batch_formation": form, "transformer": tfm,
         }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

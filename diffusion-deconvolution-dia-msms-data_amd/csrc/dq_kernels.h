@@ -29,6 +29,10 @@ int launch_ms1_loss(const float* out, const float* x_t, const float* ms1, float 
 int launch_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, float* partials, float gscale, float max_norm,
                       double lr, double b1, double b2, double eps, double wd, int step, float* gnorm_out, hipStream_t s);
 
+// the same with lr and the step count in device memory (graph replay): increments *step_dev, then uses it
+int launch_adamw_clip_dev(float* p, const float* g, float* m, float* v, int64_t n, float* partials, float gscale, float max_norm,
+                          const float* lr_dev, double b1, double b2, double eps, double wd, int* step_dev, float* gnorm_out, hipStream_t s);
+
 int launch_axpy(float* dst, const float* src, int64_t n, hipStream_t s);  // dst += src
 int launch_zero(float* dst, int64_t n, hipStream_t s);  // dst = 0 (a kernel, not a memset node)
 int launch_copy(float* dst, const float* src, int64_t n, hipStream_t s);  // dst = src (a kernel, not a memcpy node)

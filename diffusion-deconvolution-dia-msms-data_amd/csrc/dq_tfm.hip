@@ -24,9 +24,10 @@ struct dq_tfm {
   int64_t total = 0;
   int64_t in_w, in_b, out_w, out_b, c_w, c_b, t1_w, t1_b, t2_w, t2_b;
   std::vector<dq::TfmLayer> L;
-  // what the last dq_tfm_fwd(save_for_bwd) left in the workspace
-  int saved_B = 0, saved_S1 = 0, saved_S2 = 0;
-  const void* saved_ws = nullptr;
+  // which training workspaces hold a forward's saved activations (one entry per workspace; several forwards may be in flight before
+  // their backwards run: micro-batches whose losses are summed).  An entry stays until the same workspace takes another forward.
+  struct Saved { const void* ws; int B, S1, S2; };
+  std::vector<Saved> saved;
   int precision = dq::GEMM_FP32;  // arithmetic of the dense products (dq_tfm_set_precision)
 };
 
@@ -289,7 +290,12 @@ int dq_tfm_fwd(dq_tfm* p, const float* params, const float* rope_sin, const floa
     x = b.xo;
   }
   if (int rc = linear_fwd(x, P + p->out_w, P + p->out_b, out, R1, D, H, w, s)) return rc;  // :258
-  p->saved_B = training ? B : 0; p->saved_S1 = S1; p->saved_S2 = S2; p->saved_ws = training ? workspace : nullptr;
+  for (size_t i = 0; i < p->saved.size(); ++i)
+    if (p->saved[i].ws == workspace) { p->saved.erase(p->saved.begin() + i); break; }  // (an inference forward overwrites what was saved there)
+  if (training) {
+    if (p->saved.size() >= 64) p->saved.erase(p->saved.begin());
+    p->saved.push_back({workspace, B, S1, S2});
+  }
   return 0;
 }
 
@@ -298,8 +304,11 @@ int dq_tfm_bwd(dq_tfm* p, const float* params, const float* rope_sin, const floa
                int S1, int S2, void* stream) {
   if (int rc = check_shapes(p, B, S1, S2)) return rc;
   DQ_REQUIRE(params && rope_sin && rope_cos && x_t && x_cond && dout && grads && workspace, "dq_tfm_bwd: missing operand");
-  DQ_REQUIRE(p->saved_ws == workspace && p->saved_B == B && p->saved_S1 == S1 && p->saved_S2 == S2,
-             "dq_tfm_bwd: no matching dq_tfm_fwd(save_for_bwd = 1) on this workspace");
+  {
+    bool found = false;
+    for (const auto& e : p->saved) found = found || (e.ws == workspace && e.B == B && e.S1 == S1 && e.S2 == S2);
+    DQ_REQUIRE(found, "dq_tfm_bwd: no matching dq_tfm_fwd(save_for_bwd = 1) on this workspace");
+  }
   DQ_REQUIRE(((uintptr_t)grads & 15) == 0 && ((uintptr_t)dout & 15) == 0, "dq_tfm_bwd: grads and dout must be 16-byte aligned");
   PrecisionScope prec(p->precision);
   Ws w = carve(*p, (float*)workspace, B, S1, S2, true);

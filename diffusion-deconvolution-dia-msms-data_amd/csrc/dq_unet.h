@@ -17,6 +17,7 @@ struct DevTables {
 int launch_time_embed_fwd(const Plan& p, const DevTables& dt, const float* params, const int64_t* t, int t_scalar, float* tbuf,
                           float* ss, int B, const int* step_tab, const int* step_ptr, hipStream_t s);
 int launch_ss_heads(const float* temb, const float* w, const float* bias, float* ss, int B, int m, hipStream_t s);
+int launch_ss_heads_strided(const float* temb, const float* w, const float* bias, float* ss, int stride, int B, int m, hipStream_t s);
 int launch_time_mlp_fwd(const float* w1, const float* b1, const float* w2, const float* b2, const int64_t* t, float* tbuf, int B,
                         hipStream_t s);
 int launch_time_embed_bwd(const Plan& p, const DevTables& dt, const float* params, float* grads, float* tbuf, const float* dss,
@@ -67,6 +68,7 @@ struct dq_plan {
   hipEvent_t events[NUM_EVENTS] = {};
   unsigned ev_next = 0;
   bool side_used = false;
+  bool no_side = false;  // dq_plan_set_side_stream(plan, 0): weight-gradient launches on the caller's stream (captured train steps)
   hipStream_t cap_stream = nullptr;  // capture-only stream (the caller's may be the uncapturable legacy default stream)
   const void* g_params = nullptr; const void* g_rope = nullptr; const void* g_ws = nullptr;
   int g_B = 0, g_RT = 0, g_norm = -1, g_pred = -1;

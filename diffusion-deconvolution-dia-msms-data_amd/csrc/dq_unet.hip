@@ -1110,7 +1110,7 @@ int dq_unet_bwd(dq_plan* plan, const float* params, const float* rope_freqs, con
   DQ_REQUIRE(workspace_bytes >= 2 * (int64_t)sizeof(float) * plan->arena.floats, "dq_unet_bwd: workspace too small (training=1)");
   float* W = (float*)workspace;
   Ctx c{plan->plan, plan->arena, params, W, W + plan->arena.floats, grads, B, RT, (hipStream_t)stream};
-  c.owner = side_stream_enabled() ? plan : nullptr;
+  c.owner = (side_stream_enabled() && !plan->no_side) ? plan : nullptr;
   return unet_backward(c, rope_freqs, init_cond, cond_mul, cond_add, plan->dev, grad_out, grad_x);
 }
 
@@ -1146,6 +1146,20 @@ int dq_adamw_clip_step(float* params, const float* grads, float* exp_avg, float*
                            weight_decay, step, gnorm_out, (hipStream_t)stream);
 }
 
+int dq_adamw_clip_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float* scratch, float grad_scale,
+                           float max_norm, const float* lr_dev, double beta1, double beta2, double eps, double weight_decay, int* step_dev,
+                           float* gnorm_out, void* stream) {
+  DQ_REQUIRE(params && grads && exp_avg && exp_avg_sq && scratch && lr_dev && step_dev, "dq_adamw_clip_step_dev: null argument");
+  return launch_adamw_clip_dev(params, grads, exp_avg, exp_avg_sq, n, scratch, grad_scale, max_norm, lr_dev, beta1, beta2, eps, weight_decay,
+                               step_dev, gnorm_out, (hipStream_t)stream);
+}
+
+int dq_plan_set_side_stream(dq_plan* plan, int on) {
+  DQ_REQUIRE(plan, "dq_plan_set_side_stream: null plan");
+  plan->no_side = on ? false : true;
+  return 0;
+}
+
 int dq_train_step(dq_plan* plan, const float* params, const float* rope_freqs, const float* alpha_bars_dev, const float* x0,
                   const float* ms2_cond, const float* ms1_cond, const int64_t* t, const float* noise, int auto_normalize,
                   int pred_type, const float* loss_weight_dev, float ms1_loss_weight, float* grads, float* loss_out, void* workspace,
@@ -1162,7 +1176,7 @@ int dq_train_step(dq_plan* plan, const float* params, const float* rope_freqs, c
   hipStream_t s = (hipStream_t)stream;
   float* W = (float*)workspace;
   Ctx c{plan->plan, a, params, W, W + a.floats, grads, B, RT, s};
-  c.owner = side_stream_enabled() ? plan : nullptr;
+  c.owner = (side_stream_enabled() && !plan->no_side) ? plan : nullptr;
   const int64_t per = (int64_t)RT * plan->plan.mz;
   const float cm = auto_normalize ? 2.f : 1.f, ca = auto_normalize ? -1.f : 0.f;
   DQ_TRY(launch_q_sample(alpha_bars_dev, x0, t, noise, c.w(a.xa), B, per, auto_normalize, s));               // model.py:349-352
@@ -1409,6 +1423,12 @@ int64_t dq_resblock_workspace_floats(int cin, int cout, int rows, int n, int row
   return 2 * w.half;
 }
 
+int64_t dq_resblock_dout_offset(int cin, int cout, int rows, int n, int rows_per_sample) {
+  BlockWs w;
+  if (block_ws(w, cin, cout, rows, n, rows_per_sample)) return -1;
+  return w.half + w.rb.out;
+}
+
 int dq_resblock_fwd(const float* params, const float* xA, int cinA, const float* xB, int cinB, const float* temb, float* out, int cout,
                     int rows, int n, int rows_per_sample, int save_for_bwd, float* workspace, int64_t workspace_floats, void* stream) {
   DQ_REQUIRE(params && xA && temb && out && workspace, "dq_resblock_fwd: null argument");
@@ -1426,16 +1446,61 @@ int dq_resblock_fwd(const float* params, const float* xA, int cinA, const float*
 int dq_resblock_bwd(const float* params, const float* xA, int cinA, const float* xB, int cinB, const float* dout, float* dxA, float* dxB,
                     float* grads, float* dss, int cout, int rows, int n, int rows_per_sample, float* workspace, int64_t workspace_floats,
                     void* stream) {
-  DQ_REQUIRE(params && xA && dout && grads && dss && workspace, "dq_resblock_bwd: null argument");
+  DQ_REQUIRE(params && xA && grads && workspace, "dq_resblock_bwd: null argument");
   BlockWs w;
   DQ_TRY(block_ws(w, cinA + cinB, cout, rows, n, rows_per_sample));
   DQ_REQUIRE(workspace_floats >= 2 * w.half, "dq_resblock_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   Ctx c{w.plan, w.ar, params, workspace, workspace + w.half, grads, w.B, rows_per_sample, s};  // no side stream: everything on s
-  DQ_TRY(launch_zero(c.g(w.ar.ss), (int64_t)w.B * w.plan.ss_total, s));
-  DQ_TRY(launch_copy(c.g(w.rb.out), dout, (int64_t)rows * cout * n, s));
-  DQ_TRY(res_bwd(c, w.r, w.rb, xA, dxA, cinA, cinB ? xB : nullptr, cinB ? dxB : nullptr, cinB, rows, n, rows_per_sample, 0, 0));
+  // dout == NULL: the gradient of the block output is already in the workspace (at dq_resblock_dout_offset floats; a benchmark fills it
+  // once), dxA / dxB are plain stores and dss (nullable) is not copied out: the call is then the backward launches and nothing else
+  const int first_writer = dout ? 0 : 1;
+  if (dout) {
+    DQ_TRY(launch_zero(c.g(w.ar.ss), (int64_t)w.B * w.plan.ss_total, s));
+    DQ_TRY(launch_copy(c.g(w.rb.out), dout, (int64_t)rows * cout * n, s));
+  }
+  DQ_TRY(res_bwd(c, w.r, w.rb, xA, dxA, cinA, cinB ? xB : nullptr, cinB ? dxB : nullptr, cinB, rows, n, rows_per_sample, first_writer, first_writer));
+  if (!dout || !dss) return 0;
   return launch_copy(dss, c.g(w.ar.ss), (int64_t)w.B * w.plan.ss_total, s);
+}
+
+// ---- stand-alone level forward (tests, bench): y = ResnetBlock_1(cat(ResnetBlock_0(cat(stage(x), skip0)), skip1)) in ONE launch -------
+// params: [stage conv weight (C, cp, K) | bias (C)] (pre != 0) followed by the two blocks, each laid out as dq_resblock_* expects
+// (cin = C + cs).  workspace: 2 * B * (4 C) floats (the blocks' scale / shift vectors).
+int64_t dq_level_param_floats(int pre, int C, int cp, int cs, int nblocks) {
+  const int K = pre == LEVEL_PRE_DOWN ? 4 : 3;
+  Plan p; ResP r;
+  build_resblock_plan(p, r, C + cs, C);
+  return (pre ? (int64_t)C * cp * K + C : 0) + (int64_t)nblocks * p.total_floats;
+}
+int dq_level_fwd(const float* params, int pre, const float* x, int cp, const float* skip0, const float* skip1, int cs, const float* temb,
+                 float* out0, float* out1, int C, int nblocks, int rows, int n, int rows_per_sample, float* workspace,
+                 int64_t workspace_floats, void* stream) {
+  DQ_REQUIRE(params && x && temb && workspace && (nblocks == 1 || nblocks == 2) && (nblocks == 1 ? out0 != nullptr : out1 != nullptr),
+             "dq_level_fwd: null argument");
+  DQ_REQUIRE(rows > 0 && rows_per_sample > 0 && rows % rows_per_sample == 0, "dq_level_fwd: bad rows");
+  const int B = rows / rows_per_sample, K = pre == LEVEL_PRE_DOWN ? 4 : 3;
+  Plan p; ResP r;
+  build_resblock_plan(p, r, C + cs, C);
+  DQ_REQUIRE(workspace_floats >= (int64_t)2 * B * p.ss_total, "dq_level_fwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const float* blk0 = params + (pre ? (int64_t)C * cp * K + C : 0);
+  LevelFwd f;
+  f.params = params; f.in = x; f.pre = pre; f.nblocks = nblocks; f.C = C; f.rows = rows; f.n = n; f.rows_per_sample = rows_per_sample;
+  if (pre) { f.cp = cp; f.pw = params; f.pb = params + (int64_t)C * cp * K; }
+  for (int i = 0; i < nblocks; ++i) {
+    const float* bp = blk0 + (int64_t)i * p.total_floats;
+    float* ss = workspace + (int64_t)i * p.ss_total;  // [b][2 blocks][2 C]: stride 2 * ss_total
+    ResFwd k;
+    k.inB = cs ? (i == 0 ? skip0 : skip1) : nullptr; k.cinB = cs;
+    k.w1 = bp + r.c1.w; k.b1 = bp + r.c1.b; k.g1 = bp + r.g1; k.w2 = bp + r.c2.w; k.b2 = bp + r.c2.b; k.g2 = bp + r.g2;
+    if (r.res.cout) { k.wr = bp + r.res.w; k.br = bp + r.res.b; }
+    k.ss = ss; k.ss_stride = 2 * p.ss_total;
+    k.out = i == 0 ? out0 : out1;
+    f.blk[i] = k;
+    DQ_TRY(launch_ss_heads_strided(temb, bp + r.mlp_w, bp + r.mlp_b, ss, 2 * p.ss_total, B, 2 * C, s));  // unet1d.py:315-318
+  }
+  return launch_level_fwd(f, s);
 }
 
 int dq_rope(float* qk, const float* freqs, int B, int64_t batch_stride, int RT, float sign, void* stream) {

@@ -415,6 +415,64 @@ __global__ void __launch_bounds__(256) k_adamw_clip(float* __restrict__ p, const
   }
 }
 
+// ---- the same step with the step count and the learning rate in DEVICE memory: nothing about the call changes from one step to the next, so
+// a captured graph of it can be replayed (the host-side variant bakes lr and the bias corrections of step t into its launch arguments).
+// hyp (8 floats behind the partial sums): decay, step_size, bc2_sqrt -- formed in double from the device step counter exactly as
+// launch_adamw_clip forms them on the host; the counter is incremented first (step t = 1 for the first call).
+__global__ void k_adamw_hyper(int* __restrict__ step, const float* __restrict__ lr_dev, double b1, double b2, double wd, float* __restrict__ hyp) {
+  const int t = step[0] + 1;
+  step[0] = t;
+  const double lr = (double)lr_dev[0];
+  const double bc1 = 1.0 - pow(b1, (double)t), bc2 = 1.0 - pow(b2, (double)t);
+  hyp[0] = (float)(1.0 - lr * wd);
+  hyp[1] = (float)(lr / bc1);
+  hyp[2] = (float)sqrt(bc2);
+}
+__global__ void __launch_bounds__(256) k_adamw_clip_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, int64_t n, const float* __restrict__ partials, int n_partials,
+                                                        float gscale, float max_norm, const float* __restrict__ hyp, float one_m_b1, float b2,
+                                                        float one_m_b2, float eps, float* __restrict__ gnorm_out) {
+  __shared__ float s_coef;
+  if (threadIdx.x < 64) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n_partials; i += 64) acc += partials[i];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) {
+      const float nrm = sqrtf(acc);
+      const float c = max_norm / (nrm + 1e-6f);
+      s_coef = (max_norm > 0.f) ? fminf(c, 1.0f) : 1.0f;
+      if (blockIdx.x == 0 && gnorm_out) gnorm_out[0] = nrm;
+    }
+  }
+  __syncthreads();
+  const float coef = s_coef * gscale;
+  const float decay = hyp[0], step_size = hyp[1], bc2_sqrt = hyp[2];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * coef;
+    float pi = p[i] * decay;
+    const float mo = m[i];
+    const float mi = mo + one_m_b1 * (gi - mo);
+    const float vi = fmaf(one_m_b2 * gi, gi, b2 * v[i]);
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+int launch_adamw_clip_dev(float* p, const float* g, float* m, float* v, int64_t n, float* partials, float gscale, float max_norm,
+                          const float* lr_dev, double b1, double b2, double eps, double wd, int* step_dev, float* gnorm_out, hipStream_t s) {
+  DQ_REQUIRE(n > 0 && lr_dev && step_dev, "adamw: need n > 0, the device learning rate and the device step counter");
+  const int grid = (int)std::min<int64_t>(cdiv(n, 256), MSE_MAX_BLOCKS - 8);
+  float* hyp = partials + (MSE_MAX_BLOCKS - 8);  // (the partial-sum scratch has MSE_MAX_BLOCKS floats)
+  hipLaunchKernelGGL(k_adamw_hyper, dim3(1), dim3(1), 0, s, step_dev, lr_dev, b1, b2, wd, hyp);
+  DQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_sumsq, dim3(grid), dim3(256), 0, s, g, n, gscale, partials);
+  DQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_adamw_clip_dev, dim3(grid), dim3(256), 0, s, p, g, m, v, n, partials, grid, gscale, max_norm, hyp, (float)(1.0 - b1), (float)b2,
+                     (float)(1.0 - b2), (float)eps, gnorm_out);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, float* partials, float gscale, float max_norm,
                       double lr, double b1, double b2, double eps, double wd, int step, float* gnorm_out, hipStream_t s) {
   DQ_REQUIRE(n > 0 && step >= 1, "adamw: need n > 0 and step >= 1");

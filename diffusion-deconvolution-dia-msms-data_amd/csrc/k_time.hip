@@ -67,17 +67,24 @@ __global__ void __launch_bounds__(64) k_time_fwd(const float* __restrict__ P, co
 
 // stand-alone heads (dq_scale_shift_fwd): ss[b][r] = Linear(SiLU(temb_b))[r] for a caller-supplied temb
 __global__ void __launch_bounds__(64) k_ss_heads(const float* __restrict__ temb, const float* __restrict__ w, const float* __restrict__ bias,
-                                                 float* __restrict__ ss, int m) {
+                                                 float* __restrict__ ss, int m, int stride) {
   __shared__ float st[16];
   const int b = blockIdx.x;
   if (threadIdx.x < 16) st[threadIdx.x] = silu_f(temb[(int64_t)b * 16 + threadIdx.x]);
   __syncthreads();
-  for (int r = threadIdx.x; r < m; r += 64) ss[(int64_t)b * m + r] = ss_head_row(w + (int64_t)r * 16, bias[r], st);
+  for (int r = threadIdx.x; r < m; r += 64) ss[(int64_t)b * stride + r] = ss_head_row(w + (int64_t)r * 16, bias[r], st);
+}
+
+int launch_ss_heads_strided(const float* temb, const float* w, const float* bias, float* ss, int stride, int B, int m, hipStream_t s) {
+  if (B == 0 || m == 0) return 0;
+  hipLaunchKernelGGL(k_ss_heads, dim3(B), dim3(64), 0, s, temb, w, bias, ss, m, stride);
+  DQ_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_ss_heads(const float* temb, const float* w, const float* bias, float* ss, int B, int m, hipStream_t s) {
   if (B == 0 || m == 0) return 0;
-  hipLaunchKernelGGL(k_ss_heads, dim3(B), dim3(64), 0, s, temb, w, bias, ss, m);
+  hipLaunchKernelGGL(k_ss_heads, dim3(B), dim3(64), 0, s, temb, w, bias, ss, m, m);
   DQ_LAUNCH_CHECK();
   return 0;
 }

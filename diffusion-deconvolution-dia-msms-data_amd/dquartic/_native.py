@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DQ_HIP_LIB", os.path.join(os.path.dirname(_HERE), "libdq_hip.so"))
 
 _lib = None
-ABI_VERSION = 5  # DQ_ABI_VERSION of include/dq_hip.h this table was written against
+ABI_VERSION = 7  # DQ_ABI_VERSION of include/dq_hip.h this table was written against
 PRED_TYPES = {"eps": 0, "x0": 1}  # DQ_PRED_EPS / DQ_PRED_X0
 PRECISIONS = {"fp32": 0, "bf16x3": 1}  # DQ_PRECISION_FP32 / DQ_PRECISION_BF16X3
 
@@ -32,6 +32,9 @@ PROTOTYPES = {
     "dq_mse_loss_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "dq_mse_loss_weighted_fwd_bwd": (c_int, [c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_int, c_int64, c_void_p]),
+    "dq_adamw_clip_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_void_p,
+                                       c_double, c_double, c_double, c_double, c_void_p, c_void_p, c_void_p]),
+    "dq_plan_set_side_stream": (c_int, [c_void_p, c_int]),
     "dq_adamw_clip_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_double,
                                    c_double, c_double, c_double, c_double, c_int, c_void_p, c_void_p]),
     "dq_train_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
@@ -67,6 +70,9 @@ PROTOTYPES = {
     "dq_prep_inputs_fwd": (c_int, [c_void_p] * 4 + [c_float, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dq_conv_fwd": (c_int, [c_void_p] * 4 + [c_int, c_void_p] + [c_int] * 7 + [c_void_p]),
     "dq_resblock_workspace_floats": (c_int64, [c_int] * 5),
+    "dq_level_param_floats": (c_int64, [c_int] * 5),
+    "dq_level_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_int64, c_void_p]),
+    "dq_resblock_dout_offset": (c_int64, [c_int] * 5),
     "dq_resblock_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_int64, c_void_p]),
     "dq_resblock_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p, c_int64, c_void_p]),
     "dq_rope": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_void_p]),

@@ -89,6 +89,8 @@ class FlatAdamW(torch.optim.Optimizer):
         self.grad_scale = 1.0
         self._m = self._v = self._scratch = self._gnorm = None
         self._step = 0
+        self._step_dev = self._lr_dev = None   # device copies of the step count / learning rate (step_dev(): graph-replayable step)
+        self._lr_dev_value = None
 
     def _buffers(self):
         flat = self.net.flat_params
@@ -117,9 +119,45 @@ class FlatAdamW(torch.optim.Optimizer):
                                            float(self.grad_scale), float(self.max_norm), float(g["lr"]), float(g["betas"][0]),
                                            float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), int(self._step),
                                            N.ptr(self._gnorm), N.stream_ptr()), "dq_adamw_clip_step")
+        return None  # (the per-parameter "step" entries are refreshed by state_dict(): 395 tensor constructions per step cost ~1 ms of host time)
+
+    def state_dict(self):
         for st in self.state.values():
             st["step"] = torch.tensor(float(self._step))
+        return super().state_dict()
+
+    def _dev_state(self):
+        """Device copies of the step count and the learning rate for ``step_dev``; the lr copy is refreshed when the scheduler changed it."""
+        flat = self._buffers()
+        if self._step_dev is None or self._step_dev.device != flat.device:
+            self._step_dev = torch.tensor([self._step], dtype=torch.int32, device=flat.device)
+            self._lr_dev = torch.zeros(1, dtype=torch.float32, device=flat.device)
+            self._lr_dev_value = None
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_dev_value:
+            self._lr_dev.fill_(lr)
+            self._lr_dev_value = lr
+        return flat
+
+    @torch.no_grad()
+    def step_dev(self, count: bool = True):
+        """The same update with the step count and lr read from device memory (``dq_adamw_clip_step_dev``): the call is identical from
+        step to step, so it can sit in a captured graph.  ``count=False`` while a graph is being captured (the replay counts instead)."""
+        flat = self._dev_state()
+        grads = self.net.flat_grads()
+        g = self.param_groups[0]
+        if count:
+            self._step += 1
+        N.check(N.lib().dq_adamw_clip_step_dev(N.ptr(flat), N.ptr(grads), N.ptr(self._m), N.ptr(self._v), flat.numel(), N.ptr(self._scratch),
+                                               float(self.grad_scale), float(self.max_norm), N.ptr(self._lr_dev), float(g["betas"][0]),
+                                               float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), N.ptr(self._step_dev),
+                                               N.ptr(self._gnorm), N.stream_ptr()), "dq_adamw_clip_step_dev")
         return None
+
+    def sync_step_dev(self):
+        """After the host-side step count changed outside step_dev (plain step(), load_state_dict): push it to the device copy."""
+        if self._step_dev is not None:
+            self._step_dev.fill_(self._step)
 
     def zero_grad(self, set_to_none: bool = False):
         self.net.flat_grads(zero=True)
@@ -143,6 +181,62 @@ class FlatAdamW(torch.optim.Optimizer):
                 step = int(float(st["step"]))
         self._step = step
         self._publish_state()
+        self.sync_step_dev()
+
+
+class TrainStepGraph:
+    """One optimiser step of ``_train_one_batch`` -- draw t and noise, q_sample, forward, loss, backward, clip, AdamW -- captured in a
+    hipGraph (through ``torch.cuda.graph``: the library's launches go to the capture stream like every other caller's stream) and replayed
+    with ONE host call per step.  Single-process training only (a gradient all-reduce is not captured).  The inputs are copied into fixed
+    buffers before each replay; t and noise come from torch's graph-safe generator, so successive replays draw fresh values; the step
+    count and lr are read from device memory by the optimiser kernel.  The backward's remaining weight-gradient launches run on the capture
+    stream (``dq_plan_set_side_stream(plan, 0)``): a fork / join inside a graph was measured slower than the chain."""
+
+    def __init__(self, dm, x_0, ms2_cond, ms1_cond, ms1_loss_weight=0.0):
+        self.dm, self.opt, self.net = dm, dm.optimizer, dm.model
+        self.key = (tuple(x_0.shape), tuple(ms1_cond.shape), float(ms1_loss_weight or 0.0), float(dm.optimizer.grad_scale))
+        self.x0, self.c2, self.c1 = (torch.empty_like(v, dtype=torch.float32).copy_(v) for v in (x_0, ms2_cond, ms1_cond))
+        self.w = float(ms1_loss_weight or 0.0)
+        N.check(N.lib().dq_plan_set_side_stream(self.net._plan, 0), "dq_plan_set_side_stream")
+        self.opt._dev_state()
+        self.opt.sync_step_dev()
+        # warm-up on a side stream (workspaces, occupancy queries, lazy stream creation: nothing may allocate during capture) -- on a
+        # SNAPSHOT of the training state: parameters, moments, step count and the generator state are put back afterwards, so that
+        # building the graph is not a training step
+        snap = (self.net.flat_params.detach().clone(), self.opt._m.clone(), self.opt._v.clone(), self.opt._step, torch.cuda.get_rng_state(x_0.device))
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._body(count=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            self.net.flat_params.copy_(snap[0]); self.opt._m.copy_(snap[1]); self.opt._v.copy_(snap[2])
+        self.opt._step = snap[3]
+        self.opt.sync_step_dev()
+        torch.cuda.set_rng_state(snap[4], x_0.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._body(count=False)
+
+    def _body(self, count):
+        loss = self.dm.train_step_fused(self.x0, self.c2, self.c1, zero_grads=True, ms1_loss_weight=self.w)
+        self.opt.step_dev(count=count)
+        return loss
+
+    def matches(self, x_0, ms1_cond, ms1_loss_weight, grad_scale):
+        return self.key == (tuple(x_0.shape), tuple(ms1_cond.shape), float(ms1_loss_weight or 0.0), float(grad_scale))
+
+    def step(self, x_0, ms2_cond, ms1_cond):
+        self.x0.copy_(x_0); self.c2.copy_(ms2_cond); self.c1.copy_(ms1_cond)
+        self.opt._dev_state()      # (a changed lr reaches its device copy here, outside the graph)
+        self.opt._step += 1
+        self.graph.replay()
+        return self.loss
+
+    def close(self):
+        N.check(N.lib().dq_plan_set_side_stream(self.net._plan, 1), "dq_plan_set_side_stream")
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -203,9 +297,14 @@ class ModelInterface(object):
         latest = os.path.join(ckpt_dir, "dquartic_latest_checkpoint.ckpt")
         start_epoch, best_loss, lr_scheduler = self.load_checkpoint(lr_scheduler, latest, self.device)
         self._sync_replicas()  # data-parallel: every rank continues from rank 0's weights / moments (also after a resume)
+        # ... and from rank 0's epoch counter, best loss, lr-schedule state and current lr: with the "latest" checkpoint visible to rank 0
+        # only (node-local disks), the ranks would otherwise run epoch loops of different lengths and hang in the per-step all-reduce
+        start_epoch, best_loss = self._sync_resume_state(start_epoch, best_loss, lr_scheduler)
         best_epoch = start_epoch
         rank0 = _rank() == 0
         for epoch in range(start_epoch, num_epochs):
+            if hasattr(getattr(dataloader, "sampler", None), "set_epoch"):
+                dataloader.sampler.set_epoch(epoch)  # DistributedSampler: a different permutation every epoch
             if hasattr(dataloader.dataset, "reset_epoch"):
                 dataloader.dataset.reset_epoch()
             batch_loss = self._train_one_epoch(epoch, dataloader)
@@ -251,6 +350,28 @@ class ModelInterface(object):
         else:
             for t in list(self.model.parameters()) + list(self.model.buffers()):
                 d.broadcast(t.data, src=src)
+
+    def _sync_resume_state(self, start_epoch, best_loss, lr_scheduler, src: int = 0):
+        """Rank ``src``'s (start_epoch, best_loss), LambdaLR state and per-group lr on every rank (no-op outside a process group)."""
+        d = torch.distributed
+        if not (d.is_available() and d.is_initialized()) or d.get_world_size() == 1:
+            return start_epoch, best_loss
+        mine = d.get_rank() == src
+        box = [{"start_epoch": start_epoch, "best_loss": best_loss,
+                "scheduler": lr_scheduler.lambda_lr.state_dict() if lr_scheduler is not None else None,
+                "lrs": [g["lr"] for g in self.optimizer.param_groups] if self.optimizer is not None else None} if mine else None]
+        dev = None
+        if d.get_backend() == "nccl":  # (object collectives stage through the current device with RCCL)
+            dev = self.model.flat_params.device if hasattr(self.model, "flat_params") else next(self.model.parameters()).device
+        d.broadcast_object_list(box, src=src, device=dev)
+        st = box[0]
+        if not mine:
+            if lr_scheduler is not None and st["scheduler"] is not None:
+                lr_scheduler.lambda_lr.load_state_dict(st["scheduler"])
+            if self.optimizer is not None and st["lrs"] is not None:
+                for g, lr in zip(self.optimizer.param_groups, st["lrs"]):
+                    g["lr"] = lr
+        return st["start_epoch"], st["best_loss"]
 
     def _global_mean(self, value: float) -> float:
         """Mean over the ranks of a per-rank scalar (the epoch's mean loss): identical on every rank afterwards, so the
@@ -346,9 +467,29 @@ class ModelInterface(object):
             self.callback_handler.batch_callback(batch_idx, loss)
         return batch_loss
 
+    def enable_train_graph(self, on: bool = True):
+        """Run ``_train_one_batch`` as one captured hipGraph replay per step (``TrainStepGraph``): the reference trains at batch_size 1
+        (dquartic_train_config.json:12), where a step is a chain of ~250 short launches and the host's launch rate is the limit.  Same
+        kernels in the same order as the eager step (bit-identical given the same t / noise); single-process runs with drawn t / noise."""
+        self.train_graph = bool(on)
+        if not on and getattr(self, "_train_graph_obj", None) is not None:
+            self._train_graph_obj.close()
+            self._train_graph_obj = None
+
     def _train_one_batch(self, x_0, ms2_cond=None, ms1_cond=None, noise=None, ms1_loss_weight=0.0, t=None, sync=True):
         """Reference :1090-1123.  Returns the loss as a float (``sync=False``: a 0-dim device tensor, no host sync)."""
         fused = self._native_net() and isinstance(self.optimizer, FlatAdamW) and x_0.is_cuda and hasattr(self, "train_step_fused")
+        if fused and getattr(self, "train_graph", False) and noise is None and t is None and _world() == 1 and hasattr(self.model, "_plan"):
+            # the whole step as one captured graph (enable_train_graph): drawn t / noise, single process
+            tg = getattr(self, "_train_graph_obj", None)
+            if tg is None or not tg.matches(x_0, ms1_cond, ms1_loss_weight, 1.0):
+                if tg is not None:
+                    tg.close()
+                self.optimizer.grad_scale = 1.0
+                tg = self._train_graph_obj = TrainStepGraph(self, x_0, ms2_cond, ms1_cond, ms1_loss_weight)
+            loss = tg.step(x_0, ms2_cond, ms1_cond)
+            self.last_grad_norm = self.optimizer.last_grad_norm
+            return loss.item() if sync else loss
         if fused:
             if noise is not None:
                 noise = self.normalize(noise)  # reference quirk: a passed noise is mapped 2n-1 (model.py:346)
@@ -358,6 +499,7 @@ class ModelInterface(object):
                 torch.distributed.all_reduce(self.model.flat_grads())  # one flat RCCL all-reduce (sum) of 515 KB
             self.optimizer.grad_scale = 1.0 / world
             self.optimizer.step()
+            self.optimizer.sync_step_dev() if self.optimizer._step_dev is not None else None
             self.last_grad_norm = self.optimizer.last_grad_norm
             return loss.item() if sync else loss
         self.optimizer.zero_grad()

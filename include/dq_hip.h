@@ -45,7 +45,7 @@ const char* dq_last_error(void);
  * dq_rope, dq_attn_*); dq_train_step takes ms1_loss_weight, dq_ms1_loss_fwd_bwd;
  * dq_tfm_set_precision, dq_gemm_bf16x3. */
 int dq_abi_version(void);
-#define DQ_ABI_VERSION 5
+#define DQ_ABI_VERSION 7
 
 /* DDIMDiffusionModel.pred_type (model.py:205-213, 269-280, 354-389); any other value is rejected ("Unknown pred_type"). */
 enum { DQ_PRED_EPS = 0, DQ_PRED_X0 = 1 };
@@ -114,6 +114,14 @@ int dq_mse_loss_weighted_fwd_bwd(const float* pred, const float* target, float t
 int dq_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float* scratch,
                        float grad_scale, float max_norm, double lr, double beta1, double beta2, double eps, double weight_decay,
                        int step, float* gnorm_out, void* stream);
+/* The same step with the learning rate (*lr_dev, fp32) and the step count (*step_dev, int32: incremented by the call, 0 before the first
+ * step) in device memory: the call's arguments do not change from step to step, so a captured graph of it can be replayed.  scratch as above. */
+int dq_adamw_clip_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float* scratch, float grad_scale,
+                           float max_norm, const float* lr_dev, double beta1, double beta2, double eps, double weight_decay, int* step_dev,
+                           float* gnorm_out, void* stream);
+/* on = 0: the backward's remaining weight-gradient launches run on the caller's stream instead of the plan's side stream (a captured train
+ * step is then one chain; the fork / join inside a graph was measured slower than the chain).  Default 1. */
+int dq_plan_set_side_stream(dq_plan* plan, int on);
 
 /* ---- the MS1 term of train_step with ms1_loss_weight = w in (0, 1] (model.py:364-371, 379-386, 398-402) -----------------
  * The reference's branch raises (torch.max(x, dim=-1) returns a tuple that is then divided), so the semantics are chosen
@@ -250,9 +258,23 @@ int dq_resblock_fwd(const float* params, const float* xA, int cinA, const float*
 /* Backward of the call above: dxA / dxB += (zero them first; nullable), grads (same layout as params) += for the conv / norm
  * tensors; dss (rows / rows_per_sample, 2*cout) = d loss / d [scale | shift] (the mlp's gradients follow from it:
  * d mlp.1.bias = sum_b dss_b, d mlp.1.weight = sum_b dss_b (x) SiLU(temb_b); the network does that in its time-embedding backward). */
+/* dout == NULL (benchmarks): the gradient of the block output is already in the workspace at dq_resblock_dout_offset(...) floats;
+ * dxA / dxB are then plain stores, dss is not copied out, and the call consists of the backward launches only. */
+int64_t dq_resblock_dout_offset(int cin, int cout, int rows, int n, int rows_per_sample);
 int dq_resblock_bwd(const float* params, const float* xA, int cinA, const float* xB, int cinB, const float* dout, float* dxA, float* dxB,
                     float* grads, float* dss, int cout, int rows, int n, int rows_per_sample, float* workspace, int64_t workspace_floats,
                     void* stream);
+/* The convolutional part of a U-Net level in ONE launch (unet1d.py:1134-1142, 1150-1158, 1160-1163; k_level.hip):
+ *   out_i = ResnetBlock_i(cat(h, skip_i)),  h = stage(x) for i = 0, h = out_0 for i = 1
+ * pre: 0 none (x is (rows, C, n)), 1 Downsample k4 s2 (x is (rows, cp, 2n)), 2 Upsample nearest x2 + k3 (x is (rows, cp, n/2)), 3 k3 conv
+ * (x is (rows, cp, n)); skip_i (rows, cs, n), nullable with cs = 0 (then the residual is the identity); temb (rows / rows_per_sample, 16).
+ * params: [stage weight (C, cp, K) | stage bias (C)] (pre != 0), then nblocks (1 or 2) blocks in the dq_resblock_fwd layout with
+ * cin = C + cs (dq_level_param_floats floats in all).  out0 nullable when nblocks = 2 (inference on the way up keeps only out1).
+ * n: a power of two <= 64; C in {4, 8, 12, 16}.  workspace: 2 * (rows / rows_per_sample) * 2 * C floats. */
+int64_t dq_level_param_floats(int pre, int C, int cp, int cs, int nblocks);
+int dq_level_fwd(const float* params, int pre, const float* x, int cp, const float* skip0, const float* skip1, int cs, const float* temb,
+                 float* out0, float* out1, int C, int nblocks, int rows, int n, int rows_per_sample, float* workspace,
+                 int64_t workspace_floats, void* stream);
 /* RoPE of the bottleneck attention (rotary_embedding_torch 'lang' mode as restated in DESIGN.md section 5; unet1d.py:529,
  * 560-561), in place on the 4 heads x 32 channels at the start of each sample of qk (B, >=128, RT); batch_stride in floats;
  * sign +1 forward, -1 the transposed rotation (backward). */

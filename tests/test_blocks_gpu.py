@@ -180,6 +180,64 @@ def test_resnet_block_backward_vs_oracle_autograd(N, cin, cout, n, rows, rps, sp
     assert rel(dss.t() @ torch.nn.functional.silu(temb), p["b.mlp.1.weight"].grad) < 5e-5
 
 
+# ------------------------------------------------------------------------------------------------ a level's convolutional part in one launch
+@pytest.mark.parametrize("pre,C,cp,cs,n,rows,rps,nblocks", [(0, 4, 4, 0, 64, 70, 35, 2), (1, 8, 4, 0, 16, 90, 45, 2), (1, 12, 12, 0, 2, 66, 33, 2),
+                                                            (2, 8, 12, 8, 16, 36, 12, 2), (2, 16, 16, 12, 2, 160, 80, 2), (2, 4, 8, 4, 64, 26, 13, 2),
+                                                            (3, 4, 4, 4, 64, 26, 13, 1), (0, 16, 16, 16, 1, 130, 65, 2), (1, 16, 12, 0, 1, 128, 64, 2)])
+def test_level_forward_vs_oracle(N, pre, C, cp, cs, n, rows, rps, nblocks):
+    """k_level_fwd (dq_level_fwd): [Downsample | Upsample | k3 conv] -> ResnetBlock -> ResnetBlock with the skip concatenations of the up
+    path, against the oracle's conv + resnet_block composition (reference unet1d.py:82-110, 271-323, 1134-1163)."""
+    import torch.nn.functional as F
+    from oracle import dq_oracle as O
+
+    gen = torch.Generator().manual_seed(1000 * pre + 10 * C + n)
+    r = lambda *s: torch.randn(*s, generator=gen)
+    B, K = rows // rps, 4 if pre == 1 else 3
+    n_in = {0: n, 1: 2 * n, 2: n // 2, 3: n}[pre]
+    x = r(rows, cp if pre else C, n_in)
+    temb = r(B, 16)
+    pw, pb = r(C, cp, K) * 0.3, r(C) * 0.1
+    blocks, flat = [], ([pw.reshape(-1), pb] if pre else [])
+    for _ in range(nblocks):
+        cin = C + cs
+        wd = {"mlp.1.weight": r(2 * C, 16) * 0.3, "mlp.1.bias": r(2 * C) * 0.1, "block1.proj.weight": r(C, cin, 3) * 0.3,
+              "block1.proj.bias": r(C) * 0.1, "block1.norm.g": torch.rand(1, C, 1, generator=gen) + 0.5,
+              "block2.proj.weight": r(C, C, 3) * 0.3, "block2.proj.bias": r(C) * 0.1, "block2.norm.g": torch.rand(1, C, 1, generator=gen) + 0.5}
+        if cs:
+            wd["res_conv.weight"], wd["res_conv.bias"] = r(C, cin, 1) * 0.3, r(C) * 0.1
+        blocks.append(wd)
+        flat += [wd[k].reshape(-1) for k in RES_KEYS if k in wd]
+    skips = [r(rows, cs, n) if cs else None for _ in range(2)]
+    # oracle
+    if pre == 1:
+        h = F.conv1d(x, pw, pb, stride=2, padding=1)
+    elif pre == 2:
+        h = F.conv1d(F.interpolate(x, scale_factor=2, mode="nearest"), pw, pb, padding=1)
+    elif pre == 3:
+        h = F.conv1d(x, pw, pb, padding=1)
+    else:
+        h = x
+    outs = []
+    for i, wd in enumerate(blocks):
+        xin = torch.cat([h, skips[i]], dim=1) if cs else h
+        h = O.resnet_block({"b." + k: v for k, v in wd.items()}, "b", xin, temb, rps)
+        outs.append(h)
+    # kernel
+    L = N.lib()
+    params = torch.cat(flat).cuda()
+    assert params.numel() == L.dq_level_param_floats(pre, C, cp, cs, nblocks)
+    xd, td = x.cuda(), temb.cuda()
+    s0, s1 = (sk.cuda() if sk is not None else None for sk in skips)
+    o0, o1 = torch.empty(rows, C, n, device="cuda"), torch.empty(rows, C, n, device="cuda")
+    ws = torch.empty(2 * B * 2 * C, device="cuda")
+    N.check(L.dq_level_fwd(N.ptr(params), pre, N.ptr(xd), cp, N.ptr(s0), N.ptr(s1), cs, N.ptr(td), N.ptr(o0), N.ptr(o1) if nblocks == 2 else None, C,
+                           nblocks, rows, n, rps, N.ptr(ws), ws.numel(), N.stream_ptr()), "dq_level_fwd")
+    torch.cuda.synchronize()
+    assert rel(o0, outs[0]) < 1e-5
+    if nblocks == 2:
+        assert rel(o1, outs[1]) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------------ bottleneck attention (unet1d.py:428-443)
 def _attn_ref(q, k, v):
     B, _, RT = q.shape

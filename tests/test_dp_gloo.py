@@ -138,6 +138,60 @@ def test_unseeded_replicas_are_synchronised_and_stay_identical():
     assert moved0 > 0
 
 
+def _resume_worker(rank, world, port, q, ckpt):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "diffusion-deconvolution-dia-msms-data_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dquartic.model.model import DDIMDiffusionModel
+        from dquartic.model.unet1d import UNet1d
+
+        net = UNet1d(dim=4, channels=1, dim_mults=(1, 2), conditional=True, init_cond_channels=1, attn_cond_channels=1, downsample_dim=8, simple=True)
+        dm = DDIMDiffusionModel(model_class=net, device="cpu")
+        dm._prepare_training(1e-3)
+        sched = dm._get_lr_schedule_with_warmup(2, 10)
+        # the "latest" checkpoint exists on rank 0's disk only (what a resume looks like with node-local checkpoint directories)
+        path = ckpt if rank == 0 else ckpt + ".not-here"
+        start, best, sched = dm.load_checkpoint(sched, path, "cpu")
+        dm._sync_replicas()
+        start, best = dm._sync_resume_state(start, best, sched)
+        q.put((rank, start, best, sched.lambda_lr.state_dict()["last_epoch"], dm.optimizer.param_groups[0]["lr"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_resume_with_the_checkpoint_on_rank0_only(tmp_path):
+    """every rank loads the "latest" checkpoint itself; when only rank 0 finds it, the epoch counter, the best loss,
+    the LambdaLR state and the current lr must come from rank 0 too -- otherwise the ranks run epoch loops of different lengths and
+    the per-step all-reduce hangs."""
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "diffusion-deconvolution-dia-msms-data_amd"))
+    from dquartic.model.model import DDIMDiffusionModel
+    from dquartic.model.unet1d import UNet1d
+
+    net = UNet1d(dim=4, channels=1, dim_mults=(1, 2), conditional=True, init_cond_channels=1, attn_cond_channels=1, downsample_dim=8, simple=True)
+    dm = DDIMDiffusionModel(model_class=net, device="cpu")
+    dm._set_optimizer(1e-3)
+    sched = dm._get_lr_schedule_with_warmup(2, 10)
+    for e in range(4):
+        sched.step(e, 1.0)
+    ckpt = str(tmp_path / "dquartic_latest_checkpoint.ckpt")
+    dm.save_checkpoint(sched, 4, 0.125, ckpt)
+    lr_saved = dm.optimizer.param_groups[0]["lr"]
+    world, port = 2, 31100 + (os.getpid() % 500)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_resume_worker, args=(r, world, port, q, ckpt)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (_, s0, b0, le0, lr0), (_, s1, b1, le1, lr1) = res
+    assert s0 == s1 == 4 and b0 == b1 == 0.125
+    assert le0 == le1 and lr0 == lr1 == lr_saved
+
+
 def _gpu_dp_worker(rank, world, port, q):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "diffusion-deconvolution-dia-msms-data_amd"))

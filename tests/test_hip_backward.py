@@ -401,3 +401,51 @@ def test_train_one_batch_under_rccl_process_group_world1():
         dist.destroy_process_group()
     assert got[0] == ref[0] and torch.equal(got[1], ref[1]) and got[2] == ref[2] and got[3] == ref[3]
     assert all(np.isfinite(l) for l in got[0])
+
+
+def test_captured_train_step_equals_eager_bit_for_bit():
+    """``enable_train_graph`` replays one captured hipGraph per optimiser step (draws, q_sample, forward, loss, backward,
+    clip + AdamW with the step count / lr in device memory).  Same kernels, same order: after five steps from the same seed the parameters,
+    both moments and every loss equal the eager run's bit for bit -- and building the graph is not a training step."""
+    from dquartic.model.model import DDIMDiffusionModel
+    from dquartic.model.unet1d import UNet1d
+
+    def make():
+        torch.manual_seed(3)
+        net = UNet1d(dim=4, channels=1, dim_mults=(1, 2, 2, 3, 3, 4, 4), conditional=True, init_cond_channels=1, attn_cond_channels=1,
+                     downsample_dim=64, simple=True).cuda()
+        dm = DDIMDiffusionModel(model_class=net, device="cuda")
+        dm._set_optimizer(1e-3)
+        return net, dm
+
+    g = torch.Generator().manual_seed(5)
+    B, RT, MZ = 4, 48, 64
+    data = [(torch.rand(B, RT, MZ, generator=g).cuda(), torch.rand(B, RT, MZ, generator=g).cuda(), torch.rand(B, RT, generator=g).cuda()) for _ in range(5)]
+    # eager, with the optimiser step in its device-state form
+    net_e, dm_e = make()
+    torch.manual_seed(11)
+    losses_e = []
+    for x0, c2, c1 in data:
+        loss = dm_e.train_step_fused(x0, c2, c1, zero_grads=True)
+        dm_e.optimizer.step_dev()
+        losses_e.append(loss.clone())
+    # captured
+    net_g, dm_g = make()
+    dm_g.enable_train_graph()
+    torch.manual_seed(11)
+    losses_g = [dm_g._train_one_batch(x0, ms2_cond=c2, ms1_cond=c1, sync=False).clone() for x0, c2, c1 in data]
+    torch.cuda.synchronize()
+    assert dm_g.optimizer._step == dm_e.optimizer._step == 5
+    assert int(dm_g.optimizer._step_dev.item()) == 5
+    for a, b in zip(losses_g, losses_e):
+        assert torch.equal(a, b), (float(a), float(b))
+    assert torch.equal(net_g.flat_params, net_e.flat_params)
+    assert torch.equal(dm_g.optimizer._m, dm_e.optimizer._m) and torch.equal(dm_g.optimizer._v, dm_e.optimizer._v)
+    # the device-state step against the host-side one: the same update up to the last bit of the bias-correction scalars
+    net_h, dm_h = make()
+    torch.manual_seed(11)
+    for x0, c2, c1 in data:
+        dm_h._train_one_batch(x0, ms2_cond=c2, ms1_cond=c1, sync=False)
+    # (the bias-correction scalars come from pow() on the device there and on the host here: a parameter may differ in its last bit)
+    assert float((net_h.flat_params - net_e.flat_params).abs().max()) <= 4 * 1.1920929e-07 * float(net_e.flat_params.abs().max())
+    dm_g.enable_train_graph(False)

@@ -143,6 +143,38 @@ def test_hip_forward_backward_match_reference_fixtures(golden, tag):
 
 
 @pytest.mark.gpu
+def test_two_forwards_before_their_backwards(golden):
+    """two grad-enabled forwards in flight (micro-batches whose losses are summed), then the backwards, in either order: each
+    forward owns its training workspace and the native handle remembers every workspace that holds saved activations, so both backwards
+    run and the summed gradient equals the sum of the separate ones."""
+    g = golden("tfm_tiny.npz")
+    cfg, params, grads, x, t, c, probe, out = _case(g, TAGS[0])
+    net = _module(cfg, params)
+    x2, c2 = (x * 0.5 + 0.1).cuda(), (c * 0.7 - 0.2).cuda()
+
+    def grads_of(fn):
+        for p in net.parameters():
+            p.grad = None
+        fn()
+        return torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()
+
+    f1 = lambda: (net(x.cuda(), t.cuda(), c.cuda()) * probe.cuda()).sum()
+    f2 = lambda: (net(x2, t.cuda(), c2) ** 2).mean()
+    g1 = grads_of(lambda: f1().backward())
+    g2 = grads_of(lambda: f2().backward())
+    both = grads_of(lambda: (f1() + f2()).backward())  # forward 1, forward 2, one backward through both (the later forward's first)
+
+    def earlier_first():
+        a, b = f1(), f2()
+        a.backward()   # the EARLIER forward's backward while the later one is still pending
+        b.backward()
+    sep = grads_of(earlier_first)
+    tol = 2e-5 * float((g1 + g2).abs().max())
+    assert float((both - (g1 + g2)).abs().max()) < tol
+    assert float((sep - (g1 + g2)).abs().max()) < tol
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("D,H,heads,layers,B,S1,S2", [(200, 64, 4, 2, 3, 34, 20), (1000, 128, 1, 1, 2, 70, 9), (64, 256, 8, 3, 5, 17, 34),
                                                      (96, 512, 8, 1, 2, 34, 34), (72, 1008, 4, 1, 1, 9, 5), (48, 1032, 2, 1, 1, 5, 7)])
 def test_hip_matches_oracle_at_larger_shapes(D, H, heads, layers, B, S1, S2):

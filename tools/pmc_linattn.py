@@ -21,5 +21,27 @@ for _ in range(5):
 ab = torch.linspace(0.9, 0.1, 1000).cuda(); t = torch.zeros(50, dtype=torch.long).cuda()
 for _ in range(5):
     N.check(L.dq_q_sample(N.ptr(ab), N.ptr(x), N.ptr(t), N.ptr(dy), N.ptr(y), 50, x.numel() // 50, 0, N.stream_ptr()), "q")
+# the HBM-bound kernels bench.py reports under roofline_hbm, at the same shapes
+RT = 400
+cin, cout, B = 8, 4, 32
+nparam = 2 * cout * 16 + 2 * cout + cout * cin * 3 + 2 * cout + cout * cout * 3 + 2 * cout + cout * cin + cout
+flat = (torch.randn(nparam, generator=g) * 0.3).cuda()
+xA, xB = torch.randn(rows, cout, n, generator=g).cuda(), torch.randn(rows, cin - cout, n, generator=g).cuda()
+temb = torch.randn(B, 16, generator=g).cuda()
+nws = L.dq_resblock_workspace_floats(cin, cout, rows, n, RT)
+ws = torch.zeros(nws, device="cuda"); outb = torch.empty(rows, cout, n, device="cuda")
+N.check(L.dq_resblock_fwd(N.ptr(flat), N.ptr(xA), cout, N.ptr(xB), cin - cout, N.ptr(temb), N.ptr(outb), cout, rows, n, RT, 1, N.ptr(ws), nws, N.stream_ptr()), "rf")
+dA, dB, grads = torch.empty_like(xA), torch.empty_like(xB), torch.zeros_like(flat)
+for _ in range(5):
+    N.check(L.dq_resblock_bwd(N.ptr(flat), N.ptr(xA), cout, N.ptr(xB), cin - cout, None, N.ptr(dA), N.ptr(dB), N.ptr(grads), None, cout, rows, n, RT, N.ptr(ws), nws, N.stream_ptr()), "rb")
+SB = 512
+params = (torch.randn(L.dq_level_param_floats(0, 4, 4, 0, 2), generator=g) * 0.3).cuda()
+xl = torch.randn(SB * RT, 4, n, generator=g).cuda(); tl = torch.randn(SB, 16, generator=g).cuda()
+o0, o1 = torch.empty_like(xl), torch.empty_like(xl); wsl = torch.empty(2 * SB * 8, device="cuda")
+for _ in range(3):
+    N.check(L.dq_level_fwd(N.ptr(params), 0, N.ptr(xl), 4, None, None, 0, N.ptr(tl), N.ptr(o0), N.ptr(o1), 4, 2, SB * RT, n, RT, N.ptr(wsl), wsl.numel(), N.stream_ptr()), "lv")
+# calibration of FETCH_SIZE for 4-byte-per-lane reads: k_rmsnorm_fwd reads one tensor and writes one
+for _ in range(5):
+    N.check(L.dq_rmsnorm_fwd(N.ptr(x), N.ptr(g1), N.ptr(y), C, rows, n, N.stream_ptr()), "rn")
 torch.cuda.synchronize()
 print("bytes per tensor", x.numel() * 4)
