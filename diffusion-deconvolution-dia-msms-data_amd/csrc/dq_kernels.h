@@ -145,7 +145,7 @@ int launch_res_fwd_v4(const ResFwd& a, hipStream_t s);
 // k_res_mm.hip: forward with the convolutions on the 4x4x1 matrix pipe (rows of 1..64 positions, C = 4 / 8 / 12 / 16)
 bool res_mm_usable(int n, int C, int cinA, int cinB, int rows_per_sample, bool has_wr);
 int launch_res_fwd_mm(const ResFwd& a, hipStream_t s);
-enum LevelPre { LEVEL_PRE_NONE = 0, LEVEL_PRE_DOWN = 1, LEVEL_PRE_UP = 2, LEVEL_PRE_S1 = 3 };
+enum LevelPre { LEVEL_PRE_NONE = 0, LEVEL_PRE_DOWN = 1, LEVEL_PRE_UP = 2, LEVEL_PRE_S1 = 3, LEVEL_PRE_INIT = 4 };
 // k_level.hip: [resample conv that produces the level's input] -> ResnetBlock (-> ResnetBlock) in ONE launch, convolutions on the
 // matrix pipe (rows of 1..64 positions).  blk[i].inA / cinA are unused (a block's first input is in registers); blk[i].out == null:
 // that block's output is not written (inference, up path); pre_out: where the input stage's result is kept (training) or null.
@@ -156,6 +156,14 @@ struct LevelFwd {
   float* pre_out = nullptr;
   int pre = LEVEL_PRE_NONE, nblocks = 1;
   ResFwd blk[2];
+  // LEVEL_PRE_INIT (C == 4, inference): in = x_t (rows, n); cond = the mixture (rows, n), normalised as cond * cm + ca and conditioned with
+  // init_cond_proj's per-sample [scale, shift] at ss_init (same buffer / stride as the blocks' vectors); pw / pb = init_conv (4, 2, 7);
+  // pre_out = h0 (always written)
+  const float* cond = nullptr; float cm = 1.f, ca = 0.f; const float* ss_init = nullptr;
+  // head epilogue (C == 4, inference; behind the last block): eps = final_conv(out) (ew (1, 4, 1), eb) -> eps_out (nullable), and with
+  // x_t set the DDIM update of model.py:265-289 into x_out (coef: [sa, sb, sap, sbp] rows; step_ptr nullable: row index on the device)
+  const float* ew = nullptr; const float* eb = nullptr; float* eps_out = nullptr;
+  const float* x_t = nullptr; float* x_out = nullptr; const float* coef = nullptr; const int* step_ptr = nullptr; int pred_x0 = 0;
   int C = 0, rows = 0, n = 0, rows_per_sample = 1;
 };
 bool level_fwd_usable(int C, int n, int rows_per_sample, int pre_mode, int cp, int nblocks, const ResFwd* blk);
@@ -221,6 +229,7 @@ int launch_fold(const float* in, float* out, int B, int RT, int cn, int to_mid, 
 // first layer inputs: cat0 = [cond_n*(scale+1)+shift, x] as (rows, 2, MZ); ms1n = ms1*cm+ca
 int launch_prep_inputs(const float* x, const float* cond, const float* ms1, const float* ss, int ss_stride, int ss_off, float cm,
                        float ca, float* cat0, float* ms1n, int B, int RT, int MZ, hipStream_t s);
+int launch_ms1_norm(const float* ms1, float cm, float ca, float* ms1n, int64_t n, hipStream_t s);  // ms1n = ms1 * cm + ca
 // d(scale), d(shift) of init_cond_proj from dcat0 channel 0 (+= into dss; part: >= 64 * B floats of per-block partials)
 int launch_prep_inputs_bwd(const float* dcat0, const float* cond, float cm, float ca, float* dss, int ss_stride, int ss_off, int B,
                            int RT, int MZ, float* part, int64_t part_floats, hipStream_t s);

@@ -168,6 +168,11 @@ struct Ctx {
   // set by unet_backward: the slot reductions of the ResnetBlock backwards that form their own weight gradients (k_res_bwd_wg),
   // collected for ONE launch at the end of the pass (null: each is reduced right behind its launch)
   std::vector<ResWgReduce>* wg_defer = nullptr;
+  // sampling (dq_ddim_sample): the DDIM update rides in the head launch (x_out may alias x_t), and the step-invariant MS1 feature path
+  // (unet1d.py:1120-1130) + to_k + RoPE(k) were computed once before the loop
+  struct StepIO { const float* x_t = nullptr; float* x_out = nullptr; const float* coef = nullptr; const int* step_ptr = nullptr; int pred_x0 = 0;
+                  bool skip_ms1 = false; bool fused_update = false; bool want_eps = true; };
+  StepIO* step_io = nullptr;
   float* w(int64_t off) const { return W + off; }
   float* g(int64_t off) const { return G + off; }
   const float* prm(int64_t off) const { return P + off; }
@@ -651,11 +656,23 @@ struct LevelCall {
   int C = 0, n = 0, nblocks = 0;
   const ResP* r[2] = {nullptr, nullptr}; const ResBuf* rb[2] = {nullptr, nullptr};
   const float* inB[2] = {nullptr, nullptr}; int cinB[2] = {0, 0}; bool write_out[2] = {true, true};
+  const float* cond = nullptr; float cm = 1.f, ca = 0.f;      // LEVEL_PRE_INIT
+  const ConvP* head = nullptr; float* eps_out = nullptr;      // head epilogue (final_conv)
 };
 LevelFwd level_desc(const Ctx& c, const LevelCall& lc) {
   LevelFwd f;
   f.params = c.P; f.in = lc.in; f.pre = lc.pre; f.nblocks = lc.nblocks; f.C = lc.C; f.rows = c.B * c.RT; f.n = lc.n; f.rows_per_sample = c.RT;
   if (lc.pc) { f.cp = lc.pc->cin; f.pw = c.prm(lc.pc->w); f.pb = lc.pc->b >= 0 ? c.prm(lc.pc->b) : nullptr; f.pre_out = c.save ? lc.pre_out : nullptr; }
+  if (lc.pre == LEVEL_PRE_INIT) { f.cond = lc.cond; f.cm = lc.cm; f.ca = lc.ca; f.ss_init = c.w(c.ar.ss) + c.p.ss_init; f.pre_out = lc.pre_out; }
+  if (lc.head) {
+    f.ew = c.prm(lc.head->w); f.eb = c.prm(lc.head->b);
+    if (c.step_io && c.step_io->x_t) {
+      f.x_t = c.step_io->x_t; f.x_out = c.step_io->x_out; f.coef = c.step_io->coef; f.step_ptr = c.step_io->step_ptr; f.pred_x0 = c.step_io->pred_x0;
+      f.eps_out = c.step_io->want_eps ? lc.eps_out : nullptr;  // (the trajectory's eps, when the caller keeps one)
+    } else {
+      f.eps_out = lc.eps_out;
+    }
+  }
   for (int i = 0; i < lc.nblocks; ++i) f.blk[i] = level_block(c, *lc.r[i], *lc.rb[i], lc.inB[i], lc.cinB[i], lc.write_out[i]);
   return f;
 }
@@ -678,11 +695,34 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
   DQ_TRY(la_prepare_all(c));
   // K1: time embedding + every scale/shift head (unet1d.py:1105, 315-318, 677)
   DQ_TRY(launch_time_embed_fwd(p, dt, c.P, t, t_scalar, c.w(a.tbuf), c.w(a.ss), B, step_tab, step_ptr, c.s));
+  // A level whose ResnetBlocks the level kernel takes also computes its own input from the previous level's LinearAttention
+  // output (Downsample, unet1d.py:1141): that conv is then not launched and, in inference, its result never exists in memory.
+  // Level 0 in inference: the mixture conditioning + concat + init_conv (unet1d.py:1107-1118) are that launch's input stage.
+  auto down_call = [&](int lv) {
+    LevelCall lc;
+    const LevelP& l = p.downs[lv];
+    lc.C = l.r0.cout; lc.n = l.n; lc.nblocks = 2;
+    lc.r[0] = &l.r0; lc.r[1] = &l.r1; lc.rb[0] = &a.downs[lv].r0; lc.rb[1] = &a.downs[lv].r1;
+    if (lv == 0) {
+      if (!c.save && p.dim == 4 && p.init_conv.cout == 4 && p.init_conv.cin == 2 && p.init_conv.k == 7 && p.init_conv.b >= 0) {
+        lc.pre = LEVEL_PRE_INIT; lc.pc = &p.init_conv; lc.in = x; lc.cond = init_cond; lc.cm = cm; lc.ca = ca; lc.pre_out = c.w(a.h0);
+      } else {
+        lc.in = c.w(a.h0);
+      }
+    } else { lc.pre = LEVEL_PRE_DOWN; lc.pc = &p.downs[lv - 1].resample; lc.in = c.w(a.downs[lv - 1].la); lc.pre_out = c.w(a.downs[lv - 1].rs); }
+    return lc;
+  };
+  const bool init_fused = down_call(0).pre == LEVEL_PRE_INIT && level_ok(c, down_call(0));
+  const bool skip_ms1 = c.step_io && c.step_io->skip_ms1;
   // K2: mixture conditioning + concat (unet1d.py:1107-1115), then init_conv k7 (:1117)
-  DQ_TRY(launch_prep_inputs(x, init_cond, attn_cond, c.w(a.ss), p.ss_total, p.ss_init, cm, ca, c.w(a.cat0), c.w(a.ms1n), B, RT, p.mz, c.s));
-  DQ_TRY(conv_plain_fwd(c, p.init_conv, CONV_S1, c.w(a.cat0), c.w(a.h0), R, p.mz, p.mz));
+  if (init_fused) {
+    if (!skip_ms1) DQ_TRY(launch_ms1_norm(attn_cond, cm, ca, c.w(a.ms1n), (int64_t)B * RT, c.s));
+  } else {
+    DQ_TRY(launch_prep_inputs(x, init_cond, attn_cond, c.w(a.ss), p.ss_total, p.ss_init, cm, ca, c.w(a.cat0), c.w(a.ms1n), B, RT, p.mz, c.s));
+    DQ_TRY(conv_plain_fwd(c, p.init_conv, CONV_S1, c.w(a.cat0), c.w(a.h0), R, p.mz, p.mz));
+  }
   // K3: MS1 features (unet1d.py:1120-1130): (B,1,RT) -> conv k7 -> GELU -> conv k1
-  {
+  if (!skip_ms1) {
     ConvFwd f;
     f.inA = c.w(a.ms1n); f.cinA = 1; f.w = c.prm(p.ms1_c0.w); f.bias = c.prm(p.ms1_c0.b); f.cout = p.cond_dim; f.K = 7;
     f.rows = B; f.n_in = RT; f.n_out = RT; f.u_out = c.save ? c.w(a.ms1_u) : nullptr; f.y_out = c.w(a.ms1_a); f.act = ACT_GELU;
@@ -690,17 +730,6 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     DQ_TRY(conv_plain_fwd(c, p.ms1_c1, CONV_S1, c.w(a.ms1_a), c.w(a.ms1f), B, RT, RT));
   }
   // down path (unet1d.py:1134-1142)
-  // A level whose ResnetBlocks the level kernel takes also computes its own input from the previous level's LinearAttention
-  // output (Downsample, unet1d.py:1141): that conv is then not launched and, in inference, its result never exists in memory.
-  auto down_call = [&](int lv) {
-    LevelCall lc;
-    const LevelP& l = p.downs[lv];
-    lc.C = l.r0.cout; lc.n = l.n; lc.nblocks = 2;
-    lc.r[0] = &l.r0; lc.r[1] = &l.r1; lc.rb[0] = &a.downs[lv].r0; lc.rb[1] = &a.downs[lv].r1;
-    if (lv == 0) { lc.in = c.w(a.h0); }
-    else { lc.pre = LEVEL_PRE_DOWN; lc.pc = &p.downs[lv - 1].resample; lc.in = c.w(a.downs[lv - 1].la); lc.pre_out = c.w(a.downs[lv - 1].rs); }
-    return lc;
-  };
   const float* cur = c.w(a.h0);
   for (int lv = 0; lv < L; ++lv) {
     const LevelP& l = p.downs[lv];
@@ -728,10 +757,10 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
       // Residual(PreNorm(Attention(use_xattn))) (unet1d.py:552-567)
       DQ_TRY(launch_rmsnorm_fwd(c.w(a.mid1.out), c.prm(p.ag), c.w(a.xn), p.mid_c, B, RT, c.s));
       DQ_TRY(conv_plain_fwd(c, proj(p.qv_w, 2 * HID, p.mid_c), CONV_S1, c.w(a.xn), c.w(a.qv), B, RT, RT, prep_ok ? 0 : -1));
-      DQ_TRY(conv_plain_fwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.w(a.kk), B, RT, RT, prep_ok ? 1 : -1));
+      if (!skip_ms1) DQ_TRY(conv_plain_fwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.w(a.kk), B, RT, RT, prep_ok ? 1 : -1));
       if (rope) {
         DQ_TRY(launch_rope(c.w(a.qv), rope, B, (int64_t)2 * HID * RT, RT, 1.f, c.s));  // q = first 128 channels of each sample's 256
-        DQ_TRY(launch_rope(c.w(a.kk), rope, B, (int64_t)HID * RT, RT, 1.f, c.s));
+        if (!skip_ms1) DQ_TRY(launch_rope(c.w(a.kk), rope, B, (int64_t)HID * RT, RT, 1.f, c.s));
       }
       const int64_t qvbs = (int64_t)2 * HID * RT, kbs = (int64_t)HID * RT;
       DQ_TRY(launch_attn_fwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.w(a.lse), B, RT, c.s));
@@ -795,8 +824,18 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     cur = c.w(b.rs);
   }
   // head (unet1d.py:1160-1166)
-  if (level_ok(c, up_call(L))) DQ_TRY(launch_level_fwd(level_desc(c, up_call(L)), c.s));
-  else DQ_TRY(res_fwd(c, p.fin, a.fin, cur, p.dim, c.w(a.h0), p.dim, R, p.mz, RT));
+  {
+    LevelCall lh = up_call(L);
+    const bool head_fused = !c.save && p.dim == 4 && p.final_conv.cout == 1 && p.final_conv.cin == 4 && p.final_conv.k == 1 && p.final_conv.b >= 0 &&
+                            level_ok(c, lh);
+    if (head_fused) {  // inference: final_conv (and, while sampling, the DDIM update) in the final block's launch; its output is not stored
+      lh.head = &p.final_conv; lh.eps_out = out; lh.write_out[0] = false;
+      if (c.step_io && c.step_io->x_t) c.step_io->fused_update = true;
+      return launch_level_fwd(level_desc(c, lh), c.s);
+    }
+    if (level_ok(c, lh)) DQ_TRY(launch_level_fwd(level_desc(c, lh), c.s));
+    else DQ_TRY(res_fwd(c, p.fin, a.fin, cur, p.dim, c.w(a.h0), p.dim, R, p.mz, RT));
+  }
   DQ_TRY(conv_plain_fwd(c, p.final_conv, CONV_S1, c.w(a.fin.out), out, R, p.mz, p.mz));
   return 0;
 }
@@ -1238,9 +1277,28 @@ int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, 
   float* xa = c.w(a.xa);
   float* xb = c.w(a.xb);
   DQ_HIP_OK(hipMemcpyAsync(xa, x_T, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+  // The MS1 feature path (unet1d.py:1120-1130), to_k and RoPE(k) (:555, 561) depend on neither t nor x_t: once per call, not per step
+  Ctx::StepIO io;
+  io.pred_x0 = px0; io.coef = c.w(a.coef);
+  auto ms1_prologue = [&](const Ctx& cx, const float* ms1) -> int {
+    const Plan& p = cx.p;
+    if (p.wide_mid) return 0;  // (the wide bottleneck keeps its projections inside the step)
+    const bool prep_ok = (int)(p.downs.size() + p.ups.size()) <= LA_PREP_MAX;
+    DQ_TRY(la_prepare_all(cx));  // (the aligned copy of to_k's weight for the GEMM route)
+    DQ_TRY(launch_ms1_norm(ms1, cm, ca, cx.w(a.ms1n), (int64_t)B * RT, cx.s));
+    ConvFwd f;
+    f.inA = cx.w(a.ms1n); f.cinA = 1; f.w = cx.prm(p.ms1_c0.w); f.bias = cx.prm(p.ms1_c0.b); f.cout = p.cond_dim; f.K = 7;
+    f.rows = B; f.n_in = RT; f.n_out = RT; f.y_out = cx.w(a.ms1_a); f.act = ACT_GELU;
+    DQ_TRY(launch_conv_fwd(f, cx.s));
+    DQ_TRY(conv_plain_fwd(cx, p.ms1_c1, CONV_S1, cx.w(a.ms1_a), cx.w(a.ms1f), B, RT, RT));
+    DQ_TRY(conv_plain_fwd(cx, proj(p.k_w, HID, p.cond_dim), CONV_S1, cx.w(a.ms1f), cx.w(a.kk), B, RT, RT, prep_ok ? 1 : -1));
+    if (rope_freqs) DQ_TRY(launch_rope(cx.w(a.kk), rope_freqs, B, (int64_t)HID * RT, RT, 1.f, cx.s));
+    io.skip_ms1 = true;
+    return 0;
+  };
   if (use_graph && !traj_x && !traj_eps) {
     // ---- hipGraph path: one step captured once (all pointers inside the arena / parameter buffers), replayed per step.
-    // The step index lives on the device: k_time_fwd reads ts_tab[*step], k_ddim_step its coefficient row, k_inc_step bumps it.
+    // The step index lives on the device: k_time_fwd reads ts_tab[*step], the DDIM update its coefficient row, k_inc_step bumps it.
     int* ts_tab = reinterpret_cast<int*>(c.w(a.ts_tab));
     int* step = reinterpret_cast<int*>(c.w(a.step));
     DQ_HIP_OK(hipMemcpyAsync(ts_tab, ts, sizeof(int32_t) * num_steps, hipMemcpyHostToDevice, s));
@@ -1248,6 +1306,8 @@ int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, 
     DQ_HIP_OK(hipMemcpyAsync(c.w(a.c2_stage), ms2_cond, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
     DQ_HIP_OK(hipMemcpyAsync(c.w(a.c1_stage), ms1_cond, sizeof(float) * (int64_t)B * RT, hipMemcpyDeviceToDevice, s));
     DQ_HIP_OK(hipStreamSynchronize(s));  // ts is caller memory; also keeps the capture below free of pending copies
+    DQ_TRY(ms1_prologue(c, c.w(a.c1_stage)));
+    io.x_t = xa; io.x_out = xa; io.step_ptr = step; io.want_eps = false;  // in place: element-wise, read and written by the same lane
     const bool valid = plan->step_exec && plan->g_params == params && plan->g_rope == rope_freqs && plan->g_ws == workspace &&
                        plan->g_B == B && plan->g_RT == RT && plan->g_norm == auto_normalize && plan->g_pred == pred_type;
     if (!valid) {
@@ -1259,9 +1319,10 @@ int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, 
       hipStream_t cs = plan->cap_stream;
       Ctx cc{plan->plan, a, params, W, nullptr, nullptr, B, RT, cs};
       cc.save = false;
+      cc.step_io = &io;
       DQ_HIP_OK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
       int rc = unet_forward(cc, rope_freqs, xa, nullptr, 0, c.w(a.c2_stage), c.w(a.c1_stage), cm, ca, plan->dev, c.w(a.eps), ts_tab, step);
-      if (!rc) rc = launch_ddim_step(xa, c.w(a.eps), xa, c.w(a.coef), n, step, cs, px0, nullptr);  // in place: element-wise
+      if (!rc && !io.fused_update) rc = launch_ddim_step(xa, c.w(a.eps), xa, c.w(a.coef), n, step, cs, px0, nullptr);  // in place: element-wise
       if (!rc) rc = launch_inc_step(step, cs);
       hipGraph_t g = nullptr;
       const hipError_t ce = hipStreamEndCapture(cs, &g);
@@ -1275,13 +1336,16 @@ int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, 
     DQ_TRY(launch_sample_finish(xa, ms2_cond, out_x, out_noise, n, auto_normalize, s));
     return 0;
   }
+  DQ_TRY(ms1_prologue(c, ms1_cond));
+  c.step_io = &io;
   for (int i = 0; i < num_steps; ++i) {
-    // eps objective: the network output IS the trajectory's eps; x0 objective: it goes to the arena, the derived eps to the trajectory
-    float* eps = (traj_eps && !px0) ? traj_eps + (int64_t)i * n : c.w(a.eps);
-    DQ_TRY(unet_forward(c, rope_freqs, xa, nullptr, ts[i], ms2_cond, ms1_cond, cm, ca, plan->dev, eps));  // model.py:271 / :276
+    // eps objective: the network output IS the trajectory's eps; x0 objective: the derived eps goes to the trajectory
+    float* eps = traj_eps ? traj_eps + (int64_t)i * n : c.w(a.eps);
     float* xn = traj_x ? traj_x + (int64_t)i * n : xb;
-    DQ_TRY(launch_ddim_step(xa, eps, xn, c.w(a.coef) + 4 * i, n, nullptr, s, px0,
-                            (traj_eps && px0) ? traj_eps + (int64_t)i * n : nullptr));                    // model.py:273-289
+    io.x_t = xa; io.x_out = xn; io.coef = c.w(a.coef) + 4 * i; io.step_ptr = nullptr; io.want_eps = traj_eps != nullptr; io.fused_update = false;
+    DQ_TRY(unet_forward(c, rope_freqs, xa, nullptr, ts[i], ms2_cond, ms1_cond, cm, ca, plan->dev, eps));  // model.py:271 / :276
+    if (!io.fused_update)
+      DQ_TRY(launch_ddim_step(xa, eps, xn, c.w(a.coef) + 4 * i, n, nullptr, s, px0, (traj_eps && px0) ? traj_eps + (int64_t)i * n : nullptr));  // model.py:273-289
     if (traj_x) {
       DQ_HIP_OK(hipMemcpyAsync(xa, xn, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
     } else {

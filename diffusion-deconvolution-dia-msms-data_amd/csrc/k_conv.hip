@@ -909,6 +909,18 @@ int launch_prep_inputs(const float* x, const float* cond, const float* ms1, cons
   return 0;
 }
 
+// ms1n = ms1 * cm + ca alone (the first layer's other work rides in the level kernel's input stage in inference)
+__global__ void __launch_bounds__(256) k_ms1_norm(const float* __restrict__ ms1, float cm, float ca, float* __restrict__ ms1n, int64_t n) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) ms1n[i] = fmaf(ms1[i], cm, ca);
+}
+int launch_ms1_norm(const float* ms1, float cm, float ca, float* ms1n, int64_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_ms1_norm, dim3(cdiv(n, 256)), dim3(256), 0, s, ms1, cm, ca, ms1n, n);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
 __global__ void __launch_bounds__(256) k_prep_inputs_bwd(const float* __restrict__ dcat0, const float* __restrict__ cond, float cm,
                                                          float ca, float* __restrict__ part, int RT, int MZ) {
   const int b = blockIdx.y;

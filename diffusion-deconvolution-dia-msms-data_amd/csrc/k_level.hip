@@ -10,6 +10,11 @@
 //         value and in[2 q + 2] lane q + 1's first (one DPP wave shift each)
 //   UP:   out[q] = sum_k w[k] up[q - 1 + k], up[j] = in[j / 2]  -- the lane loads in[q / 2] (= up[q]); its neighbours' values are up[q -+ 1]
 //   S1:   plain k3
+//   INIT: the network's first layer (unet1d.py:1107-1118): channel 0 = mixture * (scale + 1) + shift (ConditionalScaleShift on the normalised
+//         mixture), channel 1 = x_t, then init_conv k7 p3 -- three DPP shifts either way per channel; its output (h0) is always written
+//         (the final ResnetBlock concatenates it)
+// Head epilogue (the launch that ends with final_res_block): eps = final_conv (1x1, C -> 1) of the block output and, while sampling, the
+// DDIM update x_{t-1} = f(x_t, eps) of model.py:265-289 -- the block output, eps and the separate update launch never touch memory.
 // Every global read of a tile (stage input, the skip channels of cat(x, skip), unet1d.py:1151, 1154) is requested before the first use.
 #include "dq_common.h"
 #include "dq_kernels.h"
@@ -34,7 +39,7 @@ __host__ __device__ inline Jobs level_jobs(int C, int pre_mode, int cp, int nblo
   const int G = C / 4;
   int o = 0;
   j.pre = o;
-  if (pre_mode != LEVEL_PRE_NONE) o += pad4(G * cp * (pre_mode == LEVEL_PRE_DOWN ? 4 : 3));
+  if (pre_mode != LEVEL_PRE_NONE) o += pad4(G * cp * (pre_mode == LEVEL_PRE_DOWN ? 4 : (pre_mode == LEVEL_PRE_INIT ? 7 : 3)));
   for (int b = 0; b < 2; ++b) {
     j.c1[b] = o;
     if (b < nblocks) o += pad4(G * cin[b] * 3);
@@ -59,6 +64,11 @@ struct LevelFwdK {
   const float* in; float* pre_out;
   int pw, pb, nblocks, rows_per_sample, n, ss_stride;
   LevelBlkK blk[2];
+  // INIT stage: the mixture (rows, n), its normalisation cond * cm + ca, the offset of init_cond_proj's [scale, shift] in the ss vector
+  const float* cond; float cm, ca; int ss_init;
+  // head epilogue (ep_w >= 0): final_conv weight / bias offsets in P; eps_out nullable; DDIM update when x_t is set
+  int ep_w, ep_b, pred_x0;
+  float* eps_out; const float* x_t; float* x_out; const float* coef; const int* step_ptr;
 };
 
 }  // namespace
@@ -70,7 +80,7 @@ template <int C, int PRE, int CP>
 __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __restrict__ P, const float* __restrict__ ssb, int tiles_ps, int total_tiles,
                                                    int ln) {  // ssb: the per-sample scale / shift vectors; ln = log2(n)
   constexpr int G = C / 4;
-  constexpr int KP = PRE == LEVEL_PRE_DOWN ? 4 : 3;
+  constexpr int KP = PRE == LEVEL_PRE_DOWN ? 4 : (PRE == LEVEL_PRE_INIT ? 7 : 3);
   extern __shared__ __attribute__((aligned(16))) float wl[];  // [job / 4][lane & 3][job % 4]
   const int cin_[2] = {C + a.blk[0].cinB, C + a.blk[1].cinB};
   const bool wr_[2] = {a.blk[0].wr >= 0, a.blk[1].wr >= 0};
@@ -111,6 +121,17 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
   float* prm = wl + J.total * 4;
   {
     const int b = blockIdx.y;
+    if (threadIdx.x < 8) {  // [C * 15 ..): final_conv weight (4) | bias | this sample's init_cond_proj scale + 1 | shift  (C == 4 launches only)
+      const int i = threadIdx.x;
+      float v = 0.f;
+      if (C == 4 && a.ep_w >= 0 && i < 4) v = P[a.ep_w + i];
+      if (C == 4 && a.ep_w >= 0 && i == 4) v = P[a.ep_b];
+      if (PRE == LEVEL_PRE_INIT && (i == 5 || i == 6)) {
+        const float* ssi = ssb + (int64_t)b * a.ss_stride + a.ss_init;
+        v = i == 5 ? ssi[0] + 1.0f : ssi[1];
+      }
+      prm[C * 15 + i] = v;
+    }
     for (int i = threadIdx.x; i < C * 15; i += 256) {
       const int what = i / C, c = i % C;
       float v = 0.f;
@@ -140,6 +161,11 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
   auto wop = [&](int base, int js) -> float { return wlane[(base >> 2) * 16 + (js >> 2) * 16 + (js & 3)]; };
 
   // the grid is ONE resident round (launcher); wave w takes the 64-position tiles w, w + nwaves, ... of the (sample, tile) list
+  float dsa = 1.f, dsb = 0.f, dsap = -1.f, dsbp = 0.f;  // this step's row of the DDIM coefficient table (read once, outside the tile loop)
+  if (a.x_t) {
+    const float* cf = a.coef + (a.step_ptr ? 4 * a.step_ptr[0] : 0);
+    dsa = cf[0]; dsb = cf[1]; dsap = cf[2]; dsbp = cf[3];
+  }
   // Index arithmetic per tile is kept off the critical path: n is a power of two (shifts), offsets are 32-bit element counts against
   // wave-uniform channel base pointers (the launcher checks every tensor stays below 2^31 elements), and NO load is predicated -- the
   // lanes beyond a sample's last position read its last position instead (their values reach no live lane: a sample ends at a row end)
@@ -174,6 +200,40 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
 #pragma unroll
       for (int c = 0; c < C; ++c) x[c] = ld(a.in, c, obase);
       load_skip(0);
+    } else if constexpr (PRE == LEVEL_PRE_INIT) {
+      // cat(conditioned mixture, x_t) -> init_conv k7 p3 (zero padding of the CONCATENATED tensor: the shifts bring zeros in)
+      const unsigned ioff = ((row << ln) + p) * 4u;
+      const float xt = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.in) + ioff);
+      const float cd = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.cond) + ioff);
+      load_skip(0);
+      const float4 e4 = *reinterpret_cast<const float4*>(prm + C * 15 + 4);  // bias (unused here), scale + 1, shift
+      float v[2] = {fmaf(cd, a.cm, a.ca) * e4.y + e4.z, xt};
+      f32x4 acc[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        // taps k = 0..6 read position p + k - 3
+        float m1 = lane_m1(v[c]); m1 = p >= 1 ? m1 : 0.f;
+        float m2 = lane_m1(m1);   m2 = p >= 2 ? m2 : 0.f;
+        float m3 = lane_m1(m2);   m3 = p >= 3 ? m3 : 0.f;
+        float p1 = lane_p1(v[c]); p1 = p + 1 < n ? p1 : 0.f;
+        float p2 = lane_p1(p1);   p2 = p + 2 < n ? p2 : 0.f;
+        float p3 = lane_p1(p2);   p3 = p + 3 < n ? p3 : 0.f;
+        const float tap[7] = {m3, m2, m1, v[c], p1, p2, p3};
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc[k] = mfma4(wop(J.pre, c * 7 + k), tap[k], acc[k]);
+      }
+      {
+        const float4 pb4 = prm4(0, 0);
+        const float pbv[4] = {pb4.x, pb4.y, pb4.z, pb4.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = ((acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i])) + ((acc[4][i] + acc[5][i]) + (acc[6][i] + pbv[i]));
+      }
+      if (live) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) st(a.pre_out, c, obase, x[c]);
+      }
     } else {
       f32x4 acc[G][KP];
 #pragma unroll
@@ -373,6 +433,25 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
 #pragma unroll
         for (int c = 0; c < C; ++c) st(r.out, c, obase, o[c]);
       }
+      if constexpr (C == 4) {
+        if (a.ep_w >= 0 && bi == a.nblocks - 1) {  // head: final_conv (1x1, 4 -> 1) and, while sampling, the DDIM update
+          const float4 w4 = *reinterpret_cast<const float4*>(prm + C * 15);
+          const float eb = prm[C * 15 + 4];
+          const float ev = fmaf(w4.w, o[3], fmaf(w4.z, o[2], fmaf(w4.y, o[1], fmaf(w4.x, o[0], eb))));
+          const unsigned eoff = ((row << ln) + p) * 4u;
+          if (live) {
+            float ep = ev;  // what eps_out receives: the network output, or -- while sampling with the x0 objective -- the derived eps
+            if (a.x_t) {  // model.py:265-289, the arithmetic of k_ddim_step
+              const float xv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x_t) + eoff);
+              float x0;
+              if (a.pred_x0) { x0 = ev; ep = (xv - dsa * x0) / dsb; }
+              else           { x0 = (xv - dsb * ep) / dsa; }
+              *reinterpret_cast<float*>(reinterpret_cast<char*>(a.x_out) + eoff) = dsap < 0.f ? x0 : dsap * x0 + dsbp * ep;
+            }
+            if (a.eps_out) *reinterpret_cast<float*>(reinterpret_cast<char*>(a.eps_out) + eoff) = ep;
+          }
+        }
+      }
 #pragma unroll
       for (int c = 0; c < C; ++c) x[c] = o[c];
     }
@@ -383,6 +462,7 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
 // widths that move by at most one step of 4 per level, as in the reference's configurations; anything else keeps the per-op path)
 static bool level_cp_built(int C, int pre, int cp) {
   if (pre == LEVEL_PRE_NONE) return true;
+  if (pre == LEVEL_PRE_INIT) return C == 4 && cp == 2;
   if (pre == LEVEL_PRE_DOWN) return cp == C || (cp == C - 4 && cp >= 4);
   return cp == C || (cp == C + 4 && cp <= 16);
 }
@@ -410,6 +490,11 @@ int launch_level_fwd(const LevelFwd& a, hipStream_t s) {
   DQ_REQUIRE(a.pre == LEVEL_PRE_NONE || (a.pw && a.pb), "level_fwd: the input stage needs its conv weight and bias");
   LevelFwdK k;
   auto poff = [&](const float* ptr) -> int { return ptr ? (int)(ptr - a.params) : -1; };
+  DQ_REQUIRE(a.pre != LEVEL_PRE_INIT || (a.cond && a.ss_init && a.pre_out), "level_fwd: the first-layer stage needs the mixture, its scale / shift and h0");
+  DQ_REQUIRE(!a.ew || (a.C == 4 && a.eb && (a.eps_out || a.x_t) && (!a.x_t || (a.x_out && a.coef))), "level_fwd: incomplete head epilogue");
+  k.cond = a.cond; k.cm = a.cm; k.ca = a.ca; k.ss_init = a.ss_init ? (int)(a.ss_init - a.blk[0].ss) : 0;
+  k.ep_w = poff(a.ew); k.ep_b = poff(a.eb); k.pred_x0 = a.pred_x0; k.eps_out = a.eps_out; k.x_t = a.x_t; k.x_out = a.x_out; k.coef = a.coef;
+  k.step_ptr = a.step_ptr;
   k.in = a.in; k.pre_out = a.pre_out; k.pw = poff(a.pw); k.pb = poff(a.pb); k.nblocks = a.nblocks; k.rows_per_sample = a.rows_per_sample; k.n = a.n;
   const float* ssb = a.blk[0].ss;
   k.ss_stride = a.blk[0].ss_stride;
@@ -428,13 +513,13 @@ int launch_level_fwd(const LevelFwd& a, hipStream_t s) {
   const int tiles_ps = cdiv((int64_t)a.rows_per_sample * a.n, 64);
   const int64_t total = (int64_t)tiles_ps * B;
   DQ_REQUIRE(total < (1ll << 31), "level_fwd: too many tiles");
-  DQ_REQUIRE((int64_t)a.rows * 2 * std::max(a.C, a.cp) * std::max(a.n, 2) < (1ll << 31), "level_fwd: tensors of 2^31 elements or more are not built (32-bit offsets)");
+  DQ_REQUIRE((int64_t)a.rows * 2 * std::max(a.C, a.cp) * std::max(a.n, 2) * 4 < (1ll << 32), "level_fwd: tensors of 2^31 elements or more are not built (32-bit offsets)");
   int ln = 0;
   while ((1 << ln) < a.n) ++ln;
   const int cin[2] = {a.C + a.blk[0].cinB, a.C + a.blk[1].cinB};
   const bool wr[2] = {a.blk[0].wr != nullptr, a.blk[1].wr != nullptr};
   const int cp = a.pre == LEVEL_PRE_NONE ? 4 : a.cp;
-  const size_t lds = (size_t)level_jobs(a.C, a.pre, cp, a.nblocks, cin, wr).total * 16 + (size_t)a.C * 15 * 4;
+  const size_t lds = (size_t)level_jobs(a.C, a.pre, cp, a.nblocks, cin, wr).total * 16 + ((size_t)a.C * 15 + 8) * 4;
   DQ_REQUIRE(lds <= 64 * 1024, "level_fwd: weight image too large");
   // one resident round: blocks per CU from the occupancy query, capped at 6 (at this kernel's ~106 scalar registers the hardware admits six
   // 256-thread blocks per CU where the query can say seven: MI355X_MICROARCH.md, Residency), never more blocks than tiles need
@@ -456,6 +541,7 @@ int launch_level_fwd(const LevelFwd& a, hipStream_t s) {
   DQ_LV(16, LEVEL_PRE_DOWN, 12) DQ_LV(16, LEVEL_PRE_DOWN, 16)
   DQ_LV(4, LEVEL_PRE_UP, 4) DQ_LV(4, LEVEL_PRE_UP, 8) DQ_LV(8, LEVEL_PRE_UP, 8) DQ_LV(8, LEVEL_PRE_UP, 12) DQ_LV(12, LEVEL_PRE_UP, 12) DQ_LV(12, LEVEL_PRE_UP, 16)
   DQ_LV(16, LEVEL_PRE_UP, 16)
+  DQ_LV(4, LEVEL_PRE_INIT, 2)
   DQ_LV(4, LEVEL_PRE_S1, 4) DQ_LV(4, LEVEL_PRE_S1, 8) DQ_LV(8, LEVEL_PRE_S1, 8) DQ_LV(8, LEVEL_PRE_S1, 12) DQ_LV(12, LEVEL_PRE_S1, 12) DQ_LV(12, LEVEL_PRE_S1, 16)
   DQ_LV(16, LEVEL_PRE_S1, 16)
 #undef DQ_LV

@@ -197,7 +197,8 @@ class TrainStepGraph:
         self.key = (tuple(x_0.shape), tuple(ms1_cond.shape), float(ms1_loss_weight or 0.0), float(dm.optimizer.grad_scale))
         self.x0, self.c2, self.c1 = (torch.empty_like(v, dtype=torch.float32).copy_(v) for v in (x_0, ms2_cond, ms1_cond))
         self.w = float(ms1_loss_weight or 0.0)
-        N.check(N.lib().dq_plan_set_side_stream(self.net._plan, 0), "dq_plan_set_side_stream")
+        self.keep_side = os.environ.get("DQ_GRAPH_SIDE", "0") == "1"  # A-B switch: keep the fork / join inside the captured step
+        N.check(N.lib().dq_plan_set_side_stream(self.net._plan, 1 if self.keep_side else 0), "dq_plan_set_side_stream")
         self.opt._dev_state()
         self.opt.sync_step_dev()
         # warm-up on a side stream (workspaces, occupancy queries, lazy stream creation: nothing may allocate during capture) -- on a

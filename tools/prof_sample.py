@@ -19,6 +19,8 @@ if mode == "sample":
     print(f"sample B={B} steps={steps}: {dt*1e3:.2f} ms  -> {dt/steps*1e3:.3f} ms/step  {B/ (dt/steps*50):.1f} windows/s @50 steps")
 else:
     dm._set_optimizer(1e-5)
+    if mode == "train_graph":
+        dm.enable_train_graph(True)
     for _ in range(2): dm._train_one_batch(c2, ms2_cond=c2, ms1_cond=c1, sync=False)
     torch.cuda.synchronize(); t0 = time.time()
     for _ in range(steps): dm._train_one_batch(c2, ms2_cond=c2, ms1_cond=c1, sync=False)
