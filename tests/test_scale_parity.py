@@ -179,3 +179,11 @@ def test_large_window_2000x256_vs_oracle():
     e = float((y.cpu() - eps_o).abs().max() / eps_o.abs().max())
     print("2000x256 window: loss", float(loss), "oracle", lo, "eps rel err", e, "worst grad", worst)
     assert e < EPS_TOL, e
+    # batch independence at this shape too: window 0 of a batch of two is the batch-1 result, bit for bit
+    with torch.no_grad():
+        x2 = torch.cat([xt, torch.rand(1, RT, MZ, generator=g) * 2 - 1]).cuda()
+        t2 = torch.cat([t, torch.tensor([77])]).cuda()
+        c22 = torch.cat([O.normalize(c2), torch.rand(1, RT, MZ, generator=g) * 2 - 1]).cuda()
+        c12 = torch.cat([O.normalize(c1), torch.rand(1, RT, generator=g) * 2 - 1]).cuda()
+        y2 = net(x2, t2, c22, c12)
+    assert torch.equal(y2[:1], y)
