@@ -76,7 +76,8 @@ struct LevelFwdK {
 // CP: input channels of the stage (compile time: every global read of a tile is issued up front from statically indexed registers --
 // with the channel quads walked in a run-time load -> use loop a wave exposed one memory latency per quad and the launch ran at a
 // third of the rate its loads in flight allow)
-template <int C, int PRE, int CP>
+// N64: rows of exactly 64 positions = one row per wave: the wave shifts' zero fill at lanes 0 / 63 IS the conv's zero padding, no masks
+template <int C, int PRE, int CP, bool N64>
 __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __restrict__ P, const float* __restrict__ ssb, int tiles_ps, int total_tiles,
                                                    int ln) {  // ssb: the per-sample scale / shift vectors; ln = log2(n)
   constexpr int G = C / 4;
@@ -177,7 +178,7 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
     const int itc = live ? it : per_sample - 1;
     const int rr = itc >> ln, p = itc & (n - 1);
     const unsigned row = (unsigned)(b * a.rows_per_sample + rr);
-    const bool hasL = p > 0, hasR = p + 1 < n;
+    const bool hasL = N64 || p > 0, hasR = N64 || p + 1 < n;  // (N64: constant true -- the selects below fold away)
     const unsigned obase = (((row * C) << ln) + p) * 4u;  // BYTE offset of (row, channel 0, p) in a (rows, C, n) tensor
     // tensor base + channel (wave-uniform, scalar registers) + the lane's 32-bit byte offset: one address register per lane
     auto ld = [&](const float* base, int c, unsigned boff) -> float {
@@ -214,12 +215,12 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         // taps k = 0..6 read position p + k - 3
-        float m1 = lane_m1(v[c]); m1 = p >= 1 ? m1 : 0.f;
-        float m2 = lane_m1(m1);   m2 = p >= 2 ? m2 : 0.f;
-        float m3 = lane_m1(m2);   m3 = p >= 3 ? m3 : 0.f;
-        float p1 = lane_p1(v[c]); p1 = p + 1 < n ? p1 : 0.f;
-        float p2 = lane_p1(p1);   p2 = p + 2 < n ? p2 : 0.f;
-        float p3 = lane_p1(p2);   p3 = p + 3 < n ? p3 : 0.f;
+        float m1 = lane_m1(v[c]); m1 = (N64 || p >= 1) ? m1 : 0.f;
+        float m2 = lane_m1(m1);   m2 = (N64 || p >= 2) ? m2 : 0.f;
+        float m3 = lane_m1(m2);   m3 = (N64 || p >= 3) ? m3 : 0.f;
+        float p1 = lane_p1(v[c]); p1 = (N64 || p + 1 < n) ? p1 : 0.f;
+        float p2 = lane_p1(p1);   p2 = (N64 || p + 2 < n) ? p2 : 0.f;
+        float p3 = lane_p1(p2);   p3 = (N64 || p + 3 < n) ? p3 : 0.f;
         const float tap[7] = {m3, m2, m1, v[c], p1, p2, p3};
 #pragma unroll
         for (int k = 0; k < 7; ++k) acc[k] = mfma4(wop(J.pre, c * 7 + k), tap[k], acc[k]);
@@ -523,18 +524,23 @@ int launch_level_fwd(const LevelFwd& a, hipStream_t s) {
   DQ_REQUIRE(lds <= 64 * 1024, "level_fwd: weight image too large");
   // one resident round: blocks per CU from the occupancy query, capped at 6 (at this kernel's ~106 scalar registers the hardware admits six
   // 256-thread blocks per CU where the query can say seven: MI355X_MICROARCH.md, Residency), never more blocks than tiles need
-#define DQ_LV(CC, PP, PC)                                                                                                     \
-  if (a.C == CC && a.pre == PP && cp == PC) {                                                                                 \
+#define DQ_LVN(CC, PP, PC, NN)                                                                                                \
+  {                                                                                                                           \
     static int occ = 0;                                                                                                       \
     if (!occ) {                                                                                                               \
       int nb = 0;                                                                                                             \
-      DQ_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_level_fwd<CC, PP, PC>, 256, lds));                        \
+      DQ_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_level_fwd<CC, PP, PC, NN>, 256, lds));                    \
       occ = std::max(1, std::min(nb, 6));                                                                                     \
     }                                                                                                                         \
     const int gx = std::max(1, std::min(occ * num_cus() / B, (tiles_ps + 3) / 4));  /* workgroups per sample */                \
-    hipLaunchKernelGGL((k_level_fwd<CC, PP, PC>), dim3(gx, B), dim3(256), lds, s, k, a.params, ssb, tiles_ps, (int)total, ln);  \
+    hipLaunchKernelGGL((k_level_fwd<CC, PP, PC, NN>), dim3(gx, B), dim3(256), lds, s, k, a.params, ssb, tiles_ps, (int)total, ln); \
     DQ_LAUNCH_CHECK();                                                                                                        \
     return 0;                                                                                                                 \
+  }
+#define DQ_LV(CC, PP, PC)                                                                                                     \
+  if (a.C == CC && a.pre == PP && cp == PC) {                                                                                 \
+    if (CC == 4 && a.n == 64) DQ_LVN(CC, PP, PC, (CC == 4))                                                                    \
+    DQ_LVN(CC, PP, PC, false)                                                                                                 \
   }
   DQ_LV(4, LEVEL_PRE_NONE, 4) DQ_LV(8, LEVEL_PRE_NONE, 4) DQ_LV(12, LEVEL_PRE_NONE, 4) DQ_LV(16, LEVEL_PRE_NONE, 4)
   DQ_LV(4, LEVEL_PRE_DOWN, 4) DQ_LV(8, LEVEL_PRE_DOWN, 4) DQ_LV(8, LEVEL_PRE_DOWN, 8) DQ_LV(12, LEVEL_PRE_DOWN, 8) DQ_LV(12, LEVEL_PRE_DOWN, 12)
@@ -545,6 +551,7 @@ int launch_level_fwd(const LevelFwd& a, hipStream_t s) {
   DQ_LV(4, LEVEL_PRE_S1, 4) DQ_LV(4, LEVEL_PRE_S1, 8) DQ_LV(8, LEVEL_PRE_S1, 8) DQ_LV(8, LEVEL_PRE_S1, 12) DQ_LV(12, LEVEL_PRE_S1, 12) DQ_LV(12, LEVEL_PRE_S1, 16)
   DQ_LV(16, LEVEL_PRE_S1, 16)
 #undef DQ_LV
+#undef DQ_LVN
   set_error("level_fwd: unsupported (C, stage, stage input width)");
   return 2;
 }
