@@ -86,34 +86,50 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
   const int cin_[2] = {C + a.blk[0].cinB, C + a.blk[1].cinB};
   const bool wr_[2] = {a.blk[0].wr >= 0, a.blk[1].wr >= 0};
   const Jobs J = level_jobs(C, PRE, CP, a.nblocks, cin_, wr_);
-  for (int idx = threadIdx.x; idx < J.total * 4; idx += 256) {
-    const int j = (idx >> 4) * 4 + (idx & 3), li = (idx >> 2) & 3;
-    float v = 0.f;
-    if (PRE != LEVEL_PRE_NONE && j < J.c1[0]) {  // stage: job = (c * G + g) * KP + k
-      const int jj = j - J.pre;
-      if (jj < G * CP * KP) {
+  // Staging of the operand image: the source offset of every element is formed WITHOUT control flow and the loads of four elements are
+  // in flight together -- as a loop of dependent "decode, branch, load, store" iterations the staging of a 16-channel level's 25 KB
+  // took ~25 us per workgroup, which at training batch sizes (one or two tiles per wave) was most of the launch.
+  {
+    auto src_of = [&](int idx) -> int {  // offset into P of image element idx, or -1 (padding)
+      const int j = (idx >> 4) * 4 + (idx & 3), li = (idx >> 2) & 3;
+      int off = -1;
+      if (PRE != LEVEL_PRE_NONE) {  // stage: job = (c * G + g) * KP + k
+        const int jj = j - J.pre;
         const int k = jj % KP, g = (jj / KP) % G, c = jj / (KP * G);
-        v = P[a.pw + ((4 * g + li) * CP + c) * KP + k];
+        off = (jj >= 0 && jj < G * CP * KP) ? a.pw + ((4 * g + li) * CP + c) * KP + k : off;
       }
-    } else {
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        if (b >= a.nblocks) break;
         const LevelBlkK& r = a.blk[b];
         const int cin = cin_[b];
-        if (j >= J.c1[b] && j < J.c2[b]) {          // conv1: job = (c * G + g) * 3 + k
-          const int jj = j - J.c1[b];
-          if (jj < G * cin * 3) { const int k = jj % 3, g = (jj / 3) % G, c = jj / (3 * G); v = P[r.w1 + ((4 * g + li) * cin + c) * 3 + k]; }
-        } else if (j >= J.c2[b] && j < J.rs[b]) {   // conv2
-          const int jj = j - J.c2[b];
-          if (jj < G * C * 3) { const int k = jj % 3, g = (jj / 3) % G, c = jj / (3 * G); v = P[r.w2 + ((4 * g + li) * C + c) * 3 + k]; }
-        } else if (wr_[b] && j >= J.rs[b] && j < J.rs[b] + G * cin) {  // res_conv: job = c * G + g
-          const int jj = j - J.rs[b], g = jj % G, c = jj / G;
-          v = P[r.wr + (4 * g + li) * cin + c];
+        const bool on = b < a.nblocks;
+        {
+          const int jj = j - J.c1[b], k = jj % 3, g = (jj / 3) % G, c = jj / (3 * G);          // conv1: job = (c * G + g) * 3 + k
+          off = (on && jj >= 0 && jj < G * cin * 3) ? r.w1 + ((4 * g + li) * cin + c) * 3 + k : off;
+        }
+        {
+          const int jj = j - J.c2[b], k = jj % 3, g = (jj / 3) % G, c = jj / (3 * G);          // conv2
+          off = (on && jj >= 0 && jj < G * C * 3) ? r.w2 + ((4 * g + li) * C + c) * 3 + k : off;
+        }
+        {
+          const int jj = j - J.rs[b], g = jj % G, c = jj / G;                                  // res_conv: job = c * G + g
+          off = (on && wr_[b] && jj >= 0 && jj < G * cin) ? r.wr + (4 * g + li) * cin + c : off;
         }
       }
+      return off;
+    };
+    const int total = J.total * 4;
+    for (int base = threadIdx.x; base < total; base += 256 * 4) {
+      int off[4];
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) off[u] = base + u * 256 < total ? src_of(base + u * 256) : -1;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = P[off[u] < 0 ? 0 : off[u]];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (base + u * 256 < total) wl[base + u * 256] = off[u] < 0 ? 0.f : v[u];
     }
-    wl[idx] = v;
   }
   // Per-channel parameters and THIS SAMPLE's scale / shift vectors (a workgroup works on one sample, blockIdx.y), also in LDS:
   // [stage bias C][per block: b1 | g1 | b2 | g2 | br | scale + 1 | shift] -- read back as 16-byte broadcasts.  Inside the tile loop a
