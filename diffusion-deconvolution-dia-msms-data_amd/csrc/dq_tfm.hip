@@ -299,9 +299,25 @@ int dq_tfm_fwd(dq_tfm* p, const float* params, const float* rope_sin, const floa
   return 0;
 }
 
-int dq_tfm_bwd(dq_tfm* p, const float* params, const float* rope_sin, const float* rope_cos, const float* x_t, const float* x_cond,
-               const float* dout, float* grads, int accumulate, float* dx_t, float* dx_cond, void* workspace, int64_t workspace_bytes, int B,
-               int S1, int S2, void* stream) {
+}  // extern "C"
+
+// Gradient buckets, in the order the backward completes them: layers L-1 .. 0 (each layer's parameters are one contiguous slice of
+// the flat buffer), then everything registered before the layers (input / output / conditional projections, time MLP), whose last
+// gradients are written at the very end.
+static void tfm_bucket(const dq_tfm& p, int i, int64_t* off, int64_t* count) {
+  if (i < p.layers) {
+    const int l = p.layers - 1 - i;
+    *off = p.L[l].in_w;
+    *count = (l + 1 < p.layers ? p.L[l + 1].in_w : p.total) - *off;
+  } else {
+    *off = 0;
+    *count = p.L[0].in_w;
+  }
+}
+
+static int tfm_bwd_impl(dq_tfm* p, const float* params, const float* rope_sin, const float* rope_cos, const float* x_t, const float* x_cond,
+                        const float* dout, float* grads, int accumulate, float* dx_t, float* dx_cond, void* workspace,
+                        int64_t workspace_bytes, int B, int S1, int S2, void* stream, dq_tfm_bucket_fn on_bucket, void* user) {
   if (int rc = check_shapes(p, B, S1, S2)) return rc;
   DQ_REQUIRE(params && rope_sin && rope_cos && x_t && x_cond && dout && grads && workspace, "dq_tfm_bwd: missing operand");
   {
@@ -350,6 +366,11 @@ int dq_tfm_bwd(dq_tfm* p, const float* params, const float* rope_sin, const floa
     hipLaunchKernelGGL(k_split_comb, dim3(grid_for((int64_t)B * Sk * H)), dim3(256), 0, s, w.dcomb, w.dcp, d2, B, S1, S2, H);
     DQ_LAUNCH_CHECK();
     dx = d2; other = d1;
+    if (on_bucket) {  // every kernel that writes this layer's gradient slice is enqueued
+      int64_t off, cnt;
+      tfm_bucket(*p, p->layers - 1 - l, &off, &cnt);
+      on_bucket(user, p->layers - 1 - l, off, cnt);
+    }
   }
   // x0 = rope(x_t Win^T + b) + temb
   if (int rc = launch_seqsum(dx, B, S1, H, w.dtemb, s)) return rc;
@@ -360,6 +381,35 @@ int dq_tfm_bwd(dq_tfm* p, const float* params, const float* rope_sin, const floa
   if (int rc = linear_bwd(w.tg, P + p->t2_w, w.dtemb, G + p->t2_w, G + p->t2_b, w.dtg, 0, B, H, 4 * H, w, s, acc)) return rc;
   if (int rc = launch_gelu_bwd(w.th, w.dtg, w.dtg, (int64_t)B * 4 * H, s)) return rc;
   if (int rc = linear_bwd(w.tfeat, P + p->t1_w, w.dtg, G + p->t1_w, G + p->t1_b, nullptr, 0, B, 4 * H, H, w, s, acc)) return rc;
+  if (on_bucket) {
+    int64_t off, cnt;
+    tfm_bucket(*p, p->layers, &off, &cnt);
+    on_bucket(user, p->layers, off, cnt);
+  }
+  return 0;
+}
+
+extern "C" {
+
+int dq_tfm_bwd(dq_tfm* p, const float* params, const float* rope_sin, const float* rope_cos, const float* x_t, const float* x_cond,
+               const float* dout, float* grads, int accumulate, float* dx_t, float* dx_cond, void* workspace, int64_t workspace_bytes, int B,
+               int S1, int S2, void* stream) {
+  return tfm_bwd_impl(p, params, rope_sin, rope_cos, x_t, x_cond, dout, grads, accumulate, dx_t, dx_cond, workspace, workspace_bytes, B, S1,
+                      S2, stream, nullptr, nullptr);
+}
+
+int dq_tfm_bwd_buckets(dq_tfm* p, const float* params, const float* rope_sin, const float* rope_cos, const float* x_t,
+                       const float* x_cond, const float* dout, float* grads, int accumulate, float* dx_t, float* dx_cond, void* workspace,
+                       int64_t workspace_bytes, int B, int S1, int S2, void* stream, dq_tfm_bucket_fn on_bucket, void* user) {
+  return tfm_bwd_impl(p, params, rope_sin, rope_cos, x_t, x_cond, dout, grads, accumulate, dx_t, dx_cond, workspace, workspace_bytes, B, S1,
+                      S2, stream, on_bucket, user);
+}
+
+int dq_tfm_num_buckets(const dq_tfm* p) { return p ? p->layers + 1 : 0; }
+
+int dq_tfm_bucket_info(const dq_tfm* p, int i, int64_t* offset, int64_t* count) {
+  DQ_REQUIRE(p && offset && count && i >= 0 && i <= p->layers, "dq_tfm_bucket_info: bucket index out of range");
+  tfm_bucket(*p, i, offset, count);
   return 0;
 }
 

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DQ_HIP_LIB", os.path.join(os.path.dirname(_HERE), "libdq_hip.so"))
 
 _lib = None
-ABI_VERSION = 7  # DQ_ABI_VERSION of include/dq_hip.h this table was written against
+ABI_VERSION = 8  # DQ_ABI_VERSION of include/dq_hip.h this table was written against
 PRED_TYPES = {"eps": 0, "x0": 1}  # DQ_PRED_EPS / DQ_PRED_X0
 PRECISIONS = {"fp32": 0, "bf16x3": 1}  # DQ_PRECISION_FP32 / DQ_PRECISION_BF16X3
 
@@ -61,6 +61,9 @@ PROTOTYPES = {
                         c_void_p]),
     "dq_gemm_bf16x3": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int64,
                                c_void_p]),
+    "dq_tfm_bwd_buckets": (c_int, [c_void_p] * 8 + [c_int] + [c_void_p] * 3 + [c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dq_tfm_num_buckets": (c_int, [c_void_p]),
+    "dq_tfm_bucket_info": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "dq_tfm_set_precision": (c_int, [c_void_p, c_int]),
     "dq_linattn_fwd": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p]),
     "dq_linattn_bwd": (c_int, [c_void_p] * 15 + [c_int, c_int, c_int, c_void_p]),

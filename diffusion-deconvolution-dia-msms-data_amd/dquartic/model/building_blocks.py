@@ -21,6 +21,8 @@ from torch import nn
 from .. import _native as N
 from .unet1d import _attach
 
+_BUCKET_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64)  # dq_tfm_bucket_fn
+
 __all__ = ["CustomTransformer", "DDIMTransformerAdapter", "apply_rope_tables", "time_embedding_freqs"]
 
 
@@ -226,7 +228,9 @@ class CustomTransformer(nn.Module):
                                    N.ptr(out), 1 if training else 0, N.ptr(ws), ws.numel(), B, S1, S2, N.stream_ptr()), "dq_tfm_fwd")
         return out
 
-    def _run_bwd(self, xs, cs, gout, grads, want_dx, want_dc, accumulate=True, ws=None):
+    def _run_bwd(self, xs, cs, gout, grads, want_dx, want_dc, accumulate=True, ws=None, on_bucket=None):
+        """``on_bucket(i, offset, count)``: called while the backward is being enqueued, once per gradient bucket, when the kernels
+        writing ``grads[offset:offset+count]`` are all on the stream (dq_tfm_bwd_buckets; model_interface.BucketedAllReduce)."""
         B, S1, _ = xs.shape
         S2 = cs.shape[1]
         if ws is None:
@@ -234,9 +238,33 @@ class CustomTransformer(nn.Module):
         sin, cos, _ = self.tables(max(S1, S2), xs.device)
         gx = torch.empty_like(xs) if want_dx else None
         gc = torch.empty_like(cs) if want_dc else None
-        N.check(N.lib().dq_tfm_bwd(self._tfm, N.ptr(self._flat), N.ptr(sin), N.ptr(cos), N.ptr(xs), N.ptr(cs), N.ptr(gout), N.ptr(grads),
-                                   1 if accumulate else 0, N.ptr(gx), N.ptr(gc), N.ptr(ws), ws.numel(), B, S1, S2, N.stream_ptr()), "dq_tfm_bwd")
+        args = (self._tfm, N.ptr(self._flat), N.ptr(sin), N.ptr(cos), N.ptr(xs), N.ptr(cs), N.ptr(gout), N.ptr(grads),
+                1 if accumulate else 0, N.ptr(gx), N.ptr(gc), N.ptr(ws), ws.numel(), B, S1, S2, N.stream_ptr())
+        if on_bucket is None:
+            N.check(N.lib().dq_tfm_bwd(*args), "dq_tfm_bwd")
+        else:
+            raised = []
+
+            def hook(_user, i, off, cnt):  # an exception cannot cross the C frame: keep it and re-raise after the call
+                try:
+                    on_bucket(int(i), int(off), int(cnt))
+                except BaseException as e:  # noqa: BLE001
+                    raised.append(e)
+
+            cb = _BUCKET_FN(hook)
+            N.check(N.lib().dq_tfm_bwd_buckets(*args, ctypes.cast(cb, ctypes.c_void_p), None), "dq_tfm_bwd_buckets")
+            if raised:
+                raise raised[0]
         return gx, gc
+
+    def grad_buckets(self):
+        """[(offset, count)] of the flat gradient buffer in the order the backward completes them (dq_tfm_bucket_info)."""
+        out = []
+        for i in range(N.lib().dq_tfm_num_buckets(self._tfm)):
+            off, cnt = ctypes.c_int64(), ctypes.c_int64()
+            N.check(N.lib().dq_tfm_bucket_info(self._tfm, i, ctypes.byref(off), ctypes.byref(cnt)), "dq_tfm_bucket_info")
+            out.append((off.value, cnt.value))
+        return out
 
 
 class _TfmFn(torch.autograd.Function):

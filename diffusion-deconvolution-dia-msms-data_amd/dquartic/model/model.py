@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _native as N
-from .model_interface import ModelInterface
+from .model_interface import BucketedAllReduce, ModelInterface
 from .unet1d import UNet1d
 
 
@@ -319,5 +319,12 @@ class DDIMDiffusionModel(ModelInterface):
             N.check(lib.dq_ms1_loss_fwd_bwd(N.ptr(out), N.ptr(x_t) if self.pred_type == "eps" else None, N.ptr(c1), 2.0 if norm else 1.0,
                                             -1.0 if norm else 0.0, lwp, N.ptr(t), float(ms1_loss_weight), N.ptr(loss), N.ptr(dout), N.ptr(sc),
                                             B_, RT_, MZ_, N.stream_ptr()), "dq_ms1_loss_fwd_bwd")
-        tfm._run_bwd(x_t, c1n, dout, grads, False, False, accumulate=not zero_grads)
+        if zero_grads and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            # data parallel: each layer's gradient slice is all-reduced while the layers below it are still in backward
+            red = BucketedAllReduce(grads)
+            tfm._run_bwd(x_t, c1n, dout, grads, False, False, accumulate=False, on_bucket=red.on_bucket)
+            red.finish()
+            self._grads_reduced = True  # tells _train_one_batch to skip its flat all-reduce
+        else:
+            tfm._run_bwd(x_t, c1n, dout, grads, False, False, accumulate=not zero_grads)
         return loss

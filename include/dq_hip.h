@@ -43,9 +43,9 @@ const char* dq_last_error(void);
  * 4: dq_tfm_bwd takes an accumulate flag.  5: dq_ddim_sample takes num_timesteps (the plan no longer fixes T); stand-alone
  * building blocks (dq_rmsnorm_fwd, dq_time_mlp_fwd, dq_scale_shift_fwd, dq_prep_inputs_fwd, dq_conv_fwd, dq_resblock_*,
  * dq_rope, dq_attn_*); dq_train_step takes ms1_loss_weight, dq_ms1_loss_fwd_bwd;
- * dq_tfm_set_precision, dq_gemm_bf16x3. */
+ * dq_tfm_set_precision, dq_gemm_bf16x3.  8: dq_tfm_bwd_buckets, dq_tfm_num_buckets, dq_tfm_bucket_info. */
 int dq_abi_version(void);
-#define DQ_ABI_VERSION 7
+#define DQ_ABI_VERSION 8
 
 /* DDIMDiffusionModel.pred_type (model.py:205-213, 269-280, 354-389); any other value is rejected ("Unknown pred_type"). */
 enum { DQ_PRED_EPS = 0, DQ_PRED_X0 = 1 };
@@ -200,6 +200,19 @@ int dq_tfm_fwd(dq_tfm* tfm, const float* params, const float* rope_sin, const fl
 int dq_tfm_bwd(dq_tfm* tfm, const float* params, const float* rope_sin, const float* rope_cos, const float* x_t,
                const float* x_cond, const float* dout, float* grads, int accumulate, float* dx_t, float* dx_cond,
                void* workspace, int64_t workspace_bytes, int B, int S1, int S2, void* stream);
+/* The same backward for data-parallel training (the reference wraps the model in DistributedDataParallel, model_interface.py
+ * :953-957, whose reducer all-reduces gradient buckets while the backward is still running): the flat gradient buffer is cut into
+ * dq_tfm_num_buckets() = num_layers + 1 contiguous slices -- bucket i < num_layers is layer num_layers-1-i, the last bucket is
+ * everything registered before the layers -- and on_bucket(user, i, offset, count) is called ON THE CALLING THREAD as soon as every
+ * kernel writing grads[offset .. offset+count) has been enqueued on `stream`, in bucket order.  The callback typically records an
+ * event on `stream` and starts that slice's all-reduce on a communication stream; it must not touch other slices. */
+typedef void (*dq_tfm_bucket_fn)(void* user, int bucket, int64_t offset, int64_t count);
+int dq_tfm_bwd_buckets(dq_tfm* tfm, const float* params, const float* rope_sin, const float* rope_cos, const float* x_t,
+                       const float* x_cond, const float* dout, float* grads, int accumulate, float* dx_t, float* dx_cond,
+                       void* workspace, int64_t workspace_bytes, int B, int S1, int S2, void* stream,
+                       dq_tfm_bucket_fn on_bucket, void* user);
+int dq_tfm_num_buckets(const dq_tfm* tfm);
+int dq_tfm_bucket_info(const dq_tfm* tfm, int i, int64_t* offset, int64_t* count); /* floats, into the flat buffer */
 /* Arithmetic of the transformer's dense products: DQ_PRECISION_FP32 (default) = exact fp32 on v_mfma_f32_32x32x2_f32, the precision
  * every parity statement of this library is made in; DQ_PRECISION_BF16X3 = three bf16 matrix-core passes over operands split into
  * hi + lo bf16 halves with fp32 accumulation (~16 mantissa bits per operand, relative error ~1e-5 per product term): a separate,

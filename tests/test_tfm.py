@@ -283,6 +283,45 @@ def test_ddim_adapter_trains_the_transformer():
     assert xs.shape == (2, 10, 64) and torch.isfinite(xs).all()
 
 
+@pytest.mark.gpu
+def test_bucketed_backward_reports_every_slice_and_overlapped_allreduce_keeps_the_gradient(tmp_path):
+    """dq_tfm_bwd_buckets: the callbacks arrive in the order of dq_tfm_bucket_info with its slices, the gradient is the plain
+    backward's, and BucketedAllReduce (communication stream + events, RCCL with one rank: sum over one rank = identity) leaves it
+    unchanged -- the stream choreography is what runs here; the two-rank arithmetic is tests/test_dp_gloo.py."""
+    import torch.distributed as dist
+    from dquartic.model.building_blocks import CustomTransformer
+    from dquartic.model.model_interface import BucketedAllReduce
+
+    D, H, heads, layers, B, S1, S2 = 64, 128, 4, 3, 2, 17, 9
+    net = CustomTransformer(input_dim=D, hidden_dim=H, num_heads=heads, num_layers=layers)
+    net.load_state_dict(OT.init_params(D, H, layers, seed=9))
+    net = net.cuda()
+    net._ensure_flat()
+    g = torch.Generator().manual_seed(2)
+    x, c = torch.randn(B, S1, D, generator=g).cuda(), torch.randn(B, S2, generator=g).cuda()
+    t, gout = torch.tensor([5, 900]).cuda(), torch.randn(B, S1, D, generator=g).cuda()
+    net._run_fwd(x, t, c, training=True)
+    plain = torch.empty_like(net.flat_params)
+    net._run_bwd(x, c, gout, plain, False, False, accumulate=False)
+    seen = []
+    hooked = torch.full_like(plain, float("nan"))
+    net._run_bwd(x, c, gout, hooked, False, False, accumulate=False, on_bucket=lambda i, o, n: seen.append((i, o, n)))
+    assert seen == [(i, o, n) for i, (o, n) in enumerate(net.grad_buckets())] and len(seen) == layers + 1
+    assert torch.equal(hooked, plain)
+    with pytest.raises(ValueError, match="boom"):  # an exception inside the callback surfaces after the native call returns
+        net._run_bwd(x, c, gout, hooked, False, False, accumulate=False, on_bucket=lambda i, o, n: (_ for _ in ()).throw(ValueError("boom")))
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1)
+    try:
+        reduced = torch.full_like(plain, float("nan"))
+        red = BucketedAllReduce(reduced)
+        net._run_bwd(x, c, gout, reduced, False, False, accumulate=False, on_bucket=red.on_bucket)
+        red.finish()
+        torch.cuda.synchronize()
+        assert torch.equal(reduced, plain)
+    finally:
+        dist.destroy_process_group()
+
+
 # ------------------------------------------------------------------------------------------------ data-parallel (CPU, gloo)
 def _dp_worker(rank, world, port, q):
     import os
