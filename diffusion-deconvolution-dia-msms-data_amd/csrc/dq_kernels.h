@@ -165,9 +165,16 @@ struct LevelFwd {
   const float* ew = nullptr; const float* eb = nullptr; float* eps_out = nullptr;
   const float* x_t = nullptr; float* x_out = nullptr; const float* coef = nullptr; const int* step_ptr = nullptr; int pred_x0 = 0;
   int C = 0, rows = 0, n = 0, rows_per_sample = 1;
+  // nullable: this launch's MFMA operand image (level_img_floats floats, 16-byte aligned) as launch_level_images built it from the SAME
+  // parameter values -- the kernel's workgroups then copy it to LDS instead of gathering it from the parameter tensors themselves
+  const float* img = nullptr;
 };
 bool level_fwd_usable(int C, int n, int rows_per_sample, int pre_mode, int cp, int nblocks, const ResFwd* blk);
 int launch_level_fwd(const LevelFwd& a, hipStream_t s);
+constexpr int LEVEL_IMG_MAX = 20;          // launches per launch_level_images call
+constexpr int LEVEL_IMG_FLOATS = 8192;     // upper bound of level_img_floats over the built instantiations (16 channels, 32-channel blocks)
+int64_t level_img_floats(const LevelFwd& a);
+int launch_level_images(const LevelFwd* calls, int count, hipStream_t s);  // writes calls[i].img (must be set) for every call, ONE launch
 int launch_res_fwd(const ResFwd& a, hipStream_t s);
 int launch_res_bwd(const ResBwd& a, hipStream_t s);
 // k_res_wg.hip: ResnetBlock backward of the wide levels (C = 4 / 8, rows of 8..256 positions) with the block's weight gradients formed

@@ -128,6 +128,7 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
   a.la_part_floats = std::max<int64_t>(a.la_part_floats, (int64_t)LA_MAX_WAVES * 512 * 16);
   a.la_part = take_nz(a.la_part_floats);
   a.la_prep = take_nz((int64_t)LA_PREP_MAX * LA_PREP_FLOATS);  // prepared LinearAttention weights, one slot per layer (downs, then ups)
+  a.wimg = take_nz((int64_t)LEVEL_IMG_MAX * LEVEL_IMG_FLOATS);  // MFMA operand images of the level kernels' weights, one slot per launch (downs, then ups, then the head)
   a.bb_part_floats = (int64_t)64 * B * 4 * std::max(p.wide_mid ? 2 : p.mid_c, 2);  // partial sums of the PreNorm backward / the input affine
   a.bb_part = take_nz(a.bb_part_floats);
   a.ms1_scratch = take_nz(5 * R + B + 64);  // the MS1 loss term (ms1_loss_weight > 0): per-row sums / maxima and their gradients
@@ -171,8 +172,10 @@ struct Ctx {
   // sampling (dq_ddim_sample): the DDIM update rides in the head launch (x_out may alias x_t), and the step-invariant MS1 feature path
   // (unet1d.py:1120-1130) + to_k + RoPE(k) were computed once before the loop
   struct StepIO { const float* x_t = nullptr; float* x_out = nullptr; const float* coef = nullptr; const int* step_ptr = nullptr; int pred_x0 = 0;
-                  bool skip_ms1 = false; bool fused_update = false; bool want_eps = true; };
+                  bool skip_ms1 = false; bool fused_update = false; bool want_eps = true;
+                  bool prepared = false; };  // prepared: the once-per-parameter-state launches (la_prepare_all, operand images) ran before the loop
   StepIO* step_io = nullptr;
+  bool prepare_only = false;  // unet_forward: run just those launches and return
   float* w(int64_t off) const { return W + off; }
   float* g(int64_t off) const { return G + off; }
   const float* prm(int64_t off) const { return P + off; }
@@ -692,9 +695,6 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
   const Arena& a = c.ar;
   const int B = c.B, RT = c.RT, R = B * RT, L = p.levels;
   const bool prep_ok = (int)(p.downs.size() + p.ups.size()) <= LA_PREP_MAX;
-  DQ_TRY(la_prepare_all(c));
-  // K1: time embedding + every scale/shift head (unet1d.py:1105, 315-318, 677)
-  DQ_TRY(launch_time_embed_fwd(p, dt, c.P, t, t_scalar, c.w(a.tbuf), c.w(a.ss), B, step_tab, step_ptr, c.s));
   // A level whose ResnetBlocks the level kernel takes also computes its own input from the previous level's LinearAttention
   // output (Downsample, unet1d.py:1141): that conv is then not launched and, in inference, its result never exists in memory.
   // Level 0 in inference: the mixture conditioning + concat + init_conv (unet1d.py:1107-1118) are that launch's input stage.
@@ -714,6 +714,51 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
   };
   const bool init_fused = down_call(0).pre == LEVEL_PRE_INIT && level_ok(c, down_call(0));
   const bool skip_ms1 = c.step_io && c.step_io->skip_ms1;
+  // up path (unet1d.py:1150-1158): first pop = post-attention skip, second pop = post-block1 skip
+  auto up_call = [&](int ui) {  // ui == L: the final ResnetBlock behind the last level's k3 conv (unet1d.py:1160-1163)
+    LevelCall lc;
+    if (ui < L) {
+      const LevelP& l = p.ups[ui];
+      const int lv = L - 1 - ui, cs = l.r0.cin - l.r0.cout;
+      lc.C = l.r0.cout; lc.n = l.n; lc.nblocks = 2;
+      lc.r[0] = &l.r0; lc.r[1] = &l.r1; lc.rb[0] = &a.ups[ui].r0; lc.rb[1] = &a.ups[ui].r1;
+      lc.inB[0] = c.w(a.downs[lv].la); lc.inB[1] = c.w(a.downs[lv].r0.out); lc.cinB[0] = lc.cinB[1] = cs;
+      lc.write_out[0] = false;  // (inference: only the second block's output leaves the launch)
+    } else {
+      lc.C = p.fin.cout; lc.n = p.mz; lc.nblocks = 1;
+      lc.r[0] = &p.fin; lc.rb[0] = &a.fin; lc.inB[0] = c.w(a.h0); lc.cinB[0] = p.dim;
+    }
+    if (ui == 0) { lc.in = c.w(a.mid_back); }
+    else {
+      const LevelP& lp = p.ups[ui - 1];
+      lc.pre = lp.last ? LEVEL_PRE_S1 : LEVEL_PRE_UP; lc.pc = &lp.resample; lc.in = c.w(a.ups[ui - 1].la); lc.pre_out = c.w(a.ups[ui - 1].rs);
+    }
+    return lc;
+  };
+  // The launches that depend on the parameter values only -- W2 / the q | k operand images of the LinearAttention layers, the MFMA operand
+  // images of the level kernels (slot = level on the way down, L + ui on the way up, 2 L = the head) -- run once per parameter state:
+  // every forward in training, once per dq_ddim_sample call (its prologue calls this function with prepare_only).
+  const bool imgs_ok = 2 * L + 1 <= LEVEL_IMG_MAX;
+  auto img_slot = [&](int slot) -> const float* { return imgs_ok ? c.w(a.wimg) + (int64_t)slot * LEVEL_IMG_FLOATS : nullptr; };
+  auto with_img = [&](const LevelCall& lc, int slot) {
+    LevelFwd f = level_desc(c, lc);
+    f.img = img_slot(slot);
+    if (f.img && level_img_floats(f) > LEVEL_IMG_FLOATS) f.img = nullptr;
+    return f;
+  };
+  if (!(c.step_io && c.step_io->prepared)) {
+    DQ_TRY(la_prepare_all(c));
+    LevelFwd calls[LEVEL_IMG_MAX];
+    int nc = 0;
+    for (int lv = 0; lv < L; ++lv)
+      if (level_ok(c, down_call(lv))) { const LevelFwd f = with_img(down_call(lv), lv); if (f.img) calls[nc++] = f; }
+    for (int ui = 0; ui <= L; ++ui)
+      if (level_ok(c, up_call(ui))) { const LevelFwd f = with_img(up_call(ui), L + ui); if (f.img) calls[nc++] = f; }
+    DQ_TRY(launch_level_images(calls, nc, c.s));
+  }
+  if (c.prepare_only) return 0;
+  // K1: time embedding + every scale/shift head (unet1d.py:1105, 315-318, 677)
+  DQ_TRY(launch_time_embed_fwd(p, dt, c.P, t, t_scalar, c.w(a.tbuf), c.w(a.ss), B, step_tab, step_ptr, c.s));
   // K2: mixture conditioning + concat (unet1d.py:1107-1115), then init_conv k7 (:1117)
   if (init_fused) {
     if (!skip_ms1) DQ_TRY(launch_ms1_norm(attn_cond, cm, ca, c.w(a.ms1n), (int64_t)B * RT, c.s));
@@ -737,7 +782,7 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     const int C = l.r0.cin;
     const LevelCall lc = down_call(lv);
     if (level_ok(c, lc)) {
-      DQ_TRY(launch_level_fwd(level_desc(c, lc), c.s));
+      DQ_TRY(launch_level_fwd(with_img(lc, lv), c.s));
     } else {
       DQ_TRY(res_fwd(c, l.r0, b.r0, cur, C, nullptr, 0, R, l.n, RT));
       DQ_TRY(res_fwd(c, l.r1, b.r1, c.w(b.r0.out), C, nullptr, 0, R, l.n, RT));
@@ -784,27 +829,6 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     DQ_TRY(res_fwd(c, p.mid2, a.mid2, c.w(a.attn_out), p.mid_c, nullptr, 0, B, RT, 1));
     DQ_TRY(launch_fold(c.w(a.mid2.out), c.w(a.mid_back), B, RT, p.mid_c, 0, 0, c.s));
   }
-  // up path (unet1d.py:1150-1158): first pop = post-attention skip, second pop = post-block1 skip
-  auto up_call = [&](int ui) {  // ui == L: the final ResnetBlock behind the last level's k3 conv (unet1d.py:1160-1163)
-    LevelCall lc;
-    if (ui < L) {
-      const LevelP& l = p.ups[ui];
-      const int lv = L - 1 - ui, cs = l.r0.cin - l.r0.cout;
-      lc.C = l.r0.cout; lc.n = l.n; lc.nblocks = 2;
-      lc.r[0] = &l.r0; lc.r[1] = &l.r1; lc.rb[0] = &a.ups[ui].r0; lc.rb[1] = &a.ups[ui].r1;
-      lc.inB[0] = c.w(a.downs[lv].la); lc.inB[1] = c.w(a.downs[lv].r0.out); lc.cinB[0] = lc.cinB[1] = cs;
-      lc.write_out[0] = false;  // (inference: only the second block's output leaves the launch)
-    } else {
-      lc.C = p.fin.cout; lc.n = p.mz; lc.nblocks = 1;
-      lc.r[0] = &p.fin; lc.rb[0] = &a.fin; lc.inB[0] = c.w(a.h0); lc.cinB[0] = p.dim;
-    }
-    if (ui == 0) { lc.in = c.w(a.mid_back); }
-    else {
-      const LevelP& lp = p.ups[ui - 1];
-      lc.pre = lp.last ? LEVEL_PRE_S1 : LEVEL_PRE_UP; lc.pc = &lp.resample; lc.in = c.w(a.ups[ui - 1].la); lc.pre_out = c.w(a.ups[ui - 1].rs);
-    }
-    return lc;
-  };
   cur = c.w(a.mid_back);
   for (int ui = 0; ui < L; ++ui) {
     const LevelP& l = p.ups[ui];
@@ -813,7 +837,7 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     const int cx = l.r0.cout, cs = l.r0.cin - l.r0.cout;
     const LevelCall lc = up_call(ui);
     if (level_ok(c, lc)) {
-      DQ_TRY(launch_level_fwd(level_desc(c, lc), c.s));
+      DQ_TRY(launch_level_fwd(with_img(lc, L + ui), c.s));
     } else {
       DQ_TRY(res_fwd(c, l.r0, b.r0, cur, cx, c.w(a.downs[lv].la), cs, R, l.n, RT));
       DQ_TRY(res_fwd(c, l.r1, b.r1, c.w(b.r0.out), cx, c.w(a.downs[lv].r0.out), cs, R, l.n, RT));
@@ -831,9 +855,9 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     if (head_fused) {  // inference: final_conv (and, while sampling, the DDIM update) in the final block's launch; its output is not stored
       lh.head = &p.final_conv; lh.eps_out = out; lh.write_out[0] = false;
       if (c.step_io && c.step_io->x_t) c.step_io->fused_update = true;
-      return launch_level_fwd(level_desc(c, lh), c.s);
+      return launch_level_fwd(with_img(lh, 2 * L), c.s);
     }
-    if (level_ok(c, lh)) DQ_TRY(launch_level_fwd(level_desc(c, lh), c.s));
+    if (level_ok(c, lh)) DQ_TRY(launch_level_fwd(with_img(lh, 2 * L), c.s));
     else DQ_TRY(res_fwd(c, p.fin, a.fin, cur, p.dim, c.w(a.h0), p.dim, R, p.mz, RT));
   }
   DQ_TRY(conv_plain_fwd(c, p.final_conv, CONV_S1, c.w(a.fin.out), out, R, p.mz, p.mz));
@@ -1284,7 +1308,12 @@ int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, 
     const Plan& p = cx.p;
     if (p.wide_mid) return 0;  // (the wide bottleneck keeps its projections inside the step)
     const bool prep_ok = (int)(p.downs.size() + p.ups.size()) <= LA_PREP_MAX;
-    DQ_TRY(la_prepare_all(cx));  // (the aligned copy of to_k's weight for the GEMM route)
+    {  // W2 / operand images / the aligned copy of to_k's weight for the GEMM route: unet_forward's once-per-parameter-state launches
+      Ctx cp = cx;
+      cp.save = false; cp.prepare_only = true; cp.step_io = nullptr;
+      DQ_TRY(unet_forward(cp, rope_freqs, nullptr, nullptr, 0, nullptr, nullptr, cm, ca, plan->dev, nullptr));
+      io.prepared = true;
+    }
     DQ_TRY(launch_ms1_norm(ms1, cm, ca, cx.w(a.ms1n), (int64_t)B * RT, cx.s));
     ConvFwd f;
     f.inA = cx.w(a.ms1n); f.cinA = 1; f.w = cx.prm(p.ms1_c0.w); f.bias = cx.prm(p.ms1_c0.b); f.cout = p.cond_dim; f.K = 7;
@@ -1563,6 +1592,12 @@ int dq_level_fwd(const float* params, int pre, const float* x, int cp, const flo
     k.out = i == 0 ? out0 : out1;
     f.blk[i] = k;
     DQ_TRY(launch_ss_heads_strided(temb, bp + r.mlp_w, bp + r.mlp_b, ss, 2 * p.ss_total, B, 2 * C, s));  // unet1d.py:315-318
+  }
+  // a workspace with room for the operand image behind the scale / shift vectors: built by its own launch first, as the network path does
+  const int64_t img_at = ((int64_t)2 * B * p.ss_total + 63) / 64 * 64;
+  if (((uintptr_t)workspace & 15) == 0 && workspace_floats >= img_at + level_img_floats(f) && level_fwd_usable(C, n, rows_per_sample, pre, f.cp, nblocks, f.blk)) {
+    f.img = workspace + img_at;
+    DQ_TRY(launch_level_images(&f, 1, s));
   }
   return launch_level_fwd(f, s);
 }

@@ -17,6 +17,7 @@
 // block order into the flat gradient buffer (a conv's weight and bias are adjacent there).  No atomics: bitwise repeatable.
 #include "dq_common.h"
 #include "dq_kernels.h"
+#include "dq_probe.h"
 #include <algorithm>
 
 namespace dq {
@@ -62,6 +63,7 @@ __global__ void __launch_bounds__(256) k_conv_bwd_wg(ConvBwdWg a) {
   float* wl = lds;                          // JT * 4
   float* i_dy = wl + JT * 4;                // img_floats(C)
   float* i_tap = i_dy + img_floats(C);      // K x img_floats(CP)
+  DQ_PSTAMP(200000 + C * 1000 + PRE * 100 + CP, 0);
   for (int idx = threadIdx.x; idx < JT * 4; idx += 256) {
     const int j = (idx >> 4) * 4 + (idx & 3), l4 = (idx >> 2) & 3;
     float v = 0.f;
@@ -71,6 +73,7 @@ __global__ void __launch_bounds__(256) k_conv_bwd_wg(ConvBwdWg a) {
     }
     wl[idx] = v;
   }
+  DQ_PSTAMP(200000 + C * 1000 + PRE * 100 + CP, 1);
   const int b = blockIdx.y, n = a.n;
   const int per_sample = a.rows_per_sample * n;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -122,7 +125,9 @@ __global__ void __launch_bounds__(256) k_conv_bwd_wg(ConvBwdWg a) {
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) dy[c] = live ? dy[c] : 0.f;
+    DQ_PSTAMP(200000 + C * 1000 + PRE * 100 + CP, 2);
     __syncthreads();  // the previous tile's readers of the images are done (first tile: the operand image is visible)
+    DQ_PSTAMP(200000 + C * 1000 + PRE * 100 + CP, 3);
     {
       const int oy = img_at(q1, STY), ox = img_at(q1, STX);
 #pragma unroll
@@ -146,16 +151,21 @@ __global__ void __launch_bounds__(256) k_conv_bwd_wg(ConvBwdWg a) {
         for (int h = 0; h < H; ++h)
           *reinterpret_cast<float4*>(i_tap + k * img_floats(CP) + ox + 4 * h) = make_float4(t[k][4 * h], t[k][4 * h + 1], t[k][4 * h + 2], t[k][4 * h + 3]);
     }
+    DQ_PSTAMP(200000 + C * 1000 + PRE * 100 + CP, 4);
     __syncthreads();
+    DQ_PSTAMP(200000 + C * 1000 + PRE * 100 + CP, 5);
     // ---- weight / bias gradient on the matrix pipe: lane block blk walks positions 16 blk .. 16 blk + 15 of the tile
 #pragma unroll 2  // (fully unrolled, the scheduler hoists all 2 x 16 x JW LDS reads and some instantiations need 390 registers)
     for (int s = 0; s < RUN; ++s) {
       const int oy = s * STY + (s == RUN - 1 ? 4 : 0), ox = s * STX + (s == RUN - 1 ? 4 : 0);
+      // (no wave-uniform `if` around a job: a branch per MFMA ends the basic block, every LDS read is then waited for right where it is
+      // issued, and the phase ran at one LDS latency per MFMA -- 22,000 clocks for 192 MFMAs at 16 channels.  A wave's surplus jobs
+      // recompute job 0 and are not flushed.)
 #pragma unroll
-      for (int jj = 0; jj < JW; ++jj)
-        if (jv[jj]) aw[jj] = mfma4(pa[jj][oy], pb[jj][ox], aw[jj]);
-      if (do_bias) ab = mfma4(i_dy[lby + 4 * wv + oy], 1.f, ab);
+      for (int jj = 0; jj < JW; ++jj) aw[jj] = mfma4(pa[jj][oy], pb[jj][ox], aw[jj]);
+      ab = mfma4(i_dy[lby + 4 * (do_bias ? wv : 0) + oy], 1.f, ab);
     }
+    DQ_PSTAMP(200000 + C * 1000 + PRE * 100 + CP, 6);
     // ---- data gradient (transposed conv, registers + DPP shifts)
     if (a.din) {
       if constexpr (PRE == LEVEL_PRE_DOWN) {
@@ -227,6 +237,7 @@ __global__ void __launch_bounds__(256) k_conv_bwd_wg(ConvBwdWg a) {
         }
       }
     }
+    DQ_PSTAMP(200000 + C * 1000 + PRE * 100 + CP, 7);
   }  // tile
 
   // ---- the block's slot [dW (C x CP x K) | dbias (C)]
@@ -250,6 +261,7 @@ __global__ void __launch_bounds__(256) k_conv_bwd_wg(ConvBwdWg a) {
       for (int i = 0; i < 4; ++i) part[C * CP * K + 4 * wv + i] = t[i];
     }
   }
+  DQ_PSTAMP(200000 + C * 1000 + PRE * 100 + CP, 8);
 }
 
 static bool conv_wg_built(int C, int pre, int cp) {

@@ -18,6 +18,7 @@
 // Every global read of a tile (stage input, the skip channels of cat(x, skip), unet1d.py:1151, 1154) is requested before the first use.
 #include "dq_common.h"
 #include "dq_kernels.h"
+#include "dq_probe.h"
 #include <algorithm>
 
 namespace dq {
@@ -73,57 +74,99 @@ struct LevelFwdK {
 
 }  // namespace
 
+
+// Source of element idx of the operand image ([job / 4][lane & 3][job % 4]) in the flat parameter buffer, or -1 (padding).  No control flow:
+// called for several elements at a time with their loads in flight together.
+struct LevelImgSrc {
+  int pre, G, C, cp, kp, nblocks, pw;
+  int w1[2], w2[2], wr[2], cin[2];  // wr < 0: identity residual
+};
+__device__ __forceinline__ int level_img_src(const LevelImgSrc& m, const Jobs& J, int idx) {
+  const int j = (idx >> 4) * 4 + (idx & 3), li = (idx >> 2) & 3;
+  const int G = m.G, C = m.C;
+  int off = -1;
+  if (m.pre != LEVEL_PRE_NONE) {  // stage: job = (c * G + g) * KP + k
+    const int jj = j - J.pre;
+    const int k = jj % m.kp, g = (jj / m.kp) % G, c = jj / (m.kp * G);
+    off = (jj >= 0 && jj < G * m.cp * m.kp) ? m.pw + ((4 * g + li) * m.cp + c) * m.kp + k : off;
+  }
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int cin = m.cin[b];
+    const bool on = b < m.nblocks;
+    {
+      const int jj = j - J.c1[b], k = jj % 3, g = (jj / 3) % G, c = jj / (3 * G);          // conv1: job = (c * G + g) * 3 + k
+      off = (on && jj >= 0 && jj < G * cin * 3) ? m.w1[b] + ((4 * g + li) * cin + c) * 3 + k : off;
+    }
+    {
+      const int jj = j - J.c2[b], k = jj % 3, g = (jj / 3) % G, c = jj / (3 * G);          // conv2
+      off = (on && jj >= 0 && jj < G * C * 3) ? m.w2[b] + ((4 * g + li) * C + c) * 3 + k : off;
+    }
+    {
+      const int jj = j - J.rs[b], g = jj % G, c = jj / G;                                  // res_conv: job = c * G + g
+      off = (on && m.wr[b] >= 0 && jj >= 0 && jj < G * cin) ? m.wr[b] + (4 * g + li) * cin + c : off;
+    }
+  }
+  return off;
+}
+
+// The images of several launches, built ONCE per parameter state (launch_level_images): block (x, y) = a slice of image y.
+struct LevelImgItem { LevelImgSrc m; float* dst; };
+struct LevelImgMulti { LevelImgItem it[LEVEL_IMG_MAX]; };
+__global__ void __launch_bounds__(256) k_level_images(LevelImgMulti mm, const float* __restrict__ P) {
+  const LevelImgItem& it = mm.it[blockIdx.y];
+  const bool wr[2] = {it.m.wr[0] >= 0, it.m.wr[1] >= 0};
+  const Jobs J = level_jobs(it.m.C, it.m.pre, it.m.cp, it.m.nblocks, it.m.cin, wr);
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= J.total * 4) return;
+  const int off = level_img_src(it.m, J, idx);
+  it.dst[idx] = off < 0 ? 0.f : P[off];
+}
+
 // CP: input channels of the stage (compile time: every global read of a tile is issued up front from statically indexed registers --
 // with the channel quads walked in a run-time load -> use loop a wave exposed one memory latency per quad and the launch ran at a
 // third of the rate its loads in flight allow)
 // N64: rows of exactly 64 positions = one row per wave: the wave shifts' zero fill at lanes 0 / 63 IS the conv's zero padding, no masks
 template <int C, int PRE, int CP, bool N64>
 __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __restrict__ P, const float* __restrict__ ssb, int tiles_ps, int total_tiles,
-                                                   int ln) {  // ssb: the per-sample scale / shift vectors; ln = log2(n)
+                                                   int ln, const float* __restrict__ img) {  // ssb: the per-sample scale / shift vectors; ln = log2(n)
   constexpr int G = C / 4;
   constexpr int KP = PRE == LEVEL_PRE_DOWN ? 4 : (PRE == LEVEL_PRE_INIT ? 7 : 3);
   extern __shared__ __attribute__((aligned(16))) float wl[];  // [job / 4][lane & 3][job % 4]
   const int cin_[2] = {C + a.blk[0].cinB, C + a.blk[1].cinB};
   const bool wr_[2] = {a.blk[0].wr >= 0, a.blk[1].wr >= 0};
   const Jobs J = level_jobs(C, PRE, CP, a.nblocks, cin_, wr_);
-  // Staging of the operand image: the source offset of every element is formed WITHOUT control flow and the loads of four elements are
-  // in flight together -- as a loop of dependent "decode, branch, load, store" iterations the staging of a 16-channel level's 25 KB
-  // took ~25 us per workgroup, which at training batch sizes (one or two tiles per wave) was most of the launch.
-  {
-    auto src_of = [&](int idx) -> int {  // offset into P of image element idx, or -1 (padding)
-      const int j = (idx >> 4) * 4 + (idx & 3), li = (idx >> 2) & 3;
-      int off = -1;
-      if (PRE != LEVEL_PRE_NONE) {  // stage: job = (c * G + g) * KP + k
-        const int jj = j - J.pre;
-        const int k = jj % KP, g = (jj / KP) % G, c = jj / (KP * G);
-        off = (jj >= 0 && jj < G * CP * KP) ? a.pw + ((4 * g + li) * CP + c) * KP + k : off;
-      }
+  DQ_PSTAMP(C * 1000 + PRE * 100 + CP, 0);
+  // Staging of the operand image.  With a prepared image (launch_level_images, once per parameter state) it is a linear copy, every
+  // 16-byte load of a thread in flight at once.  Without one (the stand-alone entry point) the workgroup gathers it from the parameter
+  // tensors: element offsets formed without control flow, four loads in flight -- ~12 us per workgroup at 16 channels, which at training
+  // batch sizes (one or two tiles per wave at the deep levels) was a third of the launch.
+  if (img) {
+    const int total4 = J.total;  // 16-byte units
+    constexpr int MAXJ = pad4(G * CP * KP) + 2 * (pad4(G * 2 * C * 3) + pad4(G * C * 3) + pad4(G * 2 * C));
+    constexpr int NLD = (MAXJ + 255) / 256;
+    float4 v[NLD];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const LevelBlkK& r = a.blk[b];
-        const int cin = cin_[b];
-        const bool on = b < a.nblocks;
-        {
-          const int jj = j - J.c1[b], k = jj % 3, g = (jj / 3) % G, c = jj / (3 * G);          // conv1: job = (c * G + g) * 3 + k
-          off = (on && jj >= 0 && jj < G * cin * 3) ? r.w1 + ((4 * g + li) * cin + c) * 3 + k : off;
-        }
-        {
-          const int jj = j - J.c2[b], k = jj % 3, g = (jj / 3) % G, c = jj / (3 * G);          // conv2
-          off = (on && jj >= 0 && jj < G * C * 3) ? r.w2 + ((4 * g + li) * C + c) * 3 + k : off;
-        }
-        {
-          const int jj = j - J.rs[b], g = jj % G, c = jj / G;                                  // res_conv: job = c * G + g
-          off = (on && wr_[b] && jj >= 0 && jj < G * cin) ? r.wr + (4 * g + li) * cin + c : off;
-        }
-      }
-      return off;
-    };
+    for (int u = 0; u < NLD; ++u) {
+      const int i = u * 256 + (int)threadIdx.x;
+      v[u] = reinterpret_cast<const float4*>(img)[i < total4 ? i : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int i = u * 256 + (int)threadIdx.x;
+      if (i < total4) reinterpret_cast<float4*>(wl)[i] = v[u];
+    }
+  } else {
+    LevelImgSrc m;
+    m.pre = PRE; m.G = G; m.C = C; m.cp = CP; m.kp = KP; m.nblocks = a.nblocks; m.pw = a.pw;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) { m.w1[b] = a.blk[b].w1; m.w2[b] = a.blk[b].w2; m.wr[b] = a.blk[b].wr; m.cin[b] = cin_[b]; }
     const int total = J.total * 4;
     for (int base = threadIdx.x; base < total; base += 256 * 4) {
       int off[4];
       float v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) off[u] = base + u * 256 < total ? src_of(base + u * 256) : -1;
+      for (int u = 0; u < 4; ++u) off[u] = base + u * 256 < total ? level_img_src(m, J, base + u * 256) : -1;
 #pragma unroll
       for (int u = 0; u < 4; ++u) v[u] = P[off[u] < 0 ? 0 : off[u]];
 #pragma unroll
@@ -136,6 +179,7 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
   // wave then waits on nothing but its own tile's loads and LDS reads (as scalar loads from memory, re-issued per tile under
   // scalar-register pressure, they cost a full wait each: the launch time did not move with the instruction count).
   float* prm = wl + J.total * 4;
+  DQ_PSTAMP(C * 1000 + PRE * 100 + CP, 1);
   {
     const int b = blockIdx.y;
     if (threadIdx.x < 8) {  // [C * 15 ..): final_conv weight (4) | bias | this sample's init_cond_proj scale + 1 | shift  (C == 4 launches only)
@@ -166,6 +210,7 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
     }
   }
   __syncthreads();
+  DQ_PSTAMP(C * 1000 + PRE * 100 + CP, 2);
   auto prm4 = [&](int what, int g) -> float4 { return *reinterpret_cast<const float4*>(prm + what * C + 4 * g); };
   const int lane = threadIdx.x & 63, li = lane & 3;
   const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = gridDim.x * 4;
@@ -174,8 +219,30 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
   const int per_sample = a.rows_per_sample * n;
   const float sqC = sqrtf((float)C);
   const float* wlane = wl + li * 4;
-  // weight operand of job (base + js): base is a multiple of 4 at run time, js a compile-time constant -> one 16-byte read per four jobs
-  auto wop = [&](int base, int js) -> float { return wlane[(base >> 2) * 16 + (js >> 2) * 16 + (js & 3)]; };
+  // Weight operands are consumed as a STREAM of jobs in image order (one 16-byte LDS read per four jobs) through a ring of RD reads in
+  // flight: the read of jobs 4 q + 4 RD .. is issued when job 4 q is reached.  (Left to the compiler, one read was in flight -- issued
+  // four MFMAs = ~34 cycles before its use against an LDS latency of 64+: with one wave per SIMD, as at the deep levels of a training
+  // batch, every group of four MFMAs waited and a 16-channel block ran at ~20 cycles per MFMA instead of ~8.5.)
+  constexpr int RD = 3;
+  struct WRing { float4 r[RD]; float4 cur; };
+#ifdef DQ_LEVEL_NOLDS  // timing experiment (wrong results): what the launch costs without the operand reads
+  auto ldw = [&](int base, int q) -> float4 { return make_float4(base * 1.f, q * 1.f, li * 1.f, 1.f); };
+#else
+  auto ldw = [&](int base, int q) -> float4 { return *reinterpret_cast<const float4*>(wlane + (base >> 2) * 16 + q * 16); };
+#endif
+  auto ring_start = [&](WRing& R, int base) __attribute__((always_inline)) {
+#pragma unroll
+    for (int d = 0; d < RD; ++d) R.r[d] = ldw(base, d);  // (reads past a stream's last job land in the next stream / the parameter image)
+  };
+  // operand of job j of the stream at `base` (j: a compile-time constant once the loops are unrolled; jobs are taken in order)
+  auto wjob = [&](WRing& R, int base, int j) __attribute__((always_inline)) -> float {
+    if ((j & 3) == 0) {
+      R.cur = R.r[(j >> 2) % RD];
+      R.r[(j >> 2) % RD] = ldw(base, (j >> 2) + RD);
+      __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks the read to one group ahead again, to save registers)
+    }
+    return (j & 3) == 0 ? R.cur.x : (j & 3) == 1 ? R.cur.y : (j & 3) == 2 ? R.cur.z : R.cur.w;
+  };
 
   // the grid is ONE resident round (launcher); wave w takes the 64-position tiles w, w + nwaves, ... of the (sample, tile) list
   float dsa = 1.f, dsb = 0.f, dsap = -1.f, dsbp = 0.f;  // this step's row of the DDIM coefficient table (read once, outside the tile loop)
@@ -228,6 +295,8 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
       f32x4 acc[7];
 #pragma unroll
       for (int k = 0; k < 7; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      WRing R;
+      ring_start(R, J.pre);
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         // taps k = 0..6 read position p + k - 3
@@ -239,7 +308,7 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
         float p3 = lane_p1(p2);   p3 = (N64 || p + 3 < n) ? p3 : 0.f;
         const float tap[7] = {m3, m2, m1, v[c], p1, p2, p3};
 #pragma unroll
-        for (int k = 0; k < 7; ++k) acc[k] = mfma4(wop(J.pre, c * 7 + k), tap[k], acc[k]);
+        for (int k = 0; k < 7; ++k) acc[k] = mfma4(wjob(R, J.pre, c * 7 + k), tap[k], acc[k]);
       }
       {
         const float4 pb4 = prm4(0, 0);
@@ -272,6 +341,8 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
         }
       }
       load_skip(0);  // block 0's skip channels: requested together with the stage's input
+      WRing R;
+      ring_start(R, J.pre);
 #pragma unroll
       for (int c = 0; c < CP; ++c) {
         if constexpr (PRE == LEVEL_PRE_DOWN) {
@@ -280,10 +351,10 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
 #pragma unroll
           for (int g = 0; g < G; ++g) {
             const int js = (c * G + g) * 4;
-            acc[g][0] = mfma4(wop(J.pre, js + 0), xm, acc[g][0]);
-            acc[g][1] = mfma4(wop(J.pre, js + 1), v0[c], acc[g][1]);
-            acc[g][2] = mfma4(wop(J.pre, js + 2), v1[c], acc[g][2]);
-            acc[g][3] = mfma4(wop(J.pre, js + 3), xp, acc[g][3]);
+            acc[g][0] = mfma4(wjob(R, J.pre, js + 0), xm, acc[g][0]);
+            acc[g][1] = mfma4(wjob(R, J.pre, js + 1), v0[c], acc[g][1]);
+            acc[g][2] = mfma4(wjob(R, J.pre, js + 2), v1[c], acc[g][2]);
+            acc[g][3] = mfma4(wjob(R, J.pre, js + 3), xp, acc[g][3]);
           }
         } else {
           const float tm = lane_m1(v0[c]), tp = lane_p1(v0[c]);
@@ -291,9 +362,9 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
 #pragma unroll
           for (int g = 0; g < G; ++g) {
             const int js = (c * G + g) * 3;
-            acc[g][0] = mfma4(wop(J.pre, js + 0), xm, acc[g][0]);
-            acc[g][1] = mfma4(wop(J.pre, js + 1), v0[c], acc[g][1]);
-            acc[g][2] = mfma4(wop(J.pre, js + 2), xp, acc[g][2]);
+            acc[g][0] = mfma4(wjob(R, J.pre, js + 0), xm, acc[g][0]);
+            acc[g][1] = mfma4(wjob(R, J.pre, js + 1), v0[c], acc[g][1]);
+            acc[g][2] = mfma4(wjob(R, J.pre, js + 2), xp, acc[g][2]);
           }
         }
       }
@@ -314,20 +385,26 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
       }
     }
     // ---------------------------------------------------------------- the level's ResnetBlocks
+    DQ_PSTAMP(C * 1000 + PRE * 100 + CP, 3);
 #pragma unroll
     for (int bi = 0; bi < 2; ++bi) {
       if (bi >= a.nblocks) break;
+      if (bi == 1) DQ_PSTAMP(C * 1000 + PRE * 100 + CP, 4);
       const LevelBlkK& r = a.blk[bi];
       const bool wr = r.wr >= 0;
       const int pq = 1 + 7 * bi;  // this block's rows of the parameter image: b1, g1, b2, g2, br, scale + 1, shift
-      f32x4 acc[G][3], ar[G][2];
+      constexpr int NAR = G == 1 ? 4 : 2;  // independent accumulation chains of the residual conv per output quad
+      f32x4 acc[G][3], ar[G][NAR];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) acc[g][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        ar[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ar[g][1] = ar[g][0];
+#pragma unroll
+        for (int k = 0; k < NAR; ++k) ar[g][k] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      // conv1 (and the 1x1 residual conv) over the block input held in registers ...
+      // conv1 over the block input held in registers, then over the skip channels: ONE job stream (c, g, k) ...
+      WRing R;
+      ring_start(R, J.c1[bi]);
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const float tm = lane_m1(x[c]), tp = lane_p1(x[c]);
@@ -335,34 +412,45 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           const int js = (c * G + g) * 3;
-          acc[g][0] = mfma4(wop(J.c1[bi], js + 0), xm, acc[g][0]);
-          acc[g][1] = mfma4(wop(J.c1[bi], js + 1), x[c], acc[g][1]);
-          acc[g][2] = mfma4(wop(J.c1[bi], js + 2), xp, acc[g][2]);
+          acc[g][0] = mfma4(wjob(R, J.c1[bi], js + 0), xm, acc[g][0]);
+          acc[g][1] = mfma4(wjob(R, J.c1[bi], js + 1), x[c], acc[g][1]);
+          acc[g][2] = mfma4(wjob(R, J.c1[bi], js + 2), xp, acc[g][2]);
         }
       }
-      if (wr) {
-#pragma unroll
-        for (int c = 0; c < C; ++c)
-#pragma unroll
-          for (int g = 0; g < G; ++g) ar[g][c & 1] = mfma4(wop(J.rs[bi], c * G + g), x[c], ar[g][c & 1]);
-      }
-      // ... and over the skip channels (a block with skip channels has a residual conv)
+      if (bi == 1) DQ_PSTAMP(C * 1000 + PRE * 100 + CP, 7);
       if (bi == 0 && a.nblocks > 1) load_skip(1);  // block 1's skip channels travel while block 0 computes
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        if (c < r.cinB) {  // wave-uniform
+        if (c < r.cinB) {  // wave-uniform; the skip channels are a prefix: the stream is never resumed after a skipped channel
           const float tm = lane_m1(xb[bi][c]), tp = lane_p1(xb[bi][c]);
           const float xm = hasL ? tm : 0.f, xp = hasR ? tp : 0.f;
 #pragma unroll
           for (int g = 0; g < G; ++g) {
             const int js = ((C + c) * G + g) * 3;
-            acc[g][0] = mfma4(wop(J.c1[bi], js + 0), xm, acc[g][0]);
-            acc[g][1] = mfma4(wop(J.c1[bi], js + 1), xb[bi][c], acc[g][1]);
-            acc[g][2] = mfma4(wop(J.c1[bi], js + 2), xp, acc[g][2]);
-            ar[g][c & 1] = mfma4(wop(J.rs[bi], (C + c) * G + g), xb[bi][c], ar[g][c & 1]);
+            acc[g][0] = mfma4(wjob(R, J.c1[bi], js + 0), xm, acc[g][0]);
+            acc[g][1] = mfma4(wjob(R, J.c1[bi], js + 1), xb[bi][c], acc[g][1]);
+            acc[g][2] = mfma4(wjob(R, J.c1[bi], js + 2), xp, acc[g][2]);
           }
         }
       }
+      if (bi == 1) DQ_PSTAMP(C * 1000 + PRE * 100 + CP, 8);
+      // ... and the 1x1 residual conv of cat(x, skip) as a second stream (c, g) (a block with skip channels has one)
+      if (wr) {
+        ring_start(R, J.rs[bi]);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+          for (int g = 0; g < G; ++g) ar[g][c & (NAR - 1)] = mfma4(wjob(R, J.rs[bi], c * G + g), x[c], ar[g][c & (NAR - 1)]);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          if (c < r.cinB) {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+              ar[g][c & (NAR - 1)] = mfma4(wjob(R, J.rs[bi], (C + c) * G + g), xb[bi][c], ar[g][c & (NAR - 1)]);
+          }
+        }
+      }
+      if (bi == 1) DQ_PSTAMP(C * 1000 + PRE * 100 + CP, 9);
       float u[C];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -392,11 +480,13 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
 #pragma unroll
         for (int c = 0; c < C; ++c) st(r.a1, c, obase, u[c]);
       }
+      if (bi == 1) DQ_PSTAMP(C * 1000 + PRE * 100 + CP, 10);
       // conv2 over the block-1 activation
 #pragma unroll
       for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int k = 0; k < 3; ++k) acc[g][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      ring_start(R, J.c2[bi]);
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const float tm = lane_m1(u[c]), tp = lane_p1(u[c]);
@@ -404,11 +494,12 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           const int js = (c * G + g) * 3;
-          acc[g][0] = mfma4(wop(J.c2[bi], js + 0), xm, acc[g][0]);
-          acc[g][1] = mfma4(wop(J.c2[bi], js + 1), u[c], acc[g][1]);
-          acc[g][2] = mfma4(wop(J.c2[bi], js + 2), xp, acc[g][2]);
+          acc[g][0] = mfma4(wjob(R, J.c2[bi], js + 0), xm, acc[g][0]);
+          acc[g][1] = mfma4(wjob(R, J.c2[bi], js + 1), u[c], acc[g][1]);
+          acc[g][2] = mfma4(wjob(R, J.c2[bi], js + 2), xp, acc[g][2]);
         }
       }
+      if (bi == 1) DQ_PSTAMP(C * 1000 + PRE * 100 + CP, 11);
       float o[C];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -440,7 +531,11 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
           const float4 t = prm4(pq + 4, g);
           const float tv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-          for (int i = 0; i < 4; ++i) o[4 * g + i] += (ar[g][0][i] + ar[g][1][i]) + tv[i];
+          for (int i = 0; i < 4; ++i) {
+            float rs = ar[g][0][i] + ar[g][1][i];
+            if constexpr (NAR == 4) rs += ar[g][2][i] + ar[g][3][i];
+            o[4 * g + i] += rs + tv[i];
+          }
         }
       } else {
 #pragma unroll
@@ -472,7 +567,9 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
 #pragma unroll
       for (int c = 0; c < C; ++c) x[c] = o[c];
     }
+    DQ_PSTAMP(C * 1000 + PRE * 100 + CP, 5);
   }
+  DQ_PSTAMP(C * 1000 + PRE * 100 + CP, 6);
 }
 
 // stage input widths that are instantiated: a Downsample from C - 4 or C channels, an Upsample / k3 conv from C or C + 4 (channel
@@ -499,6 +596,43 @@ bool level_fwd_usable(int C, int n, int rows_per_sample, int pre_mode, int cp, i
     if (r.cinB % 4 != 0 || r.cinB < 0 || r.cinB > C || (r.cinB > 0) != (r.wr != nullptr)) return false;
   }
   return true;
+}
+
+static int level_img_item(const LevelFwd& a, LevelImgSrc* m) {
+  auto poff = [&](const float* ptr) -> int { return ptr ? (int)(ptr - a.params) : -1; };
+  m->pre = a.pre; m->G = a.C / 4; m->C = a.C; m->cp = a.pre == LEVEL_PRE_NONE ? 4 : a.cp;
+  m->kp = a.pre == LEVEL_PRE_DOWN ? 4 : (a.pre == LEVEL_PRE_INIT ? 7 : 3);
+  m->nblocks = a.nblocks; m->pw = poff(a.pw);
+  for (int b = 0; b < 2; ++b) {
+    const ResFwd& r = a.blk[b < a.nblocks ? b : 0];
+    m->w1[b] = poff(r.w1); m->w2[b] = poff(r.w2); m->wr[b] = poff(r.wr); m->cin[b] = a.C + (b < a.nblocks ? r.cinB : 0);
+  }
+  return 0;
+}
+int64_t level_img_floats(const LevelFwd& a) {
+  const int cin[2] = {a.C + a.blk[0].cinB, a.C + (a.nblocks > 1 ? a.blk[1].cinB : 0)};
+  const bool wr[2] = {a.blk[0].wr != nullptr, a.nblocks > 1 && a.blk[1].wr != nullptr};
+  return (int64_t)level_jobs(a.C, a.pre, a.pre == LEVEL_PRE_NONE ? 4 : a.cp, a.nblocks, cin, wr).total * 4;
+}
+int launch_level_images(const LevelFwd* calls, int count, hipStream_t s) {
+  if (count == 0) return 0;
+  DQ_REQUIRE(count <= LEVEL_IMG_MAX, "level images: too many launches");
+  LevelImgMulti mm;
+  int64_t mx = 0;
+  for (int i = 0; i < count; ++i) {
+    const LevelFwd& a = calls[i];
+    DQ_REQUIRE(a.img && ((uintptr_t)a.img & 15) == 0 && a.params, "level images: missing / misaligned image buffer");
+    DQ_REQUIRE(level_fwd_usable(a.C, a.n, a.rows_per_sample, a.pre, a.cp, a.nblocks, a.blk), "level images: unsupported shape");
+    DQ_REQUIRE(a.params == calls[0].params, "level images: the launches must share one parameter buffer");
+    level_img_item(a, &mm.it[i].m);
+    mm.it[i].dst = const_cast<float*>(a.img);
+    const int64_t fl = level_img_floats(a);
+    DQ_REQUIRE(fl <= LEVEL_IMG_FLOATS, "level images: image larger than its slot");
+    mx = std::max(mx, fl);
+  }
+  hipLaunchKernelGGL(k_level_images, dim3(cdiv(mx, 256), count), dim3(256), 0, s, mm, calls[0].params);
+  DQ_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_level_fwd(const LevelFwd& a, hipStream_t s) {
@@ -549,7 +683,7 @@ int launch_level_fwd(const LevelFwd& a, hipStream_t s) {
       occ = std::max(1, std::min(nb, 6));                                                                                     \
     }                                                                                                                         \
     const int gx = std::max(1, std::min(occ * num_cus() / B, (tiles_ps + 3) / 4));  /* workgroups per sample */                \
-    hipLaunchKernelGGL((k_level_fwd<CC, PP, PC, NN>), dim3(gx, B), dim3(256), lds, s, k, a.params, ssb, tiles_ps, (int)total, ln); \
+    hipLaunchKernelGGL((k_level_fwd<CC, PP, PC, NN>), dim3(gx, B), dim3(256), lds, s, k, a.params, ssb, tiles_ps, (int)total, ln, a.img); \
     DQ_LAUNCH_CHECK();                                                                                                        \
     return 0;                                                                                                                 \
   }

@@ -25,6 +25,7 @@
 #include "dq_common.h"
 #include "dq_kernels.h"
 #include "k_res_common.h"
+#include "dq_probe.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -95,6 +96,7 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
   __shared__ __attribute__((aligned(16))) float wl[JTT * 4];
   __shared__ __attribute__((aligned(16))) float prm[4 * C];  // g2 | g1 | scale | shift (this sample's): no global reads of them inside the tile loop
   const int cin = a.cinA + a.cinB;  // C (identity residual) or C + cinB, cinB in {4, .., C} (checked by the launcher)
+  DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 0);
   for (int idx = threadIdx.x; idx < JTT * 4; idx += 256) {
     const int j = (idx >> 4) * 4 + (idx & 3), l4 = (idx >> 2) & 3;
     float v = 0.f;
@@ -116,6 +118,7 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
     prm[i] = what == 0 ? a.g2[c] : what == 1 ? a.g1[c] : what == 2 ? ssp[c] : ssp[C + c];
   }
   __syncthreads();  // (the first tile reads prm before its first barrier)
+  DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 1);
   const int b = blockIdx.y, n = a.n;
   const int per_sample = a.rows_per_sample * n;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -194,6 +197,7 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
 #pragma unroll
       for (int c = 0; c < C; ++c) a1v[c] = silu_f(fmaf(u1v[c] * inv * prm[C + c], prm[2 * C + c] + 1.0f, prm[3 * C + c]));
     }
+    DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 2);
     __syncthreads();  // the previous tile's readers of the images are done (first tile: the staged weights are visible)
     {
       const int o = I::at(q);
@@ -210,6 +214,7 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
       }
     }
     __syncthreads();
+    DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 3);
     // ---- matrix pipe: dW2 (+ db2), dWr (+ dbr)
 #ifndef DQ_WG_V_NOMFMA
     if (doW2) {
@@ -226,7 +231,7 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
         aW2[0] = mfma4(av, b0, aW2[0]);
         aW2[1] = mfma4(av, bcur, aW2[1]);
         aW2[2] = mfma4(av, b2, aW2[2]);
-        if (doB2) aB2 = mfma4(av, 1.f, aB2);
+        aB2 = mfma4(av, 1.f, aB2);  // (every wave that runs this phase: flushed only where doB2 -- no branch per MFMA, k_conv_wg.hip)
         bprev = bcur; bcur = bnext;
       }
     }
@@ -238,13 +243,14 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
 #pragma unroll
       for (int s = 0; s < RUN; ++s) {
         const float av = A[run_off<ST>(s)];
-        if (v_r0) aWr[0] = mfma4(av, X0[run_off<ST>(s)], aWr[0]);
-        if (v_r1) aWr[1] = mfma4(av, X1[run_off<ST>(s)], aWr[1]);
-        if (doBr) aBr = mfma4(av, 1.f, aBr);
+        aWr[0] = mfma4(av, X0[run_off<ST>(s)], aWr[0]);  // (jobs that are not this wave's read a valid image and are not flushed)
+        aWr[1] = mfma4(av, X1[run_off<ST>(s)], aWr[1]);
+        aBr = mfma4(av, 1.f, aBr);
       }
      }
     }
 #endif
+    DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 4);
     // ---- d a1[ci][p] = sum_co sum_k W2[co][ci][k] dU2[co][p + 1 - k]  (matrix pipe; tap k reads position p + 1 - k)
     float da1[C];
     {
@@ -271,6 +277,7 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) da1[4 * gg + i] = (acc[gg][0][i] + acc[gg][1][i]) + acc[gg][2][i];
     }
+    DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 5);
     // ---- block1: dU1
 #pragma unroll
     for (int c = 0; c < C; ++c) u[c] = u1v[c];
@@ -283,7 +290,9 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
         *reinterpret_cast<float4*>(i_du1 + o + c) = live ? make_float4(da1[c], da1[c + 1], da1[c + 2], da1[c + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
+    DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 6);
     __syncthreads();
+    DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 7);
     // ---- matrix pipe: dW1 (+ db1)
 #ifndef DQ_WG_V_NOMFMA
     if (doW1) {
@@ -299,21 +308,20 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
         float l0 = p0, r0 = n0, l1 = p1, r1 = n1;
         if (s == 8) { l0 = n8 ? 0.f : l0; l1 = n8 ? 0.f : l1; }
         if (s == 7) { r0 = n8 ? 0.f : r0; r1 = n8 ? 0.f : r1; }
-        if (v_10) {
-          aW1[0][0] = mfma4(av, l0, aW1[0][0]);
-          aW1[0][1] = mfma4(av, c0, aW1[0][1]);
-          aW1[0][2] = mfma4(av, r0, aW1[0][2]);
-        }
-        if (v_11) {
+        aW1[0][0] = mfma4(av, l0, aW1[0][0]);
+        aW1[0][1] = mfma4(av, c0, aW1[0][1]);
+        aW1[0][2] = mfma4(av, r0, aW1[0][2]);
+        if constexpr (C == 8 && WR) {  // (the only shape with a second input-channel quad per wave)
           aW1[1][0] = mfma4(av, l1, aW1[1][0]);
           aW1[1][1] = mfma4(av, c1, aW1[1][1]);
           aW1[1][2] = mfma4(av, r1, aW1[1][2]);
         }
-        if (doB1) aB1 = mfma4(av, 1.f, aB1);
+        aB1 = mfma4(av, 1.f, aB1);
         p0 = c0; c0 = n0; p1 = c1; c1 = n1;
       }
     }
 #endif
+    DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 8);
     // ---- d x[ci][p] = sum_co sum_k W1[co][ci][k] dU1[co][p + 1 - k]  (+ residual branch) into dA / dB  (matrix pipe)
     if (a.dA || a.dB) {
       f32x4 acc[GI][3], ar[GI];
@@ -330,13 +338,13 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
         const float dr = hasR ? tp : 0.f, dl = hasL ? tm : 0.f;
 #pragma unroll
         for (int gi = 0; gi < GI; ++gi) {
-          if (gi < cinq) {  // wave-uniform
-            const int j = OT1 + (co * GI + gi) * 3;
-            acc[gi][0] = mfma4(wop(j + 0), dr, acc[gi][0]);
-            acc[gi][1] = mfma4(wop(j + 1), dc, acc[gi][1]);
-            acc[gi][2] = mfma4(wop(j + 2), dl, acc[gi][2]);
-            if constexpr (WR) ar[gi] = mfma4(wop(OTR + co * GI + gi), dout[co], ar[gi]);
-          }
+          // (every quad, also those beyond cin: their operands are the image's zero padding and their results are not stored -- a
+          // wave-uniform branch per quad made every group of four MFMAs its own basic block with its LDS reads waited for in place)
+          const int j = OT1 + (co * GI + gi) * 3;
+          acc[gi][0] = mfma4(wop(j + 0), dr, acc[gi][0]);
+          acc[gi][1] = mfma4(wop(j + 1), dc, acc[gi][1]);
+          acc[gi][2] = mfma4(wop(j + 2), dl, acc[gi][2]);
+          if constexpr (WR) ar[gi] = mfma4(wop(OTR + co * GI + gi), dout[co], ar[gi]);
         }
       }
       if (live) {
@@ -364,6 +372,7 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
         }
       }
     }
+    DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 9);
   }  // tile
 
   // ---- the block's slot: MFMA results (each job belongs to exactly one wave), then the VALU sums
@@ -412,6 +421,7 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
     const int what = i / C, c = i % C;
     part[(what == 0 ? oG2 : what == 1 ? oG1 : what == 2 ? nglob : nglob + C) + c] = v;
   }
+  DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 10);
 }
 
 // -----------------------------------------------------------------------------------------------------------------

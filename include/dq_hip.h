@@ -283,7 +283,9 @@ int dq_resblock_bwd(const float* params, const float* xA, int cinA, const float*
  * (x is (rows, cp, n)); skip_i (rows, cs, n), nullable with cs = 0 (then the residual is the identity); temb (rows / rows_per_sample, 16).
  * params: [stage weight (C, cp, K) | stage bias (C)] (pre != 0), then nblocks (1 or 2) blocks in the dq_resblock_fwd layout with
  * cin = C + cs (dq_level_param_floats floats in all).  out0 nullable when nblocks = 2 (inference on the way up keeps only out1).
- * n: a power of two <= 64; C in {4, 8, 12, 16}.  workspace: 2 * (rows / rows_per_sample) * 2 * C floats. */
+ * n: a power of two <= 64; C in {4, 8, 12, 16}.  workspace: 2 * (rows / rows_per_sample) * 2 * C floats; with 8256 floats more (and 16-byte
+ * aligned) the MFMA operand image of the weights is built there by one launch of its own and the workgroups copy it, as in the network
+ * path, instead of each gathering it from the parameter tensors. */
 int64_t dq_level_param_floats(int pre, int C, int cp, int cs, int nblocks);
 int dq_level_fwd(const float* params, int pre, const float* x, int cp, const float* skip0, const float* skip1, int cs, const float* temb,
                  float* out0, float* out1, int C, int nblocks, int rows, int n, int rows_per_sample, float* workspace,

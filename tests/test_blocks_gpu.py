@@ -236,6 +236,15 @@ def test_level_forward_vs_oracle(N, pre, C, cp, cs, n, rows, rps, nblocks):
     assert rel(o0, outs[0]) < 1e-5
     if nblocks == 2:
         assert rel(o1, outs[1]) < 1e-5
+    # the same launch fed from a prepared operand image (k_level_images; the network path): the same numbers, bit for bit
+    p0, p1 = torch.full_like(o0, float("nan")), torch.full_like(o1, float("nan"))
+    ws2 = torch.empty(2 * B * 2 * C + 8256, device="cuda")
+    N.check(L.dq_level_fwd(N.ptr(params), pre, N.ptr(xd), cp, N.ptr(s0), N.ptr(s1), cs, N.ptr(td), N.ptr(p0), N.ptr(p1) if nblocks == 2 else None, C,
+                           nblocks, rows, n, rps, N.ptr(ws2), ws2.numel(), N.stream_ptr()), "dq_level_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(p0, o0)
+    if nblocks == 2:
+        assert torch.equal(p1, o1)
 
 
 # ------------------------------------------------------------------------------------------------ bottleneck attention (unet1d.py:428-443)
