@@ -17,6 +17,7 @@
 // block order into the flat gradient buffer (a conv's weight and bias are adjacent there).  No atomics: bitwise repeatable.
 #include "dq_common.h"
 #include "dq_kernels.h"
+#include "k_res_common.h"
 #include "dq_probe.h"
 #include <algorithm>
 
@@ -36,18 +37,6 @@ constexpr int img_st(int c) { return c == 4 ? 4 : (c == 8 ? 12 : 20); }
 constexpr int img_floats(int c) { return (TILE + 2) * img_st(c) + ((TILE + 2) / RUN + 1) * 4; }
 __device__ __forceinline__ int img_at(int q, int st) { return q * st + (q >> 4) * 4; }
 
-__device__ __forceinline__ f32x4 blocks_sum(f32x4 v) {  // sum over the 16 lane blocks; lanes 0..3 hold the total
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float t = v[i];
-    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x124, 0xF, 0xF, false));  // row_ror:4
-    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xF, 0xF, false));  // row_ror:8
-    t += __shfl_xor(t, 16, 64);
-    t += __shfl_xor(t, 32, 64);
-    v[i] = t;
-  }
-  return v;
-}
 
 }  // namespace
 

@@ -34,4 +34,24 @@ __device__ __forceinline__ void norm_act_bwd(const float* u, float* d, const flo
   for (int c = 0; c < C; ++c) d[c] = clamped ? d[c] * inv : inv * (d[c] - uh[c] * dot);
 }
 
+// Sum of the 16 four-lane blocks' 4 x 4 MFMA results: afterwards every lane (in particular lanes 0..3 = block 0, column j = lane) holds
+// the total in every register.  Two DPP row rotations (the 4 blocks of a 16-lane row), then gfx950's v_permlane16_swap /
+// v_permlane32_swap (tools/probe/blocks_sum.hip): all VALU.  As two __shfl_xor (ds_bpermute) per value -- a dependent LDS round trip
+// each -- the flush of a weight-gradient kernel's ~50 values per wave took 10-17,000 clocks per workgroup, as much as a tile's work.
+// The additions pair the same operands in the same order as that form did: the sums are bit-identical.
+typedef float f32x4_sum __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4_sum blocks_sum(f32x4_sum v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float t = v[i];
+    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x124, 0xF, 0xF, false));  // row_ror:4
+    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xF, 0xF, false));  // row_ror:8
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_int(t), __float_as_int(t), false, false);  // rows 0 <-> 1, 2 <-> 3
+    t = __int_as_float(a[0]) + __int_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_int(t), __float_as_int(t), false, false);  // halves
+    v[i] = __int_as_float(b[0]) + __int_as_float(b[1]);
+  }
+  return v;
+}
+
 }  // namespace dq

@@ -58,24 +58,6 @@ struct Img {
 template <int ST>
 __device__ __forceinline__ constexpr int run_off(int s) { return s * ST + (s == RUN - 1 ? 4 : 0); }
 
-__device__ __forceinline__ float dpp_ror(float v, int ctrl4or8) {
-  const int x = __float_as_int(v);
-  return ctrl4or8 == 4 ? __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x124, 0xF, 0xF, false))
-                       : __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, false));
-}
-// sum of the 16 lane blocks' 4 x 4 results: afterwards lanes 0..3 (block 0, column j = lane) hold the total in every register
-__device__ __forceinline__ f32x4 blocks_sum(f32x4 v) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float t = v[i];
-    t += dpp_ror(t, 4);
-    t += dpp_ror(t, 8);   // every lane: the 4 blocks of its 16-lane row
-    t += __shfl_xor(t, 16, 64);
-    t += __shfl_xor(t, 32, 64);
-    v[i] = t;
-  }
-  return v;
-}
 
 }  // namespace
 
@@ -169,20 +151,30 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
     // (no load is predicated: the threads beyond the sample's last position read its last position and contribute zeros -- d out := 0)
     const int itc = live ? it : per_sample - 1;
     const int row = b * a.rows_per_sample + itc / n, p = itc % n;
-    const int64_t obase = ((int64_t)row * C) * n + p;
+    // addresses: wave-uniform (tensor + channel) base in scalar registers + ONE 32-bit byte offset per lane and tensor shape (the launcher
+    // checks every tensor stays below 4 GB); as 64-bit element indices per channel the address arithmetic of the 16 stores at the end
+    // of a tile alone took ~9,000 clocks
+    const unsigned boA = (((unsigned)row * C) * (unsigned)n + (unsigned)p) * 4u;  // (row, channel 0, p) of a (rows, C, n) tensor
+    const unsigned boB = (((unsigned)row * (unsigned)a.cinB) * (unsigned)n + (unsigned)p) * 4u;
+    auto ld = [&](const float* base, int c, unsigned boff) -> float {
+      return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + (size_t)c * n) + boff);
+    };
+    auto st = [&](float* base, int c, unsigned boff, float v) {
+      *reinterpret_cast<float*>(reinterpret_cast<char*>(base + (size_t)c * n) + boff) = v;
+    };
     const bool hasL = live && p > 0, hasR = live && p + 1 < n;
     // ---- every global read of the tile up front
     float dout[C], d[C], u[C], u1v[C], xa[C], xb[WR ? C : 1];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      dout[c] = a.dout[obase + (int64_t)c * n];
-      u[c] = a.u2[obase + (int64_t)c * n];
-      u1v[c] = a.u1[obase + (int64_t)c * n];
-      xa[c] = a.inA[obase + (int64_t)c * n];  // cinA == C
+      dout[c] = ld(a.dout, c, boA);
+      u[c] = ld(a.u2, c, boA);
+      u1v[c] = ld(a.u1, c, boA);
+      xa[c] = ld(a.inA, c, boA);  // cinA == C
     }
     if constexpr (WR) {
 #pragma unroll
-      for (int c = 0; c < C; ++c) xb[c] = c < a.cinB ? a.inB[((int64_t)row * a.cinB + c) * n + p] : 0.f;
+      for (int c = 0; c < C; ++c) xb[c] = c < a.cinB ? ld(a.inB, c, boB) : 0.f;
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) { dout[c] = live ? dout[c] : 0.f; d[c] = dout[c]; }
@@ -347,28 +339,42 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
           if constexpr (WR) ar[gi] = mfma4(wop(OTR + co * GI + gi), dout[co], ar[gi]);
         }
       }
+      DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 11);
       if (live) {
-        // the old values of dA / dB (a gradient tensor this launch is not the first writer of) are requested together before the first store
-        float v[4 * GI], oldv[4 * GI];
+        float v[4 * GI];
 #pragma unroll
         for (int gi = 0; gi < GI; ++gi)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             v[4 * gi + i] = (acc[gi][0][i] + acc[gi][1][i]) + (acc[gi][2][i] + (WR ? ar[gi][i] : dout[4 * gi + i]));
           }
+        // channels 0 .. C - 1 of cat(A, B) are A's (cinA == C), the rest B's.  The old values of a gradient tensor this launch is not the
+        // first writer of are requested together, before the first store.
+        if (a.dA) {
+          float oldv[C];
 #pragma unroll
-        for (int ci = 0; ci < 4 * GI; ++ci) {
-          float* dst = nullptr;
-          if (ci < a.cinA) { if (a.dA) dst = a.dA + ((int64_t)row * a.cinA + ci) * n + p; }
-          else if (ci < cin) { if (a.dB) dst = a.dB + ((int64_t)row * a.cinB + (ci - a.cinA)) * n + p; }
-          oldv[ci] = (dst && !(ci < a.cinA ? a.dA_store : a.dB_store)) ? *dst : 0.f;
+          for (int c = 0; c < C; ++c) oldv[c] = 0.f;
+          if (!a.dA_store) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) oldv[c] = ld(a.dA, c, boA);
+          }
+          DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 12);
+#pragma unroll
+          for (int c = 0; c < C; ++c) st(a.dA, c, boA, oldv[c] + v[c]);
         }
+        if constexpr (WR) {
+          if (a.dB) {
+            float oldv[C];
 #pragma unroll
-        for (int ci = 0; ci < 4 * GI; ++ci) {
-          float* dst = nullptr;
-          if (ci < a.cinA) { if (a.dA) dst = a.dA + ((int64_t)row * a.cinA + ci) * n + p; }
-          else if (ci < cin) { if (a.dB) dst = a.dB + ((int64_t)row * a.cinB + (ci - a.cinA)) * n + p; }
-          if (dst) *dst = oldv[ci] + v[ci];
+            for (int c = 0; c < C; ++c) oldv[c] = 0.f;
+            if (!a.dB_store) {
+#pragma unroll
+              for (int c = 0; c < C; ++c) oldv[c] = c < a.cinB ? ld(a.dB, c, boB) : 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+              if (c < a.cinB) st(a.dB, c, boB, oldv[c] + v[C + c]);
+          }
         }
       }
     }
@@ -488,6 +494,7 @@ int launch_res_bwd_wg(const ResBwdWg& a_in, hipStream_t s, ResWgReduce* red_out)
   ResBwdWg a = a_in;
   DQ_REQUIRE(res_wg_usable(a.n, a.C, a.cinA, a.cinB, a.rows_per_sample), "res_bwd_wg: unsupported shape");
   DQ_REQUIRE(a.rows % a.rows_per_sample == 0, "res_bwd_wg: rows must be a multiple of rows_per_sample");
+  DQ_REQUIRE((int64_t)a.rows * a.C * a.n * 4 < (1ll << 32), "res_bwd_wg: tensors of 4 GB or more are not built (32-bit byte offsets)");
   DQ_REQUIRE(a.wr || a.cinB == 0, "res_bwd_wg: identity residual needs C input channels");
   DQ_REQUIRE(a.dout && a.u1 && a.u2 && a.inA && (a.cinB == 0 || a.inB) && a.w1 && a.w2 && a.g1 && a.g2 && a.ss && a.part,
              "res_bwd_wg: missing operand");

@@ -36,6 +36,8 @@ st = buf.reshape(4096, 16).astype(np.int64)
 st = st[st[:, 0] > 0]
 print(f"id {ident}: {len(st)} workgroups")
 idx = [i for i in range(16) if (st[:, i] > 0).all()]
+med = {i: int(np.median(st[:, i] - st[:, 0])) for i in idx}
+idx.sort(key=lambda i: med[i] if i > 1 else i - 2)  # (stamps 0, 1: prologue; the rest in time order of the last tile)
 for a_, b_ in zip(idx, idx[1:]):
     d = st[:, b_] - st[:, a_]
     print(f"  stamp {a_:2d} -> {b_:2d}: {int(np.median(d)):8d} {int(d.max()):8d}")
