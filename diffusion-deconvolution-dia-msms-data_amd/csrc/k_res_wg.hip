@@ -42,6 +42,9 @@ __device__ __forceinline__ float lane_p1(float v) { return __int_as_float(__buil
 constexpr int pad4(int x) { return (x + 3) / 4 * 4; }
 
 constexpr int TILE = 256;
+#ifndef DQ_WG8_WAVES
+#define DQ_WG8_WAVES 2
+#endif
 constexpr int RUN = 16;  // consecutive positions a 4-lane block of the MFMA walks
 
 // LDS image of one C-channel operand over a tile: [position + 1 (one halo slot on either side)][channel], C = 8 padded to 12
@@ -62,7 +65,7 @@ __device__ __forceinline__ constexpr int run_off(int s) { return s * ST + (s == 
 }  // namespace
 
 template <int C, bool WR>
-__global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
+__global__ void __launch_bounds__(256, (C == 8 && WR) ? DQ_WG8_WAVES : 2) k_res_bwd_wg(ResBwdWg a) {
   using I = Img<C>;
   constexpr int ST = I::ST, CQ = C / 4;
   __shared__ __attribute__((aligned(16))) float i_du2[I::FLOATS], i_du1[I::FLOATS], i_a1[I::FLOATS], i_xa[I::FLOATS];
@@ -315,55 +318,58 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
 #endif
     DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 8);
     // ---- d x[ci][p] = sum_co sum_k W1[co][ci][k] dU1[co][p + 1 - k]  (+ residual branch) into dA / dB  (matrix pipe)
+    // The input-channel quads of cat(A, B) in two passes (A's, then B's): half the accumulators live at a time -- with all 2 C / 4 quads
+    // of a residual-conv block in flight the 8-channel instantiation needed 285 registers against the 256 of two waves per SIMD, and
+    // its spill reloads waited behind the tile's stores.
     if (a.dA || a.dB) {
-      f32x4 acc[GI][3], ar[GI];
 #pragma unroll
-      for (int gi = 0; gi < GI; ++gi) {
+      for (int pass = 0; pass < (WR ? 2 : 1); ++pass) {
+        f32x4 acc[CQ][3], ar[CQ];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) acc[gi][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        ar[gi] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+        for (int q4 = 0; q4 < CQ; ++q4) {
 #pragma unroll
-      for (int co = 0; co < C; ++co) {
-        const float dc = live ? da1[co] : 0.f;  // dU1
-        const float tp = lane_p1(dc), tm = lane_m1(dc);
-        const float dr = hasR ? tp : 0.f, dl = hasL ? tm : 0.f;
-#pragma unroll
-        for (int gi = 0; gi < GI; ++gi) {
-          // (every quad, also those beyond cin: their operands are the image's zero padding and their results are not stored -- a
-          // wave-uniform branch per quad made every group of four MFMAs its own basic block with its LDS reads waited for in place)
-          const int j = OT1 + (co * GI + gi) * 3;
-          acc[gi][0] = mfma4(wop(j + 0), dr, acc[gi][0]);
-          acc[gi][1] = mfma4(wop(j + 1), dc, acc[gi][1]);
-          acc[gi][2] = mfma4(wop(j + 2), dl, acc[gi][2]);
-          if constexpr (WR) ar[gi] = mfma4(wop(OTR + co * GI + gi), dout[co], ar[gi]);
+          for (int k = 0; k < 3; ++k) acc[q4][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+          ar[q4] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-      }
-      DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 11);
-      if (live) {
-        float v[4 * GI];
 #pragma unroll
-        for (int gi = 0; gi < GI; ++gi)
+        for (int co = 0; co < C; ++co) {
+          const float dc = live ? da1[co] : 0.f;  // dU1
+          const float tp = lane_p1(dc), tm = lane_m1(dc);
+          const float dr = hasR ? tp : 0.f, dl = hasL ? tm : 0.f;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            v[4 * gi + i] = (acc[gi][0][i] + acc[gi][1][i]) + (acc[gi][2][i] + (WR ? ar[gi][i] : dout[4 * gi + i]));
+          for (int q4 = 0; q4 < CQ; ++q4) {
+            // (every quad, also those beyond cin: their operands are the image's zero padding and their results are not stored -- a
+            // wave-uniform branch per quad made every group of four MFMAs its own basic block with its LDS reads waited for in place)
+            const int gi = pass * CQ + q4;
+            const int j = OT1 + (co * GI + gi) * 3;
+            acc[q4][0] = mfma4(wop(j + 0), dr, acc[q4][0]);
+            acc[q4][1] = mfma4(wop(j + 1), dc, acc[q4][1]);
+            acc[q4][2] = mfma4(wop(j + 2), dl, acc[q4][2]);
+            if constexpr (WR) ar[q4] = mfma4(wop(OTR + co * GI + gi), dout[co], ar[q4]);
           }
-        // channels 0 .. C - 1 of cat(A, B) are A's (cinA == C), the rest B's.  The old values of a gradient tensor this launch is not the
-        // first writer of are requested together, before the first store.
-        if (a.dA) {
-          float oldv[C];
-#pragma unroll
-          for (int c = 0; c < C; ++c) oldv[c] = 0.f;
-          if (!a.dA_store) {
-#pragma unroll
-            for (int c = 0; c < C; ++c) oldv[c] = ld(a.dA, c, boA);
-          }
-          DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 12);
-#pragma unroll
-          for (int c = 0; c < C; ++c) st(a.dA, c, boA, oldv[c] + v[c]);
         }
-        if constexpr (WR) {
-          if (a.dB) {
+        if (pass == 0) DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 11);
+        float v[C];
+#pragma unroll
+        for (int q4 = 0; q4 < CQ; ++q4)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[4 * q4 + i] = (acc[q4][0][i] + acc[q4][1][i]) + (acc[q4][2][i] + (WR ? ar[q4][i] : dout[4 * q4 + i]));
+        // The old values of a gradient tensor this launch is not the first writer of are requested together, before the first store.
+        if (pass == 0) {  // channels 0 .. C - 1 of cat(A, B) are A's (cinA == C)
+          if (live && a.dA) {
+            float oldv[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) oldv[c] = 0.f;
+            if (!a.dA_store) {
+#pragma unroll
+              for (int c = 0; c < C; ++c) oldv[c] = ld(a.dA, c, boA);
+            }
+            DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 12);
+#pragma unroll
+            for (int c = 0; c < C; ++c) st(a.dA, c, boA, oldv[c] + v[c]);
+          }
+        } else {
+          if (live && a.dB) {
             float oldv[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) oldv[c] = 0.f;
@@ -373,7 +379,7 @@ __global__ void __launch_bounds__(256, 2) k_res_bwd_wg(ResBwdWg a) {
             }
 #pragma unroll
             for (int c = 0; c < C; ++c)
-              if (c < a.cinB) st(a.dB, c, boB, oldv[c] + v[C + c]);
+              if (c < a.cinB) st(a.dB, c, boB, oldv[c] + v[c]);
           }
         }
       }
