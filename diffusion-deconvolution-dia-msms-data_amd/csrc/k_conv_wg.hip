@@ -71,7 +71,21 @@ __global__ void __launch_bounds__(256) k_conv_bwd_wg(ConvBwdWg a) {
   const int blk = lane >> 2, li = lane & 3;
   const int lby = img_at(blk * RUN + 1, STY) + li, lbx = img_at(blk * RUN + 1, STX) + li;
   const float* wlane = wl + li * 4;
-  auto wop = [&](int j) -> float { return wlane[(j >> 2) * 16 + (j & 3)]; };
+  // the transposed conv takes its weight operands as a stream of jobs in image order through a ring of RD 16-byte reads in flight
+  // (k_level.hip: left to the compiler one read is in flight, issued ~34 cycles before its use against an LDS latency of 64+)
+  constexpr int RD = 3;
+  struct WRing { float4 r[RD]; float4 cur; };
+  auto ldw = [&](int q) -> float4 { return *reinterpret_cast<const float4*>(wlane + q * 16); };
+  auto ring_start = [&](WRing& R) __attribute__((always_inline)) {
+#pragma unroll
+    for (int d = 0; d < RD; ++d) R.r[d] = ldw(d);  // (reads past the last job land in the position images behind the weight image)
+  };
+  auto wgroup = [&](WRing& R, int q) __attribute__((always_inline)) {  // makes group q (jobs 4 q .. 4 q + 3) current; groups are taken in order
+    R.cur = R.r[q % RD];
+    R.r[q % RD] = ldw(q + RD);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto wcur = [&](const WRing& R, int j) -> float { return (j & 3) == 0 ? R.cur.x : (j & 3) == 1 ? R.cur.y : (j & 3) == 2 ? R.cur.z : R.cur.w; };
   // this wave's weight-gradient jobs j = wv * JW + jj = (g * H + h) * K + k, and the bias sum of channel quad g == wv
   f32x4 aw[JW], ab = {0.f, 0.f, 0.f, 0.f};
   const float* pa[JW]; const float* pb[JW];
@@ -100,16 +114,19 @@ __global__ void __launch_bounds__(256) k_conv_bwd_wg(ConvBwdWg a) {
     const bool hasL = live && p > 0, hasR = live && p + 1 < n;
     const int p_in = PRE == LEVEL_PRE_DOWN ? 2 * p : (PRE == LEVEL_PRE_UP ? p >> 1 : p);
     float dy[C], v0[CP], v1[PRE == LEVEL_PRE_DOWN ? CP : 1];
+    // wave-uniform (tensor + channel) bases + one 32-bit byte offset per lane and tensor (the launcher checks the tensors stay below 4 GB)
+    const unsigned boY = (((unsigned)row * C) * (unsigned)n + (unsigned)p) * 4u;
+    const unsigned boX = (((unsigned)row * CP) * (unsigned)n_in + (unsigned)p_in) * 4u;
 #pragma unroll
-    for (int c = 0; c < C; ++c) dy[c] = a.dy[((int64_t)row * C + c) * n + p];
+    for (int c = 0; c < C; ++c) dy[c] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.dy + (size_t)c * n) + boY);
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
-      const float* s = a.in + ((int64_t)row * CP + c) * n_in + p_in;
+      const char* s = reinterpret_cast<const char*>(a.in + (size_t)c * n_in) + boX;
       if constexpr (PRE == LEVEL_PRE_DOWN) {
         const float2 v = *reinterpret_cast<const float2*>(s);
         v0[c] = v.x; v1[c] = v.y;
       } else {
-        v0[c] = *s;
+        v0[c] = *reinterpret_cast<const float*>(s);
       }
     }
 #pragma unroll
@@ -144,15 +161,35 @@ __global__ void __launch_bounds__(256) k_conv_bwd_wg(ConvBwdWg a) {
     __syncthreads();
     DQ_PSTAMP(200000 + C * 1000 + PRE * 100 + CP, 5);
     // ---- weight / bias gradient on the matrix pipe: lane block blk walks positions 16 blk .. 16 blk + 15 of the tile
-#pragma unroll 2  // (fully unrolled, the scheduler hoists all 2 x 16 x JW LDS reads and some instantiations need 390 registers)
-    for (int s = 0; s < RUN; ++s) {
-      const int oy = s * STY + (s == RUN - 1 ? 4 : 0), ox = s * STX + (s == RUN - 1 ? 4 : 0);
-      // (no wave-uniform `if` around a job: a branch per MFMA ends the basic block, every LDS read is then waited for right where it is
-      // issued, and the phase ran at one LDS latency per MFMA -- 22,000 clocks for 192 MFMAs at 16 channels.  A wave's surplus jobs
-      // recompute job 0 and are not flushed.)
+    // (no wave-uniform `if` around a job: a branch per MFMA ends the basic block, every LDS read is then waited for right where it is
+    // issued, and the phase ran at one LDS latency per MFMA -- 22,000 clocks for 192 MFMAs at 16 channels.  A wave's surplus jobs
+    // recompute job 0 and are not flushed.)  The operands of step s + 1 are read while step s multiplies; the scheduling barrier keeps
+    // the scheduler from hoisting all 16 steps' reads (390 registers in some instantiations) or sinking them next to their use.
+    {
+      float ca[JW], cb[JW], cbias;
+      const int bq = lby + 4 * (do_bias ? wv : 0);
 #pragma unroll
-      for (int jj = 0; jj < JW; ++jj) aw[jj] = mfma4(pa[jj][oy], pb[jj][ox], aw[jj]);
-      ab = mfma4(i_dy[lby + 4 * (do_bias ? wv : 0) + oy], 1.f, ab);
+      for (int jj = 0; jj < JW; ++jj) { ca[jj] = pa[jj][0]; cb[jj] = pb[jj][0]; }
+      cbias = i_dy[bq];
+#pragma unroll
+      for (int s = 0; s < RUN; ++s) {
+        float na[JW], nb[JW], nbias = 0.f;
+        if (s + 1 < RUN) {
+          const int oy = (s + 1) * STY + (s + 1 == RUN - 1 ? 4 : 0), ox = (s + 1) * STX + (s + 1 == RUN - 1 ? 4 : 0);
+#pragma unroll
+          for (int jj = 0; jj < JW; ++jj) { na[jj] = pa[jj][oy]; nb[jj] = pb[jj][ox]; }
+          nbias = i_dy[bq + oy];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj) aw[jj] = mfma4(ca[jj], cb[jj], aw[jj]);
+        ab = mfma4(cbias, 1.f, ab);
+        if (s + 1 < RUN) {
+#pragma unroll
+          for (int jj = 0; jj < JW; ++jj) { ca[jj] = na[jj]; cb[jj] = nb[jj]; }
+          cbias = nbias;
+        }
+      }
     }
     DQ_PSTAMP(200000 + C * 1000 + PRE * 100 + CP, 6);
     // ---- data gradient (transposed conv, registers + DPP shifts)
@@ -161,6 +198,8 @@ __global__ void __launch_bounds__(256) k_conv_bwd_wg(ConvBwdWg a) {
         f32x4 e0[H], e1[H], o0[H], o1[H];
 #pragma unroll
         for (int h = 0; h < H; ++h) e0[h] = e1[h] = o0[h] = o1[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        WRing R;
+        ring_start(R);
 #pragma unroll
         for (int co = 0; co < C; ++co) {
           const float tm = lane_m1(dy[co]), tp = lane_p1(dy[co]);
@@ -168,24 +207,26 @@ __global__ void __launch_bounds__(256) k_conv_bwd_wg(ConvBwdWg a) {
 #pragma unroll
           for (int h = 0; h < H; ++h) {
             const int j = (co * H + h) * 4;
-            e0[h] = mfma4(wop(j + 1), dy[co], e0[h]);
-            e1[h] = mfma4(wop(j + 3), dl, e1[h]);
-            o0[h] = mfma4(wop(j + 2), dy[co], o0[h]);
-            o1[h] = mfma4(wop(j + 0), dr, o1[h]);
+            wgroup(R, j >> 2);
+            e0[h] = mfma4(wcur(R, 1), dy[co], e0[h]);
+            e1[h] = mfma4(wcur(R, 3), dl, e1[h]);
+            o0[h] = mfma4(wcur(R, 2), dy[co], o0[h]);
+            o1[h] = mfma4(wcur(R, 0), dr, o1[h]);
           }
         }
         if (live) {
-          float2* dst[CP];
           float2 old[CP];
 #pragma unroll
-          for (int c = 0; c < CP; ++c) {
-            dst[c] = reinterpret_cast<float2*>(a.din + ((int64_t)row * CP + c) * n_in + p_in);
-            old[c] = a.accumulate ? *dst[c] : make_float2(0.f, 0.f);
+          for (int c = 0; c < CP; ++c) old[c] = make_float2(0.f, 0.f);
+          if (a.accumulate) {
+#pragma unroll
+            for (int c = 0; c < CP; ++c) old[c] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.din + (size_t)c * n_in) + boX);
           }
 #pragma unroll
           for (int c = 0; c < CP; ++c) {
             const int h = c >> 2, i = c & 3;
-            *dst[c] = make_float2(old[c].x + (e0[h][i] + e1[h][i]), old[c].y + (o0[h][i] + o1[h][i]));
+            *reinterpret_cast<float2*>(reinterpret_cast<char*>(a.din + (size_t)c * n_in) + boX) =
+                make_float2(old[c].x + (e0[h][i] + e1[h][i]), old[c].y + (o0[h][i] + o1[h][i]));
           }
         }
       } else {
@@ -194,6 +235,8 @@ __global__ void __launch_bounds__(256) k_conv_bwd_wg(ConvBwdWg a) {
         for (int h = 0; h < H; ++h)
 #pragma unroll
           for (int k = 0; k < 3; ++k) acc[h][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        WRing R;
+        ring_start(R);
 #pragma unroll
         for (int co = 0; co < C; ++co) {
           const float tm = lane_m1(dy[co]), tp = lane_p1(dy[co]);
@@ -201,9 +244,12 @@ __global__ void __launch_bounds__(256) k_conv_bwd_wg(ConvBwdWg a) {
 #pragma unroll
           for (int h = 0; h < H; ++h) {
             const int j = (co * H + h) * 3;
-            acc[h][0] = mfma4(wop(j + 0), dr, acc[h][0]);     // tap k reads dY[q + 1 - k]
-            acc[h][1] = mfma4(wop(j + 1), dy[co], acc[h][1]);
-            acc[h][2] = mfma4(wop(j + 2), dl, acc[h][2]);
+            if (((j + 0) & 3) == 0) wgroup(R, (j + 0) >> 2);
+            acc[h][0] = mfma4(wcur(R, j + 0), dr, acc[h][0]);     // tap k reads dY[q + 1 - k]
+            if (((j + 1) & 3) == 0) wgroup(R, (j + 1) >> 2);
+            acc[h][1] = mfma4(wcur(R, j + 1), dy[co], acc[h][1]);
+            if (((j + 2) & 3) == 0) wgroup(R, (j + 2) >> 2);
+            acc[h][2] = mfma4(wcur(R, j + 2), dl, acc[h][2]);
           }
         }
         float v[CP];
@@ -214,15 +260,15 @@ __global__ void __launch_bounds__(256) k_conv_bwd_wg(ConvBwdWg a) {
           for (int c = 0; c < CP; ++c) v[c] += lane_x1(v[c]);
         }
         if (live && (PRE != LEVEL_PRE_UP || (lane & 1) == 0)) {
-          float* dst[CP];
           float old[CP];
 #pragma unroll
-          for (int c = 0; c < CP; ++c) {
-            dst[c] = a.din + ((int64_t)row * CP + c) * n_in + p_in;
-            old[c] = a.accumulate ? *dst[c] : 0.f;
+          for (int c = 0; c < CP; ++c) old[c] = 0.f;
+          if (a.accumulate) {
+#pragma unroll
+            for (int c = 0; c < CP; ++c) old[c] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.din + (size_t)c * n_in) + boX);
           }
 #pragma unroll
-          for (int c = 0; c < CP; ++c) *dst[c] = old[c] + v[c];
+          for (int c = 0; c < CP; ++c) *reinterpret_cast<float*>(reinterpret_cast<char*>(a.din + (size_t)c * n_in) + boX) = old[c] + v[c];
         }
       }
     }
@@ -278,6 +324,7 @@ int launch_conv_bwd_wg(const ConvBwdWg& a_in, hipStream_t s, ResWgReduce* red_ou
   ConvBwdWg a = a_in;
   DQ_REQUIRE(conv_wg_usable(a.C, a.pre, a.cp, a.n, a.rows_per_sample), "conv_bwd_wg: unsupported shape");
   DQ_REQUIRE(a.dy && a.in && a.w && a.part && a.dparams && a.rows % a.rows_per_sample == 0, "conv_bwd_wg: missing operand");
+  DQ_REQUIRE((int64_t)a.rows * std::max(a.C, a.cp) * std::max(a.n, 2) * 2 * 4 < (1ll << 32), "conv_bwd_wg: tensors of 4 GB or more are not built (32-bit byte offsets)");
   const int B = a.rows / a.rows_per_sample;
   const int K = a.pre == LEVEL_PRE_DOWN ? 4 : 3;
   int gx;
