@@ -240,7 +240,11 @@ int res_fwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, int 
 int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, float* dA, int cinA, const float* inB, float* dB, int cinB,
             int rows, int n, int rows_per_sample, int storeA = 0, int storeB = 0) {
   const float* dout = c.g(b.out);
-  if (b.wpart_floats && res_wg_usable(n, r.cout, cinA, cinB, rows_per_sample)) {
+  // (a block laid out for the fused weight-gradient kernel keeps no a1 tensor -- the arena assumes cat(x, skip) with x of cout channels, as
+  // everywhere in the network; another split of the same cin cannot be served from that layout)
+  DQ_REQUIRE(!b.wpart_floats || res_wg_usable(n, r.cout, cinA, cinB, rows_per_sample),
+             "ResnetBlock backward: the first input tensor must carry the block's output channel count (cat(x, skip) with x of cout channels)");
+  if (b.wpart_floats) {
     // wide m/z levels: the data path AND the block's weight gradients in one launch; its slots are summed by one launch per pass
     ResBwdWg k;
     k.dout = dout; k.u1 = c.w(b.u1); k.u2 = c.w(b.u2); k.inA = inA; k.inB = inB; k.cinA = cinA; k.cinB = cinB;

@@ -42,9 +42,6 @@ __device__ __forceinline__ float lane_p1(float v) { return __int_as_float(__buil
 constexpr int pad4(int x) { return (x + 3) / 4 * 4; }
 
 constexpr int TILE = 256;
-#ifndef DQ_WG8_WAVES
-#define DQ_WG8_WAVES 2
-#endif
 constexpr int RUN = 16;  // consecutive positions a 4-lane block of the MFMA walks
 
 // LDS image of one C-channel operand over a tile: [position + 1 (one halo slot on either side)][channel], C = 8 padded to 12
@@ -53,7 +50,7 @@ constexpr int RUN = 16;  // consecutive positions a 4-lane block of the MFMA wal
 // an odd multiple of 4 modulo the 32 banks of a 4-byte LDS read.
 template <int C>
 struct Img {
-  static constexpr int ST = C == 4 ? 4 : C + 4;
+  static constexpr int ST = C == 4 ? 4 : (C == 8 ? 12 : 20);  // (floats per position: an odd number of 16-byte slots)
   static constexpr int FLOATS = (TILE + 2) * ST + ((TILE + 2) / RUN + 1) * 4;
   __device__ static __forceinline__ int at(int q) { return q * ST + (q >> 4) * 4; }  // q = position in the tile + 1
 };
@@ -65,12 +62,19 @@ __device__ __forceinline__ constexpr int run_off(int s) { return s * ST + (s == 
 }  // namespace
 
 template <int C, bool WR>
-__global__ void __launch_bounds__(256, (C == 8 && WR) ? DQ_WG8_WAVES : 2) k_res_bwd_wg(ResBwdWg a) {
+__global__ void __launch_bounds__(256, C >= 12 ? 1 : 2) k_res_bwd_wg(ResBwdWg a) {
   using I = Img<C>;
   constexpr int ST = I::ST, CQ = C / 4;
-  __shared__ __attribute__((aligned(16))) float i_du2[I::FLOATS], i_du1[I::FLOATS], i_a1[I::FLOATS], i_xa[I::FLOATS];
-  __shared__ __attribute__((aligned(16))) float i_xb[WR ? I::FLOATS : 4], i_do[WR ? I::FLOATS : 4];
-  __shared__ float red[4][4 * C];
+  // (dynamic LDS: 12 / 16 channels need 84 - 140 KB -- one workgroup per CU, whose 512 registers per lane the 47 accumulator quads of a
+  // 16-channel block with a residual conv need anyway)
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  float* i_du2 = lds_all;
+  float* i_du1 = i_du2 + I::FLOATS;
+  float* i_a1 = i_du1 + I::FLOATS;
+  float* i_xa = i_a1 + I::FLOATS;
+  float* i_xb = i_xa + I::FLOATS;
+  float* i_do = i_xb + (WR ? I::FLOATS : 4);
+  float (*red)[4 * C] = reinterpret_cast<float (*)[4 * C]>(i_do + (WR ? I::FLOATS : 4));
   // operand image of the TRANSPOSED convolutions of the data path, [job / 4][lane & 3][job % 4]:
   //   T2: job (co, g, k)  = W2[co][4 g + li][k]      (d a1: C output channels = input channels of conv2)
   //   T1: job (co, gi, k) = W1[co][4 gi + li][k]     (d x: cin channels, gi < GI quads of cat(A, B))
@@ -78,8 +82,8 @@ __global__ void __launch_bounds__(256, (C == 8 && WR) ? DQ_WG8_WAVES : 2) k_res_
   constexpr int GI = WR ? 2 * CQ : CQ;
   constexpr int JT2 = C * CQ * 3, JT1 = C * GI * 3, JTR = WR ? C * GI : 0;
   constexpr int OT1 = pad4(JT2), OTR = OT1 + pad4(JT1), JTT = OTR + pad4(JTR);
-  __shared__ __attribute__((aligned(16))) float wl[JTT * 4];
-  __shared__ __attribute__((aligned(16))) float prm[4 * C];  // g2 | g1 | scale | shift (this sample's): no global reads of them inside the tile loop
+  float* wl = reinterpret_cast<float*>(red) + 4 * 4 * C;   // JTT * 4 floats
+  float* prm = wl + JTT * 4;  // 4 C floats: g2 | g1 | scale | shift (this sample's): no global reads of them inside the tile loop
   const int cin = a.cinA + a.cinB;  // C (identity residual) or C + cinB, cinB in {4, .., C} (checked by the launcher)
   DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 0);
   for (int idx = threadIdx.x; idx < JTT * 4; idx += 256) {
@@ -135,10 +139,24 @@ __global__ void __launch_bounds__(256, (C == 8 && WR) ? DQ_WG8_WAVES : 2) k_res_
   const bool v_10 = doW1 && h10 < cinq, v_11 = doW1 && h11 >= 0 && h11 < cinq;
   auto ximg = [&](int h) -> const float* { return (h < CQ || !WR ? i_xa + 4 * (h < CQ ? h : 0) : i_xb + 4 * (h - CQ)) + lb; };
 
-  f32x4 aW2[3], aWr[2], aW1[2][3], aB2 = {0.f, 0.f, 0.f, 0.f}, aBr = aB2, aB1 = aB2;
+  // 12 / 16 channels (WIDE): wave = output-channel quad (12 channels: the fourth wave repeats quad 0 and is not flushed); it runs every
+  // input-channel quad of dW2 (CQ), dWr and dW1 (GI of cat(A, B)).  Rows of any power-of-two length <= 64: the taps' zero padding per step
+  // and lane from the position's place in its row.
+  constexpr bool WIDE = C >= 12;
+  constexpr int NQ2 = WIDE ? CQ : 1, NQ1 = WIDE ? GI : 2;
+  const int gw = WIDE ? (wv < CQ ? wv : 0) : g;   // this wave's output-channel quad
+  const bool w_on = !WIDE || wv < CQ;             // its accumulators are flushed
+  f32x4 aW2[NQ2][3], aWr[NQ1], aW1[NQ1][3], aB2 = {0.f, 0.f, 0.f, 0.f}, aBr = aB2, aB1 = aB2;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { aW2[k] = aB2; aW1[0][k] = aB2; aW1[1][k] = aB2; }
-  aWr[0] = aB2; aWr[1] = aB2;
+  for (int h = 0; h < NQ2; ++h)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) aW2[h][k] = aB2;
+#pragma unroll
+  for (int h = 0; h < NQ1; ++h) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) aW1[h][k] = aB2;
+    aWr[h] = aB2;
+  }
   float dg2[C], dg1[C], dsc[C], dsh[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) dg2[c] = dg1[c] = dsc[c] = dsh[c] = 0.f;
@@ -212,6 +230,42 @@ __global__ void __launch_bounds__(256, (C == 8 && WR) ? DQ_WG8_WAVES : 2) k_res_
     DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 3);
     // ---- matrix pipe: dW2 (+ db2), dWr (+ dbr)
 #ifndef DQ_WG_V_NOMFMA
+    if constexpr (WIDE) {
+      // zero padding of the outer taps: position 16 blk + s is the first / last of its row (per lane; n is a power of two)
+      auto first_in_row = [&](int s) { return ((blk * RUN + s) & (n - 1)) == 0; };
+      auto last_in_row = [&](int s) { return ((blk * RUN + s) & (n - 1)) == n - 1; };
+      {
+        const float* A = i_du2 + lb + 4 * gw;
+        float bprev[CQ], bcur[CQ];
+#pragma unroll
+        for (int h = 0; h < CQ; ++h) { bprev[h] = (i_a1 + lb + 4 * h)[-ST]; bcur[h] = (i_a1 + lb + 4 * h)[0]; }
+#pragma unroll
+        for (int s = 0; s < RUN; ++s) {
+          const float av = A[run_off<ST>(s)];
+          const bool fl = first_in_row(s), ll = last_in_row(s);
+#pragma unroll
+          for (int h = 0; h < CQ; ++h) {
+            const float* Bp = i_a1 + lb + 4 * h;
+            const float bnext = s + 1 < RUN ? Bp[run_off<ST>(s + 1 < RUN ? s + 1 : s)] : Bp[RUN * ST + 4];
+            aW2[h][0] = mfma4(av, fl ? 0.f : bprev[h], aW2[h][0]);
+            aW2[h][1] = mfma4(av, bcur[h], aW2[h][1]);
+            aW2[h][2] = mfma4(av, ll ? 0.f : bnext, aW2[h][2]);
+            bprev[h] = bcur[h]; bcur[h] = bnext;
+          }
+          aB2 = mfma4(av, 1.f, aB2);
+        }
+      }
+      if constexpr (WR) {
+        const float* A = i_do + lb + 4 * gw;
+#pragma unroll
+        for (int s = 0; s < RUN; ++s) {
+          const float av = A[run_off<ST>(s)];
+#pragma unroll
+          for (int h = 0; h < GI; ++h) aWr[h] = mfma4(av, (h < CQ ? i_xa + 4 * h : i_xb + 4 * (h - CQ))[lb + run_off<ST>(s)], aWr[h]);
+          aBr = mfma4(av, 1.f, aBr);
+        }
+      }
+    } else {
     if (doW2) {
       const float* A = i_du2 + lb + 4 * g;
       const float* Bp = i_a1 + lb + 4 * hW2;
@@ -223,9 +277,9 @@ __global__ void __launch_bounds__(256, (C == 8 && WR) ? DQ_WG8_WAVES : 2) k_res_
         float b0 = bprev, b2 = bnext;
         if (s == 8) b0 = n8 ? 0.f : b0;
         if (s == 7) b2 = n8 ? 0.f : b2;
-        aW2[0] = mfma4(av, b0, aW2[0]);
-        aW2[1] = mfma4(av, bcur, aW2[1]);
-        aW2[2] = mfma4(av, b2, aW2[2]);
+        aW2[0][0] = mfma4(av, b0, aW2[0][0]);
+        aW2[0][1] = mfma4(av, bcur, aW2[0][1]);
+        aW2[0][2] = mfma4(av, b2, aW2[0][2]);
         aB2 = mfma4(av, 1.f, aB2);  // (every wave that runs this phase: flushed only where doB2 -- no branch per MFMA, k_conv_wg.hip)
         bprev = bcur; bcur = bnext;
       }
@@ -244,6 +298,7 @@ __global__ void __launch_bounds__(256, (C == 8 && WR) ? DQ_WG8_WAVES : 2) k_res_
       }
      }
     }
+    }  // narrow
 #endif
     DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 4);
     // ---- d a1[ci][p] = sum_co sum_k W2[co][ci][k] dU2[co][p + 1 - k]  (matrix pipe; tap k reads position p + 1 - k)
@@ -290,6 +345,32 @@ __global__ void __launch_bounds__(256, (C == 8 && WR) ? DQ_WG8_WAVES : 2) k_res_
     DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 7);
     // ---- matrix pipe: dW1 (+ db1)
 #ifndef DQ_WG_V_NOMFMA
+    if constexpr (WIDE) {
+      auto first_in_row = [&](int s) { return ((blk * RUN + s) & (n - 1)) == 0; };
+      auto last_in_row = [&](int s) { return ((blk * RUN + s) & (n - 1)) == n - 1; };
+      const float* A = i_du1 + lb + 4 * gw;
+      float xprev[GI], xcur[GI];
+#pragma unroll
+      for (int h = 0; h < GI; ++h) {
+        const float* X = (h < CQ ? i_xa + 4 * h : i_xb + 4 * (h - CQ)) + lb;
+        xprev[h] = X[-ST]; xcur[h] = X[0];
+      }
+#pragma unroll
+      for (int s = 0; s < RUN; ++s) {
+        const float av = A[run_off<ST>(s)];
+        const bool fl = first_in_row(s), ll = last_in_row(s);
+#pragma unroll
+        for (int h = 0; h < GI; ++h) {
+          const float* X = (h < CQ ? i_xa + 4 * h : i_xb + 4 * (h - CQ)) + lb;
+          const float xnext = s + 1 < RUN ? X[run_off<ST>(s + 1 < RUN ? s + 1 : s)] : X[RUN * ST + 4];
+          aW1[h][0] = mfma4(av, fl ? 0.f : xprev[h], aW1[h][0]);
+          aW1[h][1] = mfma4(av, xcur[h], aW1[h][1]);
+          aW1[h][2] = mfma4(av, ll ? 0.f : xnext, aW1[h][2]);
+          xprev[h] = xcur[h]; xcur[h] = xnext;
+        }
+        aB1 = mfma4(av, 1.f, aB1);
+      }
+    } else {
     if (doW1) {
       const float* A = i_du1 + lb + 4 * g;
       const float* X0 = ximg(v_10 ? h10 : 0);
@@ -315,6 +396,7 @@ __global__ void __launch_bounds__(256, (C == 8 && WR) ? DQ_WG8_WAVES : 2) k_res_
         p0 = c0; c0 = n0; p1 = c1; c1 = n1;
       }
     }
+    }  // narrow
 #endif
     DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 8);
     // ---- d x[ci][p] = sum_co sum_k W1[co][ci][k] dU1[co][p + 1 - k]  (+ residual branch) into dA / dB  (matrix pipe)
@@ -395,19 +477,38 @@ __global__ void __launch_bounds__(256, (C == 8 && WR) ? DQ_WG8_WAVES : 2) k_res_
     const f32x4 t = blocks_sum(acc);
     if (lane < 4) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) part[base + ((4 * g + i) * ld + 4 * h + lane) * kdim + k] = t[i];
+      for (int i = 0; i < 4; ++i) part[base + ((4 * gw + i) * ld + 4 * h + lane) * kdim + k] = t[i];
     }
   };
   auto put_b = [&](f32x4 acc, int base) {
     const f32x4 t = blocks_sum(acc);
     if (lane == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) part[base + 4 * g + i] = t[i];
+      for (int i = 0; i < 4; ++i) part[base + 4 * gw + i] = t[i];
     }
   };
+  if constexpr (WIDE) {
+    if (w_on) {  // wave-uniform
+#pragma unroll
+      for (int h = 0; h < CQ; ++h)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) put_w(aW2[h][k], oC2W, h, 3, k, C);
+      put_b(aB2, oC2B);
+#pragma unroll
+      for (int h = 0; h < GI; ++h) {
+        if (h < cinq) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) put_w(aW1[h][k], oC1W, h, 3, k, cin);
+          if constexpr (WR) put_w(aWr[h], oRW, h, 1, 0, cin);
+        }
+      }
+      put_b(aB1, oC1B);
+      if constexpr (WR) put_b(aBr, oRB);
+    }
+  } else {
   if (doW2) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) put_w(aW2[k], oC2W, hW2, 3, k, C);
+    for (int k = 0; k < 3; ++k) put_w(aW2[0][k], oC2W, hW2, 3, k, C);
   }
   if (doB2) put_b(aB2, oC2B);
   if (v_r0) put_w(aWr[0], oRW, hr0, 1, 0, cin);
@@ -422,6 +523,7 @@ __global__ void __launch_bounds__(256, (C == 8 && WR) ? DQ_WG8_WAVES : 2) k_res_
     for (int k = 0; k < 3; ++k) put_w(aW1[1][k], oC1W, h11, 3, k, cin);
   }
   if (doB1) put_b(aB1, oC1B);
+  }  // narrow
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     const float s0 = wave_sum(dg2[c]), s1 = wave_sum(dg1[c]), s2 = wave_sum(dsc[c]), s3 = wave_sum(dsh[c]);
@@ -473,9 +575,25 @@ __global__ void __launch_bounds__(256) k_res_wg_reduce(ResWgReduceMulti m) {
 }
 
 bool res_wg_usable(int n, int C, int cinA, int cinB, int rows_per_sample) {
-  // (rows of up to 64 positions: a row lives inside one wave, whose DPP shifts are the conv's neighbours)
-  return (C == 4 || C == 8) && n >= 8 && n <= 64 && (n & (n - 1)) == 0 && rows_per_sample > 1 && cinA == C &&
-         (cinB == 0 || (cinB % 4 == 0 && cinB <= C));
+  // (rows of up to 64 positions: a row lives inside one wave, whose DPP shifts are the conv's neighbours; 4 / 8 channels: rows of 8 or
+  // more, the run-of-16 walk of their weight-gradient phases special-cases only rows of 8)
+  if (!(C == 4 || C == 8 || C == 12 || C == 16)) return false;
+  // 12 / 16 channels (rows of 1..8 positions at the default widths): built and parity-tested, NOT the default -- measured inside the train
+  // step (B = 32) the 14 launches take 496 us against 279 us of k_res_bwd_cp + their weight-gradient launches on the side stream: one
+  // 256-position tile per workgroup leaves staging (15,000 clocks), the channel-strided loads of rows of 2 positions (28,000) and the flush of
+  // 47 accumulator quads (24,000) with nothing to overlap them.  DQ_WG_WIDE=1 selects it (tests/test_blocks_gpu.py runs both).
+  static const bool wide_on = [] { const char* e = std::getenv("DQ_WG_WIDE"); return e && e[0] == '1'; }();
+  if (C >= 12 && !wide_on) return false;
+  const int nmin = C >= 12 ? 1 : 8;
+  return n >= nmin && n <= 64 && (n & (n - 1)) == 0 && rows_per_sample > 1 && cinA == C && (cinB == 0 || (cinB % 4 == 0 && cinB <= C));
+}
+
+template <int C, bool WR>
+static size_t res_wg_lds_bytes() {
+  constexpr int CQ = C / 4, GI = WR ? 2 * CQ : CQ;
+  constexpr int JT2 = C * CQ * 3, JT1 = C * GI * 3, JTR = WR ? C * GI : 0;
+  constexpr int JTT = pad4(JT2) + pad4(JT1) + pad4(JTR);
+  return sizeof(float) * ((size_t)(WR ? 6 : 4) * Img<C>::FLOATS + (WR ? 0 : 8) + 16 * C + (size_t)JTT * 4 + 4 * C);
 }
 
 // grid of a launch: a workgroup takes `tpb` consecutive tiles of one sample; about 1024 workgroups in all (one resident round at
@@ -508,16 +626,21 @@ int launch_res_bwd_wg(const ResBwdWg& a_in, hipStream_t s, ResWgReduce* red_out)
   int gx;
   res_wg_grid(B, a.rows_per_sample, a.n, &a.tiles_ps, &a.tpb, &gx);
   const bool wr = a.wr != nullptr;
-  // ONE resident round: with more workgroups than the CUs hold (2-4 each: the LDS images), the few left over ran as a second round
+  // ONE resident round: with more workgroups than the CUs hold (1-4 each: the LDS images), the few left over ran as a second round
   // behind the first -- up to twice the time.  More tiles per workgroup instead (never fewer than the arena's slot count assumes).
+  const void* fn = nullptr;
+  size_t lds = 0;
+#define DQ_WGK(CC, WW) if (a.C == CC && wr == WW) { fn = (const void*)k_res_bwd_wg<CC, WW>; lds = res_wg_lds_bytes<CC, WW>(); }
+  DQ_WGK(4, true) DQ_WGK(4, false) DQ_WGK(8, true) DQ_WGK(8, false) DQ_WGK(12, true) DQ_WGK(12, false) DQ_WGK(16, true) DQ_WGK(16, false)
+#undef DQ_WGK
+  DQ_REQUIRE(fn && lds <= 160 * 1024, "res_bwd_wg: no kernel for this shape");
   {
-    static int occ[2][2] = {{0, 0}, {0, 0}};
-    int& o = occ[a.C == 8][wr];
+    static int occ[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    int& o = occ[a.C / 4 - 1][wr];
     if (!o) {
+      if (lds > 48 * 1024) DQ_HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       int nb = 0;
-      const void* fn = a.C == 4 ? (wr ? (const void*)k_res_bwd_wg<4, true> : (const void*)k_res_bwd_wg<4, false>)
-                                : (wr ? (const void*)k_res_bwd_wg<8, true> : (const void*)k_res_bwd_wg<8, false>);
-      DQ_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0));
+      DQ_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, lds));
       o = std::max(1, std::min(nb, 6));
     }
     int dev = 0;
@@ -531,13 +654,9 @@ int launch_res_bwd_wg(const ResBwdWg& a_in, hipStream_t s, ResWgReduce* red_out)
   a.nv = res_wg_nv(a.C, a.cinA + a.cinB, wr);
   DQ_REQUIRE(a.part_floats >= (int64_t)gx * B * a.nv, "res_bwd_wg: slot scratch too small");
   dim3 grid(gx, B), block(256);
-  if (a.C == 4) {
-    if (wr) hipLaunchKernelGGL((k_res_bwd_wg<4, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_res_bwd_wg<4, false>), grid, block, 0, s, a);
-  } else {
-    if (wr) hipLaunchKernelGGL((k_res_bwd_wg<8, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_res_bwd_wg<8, false>), grid, block, 0, s, a);
-  }
+#define DQ_WGL(CC, WW) if (a.C == CC && wr == WW) hipLaunchKernelGGL((k_res_bwd_wg<CC, WW>), grid, block, lds, s, a);
+  DQ_WGL(4, true) DQ_WGL(4, false) DQ_WGL(8, true) DQ_WGL(8, false) DQ_WGL(12, true) DQ_WGL(12, false) DQ_WGL(16, true) DQ_WGL(16, false)
+#undef DQ_WGL
   DQ_LAUNCH_CHECK();
   if (red_out) {
     ResWgReduce r;

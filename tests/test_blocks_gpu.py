@@ -149,7 +149,11 @@ def test_resnet_block_fixture_forward(N, golden, name, split):
 
 @pytest.mark.parametrize("cin,cout,n,rows,rps,split", [(4, 4, 64, 70, 35, 0), (8, 8, 32, 40, 20, 0), (16, 8, 16, 36, 12, 8), (24, 12, 4, 150, 50, 12),
                                                        (32, 16, 1, 66, 33, 16), (8, 4, 64, 26, 13, 4), (16, 16, 96, 2, 1, 0), (16, 16, 400, 3, 1, 0),
-                                                       (12, 8, 8, 90, 45, 8), (8, 8, 8, 64, 32, 0), (8, 4, 32, 48, 24, 4), (16, 8, 256, 6, 3, 8)])
+                                                       (12, 8, 8, 90, 45, 8), (8, 8, 8, 64, 32, 0), (8, 4, 32, 48, 24, 4), (16, 8, 256, 6, 3, 8),
+                                                       # 12 / 16 channels with the weight gradients in the same launch (k_res_bwd_wg, wide path):
+                                                       # identity residual, narrower skip than the block, several tiles per sample, rows of 1..8
+                                                       (12, 12, 8, 66, 33, 0), (16, 16, 2, 130, 65, 0), (28, 16, 2, 160, 80, 16), (16, 12, 8, 70, 35, 12),
+                                                       (24, 12, 8, 200, 100, 12), (32, 16, 4, 300, 150, 16), (16, 16, 1, 600, 300, 0)])
 def test_resnet_block_backward_vs_oracle_autograd(N, cin, cout, n, rows, rps, split):
     """every dispatch of the ResnetBlock (fused m/z-row kernels, channel-parallel deep levels, the step-by-step bottleneck path
     with rows_per_sample = 1): forward, dX, all weight gradients and d(scale, shift) against autograd over the oracle"""
