@@ -163,7 +163,7 @@ def roofline_hbm_kernels(device):
     x = torch.randn(rows, C, n, generator=g).to(device)
     temb = torch.randn(SAMPLE_BATCH, 16, generator=g).to(device)
     o0, o1 = torch.empty_like(x), torch.empty_like(x)
-    wsl = torch.empty(2 * SAMPLE_BATCH * 2 * C, device=device)
+    wsl = torch.empty(2 * SAMPLE_BATCH * 2 * C + 8256, device=device)  # (+ room for the prepared operand image: the network path's staging)
 
     def lvl():
         N.check(L.dq_level_fwd(N.ptr(params), 0, N.ptr(x), C, None, None, 0, N.ptr(temb), N.ptr(o0), N.ptr(o1), C, 2, rows, n, RT, N.ptr(wsl), wsl.numel(),
@@ -171,7 +171,7 @@ def roofline_hbm_kernels(device):
 
     t = time_kernel(lvl)  # (the two 3-us k_ss_heads launches of the entry point ride along)
     by = 12 * n * 4 * rows
-    tr, src = pmc_traffic("k_level_fwd<4, 0, 4>")
+    tr, src = pmc_traffic("k_level_fwd<4, 0, 4,")
     out["sample"] = {"bound": "hbm", "kernel": "k_level_fwd<4,0,4>: both ResnetBlocks of down level 0 in one launch, batch 512", "rows": rows,
                      "launch_us": round(t * 1e6, 2), "achieved": round(by / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(by / t / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": by, "traffic": tr, "traffic_source": src}

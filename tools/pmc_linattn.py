@@ -37,7 +37,7 @@ for _ in range(5):
 SB = 512
 params = (torch.randn(L.dq_level_param_floats(0, 4, 4, 0, 2), generator=g) * 0.3).cuda()
 xl = torch.randn(SB * RT, 4, n, generator=g).cuda(); tl = torch.randn(SB, 16, generator=g).cuda()
-o0, o1 = torch.empty_like(xl), torch.empty_like(xl); wsl = torch.empty(2 * SB * 8, device="cuda")
+o0, o1 = torch.empty_like(xl), torch.empty_like(xl); wsl = torch.empty(2 * SB * 8 + 8256, device="cuda")
 for _ in range(3):
     N.check(L.dq_level_fwd(N.ptr(params), 0, N.ptr(xl), 4, None, None, 0, N.ptr(tl), N.ptr(o0), N.ptr(o1), 4, 2, SB * RT, n, RT, N.ptr(wsl), wsl.numel(), N.stream_ptr()), "lv")
 # calibration of FETCH_SIZE for 4-byte-per-lane reads: k_rmsnorm_fwd reads one tensor and writes one
