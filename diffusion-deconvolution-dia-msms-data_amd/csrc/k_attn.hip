@@ -18,6 +18,7 @@
 #include "dq_common.h"
 #include "dq_kernels.h"
 #include "dq_mfma.h"
+#include <cstdlib>
 
 namespace dq {
 
@@ -53,20 +54,24 @@ int launch_rope(float* qk, const float* freqs, int B, int64_t batch_stride, int 
 }
 
 // ---- operand tiles (32 channels of one head x 32 positions starting at p0; zero beyond RT)
+// No load is predicated: positions beyond RT read position RT - 1 and are zeroed by a select afterwards (a predicated load is a branch
+// around the load, and the loops below keep the NEXT block's tiles in flight while the current block multiplies).
 // rows = channel (registers: rmap(r, half)), col = position (lane & 31): 16 row loads, each coalesced over the lanes
 __device__ __forceinline__ f32x16 tile_ch_rows(const float* __restrict__ src, int RT, int p0, int col, int half, float mul) {
   f32x16 t;
   const int p = p0 + col;
   const bool ok = p < RT;
+  const float* s0 = src + (ok ? p : RT - 1);
+  const float m = ok ? mul : 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) t[r] = ok ? src[(int64_t)rmap(r, half) * RT + p] * mul : 0.f;
+  for (int r = 0; r < 16; ++r) t[r] = s0[(int64_t)rmap(r, half) * RT] * m;
   return t;
 }
 // rows = position (registers: p0 + rmap(r, half)), col = channel (lane & 31): 4 x 16-B loads per lane when RT % 4 == 0
 __device__ __forceinline__ f32x16 tile_pos_rows(const float* __restrict__ src, int RT, int p0, int col, int half, float mul) {
   f32x16 t;
   const float* row = src + (int64_t)col * RT;
-  if ((RT & 3) == 0 && p0 + 32 <= RT) {
+  if ((RT & 3) == 0 && p0 + 32 <= RT) {  // (wave-uniform)
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
       const float4 v = *reinterpret_cast<const float4*>(row + p0 + 8 * q4 + 4 * half);
@@ -76,7 +81,7 @@ __device__ __forceinline__ f32x16 tile_pos_rows(const float* __restrict__ src, i
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int p = p0 + rmap(r, half);
-      t[r] = p < RT ? row[p] * mul : 0.f;
+      t[r] = row[p < RT ? p : RT - 1] * (p < RT ? mul : 0.f);
     }
   }
   return t;
@@ -87,16 +92,25 @@ __device__ __forceinline__ f32x16 rows_scalar(const float* __restrict__ v, int R
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int p = p0 + rmap(r, half);
-    t[r] = p < RT ? v[p] : fill;
+    const float x = v[p < RT ? p : RT - 1];
+    t[r] = p < RT ? x : fill;
   }
   return t;
 }
 
-// ---- forward: wave = 32 queries of one (sample, head)
-__global__ void __launch_bounds__(64) k_attn_fwd(const float* __restrict__ q, int64_t q_bs, const float* __restrict__ k, int64_t k_bs,
-                                                 const float* __restrict__ v, int64_t v_bs, float* __restrict__ o,
-                                                 float* __restrict__ lse, int RT) {
-  const int lane = threadIdx.x, col = lane & 31, half = lane >> 5;
+// How many waves share one block of 32 queries (forward, dQ), each taking every NW-th key block: the sweep over the other side is a
+// serial chain of RT / 32 steps per wave, and at a training batch (32 samples x 4 heads x 13 blocks = 1664 waves on 1024 SIMDs) nothing
+// hides its latencies.  The next block's tiles are in flight while the current one multiplies (forward / dQ / dK,dV at batch 32: 48 / 70 /
+// 157 -> 44 / 62 / 130 us; the products themselves -- dependent chains of sixteen 64-cycle fp32 MFMAs -- bound the three launches at
+// 18 / 27 / 36 us).  With a sampling batch the grid fills the SIMDs many times over and one wave per block (no merge) is the form.
+// ---- forward: NW waves = the same 32 queries of one (sample, head); their online-softmax partials (m, l, O^T) meet in LDS and are
+// merged by wave 0 in wave order (fixed order: repeatable)
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) k_attn_fwd(const float* __restrict__ q, int64_t q_bs, const float* __restrict__ k, int64_t k_bs,
+                                                      const float* __restrict__ v, int64_t v_bs, float* __restrict__ o,
+                                                      float* __restrict__ lse, int RT) {
+  const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bh = blockIdx.y, b = bh >> 2, h = bh & 3;
   const int i0 = blockIdx.x * 32, i = i0 + col;
   const float* qb = q + b * q_bs + (int64_t)h * 32 * RT;
@@ -105,9 +119,13 @@ __global__ void __launch_bounds__(64) k_attn_fwd(const float* __restrict__ q, in
   const f32x16 Qt = tile_ch_rows(qb, RT, i0, col, half, ATT_SCALE);  // rows d, col i
   f32x16 Oa = {0};                                                   // rows e, col i
   float m = -INFINITY, l = 0.f;
-  for (int j0 = 0; j0 < RT; j0 += 32) {
-    const f32x16 Kt = tile_ch_rows(kb, RT, j0, col, half, 1.f);   // rows d, col j
-    const f32x16 Vx = tile_pos_rows(vb, RT, j0, col, half, 1.f);  // rows j, col e
+  const int jlast = (RT - 1) / 32 * 32;  // (prefetches past the end re-read the last block and are not used)
+  f32x16 Kn = tile_ch_rows(kb, RT, min(wv * 32, jlast), col, half, 1.f);   // rows d, col j
+  f32x16 Vn = tile_pos_rows(vb, RT, min(wv * 32, jlast), col, half, 1.f);  // rows j, col e
+  for (int j0 = wv * 32; j0 < RT; j0 += 32 * NW) {
+    const f32x16 Kt = Kn, Vx = Vn;
+    Kn = tile_ch_rows(kb, RT, min(j0 + 32 * NW, jlast), col, half, 1.f);
+    Vn = tile_pos_rows(vb, RT, min(j0 + 32 * NW, jlast), col, half, 1.f);
     f32x16 St = xty(Kt, Qt, f32x16{0});                           // rows j, col i
     float mx = -INFINITY;
 #pragma unroll
@@ -131,6 +149,32 @@ __global__ void __launch_bounds__(64) k_attn_fwd(const float* __restrict__ q, in
     for (int r = 0; r < 16; ++r) Oa[r] *= al;
     Oa = xty(Vx, St, Oa);  // rows e, col i
   }
+  if constexpr (NW > 1) {
+    __shared__ float part[NW - 1][18][64];
+    if (wv > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[wv - 1][r][lane] = Oa[r];
+      part[wv - 1][16][lane] = m;
+      part[wv - 1][17][lane] = l;
+    }
+    __syncthreads();
+    if (wv > 0) return;
+    float mt = m;  // (wave 0 always has key block 0: finite)
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w) mt = fmaxf(mt, part[w][16][lane]);
+    const float s0 = __builtin_amdgcn_exp2f((m - mt) * LOG2E);
+    l *= s0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Oa[r] *= s0;
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w) {
+      const float sw = __builtin_amdgcn_exp2f((part[w][16][lane] - mt) * LOG2E);  // (a wave without key blocks: m = -inf, weight 0)
+      l = fmaf(part[w][17][lane], sw, l);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Oa[r] = fmaf(part[w][r][lane], sw, Oa[r]);
+    }
+    m = mt;
+  }
   if (i < RT) {
     const float rl = 1.0f / l;
     float* ob = o + (int64_t)b * 128 * RT + (int64_t)h * 32 * RT;
@@ -140,21 +184,36 @@ __global__ void __launch_bounds__(64) k_attn_fwd(const float* __restrict__ q, in
   }
 }
 
+// waves per query / key block: four while the grid would leave SIMDs short of work, one otherwise
+// waves per query block.  Forward: four while the grid would leave SIMDs short of work (measured equal to one at batch 32: 44 us), one
+// otherwise.  dQ: one -- with four the launch went from 62 to 89 us at batch 32 (its 253 registers leave two waves per SIMD either way, and
+// the merge comes on top); the four-wave form stays selectable (DQ_ATTN_NW_Q=4, tests/test_blocks_gpu.py runs it).
+static int attn_split(int B, int RT, bool query_side) {
+  static const int env_f = [] { const char* e = std::getenv("DQ_ATTN_NW_F"); return e && (e[0] == '1' || e[0] == '4') ? e[0] - '0' : 0; }();
+  static const int env_q = [] { const char* e = std::getenv("DQ_ATTN_NW_Q"); return e && (e[0] == '1' || e[0] == '4') ? e[0] - '0' : 0; }();
+  if (query_side) return env_q ? env_q : 1;
+  if (env_f) return env_f;
+  return (int64_t)cdiv(RT, 32) * B * 4 < 8192 ? 4 : 1;
+}
+
 int launch_attn_fwd(const float* q, int64_t q_bs, const float* k, int64_t k_bs, const float* v, int64_t v_bs, float* o, float* lse,
                     int B, int RT, hipStream_t s) {
   if (B == 0 || RT == 0) return 0;
-  hipLaunchKernelGGL(k_attn_fwd, dim3(cdiv(RT, 32), B * 4), dim3(64), 0, s, q, q_bs, k, k_bs, v, v_bs, o, lse, RT);
+  if (attn_split(B, RT, false) == 4) hipLaunchKernelGGL(k_attn_fwd<4>, dim3(cdiv(RT, 32), B * 4), dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, o, lse, RT);
+  else hipLaunchKernelGGL(k_attn_fwd<1>, dim3(cdiv(RT, 32), B * 4), dim3(64), 0, s, q, q_bs, k, k_bs, v, v_bs, o, lse, RT);
   DQ_LAUNCH_CHECK();
   return 0;
 }
 
 // ---- backward, query side: delta_i = dO_i . O_i ; dQ_i = 32^-0.5 * sum_j P_ij (dP_ij - delta_i) K_j
-__global__ void __launch_bounds__(64) k_attn_bwd_q(const float* __restrict__ q, int64_t q_bs, const float* __restrict__ k,
-                                                   int64_t k_bs, const float* __restrict__ v, int64_t v_bs,
-                                                   const float* __restrict__ o, const float* __restrict__ d_o,
-                                                   const float* __restrict__ lse, float* __restrict__ delta,
-                                                   float* __restrict__ dq, int64_t dq_bs, int RT) {
-  const int lane = threadIdx.x, col = lane & 31, half = lane >> 5;
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) k_attn_bwd_q(const float* __restrict__ q, int64_t q_bs, const float* __restrict__ k,
+                                                        int64_t k_bs, const float* __restrict__ v, int64_t v_bs,
+                                                        const float* __restrict__ o, const float* __restrict__ d_o,
+                                                        const float* __restrict__ lse, float* __restrict__ delta,
+                                                        float* __restrict__ dq, int64_t dq_bs, int RT) {
+  const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bh = blockIdx.y, b = bh >> 2, h = bh & 3;
   const int i0 = blockIdx.x * 32, i = i0 + col;
   const float* qb = q + b * q_bs + (int64_t)h * 32 * RT;
@@ -162,6 +221,10 @@ __global__ void __launch_bounds__(64) k_attn_bwd_q(const float* __restrict__ q, 
   const float* vb = v + b * v_bs + (int64_t)h * 32 * RT;
   const float* ob = o + (int64_t)b * 128 * RT + (int64_t)h * 32 * RT;
   const float* dob = d_o + (int64_t)b * 128 * RT + (int64_t)h * 32 * RT;
+  const int jlast = (RT - 1) / 32 * 32;
+  f32x16 Kn = tile_ch_rows(kb, RT, min(wv * 32, jlast), col, half, 1.f);   // rows d, col j
+  f32x16 Vn = tile_ch_rows(vb, RT, min(wv * 32, jlast), col, half, 1.f);   // rows e, col j
+  f32x16 Xn = tile_pos_rows(kb, RT, min(wv * 32, jlast), col, half, 1.f);  // rows j, col d
   const f32x16 Qt = tile_ch_rows(qb, RT, i0, col, half, ATT_SCALE);  // rows d, col i
   const f32x16 dOt = tile_ch_rows(dob, RT, i0, col, half, 1.f);      // rows e, col i
   float dl = 0.f;
@@ -173,10 +236,11 @@ __global__ void __launch_bounds__(64) k_attn_bwd_q(const float* __restrict__ q, 
   }
   const float ls = i < RT ? lse[(int64_t)bh * RT + i] : INFINITY;
   f32x16 dQa = {0};  // rows d, col i
-  for (int j0 = 0; j0 < RT; j0 += 32) {
-    const f32x16 Kt = tile_ch_rows(kb, RT, j0, col, half, 1.f);   // rows d, col j
-    const f32x16 Vt = tile_ch_rows(vb, RT, j0, col, half, 1.f);   // rows e, col j
-    const f32x16 Kx = tile_pos_rows(kb, RT, j0, col, half, 1.f);  // rows j, col d
+  for (int j0 = wv * 32; j0 < RT; j0 += 32 * NW) {
+    const f32x16 Kt = Kn, Vt = Vn, Kx = Xn;
+    Kn = tile_ch_rows(kb, RT, min(j0 + 32 * NW, jlast), col, half, 1.f);
+    Vn = tile_ch_rows(vb, RT, min(j0 + 32 * NW, jlast), col, half, 1.f);
+    Xn = tile_pos_rows(kb, RT, min(j0 + 32 * NW, jlast), col, half, 1.f);
     f32x16 St = xty(Kt, Qt, f32x16{0});                           // rows j, col i
     const f32x16 dPt = xty(Vt, dOt, f32x16{0});                   // rows j, col i
 #pragma unroll
@@ -185,6 +249,19 @@ __global__ void __launch_bounds__(64) k_attn_bwd_q(const float* __restrict__ q, 
       St[r] = p * (dPt[r] - dl);  // dS^T
     }
     dQa = xty(Kx, St, dQa);
+  }
+  if constexpr (NW > 1) {
+    __shared__ float part[NW - 1][16][64];
+    if (wv > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[wv - 1][r][lane] = dQa[r];
+    }
+    __syncthreads();
+    if (wv > 0) return;
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dQa[r] += part[w][r][lane];
   }
   if (i < RT) {
     float* dqb = dq + b * dq_bs + (int64_t)h * 32 * RT;
@@ -195,21 +272,25 @@ __global__ void __launch_bounds__(64) k_attn_bwd_q(const float* __restrict__ q, 
 }
 
 // ---- backward, key side: dV_j = sum_i P_ij dO_i ; dK_j = 32^-0.5 * sum_i P_ij (dP_ij - delta_i) Q_i
-// Four waves per key block, each taking every fourth query block (the query loop of one wave is a serial chain of ~13 steps
-// with one or two waves per SIMD to hide it: 207 us at batch 32); the four partial (dK, dV) tiles meet in LDS and are summed
-// in wave order by wave 0 (fixed order: repeatable).
+// Four waves per key block, each taking every fourth query block with the next block's tiles in flight; the four partial (dK, dV) tiles
+// meet in LDS and are summed in wave order by wave 0 (fixed order: repeatable).
 __global__ void __launch_bounds__(256, 2) k_attn_bwd_kv(const float* __restrict__ q, int64_t q_bs, const float* __restrict__ k,
                                                      int64_t k_bs, const float* __restrict__ v, int64_t v_bs,
                                                      const float* __restrict__ d_o, const float* __restrict__ lse,
                                                      const float* __restrict__ delta, float* __restrict__ dk, int64_t dk_bs,
                                                      float* __restrict__ dv, int64_t dv_bs, int RT) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
+  const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bh = blockIdx.y, b = bh >> 2, h = bh & 3;
   const int j0 = blockIdx.x * 32, j = j0 + col;
   const float* qb = q + b * q_bs + (int64_t)h * 32 * RT;
   const float* kb = k + b * k_bs + (int64_t)h * 32 * RT;
   const float* vb = v + b * v_bs + (int64_t)h * 32 * RT;
   const float* dob = d_o + (int64_t)b * 128 * RT + (int64_t)h * 32 * RT;
+  const float* lsb = lse + (int64_t)bh * RT;
+  const float* dlb = delta + (int64_t)bh * RT;
+  const int ilast = (RT - 1) / 32 * 32;
+  f32x16 Qn = tile_ch_rows(qb, RT, min(wv * 32, ilast), col, half, ATT_SCALE), dOn = tile_ch_rows(dob, RT, min(wv * 32, ilast), col, half, 1.f);
   const f32x16 Kt = tile_ch_rows(kb, RT, j0, col, half, 1.f);  // rows d, col j
   const f32x16 Vt = tile_ch_rows(vb, RT, j0, col, half, 1.f);  // rows e, col j
   f32x16 dKa = {0}, dVa = {0};                                 // rows d / e, col j
@@ -218,9 +299,12 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_kv(const float* __restrict_
   __shared__ float acc_lds[3][2][16][64];  // partial (dK, dV) of waves 1..3
   float* ttile = ttiles[wv];
   for (int i0 = wv * 32; i0 < RT; i0 += 128) {
-    const f32x16 Qt = tile_ch_rows(qb, RT, i0, col, half, ATT_SCALE), dOt = tile_ch_rows(dob, RT, i0, col, half, 1.f);  // rows d / e, col i
-    const f32x16 lsr = rows_scalar(lse + (int64_t)bh * RT, RT, i0, half, INFINITY);  // exp(s - inf) = 0 masks the tail
-    const f32x16 dlr = rows_scalar(delta + (int64_t)bh * RT, RT, i0, half, 0.f);
+    const f32x16 Qt = Qn, dOt = dOn;  // rows d / e, col i
+    // (the per-query scalars are requested here and first used behind the two score products: registers for their prefetch are not there)
+    const f32x16 lsr = rows_scalar(lsb, RT, i0, half, INFINITY);  // exp(s - inf) = 0 masks the tail
+    const f32x16 dlr = rows_scalar(dlb, RT, i0, half, 0.f);
+    Qn = tile_ch_rows(qb, RT, min(i0 + 128, ilast), col, half, ATT_SCALE);
+    dOn = tile_ch_rows(dob, RT, min(i0 + 128, ilast), col, half, 1.f);
     const f32x16 Qx = transpose_tile(Qt, ttile, col, half);    // rows i, col d
     const f32x16 dOx = transpose_tile(dOt, ttile, col, half);  // rows i, col e
     f32x16 S = xty(Qt, Kt, f32x16{0});              // rows i, col j
@@ -255,8 +339,9 @@ int launch_attn_bwd(const float* q, int64_t q_bs, const float* k, int64_t k_bs, 
                     const float* d_o, const float* lse, float* delta, float* dq, int64_t dq_bs, float* dk, int64_t dk_bs, float* dv,
                     int64_t dv_bs, int B, int RT, hipStream_t s) {
   if (B == 0 || RT == 0) return 0;
-  dim3 grid(cdiv(RT, 32), B * 4), block(64);
-  hipLaunchKernelGGL(k_attn_bwd_q, grid, block, 0, s, q, q_bs, k, k_bs, v, v_bs, o, d_o, lse, delta, dq, dq_bs, RT);
+  dim3 grid(cdiv(RT, 32), B * 4);
+  if (attn_split(B, RT, true) == 4) hipLaunchKernelGGL(k_attn_bwd_q<4>, grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, o, d_o, lse, delta, dq, dq_bs, RT);
+  else hipLaunchKernelGGL(k_attn_bwd_q<1>, grid, dim3(64), 0, s, q, q_bs, k, k_bs, v, v_bs, o, d_o, lse, delta, dq, dq_bs, RT);
   DQ_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_attn_bwd_kv, grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, d_o, lse, delta, dk, dk_bs, dv, dv_bs, RT);
   DQ_LAUNCH_CHECK();
