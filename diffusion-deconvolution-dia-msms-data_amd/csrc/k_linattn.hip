@@ -133,7 +133,9 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int c = la_chan(C, j, half);
-      X[blk][j] = (row_ok && c < C) ? a.x[((int64_t)row * C + c) * N + pos] : 0.f;
+      // (not predicated: rows beyond the last and the padding channels of the C = 12 register map read a valid element and are zeroed)
+      const float xv = a.x[((int64_t)(row_ok ? row : a.rows - 1) * C + (c < C ? c : 0)) * N + pos];
+      X[blk][j] = (row_ok && c < C) ? xv : 0.f;
       ssq = fmaf(X[blk][j], X[blk][j], ssq);
     }
     ssq += swap32(ssq);
