@@ -277,7 +277,14 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
       const LevelBlkK& r = a.blk[bi];
       const unsigned boff = (((row * r.cinB) << ln) + p) * 4u;
 #pragma unroll
-      for (int c = 0; c < C; ++c) xb[bi][c] = (bi < a.nblocks && c < r.cinB) ? ld(r.inB, c, boff) : 0.f;
+      for (int c = 0; c < C; ++c) xb[bi][c] = 0.f;
+      if (bi < a.nblocks && r.cinB > 0) {  // ONE wave-uniform branch around the group; inside it no load is predicated (channels beyond cinB re-read channel 0)
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float v = ld(r.inB, c < r.cinB ? c : 0, boff);
+          xb[bi][c] = c < r.cinB ? v : 0.f;
+        }
+      }
     };
     // ---------------------------------------------------------------- input stage
     if constexpr (PRE == LEVEL_PRE_NONE) {
@@ -419,17 +426,23 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
       }
       if (bi == 1) DQ_PSTAMP(C * 1000 + PRE * 100 + CP, 7);
       if (bi == 0 && a.nblocks > 1) load_skip(1);  // block 1's skip channels travel while block 0 computes
+      // (one wave-uniform branch per QUAD of skip channels -- cinB is a multiple of 4 -- not per channel: a branch ends the basic block and
+      // the operand reads in flight are waited for there; the skip channels are a prefix, the stream is never resumed after a skipped quad)
 #pragma unroll
-      for (int c = 0; c < C; ++c) {
-        if (c < r.cinB) {  // wave-uniform; the skip channels are a prefix: the stream is never resumed after a skipped channel
-          const float tm = lane_m1(xb[bi][c]), tp = lane_p1(xb[bi][c]);
-          const float xm = hasL ? tm : 0.f, xp = hasR ? tp : 0.f;
+      for (int cq = 0; cq < G; ++cq) {
+        if (4 * cq < r.cinB) {
 #pragma unroll
-          for (int g = 0; g < G; ++g) {
-            const int js = ((C + c) * G + g) * 3;
-            acc[g][0] = mfma4(wjob(R, J.c1[bi], js + 0), xm, acc[g][0]);
-            acc[g][1] = mfma4(wjob(R, J.c1[bi], js + 1), xb[bi][c], acc[g][1]);
-            acc[g][2] = mfma4(wjob(R, J.c1[bi], js + 2), xp, acc[g][2]);
+          for (int ci = 0; ci < 4; ++ci) {
+            const int c = 4 * cq + ci;
+            const float tm = lane_m1(xb[bi][c]), tp = lane_p1(xb[bi][c]);
+            const float xm = hasL ? tm : 0.f, xp = hasR ? tp : 0.f;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+              const int js = ((C + c) * G + g) * 3;
+              acc[g][0] = mfma4(wjob(R, J.c1[bi], js + 0), xm, acc[g][0]);
+              acc[g][1] = mfma4(wjob(R, J.c1[bi], js + 1), xb[bi][c], acc[g][1]);
+              acc[g][2] = mfma4(wjob(R, J.c1[bi], js + 2), xp, acc[g][2]);
+            }
           }
         }
       }
@@ -442,11 +455,15 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
 #pragma unroll
           for (int g = 0; g < G; ++g) ar[g][c & (NAR - 1)] = mfma4(wjob(R, J.rs[bi], c * G + g), x[c], ar[g][c & (NAR - 1)]);
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-          if (c < r.cinB) {
+        for (int cq = 0; cq < G; ++cq) {
+          if (4 * cq < r.cinB) {
 #pragma unroll
-            for (int g = 0; g < G; ++g)
-              ar[g][c & (NAR - 1)] = mfma4(wjob(R, J.rs[bi], (C + c) * G + g), xb[bi][c], ar[g][c & (NAR - 1)]);
+            for (int ci = 0; ci < 4; ++ci) {
+              const int c = 4 * cq + ci;
+#pragma unroll
+              for (int g = 0; g < G; ++g)
+                ar[g][c & (NAR - 1)] = mfma4(wjob(R, J.rs[bi], (C + c) * G + g), xb[bi][c], ar[g][c & (NAR - 1)]);
+            }
           }
         }
       }
