@@ -22,6 +22,7 @@
 #include "dq_common.h"
 #include "dq_kernels.h"
 #include "dq_mfma.h"
+#include "dq_probe.h"
 #include <algorithm>
 
 namespace dq {
@@ -58,8 +59,57 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   constexpr bool QUAD = N > 1 && N < 32 && !SEGM;  // masked quadratic form (rows of 2 / 4 positions)
   __shared__ float tiles[QUAD ? 4 : 1][QUAD ? 32 * 33 : 1];  // wave-private transpose tiles (quadratic form only)
   float* tile = tiles[QUAD ? (threadIdx.x >> 6) : 0];
+  DQ_PSTAMP(300000 + C * 100 + N, 0);
+  const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wv = threadIdx.x >> 6;
+  const int rl = N >= 32 ? 0 : col / N;
+  // ONE unit per wave.  (A wave walking several units of a resident grid, so that the weight staging below is paid once per resident
+  // block instead of once per four units, was measured: the sampling leg went from 879 back to 842 windows/s -- the many short
+  // blocks are what hides this kernel's latencies.)
+  const int unit = blockIdx.x * 4 + wv;
+  const int row = unit * RW + rl;
+  const bool row_ok = row < a.rows;
+  // The wave's x and the workgroup's weight images are requested TOGETHER, before anything waits: as "stage the weights in a loop, barrier,
+  // then load x" a workgroup spent 9,500 + 5,900 of its 40,400 clocks (<4,64>, batch 512) on three to five memory round trips in a row
+  // (the staging loops strode by blockDim.x, so the compiler could not unroll them: load -> store -> load ...).
+  float X[NB][NJ];
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk) {
+    const int pos = N >= 32 ? blk * 32 + col : col % N;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = la_chan(C, j, half);
+      // (not predicated: rows beyond the last and the padding channels of the C = 12 register map read a valid element and are zeroed)
+      const float xv = a.x[((int64_t)(row_ok ? row : a.rows - 1) * C + (c < C ? c : 0)) * N + pos];
+      X[blk][j] = (row_ok && c < C) ? xv : 0.f;
+    }
+  }
+  constexpr int WQ = 2 * 4 * NJ * 2 * 32;
+  __shared__ __attribute__((aligned(16))) float wqk_lds[N > 1 ? WQ : 4];
   if (a.prep) {
-    for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) w2_lds[i] = a.prep[i];
+    // prepared images (k_linattn_prepare): two linear 16-byte copies, every load of a thread in flight at once
+    constexpr int F2 = C * C, FQ = N > 1 ? WQ / 4 : 0;  // float4 counts (4 C C and WQ floats)
+    constexpr int N2 = (F2 + 255) / 256, NQ = (FQ + 255) / 256;
+    float4 v2[N2], vq[NQ > 0 ? NQ : 1];
+#pragma unroll
+    for (int u = 0; u < N2; ++u) {
+      const int i = u * 256 + (int)threadIdx.x;
+      v2[u] = reinterpret_cast<const float4*>(a.prep)[i < F2 ? i : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      const int i = u * 256 + (int)threadIdx.x;
+      vq[u] = reinterpret_cast<const float4*>(a.prep + 1024)[i < FQ ? i : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < N2; ++u) {
+      const int i = u * 256 + (int)threadIdx.x;
+      if (i < F2) reinterpret_cast<float4*>(w2_lds)[i] = v2[u];
+    }
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      const int i = u * 256 + (int)threadIdx.x;
+      if (i < FQ) reinterpret_cast<float4*>(wqk_lds)[i] = vq[u];
+    }
   } else {
     for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) {
       const int c = i % C, cp = (i / C) % C, hd = i / (C * C);
@@ -72,12 +122,8 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   // MFMA weight operands, laid out [q|k][head][j][half][col] so that a wave reads 2 x 32 consecutive floats; channels beyond C
   // are zero.  The rows carry log2(e): both softmaxes then use exp2 (v_exp_f32) directly, which changes nothing
   // mathematically (softmax(x) = 2^(x*log2e - max) / sum).
-  constexpr int WQ = 2 * 4 * NJ * 2 * 32;
-  __shared__ float wqk_lds[N > 1 ? WQ : 1];
   if (N > 1) {
-    if (a.prep) {
-      for (int i = threadIdx.x; i < WQ; i += blockDim.x) wqk_lds[i] = a.prep[1024 + i];
-    } else {
+    if (!a.prep) {
       for (int i = threadIdx.x; i < WQ; i += blockDim.x) {
         const int cc = i & 31, hh = (i >> 5) & 1, j = (i >> 6) % NJ, hd = (i / (64 * NJ)) & 3, m = i / (256 * NJ);
         const int c = la_chan(C, j, hh);
@@ -99,11 +145,10 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
     }
   }
   __syncthreads();
+  DQ_PSTAMP(300000 + C * 100 + N, 1);
 
-  const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wv = threadIdx.x >> 6;
   float* xs = xs_lds[wv];
   float* ms = ms_lds[wv];
-  const int rl = N >= 32 ? 0 : col / N;
   const float sqC = sqrtf((float)C);
   const float scale = 0.17677669529663687f;  // 32^-0.5
   bool bounded;  // (wave-uniform)
@@ -116,28 +161,15 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   } else {
     bounded = false;
   }
-  // ONE unit per wave.  (A wave walking several units of a resident grid, so that the weight staging above is paid once per resident
-  // block instead of once per four units, was measured: the sampling leg went from 879 back to 842 windows/s -- the many short
-  // blocks are what hides this kernel's latencies.)
-  const int unit = blockIdx.x * (blockDim.x >> 6) + wv;
   if (unit * RW >= a.rows) return;
-  const int row = unit * RW + rl;
-  const bool row_ok = row < a.rows;
 
-  // ---- load x, pre-norm; stage xh as [c][n] for the 4x4x1 A operands
-  float X[NB][NJ], Xh[NB][NJ];
+  // ---- pre-norm of x; stage xh as [c][n] for the 4x4x1 A operands
+  float Xh[NB][NJ];
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk) {
-    const int pos = N >= 32 ? blk * 32 + col : col % N;
     float ssq = 0.f;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int c = la_chan(C, j, half);
-      // (not predicated: rows beyond the last and the padding channels of the C = 12 register map read a valid element and are zeroed)
-      const float xv = a.x[((int64_t)(row_ok ? row : a.rows - 1) * C + (c < C ? c : 0)) * N + pos];
-      X[blk][j] = (row_ok && c < C) ? xv : 0.f;
-      ssq = fmaf(X[blk][j], X[blk][j], ssq);
-    }
+    for (int j = 0; j < NJ; ++j) ssq = fmaf(X[blk][j], X[blk][j], ssq);
     ssq += swap32(ssq);
     const float inv = sqC / fmaxf(sqrtf(ssq), RMS_EPS);
 #pragma unroll
@@ -149,6 +181,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   }
   wave_fence();
 
+  DQ_PSTAMP(300000 + C * 100 + N, 2);
   float yown[NB][NJ];  // (Wo out) of this lane's channels c' = la_chan(C, j, half)
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk)
@@ -363,6 +396,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
       add_w2(hd, 0, R, qs);
     }
   }
+  DQ_PSTAMP(300000 + C * 100 + N, 3);
 
   // ---- bias, post-norm, residual, store (this lane's channels c = la_chan(C, j, half)).  The gains and biases are read before the
   // first store: a load issued after a store waits for it, and the loop below would be 2 NJ serial round trips per block
@@ -396,6 +430,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
       }
     }
   }
+  DQ_PSTAMP(300000 + C * 100 + N, 4);
 }
 
 template <int C>
