@@ -57,6 +57,12 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 
+
+// Workgroup barrier that orders LDS accesses ONLY: this wave's LDS operations complete (lgkmcnt(0)), then s_barrier.  __syncthreads() is
+// a full fence -- the compiler puts s_waitcnt vmcnt(0) in front of it, so every global load in flight (a tile requested ahead, the next
+// unit's prefetch) is waited for at the barrier.  Use where only LDS data crosses waves.  (The "memory" clobber keeps the compiler from
+// moving memory accesses across it.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // 64-lane wave reductions (all lanes receive the result)
 // Sum over the 64 lanes, every lane receives it.  Inside a 16-lane row: four DPP adds (quad_perm swaps, then the two row
 // mirrors) -- no LDS; across the four rows: v_readlane of one lane per row.  The __shfl_xor butterfly this replaces is six

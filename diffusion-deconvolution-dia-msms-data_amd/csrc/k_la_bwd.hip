@@ -98,6 +98,9 @@ __device__ __forceinline__ float half_sum(float v) {
 // C = 8 with rows of 32 / 16 / 8 positions (measured with tools/probe/la_bwd_time.hip, 12,800 rows: <8,16> 183 -> 161 us with 44 B of
 // scratch per lane; C = 12 / 16 need 386 / 466 registers and keep one wave per SIMD).  The partner wave covers the latencies the
 // one-unit-ahead prefetch was there for, so those variants run without it.
+#ifndef DQ_LA_PF4
+#define DQ_LA_PF4 0
+#endif
 constexpr bool la_two_waves(int C, int N) { return C == 4 || (C == 8 && (N == 32 || N == 16 || N == 8)); }
 template <int C, int N>
 __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_bwd(LinAttnBwdK a) {
@@ -115,7 +118,7 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
   constexpr bool PARTNER = N >= 8;
   // C = 4 runs two waves per SIMD instead (the partner wave hides the latency); C = 16 and the 64-position C = 12 variant have
   // no registers to spare
-  constexpr bool PREFETCH = (C == 8 && !la_two_waves(C, N)) || (C == 12 && N < 64);
+  constexpr bool PREFETCH = DQ_LA_PF4 ? (C <= 8 || (C == 12 && N < 64)) : ((C == 8 && !la_two_waves(C, N)) || (C == 12 && N < 64));
   constexpr int CG = C / 4;      // channel groups of 4 (one 4x4x1 MFMA chain each)
   constexpr int NP = NB * 32;    // positions (lanes x blocks) of one unit
   static_assert(NB <= 2, "rows longer than 64 are not built");

@@ -24,6 +24,8 @@
 #include "dq_mfma.h"
 #include "dq_probe.h"
 #include <algorithm>
+#include <cstdlib>
+#include <algorithm>
 
 namespace dq {
 
@@ -52,7 +54,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   static_assert(NB <= 2, "rows longer than 64 take the two-pass path (k_la_long.hip)");
   static_assert(C % 4 == 0, "channel count must be a multiple of 4");
 
-  __shared__ __attribute__((aligned(16))) float w2_lds[4 * C * C];  // [head][c'][c] = sum_e Wo[c'][head*32+e] Wv[head*32+e][c]
+  __shared__ __attribute__((aligned(16))) float w2_lds[1024];  // [head][c'][c] = sum_e Wo[c'][head*32+e] Wv[head*32+e][c] (4 C C floats used; sized for one 16-byte copy per thread)
   __shared__ __attribute__((aligned(16))) float xs_lds[4][C * NP];  // per wave: xh as [c][n]
   constexpr int MS_ROW = C * 32 + 8;  // row stride of M: + 8 floats so that the rows of a unit start in different LDS banks
   __shared__ __attribute__((aligned(16))) float ms_lds[4][(SEGM ? RW : 1) * MS_ROW];  // per wave: M of the current head as [row][c][d]
@@ -60,57 +62,69 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   __shared__ float tiles[QUAD ? 4 : 1][QUAD ? 32 * 33 : 1];  // wave-private transpose tiles (quadratic form only)
   float* tile = tiles[QUAD ? (threadIdx.x >> 6) : 0];
   DQ_PSTAMP(300000 + C * 100 + N, 0);
+#ifdef DQ_KPROBE  // entry clocks of waves 1..3 (stamps 6..8): how far apart do the waves of a workgroup start?
+  if ((threadIdx.x & 63) == 0 && threadIdx.x > 0 && dq_kprobe_want == 300000 + C * 100 + N)
+    dq_kprobe_buf[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 16 + 5 + (threadIdx.x >> 6)] = clock64();
+#endif
   const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wv = threadIdx.x >> 6;
   const int rl = N >= 32 ? 0 : col / N;
-  // ONE unit per wave.  (A wave walking several units of a resident grid, so that the weight staging below is paid once per resident
-  // block instead of once per four units, was measured: the sampling leg went from 879 back to 842 windows/s -- the many short
-  // blocks are what hides this kernel's latencies.)
-  const int unit = blockIdx.x * 4 + wv;
-  const int row = unit * RW + rl;
-  const bool row_ok = row < a.rows;
+  // ONE unit per wave by default.  A wave can also walk the units unit0, unit0 + ustride, ... of one resident round of workgroups with the
+  // NEXT unit's x in flight while the current one is worked on (DQ_LA_FWD_OCC=<workgroups per CU>): in the network at batch 512 a wave spends
+  // 13,000 of its unit's 40,000 clocks at the top (the x loads take ~9,000 clocks to come back under that load), yet the walking form is
+  // SLOWER -- sampling 1,209 against 1,261 windows/s, as without the prefetch in round 2 (842 against 879): the SIMDs are ~80 % busy issuing
+  // (four waves each), the waiting wave costs them nothing, and the hardware's workgroup dispatch balances better than a fixed stride.
+  const int unit0 = blockIdx.x * 4 + wv, ustride = gridDim.x * 4;
   // The wave's x and the workgroup's weight images are requested TOGETHER, before anything waits: as "stage the weights in a loop, barrier,
   // then load x" a workgroup spent 9,500 + 5,900 of its 40,400 clocks (<4,64>, batch 512) on three to five memory round trips in a row
   // (the staging loops strode by blockDim.x, so the compiler could not unroll them: load -> store -> load ...).
-  float X[NB][NJ];
+  float Xn[NB][NJ], gpre_r[NJ], gout_r[NJ], bout_r[NJ];
+  // (requested BEHIND the prepared images' loads: the memory counter retires in order, so the wait for the images in front of their LDS
+  // stores would otherwise be a wait for x as well)
+  auto request_unit = [&](int unit) __attribute__((always_inline)) {  // x of `unit` -> Xn (raw: masked at its first use)
+    const int rq = unit * RW + rl;
+    const int rc = rq < a.rows ? rq : a.rows - 1;
 #pragma unroll
-  for (int blk = 0; blk < NB; ++blk) {
-    const int pos = N >= 32 ? blk * 32 + col : col % N;
+    for (int blk = 0; blk < NB; ++blk) {
+      const int pos = N >= 32 ? blk * 32 + col : col % N;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
+      for (int j = 0; j < NJ; ++j) {
+        const int c = la_chan(C, j, half);
+        // (not predicated: rows beyond the last and the padding channels of the C = 12 register map read a valid element and are zeroed)
+        Xn[blk][j] = a.x[((int64_t)rc * C + (c < C ? c : 0)) * N + pos];
+      }
+    }
+  };
+  auto request_x = [&]() __attribute__((always_inline)) {
+    request_unit(unit0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {  // (gains and bias of this lane's channels: once per wave, requested with the first unit's x)
       const int c = la_chan(C, j, half);
-      // (not predicated: rows beyond the last and the padding channels of the C = 12 register map read a valid element and are zeroed)
-      const float xv = a.x[((int64_t)(row_ok ? row : a.rows - 1) * C + (c < C ? c : 0)) * N + pos];
-      X[blk][j] = (row_ok && c < C) ? xv : 0.f;
+      gpre_r[j] = a.g_pre[c < C ? c : 0];
+      gout_r[j] = a.g_out[c < C ? c : 0];
+      bout_r[j] = a.b_out[c < C ? c : 0];
     }
-  }
+  };
+  float bflag = 0.f;
   constexpr int WQ = 2 * 4 * NJ * 2 * 32;
-  __shared__ __attribute__((aligned(16))) float wqk_lds[N > 1 ? WQ : 4];
+  __shared__ __attribute__((aligned(16))) float wqk_lds[N > 1 ? (WQ + 1023) / 1024 * 1024 : 4];  // (WQ floats used; whole 16-byte copies per thread)
   if (a.prep) {
-    // prepared images (k_linattn_prepare): two linear 16-byte copies, every load of a thread in flight at once
-    constexpr int F2 = C * C, FQ = N > 1 ? WQ / 4 : 0;  // float4 counts (4 C C and WQ floats)
-    constexpr int N2 = (F2 + 255) / 256, NQ = (FQ + 255) / 256;
-    float4 v2[N2], vq[NQ > 0 ? NQ : 1];
+    // prepared images (k_linattn_prepare): linear 16-byte copies, one (w2) + one or two (q | k operands) per thread, NO guard -- a guarded
+    // copy is a branch, the compiler sinks the load into it behind the x loads, and its wait becomes a wait for x.  (The slot holds 1024 +
+    // 4096 floats whatever C is; what lies beyond a layer's own images is copied along and never read.)
+    constexpr int NQ = N > 1 ? (WQ / 4 + 255) / 256 : 0;
+    const float4 v2 = reinterpret_cast<const float4*>(a.prep)[threadIdx.x];
+    float4 vq[NQ > 0 ? NQ : 1];
 #pragma unroll
-    for (int u = 0; u < N2; ++u) {
-      const int i = u * 256 + (int)threadIdx.x;
-      v2[u] = reinterpret_cast<const float4*>(a.prep)[i < F2 ? i : 0];
-    }
+    for (int u = 0; u < NQ; ++u) vq[u] = reinterpret_cast<const float4*>(a.prep + 1024)[u * 256 + (int)threadIdx.x];
+    bflag = a.prep[LA_PREP_BOUNDED];  // (also in front of x: read behind the barrier it was a full wait again)
+    request_x();
+    DQ_PSTAMP(300000 + C * 100 + N, 9);
+    reinterpret_cast<float4*>(w2_lds)[threadIdx.x] = v2;
 #pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-      const int i = u * 256 + (int)threadIdx.x;
-      vq[u] = reinterpret_cast<const float4*>(a.prep + 1024)[i < FQ ? i : 0];
-    }
-#pragma unroll
-    for (int u = 0; u < N2; ++u) {
-      const int i = u * 256 + (int)threadIdx.x;
-      if (i < F2) reinterpret_cast<float4*>(w2_lds)[i] = v2[u];
-    }
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-      const int i = u * 256 + (int)threadIdx.x;
-      if (i < FQ) reinterpret_cast<float4*>(wqk_lds)[i] = vq[u];
-    }
+    for (int u = 0; u < NQ; ++u) reinterpret_cast<float4*>(wqk_lds)[u * 256 + (int)threadIdx.x] = vq[u];
+    DQ_PSTAMP(300000 + C * 100 + N, 10);
   } else {
+    request_x();
     for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) {
       const int c = i % C, cp = (i / C) % C, hd = i / (C * C);
       float s = 0.f;
@@ -144,7 +158,10 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
       __syncthreads();
     }
   }
-  __syncthreads();
+  // Workgroup barrier for the LDS images only.  __syncthreads() is a full fence: it waits for vmcnt(0), i.e. for the x loads requested above --
+  // the barrier then cost a whole memory round trip (9,500 clocks at batch 512) whether or not anything was staged.
+  if (a.prep) lds_barrier();
+  else __syncthreads();
   DQ_PSTAMP(300000 + C * 100 + N, 1);
 
   float* xs = xs_lds[wv];
@@ -153,7 +170,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   const float scale = 0.17677669529663687f;  // 32^-0.5
   bool bounded;  // (wave-uniform)
   if (a.prep) {
-    bounded = a.prep[LA_PREP_BOUNDED] != 0.f;
+    bounded = __builtin_amdgcn_readfirstlane(__float_as_int(bflag)) != 0;  // (+-0.0f / 1.0f)
   } else if (N > 1) {
     float gm = 0.f;
     for (int c = 0; c < C; ++c) gm = fmaxf(gm, fabsf(a.g_pre[c]));
@@ -161,10 +178,27 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   } else {
     bounded = false;
   }
-  if (unit * RW >= a.rows) return;
-
-  // ---- pre-norm of x; stage xh as [c][n] for the 4x4x1 A operands
-  float Xh[NB][NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const bool ok = la_chan(C, j, half) < C;
+    gpre_r[j] = ok ? gpre_r[j] : 0.f;
+    gout_r[j] = ok ? gout_r[j] : 0.f;
+    bout_r[j] = ok ? bout_r[j] : 0.f;
+  }
+#pragma unroll 1
+  for (int unit = unit0; unit * RW < a.rows; unit += ustride) {
+  const int row = unit * RW + rl;
+  const bool row_ok = row < a.rows;
+  // ---- this unit's x (requested one unit ago); the next unit's is requested now; pre-norm; stage xh as [c][n] for the 4x4x1 A operands
+  float X[NB][NJ], Xh[NB][NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const bool ok = la_chan(C, j, half) < C;
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) X[blk][j] = (row_ok && ok) ? Xn[blk][j] : 0.f;
+  }
+  if ((unit + ustride) * RW < a.rows) request_unit(unit + ustride);  // (wave-uniform; never taken with one unit per wave)
+  wave_fence();                  // the previous unit's readers of xs / ms (this wave's own LDS reads) are done
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk) {
     float ssq = 0.f;
@@ -175,7 +209,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int c = la_chan(C, j, half);
-      Xh[blk][j] = X[blk][j] * inv * (c < C ? a.g_pre[c] : 0.f);
+      Xh[blk][j] = X[blk][j] * inv * gpre_r[j];
       if (c < C) xs[c * NP + blk * 32 + col] = Xh[blk][j];
     }
   }
@@ -400,13 +434,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
 
   // ---- bias, post-norm, residual, store (this lane's channels c = la_chan(C, j, half)).  The gains and biases are read before the
   // first store: a load issued after a store waits for it, and the loop below would be 2 NJ serial round trips per block
-  float gout_r[NJ], bout_r[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int c = la_chan(C, j, half);
-    gout_r[j] = c < C ? a.g_out[c] : 0.f;
-    bout_r[j] = c < C ? a.b_out[c] : 0.f;
-  }
+
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk) {
     const int pos = N >= 32 ? blk * 32 + col : col % N;
@@ -430,16 +458,33 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
       }
     }
   }
+  }  // unit
   DQ_PSTAMP(300000 + C * 100 + N, 4);
 }
 
+static int la_num_cus() {
+  static const int v = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+  return v;
+}
+static int la_fwd_occ_cap() {  // DQ_LA_FWD_OCC = n > 0: the forward as ONE resident round of n workgroups per CU whose waves walk several units (A-B switch; default 0: one unit per wave)
+  static const int v = [] { const char* e = std::getenv("DQ_LA_FWD_OCC"); return e ? std::atoi(e) : 0; }();
+  return v;
+}
 template <int C>
 static int linattn_fwd_n(const LinAttn& a, hipStream_t s) {
 #define DQ_LA(NN)                                                                      \
   case NN: {                                                                           \
     constexpr int RW = NN >= 32 ? 1 : 32 / NN;                                         \
     const int units = cdiv(a.rows, RW);                                                \
-    hipLaunchKernelGGL((k_linattn_fwd<C, NN>), dim3(cdiv(units, 4)), dim3(256), 0, s, a); \
+    static int occ = 0;                                                                \
+    if (!occ) {                                                                        \
+      int nb = 0;                                                                      \
+      DQ_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_linattn_fwd<C, NN>, 256, 0)); \
+      occ = std::max(1, nb);                                                           \
+    }                                                                                  \
+    const int cap = la_fwd_occ_cap();                                                  \
+    const int grid = cap <= 0 ? cdiv(units, 4) : std::min(cdiv(units, 4), std::min(occ, cap) * la_num_cus()); \
+    hipLaunchKernelGGL((k_linattn_fwd<C, NN>), dim3(grid), dim3(256), 0, s, a);        \
     break;                                                                             \
   }
   switch (a.n) {
