@@ -185,15 +185,16 @@ __global__ void __launch_bounds__(64 * NW) k_attn_fwd(const float* __restrict__ 
 }
 
 // waves per query / key block: four while the grid would leave SIMDs short of work, one otherwise
-// waves per query block.  Forward: four while the grid would leave SIMDs short of work (measured equal to one at batch 32: 44 us), one
-// otherwise.  dQ: one -- with four the launch went from 62 to 89 us at batch 32 (its 253 registers leave two waves per SIMD either way, and
-// the merge comes on top); the four-wave form stays selectable (DQ_ATTN_NW_Q=4, tests/test_blocks_gpu.py runs it).
+// waves per query block: ONE.  Four (each wave every fourth key block, partials merged in LDS) were measured at batch 32: forward 44 us
+// either way, dQ 62 -> 89 us (its 253 registers leave two waves per SIMD either way, and the merge comes on top).  The four-wave forms
+// stay selectable (DQ_ATTN_NW_F / DQ_ATTN_NW_Q = 4; tests/test_blocks_gpu.py is run with them).
 static int attn_split(int B, int RT, bool query_side) {
   static const int env_f = [] { const char* e = std::getenv("DQ_ATTN_NW_F"); return e && (e[0] == '1' || e[0] == '4') ? e[0] - '0' : 0; }();
   static const int env_q = [] { const char* e = std::getenv("DQ_ATTN_NW_Q"); return e && (e[0] == '1' || e[0] == '4') ? e[0] - '0' : 0; }();
-  if (query_side) return env_q ? env_q : 1;
-  if (env_f) return env_f;
-  return (int64_t)cdiv(RT, 32) * B * 4 < 8192 ? 4 : 1;
+  (void)B; (void)RT;
+  // (not chosen by grid size: a window's result must not depend on the batch it is computed in -- the four-wave merge adds the
+  // partial softmaxes in another order, and tests/test_scale_parity.py holds batch 2 against batch 512 bit for bit)
+  return query_side ? (env_q ? env_q : 1) : (env_f ? env_f : 1);
 }
 
 int launch_attn_fwd(const float* q, int64_t q_bs, const float* k, int64_t k_bs, const float* v, int64_t v_bs, float* o, float* lse,

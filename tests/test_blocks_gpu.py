@@ -260,7 +260,7 @@ def _attn_ref(q, k, v):
     return o.transpose(2, 3).reshape(B, 128, RT)
 
 
-# (164, 397): enough (sample, head, block) waves that the forward runs one wave per query block instead of four (k_attn.hip)
+# (164, 397): a grid that fills the SIMDs several times over
 @pytest.mark.parametrize("B,RT", [(2, 400), (1, 2000), (2, 413), (1, 1999), (3, 31), (1, 33), (164, 397)])
 def test_attention_fwd_bwd_standalone(N, B, RT):
     """softmax(q k^T / sqrt(32)) v over RT at the bench's 13 key blocks (RT = 400), configs[4]'s 63 (RT = 2000) and ragged tails
