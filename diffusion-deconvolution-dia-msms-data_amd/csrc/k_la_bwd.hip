@@ -245,12 +245,12 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
         for (int j = 0; j < NJ; ++j) {
           const int c = la_chan(C, j, half);
           const bool ok = row_ok && c < C;
-          // (not predicated: a branch per load; rows beyond the last / padding channels read a valid element and are zeroed)
-          const int64_t off = ((int64_t)(row_ok ? row : a.rows - 1) * C + (c < C ? c : 0)) * N + pos;
-          const float vx = a.x[off], vu = a.ypre[off], vd = a.dy[off];
-          px[b][j] = ok ? vx : 0.f;
-          pu[b][j] = ok ? vu : 0.f;
-          pd[b][j] = ok ? vd : 0.f;
+          // (predicated on purpose: the unpredicated form -- clamped row, select afterwards -- was measured: <8,32> 207 -> 290 us, the other
+          // instantiations unchanged)
+          const int64_t off = ((int64_t)row * C + c) * N + pos;
+          px[b][j] = ok ? a.x[off] : 0.f;
+          pu[b][j] = ok ? a.ypre[off] : 0.f;
+          pd[b][j] = ok ? a.dy[off] : 0.f;
         }
       }
     };
