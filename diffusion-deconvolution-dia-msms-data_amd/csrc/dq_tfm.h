@@ -24,6 +24,9 @@ struct Gemm {
   int a_kmajor = 1, b_kmajor = 1;
   int batch = 1, inner = 1;
   int64_t sAo = 0, sAi = 0, sBo = 0, sBi = 0, sCo = 0, sCi = 0;
+  // C = sum over kbatch blocks of A_b B_b^T (A_b = A + b sAk, B_b = B + b sBk; each with reduction length K): a weight gradient summed
+  // over the samples of a batch in ONE pass over C instead of one read-modify-write of C per sample
+  int kbatch = 1; int64_t sAk = 0, sBk = 0;
   const float* bias = nullptr;  // (N): added to every row
   const float* bias_m = nullptr;  // (M): added to every column (a conv bias: rows are output channels); unsplit launches only
   float alpha = 1.f;

@@ -36,6 +36,9 @@ struct GemmK {
   const float* bias; const float* bias_m; float alpha; int accumulate;
   int splits, k_per_split; float* partial;
   int tile_base, mt;  // first tile of this launch; m-tiles of the whole product (tile id = m-tile + mt * n-tile)
+  // reduction over kb blocks of K (C = sum_b A_b B_b^T with A_b = A + b sAk, B_b = B + b sBk): the k axis the splits cut is the virtual
+  // axis of kb * kp elements, kp = K rounded up to the k-tile, so that a k-tile never straddles two blocks
+  int kb, kp; int64_t sAk, sBk;
 };
 
 // one (R rows/cols x 32 k) operand tile: global -> registers (float4 units), registers -> LDS
@@ -160,8 +163,11 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm(GemmK g) {
   const int zo = z / g.inner, zi = z % g.inner;
   const float* A = g.A + zo * g.sAo + zi * g.sAi;
   const float* B = g.B + zo * g.sBo + zi * g.sBi;
-  const int kbeg = sp * g.k_per_split, kend = min(g.K, kbeg + g.k_per_split);
+  const int kvlen = g.kb > 1 ? g.kb * g.kp : g.K;
+  const int kbeg = sp * g.k_per_split, kend = min(kvlen, kbeg + g.k_per_split);
   const int nkt = (kend - kbeg + BK - 1) / BK;
+  // k-tile at virtual position kv -> (operand block, k inside it, the bound its loads are masked at)
+  auto kt_block = [&](int kv) { return g.kb > 1 ? kv / g.kp : 0; };
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -172,8 +178,9 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm(GemmK g) {
   TileIO<A_K, BM, NT> ta;
   TileIO<B_K, BN, NT> tb;
   if (nkt > 0) {
-    ta.load(A, g.lda, m0, g.M, kbeg, kend, tid);
-    tb.load(B, g.ldb, n0, g.N, kbeg, kend, tid);
+    const int bq = kt_block(kbeg);
+    ta.load(A + bq * g.sAk, g.lda, m0, g.M, kbeg - bq * g.kp, min(g.K, kend - bq * g.kp), tid);
+    tb.load(B + bq * g.sBk, g.ldb, n0, g.N, kbeg - bq * g.kp, min(g.K, kend - bq * g.kp), tid);
     ta.store(as[0], tid);
     tb.store(bs[0], tid);
   }
@@ -181,8 +188,9 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm(GemmK g) {
   for (int kt = 0; kt < nkt; ++kt) {
     const bool more = kt + 1 < nkt;
     if (more) {
-      ta.load(A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend, tid);
-      tb.load(B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend, tid);
+      const int kv = kbeg + (kt + 1) * BK, bq = kt_block(kv);
+      ta.load(A + bq * g.sAk, g.lda, m0, g.M, kv - bq * g.kp, min(g.K, kend - bq * g.kp), tid);
+      tb.load(B + bq * g.sBk, g.ldb, n0, g.N, kv - bq * g.kp, min(g.K, kend - bq * g.kp), tid);
     }
     const float* al = as[kt & 1];
     const float* bl = bs[kt & 1];
@@ -316,8 +324,11 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_s3(GemmK g) {
   const int zo = z / g.inner, zi = z % g.inner;
   const float* A = g.A + zo * g.sAo + zi * g.sAi;
   const float* B = g.B + zo * g.sBo + zi * g.sBi;
-  const int kbeg = sp * g.k_per_split, kend = min(g.K, kbeg + g.k_per_split);
+  const int kvlen = g.kb > 1 ? g.kb * g.kp : g.K;
+  const int kbeg = sp * g.k_per_split, kend = min(kvlen, kbeg + g.k_per_split);
   const int nkt = (kend - kbeg + BK - 1) / BK;
+  // k-tile at virtual position kv -> (operand block, k inside it, the bound its loads are masked at)
+  auto kt_block = [&](int kv) { return g.kb > 1 ? kv / g.kp : 0; };
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -328,8 +339,9 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_s3(GemmK g) {
   SplitIO<A_K, BM, NT> ta;
   SplitIO<B_K, BN, NT> tb;
   if (nkt > 0) {
-    ta.load(A, g.lda, m0, g.M, kbeg, kend, tid);
-    tb.load(B, g.ldb, n0, g.N, kbeg, kend, tid);
+    const int bq = kt_block(kbeg);
+    ta.load(A + bq * g.sAk, g.lda, m0, g.M, kbeg - bq * g.kp, min(g.K, kend - bq * g.kp), tid);
+    tb.load(B + bq * g.sBk, g.ldb, n0, g.N, kbeg - bq * g.kp, min(g.K, kend - bq * g.kp), tid);
     ta.store(ah[0], al[0], tid);
     tb.store(bh[0], bl[0], tid);
   }
@@ -337,8 +349,9 @@ __global__ void __launch_bounds__(WM * WN * 64) k_gemm_s3(GemmK g) {
   for (int kt = 0; kt < nkt; ++kt) {
     const bool more = kt + 1 < nkt;
     if (more) {
-      ta.load(A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend, tid);
-      tb.load(B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend, tid);
+      const int kv = kbeg + (kt + 1) * BK, bq = kt_block(kv);
+      ta.load(A + bq * g.sAk, g.lda, m0, g.M, kv - bq * g.kp, min(g.K, kend - bq * g.kp), tid);
+      tb.load(B + bq * g.sBk, g.ldb, n0, g.N, kv - bq * g.kp, min(g.K, kend - bq * g.kp), tid);
     }
     const int cur = kt & 1;
 #pragma unroll
@@ -498,12 +511,15 @@ int launch_gemm(const Gemm& g, hipStream_t s) {
   DQ_REQUIRE(g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm: leading dimensions of A and B must be multiples of 4 floats");
   DQ_REQUIRE(((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.B & 15) == 0, "gemm: A and B must be 16-byte aligned");
   DQ_REQUIRE((g.sAo % 4 == 0) && (g.sAi % 4 == 0) && (g.sBo % 4 == 0) && (g.sBi % 4 == 0), "gemm: batch strides of A and B must be multiples of 4");
-  const Shape sh = choose(g.M, g.N, g.K, g.batch, g.splits);
+  DQ_REQUIRE(g.kbatch >= 1 && (g.kbatch == 1 || (g.sAk % 4 == 0 && g.sBk % 4 == 0)), "gemm: bad k-batch count / strides");
+  const int kp = cdiv(g.K, BK) * BK;
+  const Shape sh = choose(g.M, g.N, g.kbatch > 1 ? g.kbatch * kp : g.K, g.batch, g.splits);
   GemmK k;
   k.A = g.A; k.B = g.B; k.C = g.C; k.M = g.M; k.N = g.N; k.K = g.K; k.lda = g.lda; k.ldb = g.ldb; k.ldc = g.ldc;
   k.batch = g.batch; k.inner = g.inner; k.sAo = g.sAo; k.sAi = g.sAi; k.sBo = g.sBo; k.sBi = g.sBi; k.sCo = g.sCo; k.sCi = g.sCi;
   k.bias = g.bias; k.bias_m = g.bias_m; k.alpha = g.alpha; k.accumulate = g.accumulate;
   k.splits = 1; k.k_per_split = 0; k.partial = g.partial; k.tile_base = 0; k.mt = cdiv(g.M, sh.bm);
+  k.kb = g.kbatch; k.kp = kp; k.sAk = g.sAk; k.sBk = g.sBk;
   const int64_t need = std::max(part_scratch(sh.full, sh.bm, g.batch), part_scratch(sh.rest, sh.bm, g.batch));
   if (need > 0) DQ_REQUIRE(g.partial && g.partial_floats >= need, "gemm: split-K scratch missing or too small");
   DQ_REQUIRE((int64_t)k.batch * std::max(sh.full.splits, sh.rest.splits) <= 65535, "gemm: batch x splits exceeds the grid");
