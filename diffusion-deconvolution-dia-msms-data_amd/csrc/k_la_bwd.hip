@@ -721,7 +721,7 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
             pdx[b][j] = a.dx[((int64_t)row * C + c) * N + (N >= 32 ? b * 32 + col : col % N)];
         }
       }
-      __syncthreads();
+      lds_barrier();  // (LDS-only: __syncthreads() would also wait for the dx values just requested and for a prefetched next unit)
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const int pos = N >= 32 ? b * 32 + col : col % N;
@@ -769,7 +769,7 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
           }
         }
       }
-      if (!EX2) __syncthreads();  // (single exchange buffer: nobody overwrites it before the last head's wave has read it)
+      if (!EX2) lds_barrier();  // (single exchange buffer: nobody overwrites it before the last head's wave has read it)
     }
 
     DQ_STAMP(2);
