@@ -225,11 +225,7 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
   // batch, every group of four MFMAs waited and a 16-channel block ran at ~20 cycles per MFMA instead of ~8.5.)
   constexpr int RD = 3;
   struct WRing { float4 r[RD]; float4 cur; };
-#ifdef DQ_LEVEL_NOLDS  // timing experiment (wrong results): what the launch costs without the operand reads
-  auto ldw = [&](int base, int q) -> float4 { return make_float4(base * 1.f, q * 1.f, li * 1.f, 1.f); };
-#else
   auto ldw = [&](int base, int q) -> float4 { return *reinterpret_cast<const float4*>(wlane + (base >> 2) * 16 + q * 16); };
-#endif
   auto ring_start = [&](WRing& R, int base) __attribute__((always_inline)) {
 #pragma unroll
     for (int d = 0; d < RD; ++d) R.r[d] = ldw(base, d);  // (reads past a stream's last job land in the next stream / the parameter image)

@@ -229,7 +229,6 @@ __global__ void __launch_bounds__(256, C >= 12 ? 1 : 2) k_res_bwd_wg(ResBwdWg a)
     __syncthreads();
     DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 3);
     // ---- matrix pipe: dW2 (+ db2), dWr (+ dbr)
-#ifndef DQ_WG_V_NOMFMA
     if constexpr (WIDE) {
       // zero padding of the outer taps: position 16 blk + s is the first / last of its row (per lane; n is a power of two)
       auto first_in_row = [&](int s) { return ((blk * RUN + s) & (n - 1)) == 0; };
@@ -299,7 +298,6 @@ __global__ void __launch_bounds__(256, C >= 12 ? 1 : 2) k_res_bwd_wg(ResBwdWg a)
      }
     }
     }  // narrow
-#endif
     DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 4);
     // ---- d a1[ci][p] = sum_co sum_k W2[co][ci][k] dU2[co][p + 1 - k]  (matrix pipe; tap k reads position p + 1 - k)
     float da1[C];
@@ -344,7 +342,6 @@ __global__ void __launch_bounds__(256, C >= 12 ? 1 : 2) k_res_bwd_wg(ResBwdWg a)
     __syncthreads();
     DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 7);
     // ---- matrix pipe: dW1 (+ db1)
-#ifndef DQ_WG_V_NOMFMA
     if constexpr (WIDE) {
       auto first_in_row = [&](int s) { return ((blk * RUN + s) & (n - 1)) == 0; };
       auto last_in_row = [&](int s) { return ((blk * RUN + s) & (n - 1)) == n - 1; };
@@ -397,7 +394,6 @@ __global__ void __launch_bounds__(256, C >= 12 ? 1 : 2) k_res_bwd_wg(ResBwdWg a)
       }
     }
     }  // narrow
-#endif
     DQ_PSTAMP(100000 + C * 10 + (WR ? 1 : 0), 8);
     // ---- d x[ci][p] = sum_co sum_k W1[co][ci][k] dU1[co][p + 1 - k]  (+ residual branch) into dA / dB  (matrix pipe)
     // The input-channel quads of cat(A, B) in two passes (A's, then B's): half the accumulators live at a time -- with all 2 C / 4 quads
