@@ -31,6 +31,7 @@ struct Gemm {
   const float* bias_m = nullptr;  // (M): added to every column (a conv bias: rows are output channels); unsplit launches only
   float alpha = 1.f;
   int accumulate = 0;           // C += instead of C =
+  const float* add = nullptr;   // C = add + (...): a residual read from another tensor laid out like C (unsplit launches only)
   // split-K: the reduction is cut into `splits` ranges whose partial products go to `partial` ([split][z][M][N] floats) and
   // are summed in a fixed order by a second kernel (deterministic, no atomics).  splits = 0: chosen by the launcher.
   int splits = 0; float* partial = nullptr; int64_t partial_floats = 0;

@@ -816,11 +816,11 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
       const ConvP ao = proj(p.ao_w, p.mid_c, HID);
       if (conv_is_gemm(c, ao, CONV_S1, RT, RT) && (prep_ok || ((uintptr_t)c.prm(ao.w) & 15) == 0)) {
         // to_out (1x1 conv, 128 -> mid_c channels, with bias) + the residual: attn_out = x ; attn_out += W o + b as a GEMM per sample
-        DQ_TRY(launch_copy(c.w(a.attn_out), c.w(a.mid1.out), (int64_t)B * p.mid_c * RT, c.s));
         Gemm g;
         DQ_TRY(gemm_weight(c, ao, &g.A, 2));
         g.lda = HID; g.B = c.w(a.o); g.b_kmajor = 0; g.ldb = RT; g.C = c.w(a.attn_out); g.ldc = RT; g.M = p.mid_c; g.N = RT; g.K = HID;
-        g.batch = B; g.sBo = (int64_t)HID * RT; g.sCo = (int64_t)p.mid_c * RT; g.bias_m = c.prm(p.ao_b); g.accumulate = 1;
+        g.batch = B; g.sBo = (int64_t)HID * RT; g.sCo = (int64_t)p.mid_c * RT; g.bias_m = c.prm(p.ao_b);
+        g.add = c.w(a.mid1.out); g.splits = 1;  // the residual is read by the epilogue (was: a copy launch + "+=")
         DQ_TRY(launch_gemm(g, c.s));
       } else {
         ConvFwd f;

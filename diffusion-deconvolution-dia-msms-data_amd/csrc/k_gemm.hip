@@ -34,6 +34,7 @@ struct GemmK {
   int batch, inner;
   int64_t sAo, sAi, sBo, sBi, sCo, sCi;
   const float* bias; const float* bias_m; float alpha; int accumulate;
+  const float* add;  // nullable: C = add + (...) with add laid out like C (unsplit launches)
   int splits, k_per_split; float* partial;
   int tile_base, mt;  // first tile of this launch; m-tiles of the whole product (tile id = m-tile + mt * n-tile)
   // reduction over kb blocks of K (C = sum_b A_b B_b^T with A_b = A + b sAk, B_b = B + b sBk): the k axis the splits cut is the virtual
@@ -122,14 +123,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmK& g, f32x16 (&acc)[TM][
       const int n = n0 + wn0 + 32 * jn + col;
       if (n >= g.N) continue;
       const float bias = g.bias ? g.bias[n] : 0.f;
-      const bool rmw = g.accumulate != 0;
+      const bool rmw = g.accumulate != 0 || g.add != nullptr;
+      const float* Cold = g.add ? g.add + zo * g.sCo + zi * g.sCi : C;  // (a residual read from another tensor instead of a copy + "+=")
       // all 16 reads of a += tile are issued before the first store (a load behind a store to a pointer the compiler cannot
       // tell apart would wait for it: 64 serial round trips per lane)
       float old[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm0 + 32 * i + rmap(r, half);
-        old[r] = (rmw && m < g.M) ? C[(int64_t)m * ldc + n] : 0.f;
+        old[r] = (rmw && m < g.M) ? Cold[(int64_t)m * ldc + n] : 0.f;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -517,7 +519,8 @@ int launch_gemm(const Gemm& g, hipStream_t s) {
   GemmK k;
   k.A = g.A; k.B = g.B; k.C = g.C; k.M = g.M; k.N = g.N; k.K = g.K; k.lda = g.lda; k.ldb = g.ldb; k.ldc = g.ldc;
   k.batch = g.batch; k.inner = g.inner; k.sAo = g.sAo; k.sAi = g.sAi; k.sBo = g.sBo; k.sBi = g.sBi; k.sCo = g.sCo; k.sCi = g.sCi;
-  k.bias = g.bias; k.bias_m = g.bias_m; k.alpha = g.alpha; k.accumulate = g.accumulate;
+  k.bias = g.bias; k.bias_m = g.bias_m; k.alpha = g.alpha; k.accumulate = g.accumulate; k.add = g.add;
+  DQ_REQUIRE(!g.add || (!g.accumulate && std::max(sh.full.splits, sh.rest.splits) <= 1), "gemm: `add` needs an unsplit, non-accumulating product");
   k.splits = 1; k.k_per_split = 0; k.partial = g.partial; k.tile_base = 0; k.mt = cdiv(g.M, sh.bm);
   k.kb = g.kbatch; k.kp = kp; k.sAk = g.sAk; k.sBk = g.sBk;
   const int64_t need = std::max(part_scratch(sh.full, sh.bm, g.batch), part_scratch(sh.rest, sh.bm, g.batch));
