@@ -101,7 +101,14 @@ __device__ __forceinline__ float half_sum(float v) {
 #ifndef DQ_LA_PF4
 #define DQ_LA_PF4 0
 #endif
-constexpr bool la_two_waves(int C, int N) { return C == 4 || (C == 8 && (N == 32 || N == 16 || N == 8)); }
+// DQ_LA_12TW=1 (build-time experiment): the 12-channel short-row variants at two waves per SIMD -- 256 registers by launch bounds, 79 KB of
+// LDS by dropping the second exchange buffer.  Measured: the allocator spills ~130 registers (500 B of scratch per lane) and the launches take
+// 1.4-1.5x as long (<12,8> 153 -> 225 us, <12,4> 95 -> 142, <12,2> 69 -> 94 stand-alone).  Two waves per SIMD at 12 / 16 channels needs the
+// register diet done by hand (per-head phases that keep fewer tiles live), not a launch bound.
+#ifndef DQ_LA_12TW
+#define DQ_LA_12TW 0
+#endif
+constexpr bool la_two_waves(int C, int N) { return C == 4 || (C == 8 && (N == 32 || N == 16 || N == 8)) || (DQ_LA_12TW && C == 12 && N <= 8); }
 template <int C, int N>
 __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_bwd(LinAttnBwdK a) {
   static_assert(N >= 2, "rows of one position: k_linattn_bwd1");
@@ -132,7 +139,7 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
   // d xh of the four heads of one unit, [parity of the unit][head][c][n]: double-buffered so that ONE barrier per unit is enough (a
   // wave that runs ahead writes the other parity; it cannot reach this parity again before the barrier of the unit in between).
   // The 64-position C >= 12 variants have no LDS left for the second buffer and pay a second barrier instead.
-  constexpr bool EX2 = !(C >= 12 && N == 64);
+  constexpr bool EX2 = !(C >= 12 && N == 64) && !(DQ_LA_12TW && C == 12 && N <= 8);
   __shared__ float exch[(EX2 ? 2 : 1) * 4 * C * NP];
   DQ_STAMP(0);
   for (int i = threadIdx.x; i < 2 * 4 * 2 * C * 16; i += blockDim.x) {
