@@ -30,6 +30,29 @@ __device__ __forceinline__ void exch_sync(bool wave_local) {
 }
 }
 
+// The block's three weight tensors -> LDS (plain copies) with EVERY load of a thread requested before its first store: as three loops
+// striding by blockDim.x (not unrollable) this was 4-11 memory round trips in a row per workgroup.
+template <int C, int BS>
+__device__ __forceinline__ void stage_res_weights(float* w2s, float* w1s, float* wrs, const float* __restrict__ w2, const float* __restrict__ w1,
+                                                  const float* __restrict__ wr, int cin) {
+  constexpr int N2 = (C * C * 3 + BS - 1) / BS, N1 = (C * 2 * C * 3 + BS - 1) / BS, NR = (C * 2 * C + BS - 1) / BS;
+  float v2[N2], v1[N1], vr[NR];
+  const int n1 = C * cin * 3, nr = wr ? C * cin : 0;
+  const float* wrp = wr ? wr : w2;  // (a valid address for the unused loads)
+#pragma unroll
+  for (int u = 0; u < N2; ++u) { const int i = u * BS + (int)threadIdx.x; v2[u] = w2[i < C * C * 3 ? i : 0]; }
+#pragma unroll
+  for (int u = 0; u < N1; ++u) { const int i = u * BS + (int)threadIdx.x; v1[u] = w1[i < n1 ? i : 0]; }
+#pragma unroll
+  for (int u = 0; u < NR; ++u) { const int i = u * BS + (int)threadIdx.x; vr[u] = wrp[i < nr ? i : 0]; }
+#pragma unroll
+  for (int u = 0; u < N2; ++u) { const int i = u * BS + (int)threadIdx.x; if (i < C * C * 3) w2s[i] = v2[u]; }
+#pragma unroll
+  for (int u = 0; u < N1; ++u) { const int i = u * BS + (int)threadIdx.x; if (i < n1) w1s[i] = v1[u]; }
+#pragma unroll
+  for (int u = 0; u < NR; ++u) { const int i = u * BS + (int)threadIdx.x; if (i < nr) wrs[i] = vr[u]; }
+}
+
 template <int C, int BS>
 __global__ void __launch_bounds__(BS) k_res_fwd(ResFwd a) {
   __shared__ float sh[C][BS + 2];
@@ -37,10 +60,7 @@ __global__ void __launch_bounds__(BS) k_res_fwd(ResFwd a) {
   // -- 33 us for the bottleneck's 16-channel block, one workgroup per sample
   __shared__ float w2s[C * C * 3], w1s[C * 2 * C * 3], wrs[C * 2 * C];
   const int cin = a.cinA + a.cinB;  // <= 2 C (checked by the launcher)
-  for (int i = threadIdx.x; i < C * C * 3; i += blockDim.x) w2s[i] = a.w2[i];
-  for (int i = threadIdx.x; i < C * cin * 3; i += blockDim.x) w1s[i] = a.w1[i];
-  if (a.wr)
-    for (int i = threadIdx.x; i < C * cin; i += blockDim.x) wrs[i] = a.wr[i];
+  stage_res_weights<C, BS>(w2s, w1s, wrs, a.w2, a.w1, a.wr, cin);
   __syncthreads();
   const int b = blockIdx.y;
   const int per_sample = a.rows_per_sample * a.n;
@@ -204,10 +224,7 @@ __global__ void __launch_bounds__(BS) k_res_bwd(ResBwd a) {
   __shared__ float w2s[C * C * 3], w1s[C * 2 * C * 3], wrs[C * 2 * C];
   {
     const int cin_ = a.cinA + a.cinB;  // <= 2 C (checked by the launcher)
-    for (int i = threadIdx.x; i < C * C * 3; i += blockDim.x) w2s[i] = a.w2[i];
-    for (int i = threadIdx.x; i < C * cin_ * 3; i += blockDim.x) w1s[i] = a.w1[i];
-    if (a.wr)
-      for (int i = threadIdx.x; i < C * cin_; i += blockDim.x) wrs[i] = a.wr[i];
+    stage_res_weights<C, BS>(w2s, w1s, wrs, a.w2, a.w1, a.wr, cin_);
     __syncthreads();
   }
   const int b = blockIdx.y;

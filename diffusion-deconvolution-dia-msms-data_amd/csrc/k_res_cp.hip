@@ -34,19 +34,44 @@ __device__ __forceinline__ float gsum16(float v) {  // four DPP adds inside the 
 }
 
 // stage W (cout x cin x K, row-major [co][ci][k]) as dst[((ci4 * K + k) * 16 + co) * 4 + (ci & 3)], zero padded to 16 x cin_pad
+// (256 threads.  Every element's load is requested before the first store, no load is predicated: as a loop striding by blockDim.x -- not
+// unrollable -- of `decode, branch, load, store` the three weight tensors of a block cost 14 memory round trips in a row per workgroup:
+// the 14 channel-parallel backward launches of a train step 276 -> 251 us.)
 template <int K>
 __device__ __forceinline__ void stage_w(float* dst, const float* __restrict__ w, int cout, int cin, int cin_pad) {
-  for (int i = threadIdx.x; i < cin_pad * K * 16; i += blockDim.x) {
+  constexpr int NIT = 32 * K * 16 / 256;  // cin_pad <= 32
+  float v[NIT];
+  const int total = cin_pad * K * 16;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = it * 256 + (int)threadIdx.x;
     const int q = i & 3, co = (i >> 2) & 15, k = (i >> 6) % K, ci = ((i >> 6) / K) * 4 + q;
-    dst[i] = (co < cout && ci < cin) ? w[((int64_t)co * cin + ci) * K + k] : 0.f;
+    const bool ok = i < total && co < cout && ci < cin;
+    v[it] = w[ok ? (co * cin + ci) * K + k : 0];
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = it * 256 + (int)threadIdx.x;
+    const int q = i & 3, co = (i >> 2) & 15, ci = ((i >> 6) / K) * 4 + q;
+    if (i < total) dst[i] = (co < cout && ci < cin) ? v[it] : 0.f;
   }
 }
 // transposed roles for the backward data path: dst[((co4 * K + k) * 32 + ci) * 4 + (co & 3)] = W[co][ci][k]
 template <int K>
 __device__ __forceinline__ void stage_wt(float* dst, const float* __restrict__ w, int cout, int cin) {
-  for (int i = threadIdx.x; i < 16 * K * 32; i += blockDim.x) {
+  constexpr int NIT = 16 * K * 32 / 256;
+  float v[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = it * 256 + (int)threadIdx.x;
     const int q = i & 3, ci = (i >> 2) & 31, k = (i >> 7) % K, co = ((i >> 7) / K) * 4 + q;
-    dst[i] = (co < cout && ci < cin) ? w[((int64_t)co * cin + ci) * K + k] : 0.f;
+    v[it] = w[(co < cout && ci < cin) ? (co * cin + ci) * K + k : 0];
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = it * 256 + (int)threadIdx.x;
+    const int q = i & 3, ci = (i >> 2) & 31, co = ((i >> 7) / K) * 4 + q;
+    dst[i] = (co < cout && ci < cin) ? v[it] : 0.f;
   }
 }
 }  // namespace
@@ -226,6 +251,7 @@ __global__ void __launch_bounds__(256) k_res_bwd_cp(ResBwd a) {
   const int row = b * a.rows_per_sample + (live ? rs : 0);
   const bool act = ch < C && live;
   const int64_t obase = ((int64_t)row * C + ch) * N;
+  const int64_t oload = ((int64_t)row * C + (ch < C ? ch : 0)) * N;  // (loads of the padding lanes)
 
   stage_wt<3>(w2t, a.w2, C, C);
   stage_wt<3>(w1t, a.w1, C, cin);
@@ -240,8 +266,9 @@ __global__ void __launch_bounds__(256) k_res_bwd_cp(ResBwd a) {
     const float g2 = ch < C ? a.g2[ch] : 0.f;
 #pragma unroll
     for (int p = 0; p < N; ++p) {
-      dout[p] = act ? a.dout[obase + p] : 0.f;
-      const float u = act ? a.u2[obase + p] : 0.f;
+      const float dv = a.dout[oload + p], uv = a.u2[oload + p];  // (not predicated: padding lanes re-read channel 0 / row 0 and are zeroed)
+      dout[p] = act ? dv : 0.f;
+      const float u = act ? uv : 0.f;
       float z0 = 0.f, z1 = 0.f;
       d2[p] = norm_act_bwd_cp<C, false>(u, dout[p], g2, 1.f, 0.f, act, dg2, z0, z1);
       if (!act) d2[p] = 0.f;
@@ -280,7 +307,8 @@ __global__ void __launch_bounds__(256) k_res_bwd_cp(ResBwd a) {
     const float sc = ch < C ? ss[ch] + 1.0f : 0.f, sh = ch < C ? ss[C + ch] : 0.f;
 #pragma unroll
     for (int p = 0; p < N; ++p) {
-      const float u = act ? a.u1[obase + p] : 0.f;
+      const float uv = a.u1[oload + p];
+      const float u = act ? uv : 0.f;
       da1[p] = norm_act_bwd_cp<C, true>(u, da1[p], g1, sc, sh, act, dg1, dsc, dsh);
       if (!act) da1[p] = 0.f;
     }
