@@ -45,9 +45,24 @@ __global__ void __launch_bounds__(256) k_conv_fwd(ConvFwd a) {
   const bool use_lds = COUT * cin * K <= WSH;
   if (use_lds) {
     const float* wg = a.w + (int64_t)co_base * cin * K;
-    for (int i = threadIdx.x; i < COUT * cin * K; i += blockDim.x) {
-      const int co = i / (cin * K), r = i - co * (cin * K), ci = r / K, k = r - ci * K;
-      wsh[(ci * COUT + co) * K + k] = wg[i];
+    // (256 threads; all of a thread's loads requested before its first store: as a loop striding by blockDim.x -- not unrollable -- the
+    // staging was up to 16 memory round trips in a row)
+    constexpr int NIT = WSH / 256;
+    const int tot = COUT * cin * K;
+    float v[NIT];
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+      const int i = u * 256 + (int)threadIdx.x;
+      v[u] = 0.f;
+      if (u * 256 < tot) v[u] = wg[i < tot ? i : 0];  // (wave-uniform: a 56-float weight costs one load per thread, not sixteen)
+    }
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+      const int i = u * 256 + (int)threadIdx.x;
+      if (i < tot) {
+        const int co = i / (cin * K), r = i - co * (cin * K), ci = r / K, k = r - ci * K;
+        wsh[(ci * COUT + co) * K + k] = v[u];
+      }
     }
     __syncthreads();
   }
@@ -386,9 +401,21 @@ __global__ void __launch_bounds__(256) k_conv_bwd_data(ConvBwdData a) {
   __shared__ float wsh[WSH];
   const bool use_lds = a.cout * NCI * K <= WSH;
   if (use_lds) {
-    for (int i = threadIdx.x; i < a.cout * NCI * K; i += blockDim.x) {
+    constexpr int NIT = WSH / 256;  // (as in k_conv_fwd: one memory round trip)
+    const int tot = a.cout * NCI * K;
+    float v[NIT];
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+      const int i = u * 256 + (int)threadIdx.x;
       const int co = i / (NCI * K), r = i - co * (NCI * K), ci = ci0 + r / K, k = r % K;
-      wsh[i] = ci < cin ? a.w[((int64_t)co * cin + ci) * K + k] : 0.f;
+      v[u] = 0.f;
+      if (u * 256 < tot) v[u] = a.w[(i < tot && ci < cin) ? (co * cin + ci) * K + k : 0];  // (wave-uniform)
+    }
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+      const int i = u * 256 + (int)threadIdx.x;
+      const int r = i % (NCI * K), ci = ci0 + r / K;
+      if (i < tot) wsh[i] = ci < cin ? v[u] : 0.f;
     }
     __syncthreads();
   }
