@@ -142,12 +142,20 @@ __global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_b
   constexpr bool EX2 = !(C >= 12 && N == 64) && !(DQ_LA_12TW && C == 12 && N <= 8);
   __shared__ float exch[(EX2 ? 2 : 1) * 4 * C * NP];
   DQ_STAMP(0);
-  for (int i = threadIdx.x; i < 2 * 4 * 2 * C * 16; i += blockDim.x) {
-    const int r = i & 15, c = (i >> 4) % C, hh = (i / (16 * C)) & 1, hd = (i / (32 * C)) & 3, m = i / (128 * C);
-    wp_lds[i] = a.w_qkv[(m * 128 + hd * 32 + rmap(r, hh)) * C + c];
+  {  // (every load of a thread requested before its first store: a loop striding by blockDim.x cannot be unrolled -- 4..16 round trips in a row)
+    constexpr int NW = 2 * 4 * 2 * C * 16 / 256;
+    float v[NW];
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+      const int i = u * 256 + (int)threadIdx.x;
+      const int r = i & 15, c = (i >> 4) % C, hh = (i / (16 * C)) & 1, hd = (i / (32 * C)) & 3, m = i / (128 * C);
+      v[u] = a.w_qkv[(m * 128 + hd * 32 + rmap(r, hh)) * C + c];
+    }
+#pragma unroll
+    for (int u = 0; u < NW; ++u) wp_lds[u * 256 + (int)threadIdx.x] = v[u];
   }
   if (a.prep) {
-    for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) w2_lds[i] = a.prep[i];
+    for (int i = threadIdx.x; i < 4 * C * C; i += 256) w2_lds[i] = a.prep[i];
   } else {
     for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) {
       const int c = i % C, cp = (i / C) % C, hd = i / (C * C);
@@ -1060,6 +1068,14 @@ __global__ void __launch_bounds__(256) k_linattn_dw_reduce(const float* __restri
   float s0 = 0.f, s1 = 0.f;
   if (e < nelem) {
     int b = g;
+    // (eight loads in flight, added in the order of the two-at-a-time loop: same sums bit for bit, a quarter of the memory round trips)
+    for (; b + 112 < nslots; b += 128) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(b + 16 * u) * nelem + e];
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) { s0 += v[u]; s1 += v[u + 1]; }
+    }
     for (; b + 16 < nslots; b += 32) {
       s0 += part[(int64_t)b * nelem + e];
       s1 += part[(int64_t)(b + 16) * nelem + e];
