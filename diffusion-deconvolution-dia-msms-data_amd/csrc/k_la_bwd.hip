@@ -1105,15 +1105,24 @@ __global__ void __launch_bounds__(256) k_linattn_dw_reduce_multi(LaReduceMulti m
   const LaReduceItem& it = m.it[i];
   const int C = it.C, nelem = la_slot(C), nslots = it.nslots;
   const float* __restrict__ part = it.part;
-  __shared__ float red[16][17];
-  const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
-  const int e = ((int)blockIdx.x - m.first_block[i]) * 16 + el;
+  // 32 consecutive elements x 8 slot groups per block: a half-wave reads one whole 128-byte line of a slot.  (With 16 elements x 16 groups
+  // every access was half a line -- the launch reads ~45 MB of slots per train step and ran at the rate of twice that, 28 us.)
+  __shared__ float red[8][33];
+  const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int e = ((int)blockIdx.x - m.first_block[i]) * 32 + el;
   float s0 = 0.f, s1 = 0.f;
   if (e < nelem) {
     int b = g;
-    for (; b + 16 < nslots; b += 32) {
+    for (; b + 56 < nslots; b += 64) {  // eight loads in flight, added in a fixed order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(b + 8 * u) * nelem + e];
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) { s0 += v[u]; s1 += v[u + 1]; }
+    }
+    for (; b + 8 < nslots; b += 16) {
       s0 += part[(int64_t)b * nelem + e];
-      s1 += part[(int64_t)(b + 16) * nelem + e];
+      s1 += part[(int64_t)(b + 8) * nelem + e];
     }
     if (b < nslots) s0 += part[(int64_t)b * nelem + e];
   }
@@ -1122,7 +1131,7 @@ __global__ void __launch_bounds__(256) k_linattn_dw_reduce_multi(LaReduceMulti m
   if (g == 0 && e < nelem) {
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s += red[k][el];
+    for (int k = 0; k < 8; ++k) s += red[k][el];
     const int w2b = 256 * C, gb = w2b + 4 * C * C;
     if (e < w2b) it.dw_qkv[e] += s;                 // rows 0..255 of to_qkv: q | k
     else if (e < gb) it.w2sum[e - w2b] = s;         // dW2[head][c'][c]
@@ -1244,7 +1253,7 @@ int launch_linattn_dw_reduce_multi(const LaReduceItem* items, int count, hipStre
   for (int i = 0; i < count; ++i) {
     m.it[i] = items[i];
     m.first_block[i] = blocks;
-    blocks += cdiv(la_slot(items[i].C), 16);
+    blocks += cdiv(la_slot(items[i].C), 32);
   }
   m.first_block[count] = blocks;
   hipLaunchKernelGGL(k_linattn_dw_reduce_multi, dim3(blocks), dim3(256), 0, s, m);
