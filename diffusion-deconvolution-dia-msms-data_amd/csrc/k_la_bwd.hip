@@ -109,8 +109,11 @@ __device__ __forceinline__ float half_sum(float v) {
 #define DQ_LA_12TW 0
 #endif
 constexpr bool la_two_waves(int C, int N) { return C == 4 || (C == 8 && (N == 32 || N == 16 || N == 8)) || (DQ_LA_12TW && C == 12 && N <= 8); }
+#ifndef DQ_LA_4_3W
+#define DQ_LA_4_3W 0  // build-time experiment: <4,64> at three waves per SIMD (168 registers by launch bound): 63 spilled registers, 281 -> 300 us
+#endif
 template <int C, int N>
-__global__ void __launch_bounds__(256, (la_two_waves(C, N) ? 2 : 1)) k_linattn_bwd(LinAttnBwdK a) {
+__global__ void __launch_bounds__(256, (DQ_LA_4_3W && C == 4 && N == 64) ? 3 : (la_two_waves(C, N) ? 2 : 1)) k_linattn_bwd(LinAttnBwdK a) {
   static_assert(N >= 2, "rows of one position: k_linattn_bwd1");
   constexpr int NB = N >= 32 ? N / 32 : 1;
   constexpr int RW = N >= 32 ? 1 : 32 / N;
