@@ -309,6 +309,7 @@ int launch_linattn_dw_reduce_multi(const LaReduceItem* items, int count, hipStre
 
 // ---- k_attn.hip : softmax attention over RT of the bottleneck (q,k,v,o in (B, 128, RT) conv layout)
 int launch_rope(float* qk, const float* freqs, int B, int64_t batch_stride, int RT, float sign, hipStream_t s);
+int launch_rope2(float* q, int64_t q_bs, float* k, int64_t k_bs, const float* freqs, int B, int RT, float sign, hipStream_t s);
 int launch_attn_fwd(const float* q, int64_t q_bs, const float* k, int64_t k_bs, const float* v, int64_t v_bs, float* o, float* lse,
                     int B, int RT, hipStream_t s);
 int launch_attn_bwd(const float* q, int64_t q_bs, const float* k, int64_t k_bs, const float* v, int64_t v_bs, const float* o,

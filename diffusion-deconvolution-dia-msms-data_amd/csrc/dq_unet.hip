@@ -591,8 +591,7 @@ int mid_forward_wide(const Ctx& c, const float* rope, const float* cur) {
   DQ_TRY(launch_repitch(c.w(a.qv), RT, c.w(a.w_qv), P, (int64_t)B * 2 * HID, RT, c.s));  // the attention kernels read rows of RT floats
   DQ_TRY(conv_plain_fwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.w(a.kk), B, RT, RT));
   if (rope) {
-    DQ_TRY(launch_rope(c.w(a.qv), rope, B, (int64_t)2 * HID * RT, RT, 1.f, c.s));
-    DQ_TRY(launch_rope(c.w(a.kk), rope, B, (int64_t)HID * RT, RT, 1.f, c.s));
+    DQ_TRY(launch_rope2(c.w(a.qv), (int64_t)2 * HID * RT, c.w(a.kk), (int64_t)HID * RT, rope, B, RT, 1.f, c.s));
   }
   const int64_t qvbs = (int64_t)2 * HID * RT, kbs = (int64_t)HID * RT;
   DQ_TRY(launch_attn_fwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.w(a.lse), B, RT, c.s));
@@ -624,8 +623,7 @@ int mid_backward_wide(const Ctx& c, const float* rope) {
   DQ_TRY(launch_attn_bwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.g(a.o), c.w(a.lse), c.w(a.delta), c.g(a.qv),
                          qvbs, c.g(a.kk), kbs, c.g(a.qv) + kbs, qvbs, B, RT, c.s));
   if (rope) {
-    DQ_TRY(launch_rope(c.g(a.qv), rope, B, (int64_t)2 * HID * RT, RT, -1.f, c.s));
-    DQ_TRY(launch_rope(c.g(a.kk), rope, B, (int64_t)HID * RT, RT, -1.f, c.s));
+    DQ_TRY(launch_rope2(c.g(a.qv), (int64_t)2 * HID * RT, c.g(a.kk), (int64_t)HID * RT, rope, B, RT, -1.f, c.s));
   }
   DQ_TRY(conv_plain_bwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.g(a.kk), c.g(a.ms1f), B, RT, RT, 0));
   DQ_TRY(launch_repitch(c.g(a.w_qv), P, c.g(a.qv), RT, (int64_t)B * 2 * HID, RT, c.s));
@@ -808,8 +806,9 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
       DQ_TRY(conv_plain_fwd(c, proj(p.qv_w, 2 * HID, p.mid_c), CONV_S1, c.w(a.xn), c.w(a.qv), B, RT, RT, prep_ok ? 0 : -1));
       if (!skip_ms1) DQ_TRY(conv_plain_fwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.w(a.kk), B, RT, RT, prep_ok ? 1 : -1));
       if (rope) {
-        DQ_TRY(launch_rope(c.w(a.qv), rope, B, (int64_t)2 * HID * RT, RT, 1.f, c.s));  // q = first 128 channels of each sample's 256
-        if (!skip_ms1) DQ_TRY(launch_rope(c.w(a.kk), rope, B, (int64_t)HID * RT, RT, 1.f, c.s));
+        // q = first 128 channels of each sample's 256; k rides in the same launch unless the sampling prologue rotated it already
+        if (!skip_ms1) DQ_TRY(launch_rope2(c.w(a.qv), (int64_t)2 * HID * RT, c.w(a.kk), (int64_t)HID * RT, rope, B, RT, 1.f, c.s));
+        else DQ_TRY(launch_rope(c.w(a.qv), rope, B, (int64_t)2 * HID * RT, RT, 1.f, c.s));
       }
       const int64_t qvbs = (int64_t)2 * HID * RT, kbs = (int64_t)HID * RT;
       DQ_TRY(launch_attn_fwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.w(a.lse), B, RT, c.s));
@@ -917,8 +916,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
       DQ_TRY(launch_attn_bwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.g(a.o), c.w(a.lse), c.w(a.delta),
                              c.g(a.qv), qvbs, c.g(a.kk), kbs, c.g(a.qv) + kbs, qvbs, B, RT, c.s));
       if (rope) {
-        DQ_TRY(launch_rope(c.g(a.qv), rope, B, (int64_t)2 * HID * RT, RT, -1.f, c.s));
-        DQ_TRY(launch_rope(c.g(a.kk), rope, B, (int64_t)HID * RT, RT, -1.f, c.s));
+        DQ_TRY(launch_rope2(c.g(a.qv), (int64_t)2 * HID * RT, c.g(a.kk), (int64_t)HID * RT, rope, B, RT, -1.f, c.s));
       }
       const int ws_ok = (int)(p.downs.size() + p.ups.size()) <= LA_PREP_MAX ? 0 : -2;  // slots as the forward of this step filled them
       DQ_TRY(conv_plain_bwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.g(a.kk), c.g(a.ms1f), B, RT, RT, 0, ws_ok + 1));

@@ -26,8 +26,11 @@ constexpr float ATT_SCALE = 0.17677669529663687f;  // 32^-0.5
 constexpr float LOG2E = 1.4426950408889634f;
 
 // ---- RoPE, in place.  sign = +1 forward, -1 backward (transpose of the rotation).
-__global__ void __launch_bounds__(256) k_rope(float* __restrict__ t, const float* __restrict__ freqs, int64_t batch_stride, int RT,
-                                              float sign, int64_t total) {
+// (blockIdx.y selects one of up to two tensors: q and k of the same attention in ONE launch)
+__global__ void __launch_bounds__(256) k_rope(float* __restrict__ t0, int64_t bs0, float* __restrict__ t1, int64_t bs1, const float* __restrict__ freqs,
+                                              int RT, float sign, int64_t total) {
+  float* __restrict__ t = blockIdx.y ? t1 : t0;
+  const int64_t batch_stride = blockIdx.y ? bs1 : bs0;
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int pos = (int)(i % RT);
@@ -48,7 +51,15 @@ int launch_rope(float* qk, const float* freqs, int B, int64_t batch_stride, int 
   // rotates the 4 heads x 32 channels that start at each sample's base (B, >=128, RT); batch_stride in floats
   const int64_t total = (int64_t)B * 4 * 8 * RT;
   if (total == 0) return 0;
-  hipLaunchKernelGGL(k_rope, dim3(cdiv(total, 256)), dim3(256), 0, s, qk, freqs, batch_stride, RT, sign, total);
+  hipLaunchKernelGGL(k_rope, dim3(cdiv(total, 256)), dim3(256), 0, s, qk, batch_stride, (float*)nullptr, (int64_t)0, freqs, RT, sign, total);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+// the same rotation on two tensors of the same batch and length (q inside the q | v buffer, k) in one launch
+int launch_rope2(float* q, int64_t q_bs, float* k, int64_t k_bs, const float* freqs, int B, int RT, float sign, hipStream_t s) {
+  const int64_t total = (int64_t)B * 4 * 8 * RT;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(k_rope, dim3(cdiv(total, 256), 2), dim3(256), 0, s, q, q_bs, k, k_bs, freqs, RT, sign, total);
   DQ_LAUNCH_CHECK();
   return 0;
 }

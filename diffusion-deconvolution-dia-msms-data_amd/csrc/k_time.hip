@@ -110,10 +110,19 @@ int launch_time_embed_fwd(const Plan& p, const DevTables& dt, const float* param
 
 // ---- backward ----
 // (1) per ss row r: dW[r][:] += sum_b dss[b][r] * silu(temb_b) ; db[r] += sum_b dss[b][r]
-__global__ void __launch_bounds__(64) k_time_bwd_rows(float* __restrict__ G, const float* __restrict__ tbuf,
-                                                      const float* __restrict__ dss, int ss_total, int B,
-                                                      const int64_t* __restrict__ ss_w_off, const int64_t* __restrict__ ss_b_off) {
-  const int r = blockIdx.x * 64 + threadIdx.x;
+// (launched together with (3): the last block of the launch is the time_mlp block below -- (1) does not depend on (2), (3) does, so the
+// order is (2), then (1) + (3) in one launch)
+__device__ __forceinline__ void time_bwd_mlp_block(float* __restrict__ G, const float* __restrict__ tbuf, int B, int64_t t1w, int64_t t1b, int64_t t2w,
+                                                   int64_t t2b, int dim);
+__global__ void __launch_bounds__(256) k_time_bwd_rows(float* __restrict__ G, const float* __restrict__ tbuf,
+                                                       const float* __restrict__ dss, int ss_total, int B,
+                                                       const int64_t* __restrict__ ss_w_off, const int64_t* __restrict__ ss_b_off, int64_t t1w,
+                                                       int64_t t1b, int64_t t2w, int64_t t2b, int dim) {
+  if (blockIdx.x == gridDim.x - 1) {  // (block-uniform)
+    time_bwd_mlp_block(G, tbuf, B, t1w, t1b, t2w, t2b, dim);
+    return;
+  }
+  const int r = blockIdx.x * 256 + threadIdx.x;
   if (r >= ss_total) return;
   float dw[16], db = 0.f;
 #pragma unroll
@@ -166,8 +175,8 @@ __global__ void __launch_bounds__(64) k_time_bwd_sample(const float* __restrict_
 }
 
 // (3) weights of the two time_mlp Linears: thread (o, i) loops over the batch
-__global__ void __launch_bounds__(256) k_time_bwd_mlp(float* __restrict__ G, const float* __restrict__ tbuf, int B, int64_t t1w,
-                                                      int64_t t1b, int64_t t2w, int64_t t2b, int dim) {
+__device__ __forceinline__ void time_bwd_mlp_block(float* __restrict__ G, const float* __restrict__ tbuf, int B, int64_t t1w, int64_t t1b, int64_t t2w,
+                                                   int64_t t2b, int dim) {
   const int tid = threadIdx.x, o = tid >> 4, i = tid & 15;
   float dw2 = 0.f, db2 = 0.f, dw1 = 0.f, db1 = 0.f;
   for (int b = 0; b < B; ++b) {
@@ -186,12 +195,10 @@ __global__ void __launch_bounds__(256) k_time_bwd_mlp(float* __restrict__ G, con
 int launch_time_embed_bwd(const Plan& p, const DevTables& dt, const float* params, float* grads, float* tbuf, const float* dss,
                           int B, hipStream_t s) {
   if (B == 0) return 0;
-  hipLaunchKernelGGL(k_time_bwd_rows, dim3(cdiv(p.ss_total, 64)), dim3(64), 0, s, grads, tbuf, dss, p.ss_total, B, dt.ss_w_off,
-                     dt.ss_b_off);
-  DQ_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_time_bwd_sample, dim3(B), dim3(64), 0, s, params, tbuf, dss, p.ss_total, dt.ss_w_off, p.t2_w);
   DQ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_time_bwd_mlp, dim3(1), dim3(256), 0, s, grads, tbuf, B, p.t1_w, p.t1_b, p.t2_w, p.t2_b, p.dim);
+  hipLaunchKernelGGL(k_time_bwd_rows, dim3(cdiv(p.ss_total, 256) + 1), dim3(256), 0, s, grads, tbuf, dss, p.ss_total, B, dt.ss_w_off, dt.ss_b_off,
+                     p.t1_w, p.t1_b, p.t2_w, p.t2_b, p.dim);
   DQ_LAUNCH_CHECK();
   return 0;
 }
