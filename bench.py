@@ -524,8 +524,10 @@ def main():
                      "ms_per_step": round(float(ts_) / n_sus * 1e3, 3)}
     # ------------------------------------------------------------------ small batches: the reference trains at batch_size 1
     # (dquartic_train_config.json:12), BASELINE configs[0] at 4 -- a dependency chain of ~250 short launches there
+    # Single-process runs only: with world > 1 every _train_one_batch issues the flat gradient all-reduce, and a collective that rank 0
+    # alone issues between two barriers never finds its peers.  The leg describes one GPU anyway.
     small = None
-    if rank == 0 and not args.train_only:
+    if rank == 0 and world == 1 and not args.train_only:
         small = {}
         for bsz in (1, 4):
             x0, c2, c1 = (v[:bsz].contiguous() for v in batches[0])

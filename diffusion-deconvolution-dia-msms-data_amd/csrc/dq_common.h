@@ -90,4 +90,9 @@ __device__ __forceinline__ float wave_max(float v) {
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Resident workgroups per CU of `fn` at (threads, dynamic LDS bytes) on the CURRENT device, cached per (function, LDS size, device): one
+// instantiation is launched with different LDS footprints (down / up levels, the head), and a process may drive several devices.  Raises the
+// function's dynamic-LDS limit when the launch needs more than 48 KB.  Returns < 0 after set_error().  (dq_unet.hip)
+int occ_blocks_per_cu(const void* fn, int threads, size_t lds);
+
 }  // namespace dq

@@ -269,7 +269,8 @@ struct LinAttn {
 };
 int launch_linattn_fwd(const LinAttn& a, hipStream_t s);
 constexpr int LA_PREP_BOUNDED = 1024 + 4096;          // 1.0f when the layer's softmax logits are bounded by 64 for every input (k_linattn_prepare)
-constexpr int LA_PREP_FLOATS = 1024 + 4096 + 8;       // [w2: 4 * 16 * 16][wqk: 2 * 4 * 8 * 2 * 32][bounded, 7 unused]
+constexpr int LA_PREP_BF16 = 1024 + 4096 + 8;         // split-bf16 operand image of Wq | Wk for 4 / 8 channels: 2048 la_nu(C) <= 6144 dwords (k_linattn.hip)
+constexpr int LA_PREP_FLOATS = 1024 + 4096 + 8 + 6144;  // [w2: 4 * 16 * 16][wqk: 2 * 4 * 8 * 2 * 32][bounded, 7 unused][bf16 image]
 struct LaPrepItem { const float* w_qkv; const float* w_out; int C; float* prep; const float* g_pre; };
 constexpr int LA_PREP_MAX = 16;
 struct PrepCopy { const float* src; float* dst; int n; };  // plain copies riding in the same launch (aligned weight slots)

@@ -11,6 +11,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 namespace dq {
 
@@ -18,6 +20,27 @@ constexpr int64_t WTMP_SLOT = 2 * HID * 64;  // floats per aligned weight slot (
 
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
+
+int occ_blocks_per_cu(const void* fn, int threads, size_t lds) {
+  struct Key { const void* fn; size_t lds; int threads, dev; };
+  struct Ent { Key k; int nb; };
+  static std::mutex mu;
+  static std::vector<Ent> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { set_error("occ_blocks_per_cu: hipGetDevice failed"); return -1; }
+  std::lock_guard<std::mutex> lock(mu);
+  for (const Ent& e : cache)
+    if (e.k.fn == fn && e.k.lds == lds && e.k.threads == threads && e.k.dev == dev) return e.nb;
+  if (lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    set_error("occ_blocks_per_cu: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    return -1;
+  }
+  int nb = 0;
+  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, lds);
+  if (e != hipSuccess) { set_error(std::string("hipOccupancyMaxActiveBlocksPerMultiprocessor failed: ") + hipGetErrorString(e)); return -1; }
+  cache.push_back({{fn, lds, threads, dev}, std::max(1, nb)});
+  return std::max(1, nb);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // arena

@@ -689,12 +689,9 @@ int launch_level_fwd(const LevelFwd& a, hipStream_t s) {
   // 256-thread blocks per CU where the query can say seven: MI355X_MICROARCH.md, Residency), never more blocks than tiles need
 #define DQ_LVN(CC, PP, PC, NN)                                                                                                \
   {                                                                                                                           \
-    static int occ = 0;                                                                                                       \
-    if (!occ) {                                                                                                               \
-      int nb = 0;                                                                                                             \
-      DQ_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_level_fwd<CC, PP, PC, NN>, 256, lds));                    \
-      occ = std::max(1, std::min(nb, 6));                                                                                     \
-    }                                                                                                                         \
+    const int nb = occ_blocks_per_cu((const void*)k_level_fwd<CC, PP, PC, NN>, 256, lds);  /* keyed on (instantiation, lds, device) */ \
+    if (nb < 0) return 1;                                                                                                     \
+    const int occ = std::min(nb, 6);                                                                                          \
     const int gx = std::max(1, std::min(occ * num_cus() / B, (tiles_ps + 3) / 4));  /* workgroups per sample */                \
     hipLaunchKernelGGL((k_level_fwd<CC, PP, PC, NN>), dim3(gx, B), dim3(256), lds, s, k, a.params, ssb, tiles_ps, (int)total, ln, a.img); \
     DQ_LAUNCH_CHECK();                                                                                                        \

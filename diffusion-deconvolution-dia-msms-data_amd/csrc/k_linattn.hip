@@ -25,7 +25,7 @@
 #include "dq_probe.h"
 #include <algorithm>
 #include <cstdlib>
-#include <algorithm>
+#include <string>
 
 namespace dq {
 
@@ -41,8 +41,43 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-template <int C, int N>
+// ---- split-bf16 form of the K = C projections (kT = xh^T Wk^T, q = Wq xh): an fp32 value is EXACTLY the sum of three bf16 values
+// (H = its top 16 bits, M = the top 16 bits of v - H, L = the rest: 8 + 8 + 8 significant bits), so x w = sum of nine part products; the
+// six of them at or above 2^-16 of the largest -- HH, HM, MH, MM, HL, LH -- sit in six K slots of v_mfma_f32_32x32x16_bf16 (every bf16
+// product is exact in fp32, the accumulation is fp32), the three dropped ones are <= 3 * 2^-24 of |x||w| together: the error of one fp32
+// rounding.  A K = 4 projection is two 32-cycle bf16 MFMAs instead of two 64-cycle fp32 ones, a K = 8 projection three instead of four.
+// Slot order inside a lane half: channel j of the half (la_chan) owns slots 6j .. 6j+5 = dwords 3j .. 3j+2:
+//   x parts (H, H | M, M | H, L)   weight parts (H, M | H, M | L, H)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__host__ __device__ __forceinline__ constexpr int la_nu(int C) { return (3 * (C / 2) + 3) / 4; }  // bf16 MFMAs per projection
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { union { u32x4 u; bf16x8 b; } c; c.u = v; return c.b; }
+// the three packed dwords of one x value
+__device__ __forceinline__ void la_split_x(float v, unsigned& d0, unsigned& d1, unsigned& d2) {
+  const unsigned vb = __float_as_uint(v);
+  const float r = v - __uint_as_float(vb & 0xffff0000u);          // exact
+  const unsigned rb = __float_as_uint(r);
+  const float l = r - __uint_as_float(rb & 0xffff0000u);          // exact, <= 8 significant bits
+  d0 = __builtin_amdgcn_perm(vb, vb, 0x07060706u);                 // (H, H): bytes 2, 3 of v twice
+  d1 = __builtin_amdgcn_perm(rb, rb, 0x07060706u);                 // (M, M)
+  d2 = __builtin_amdgcn_perm(__float_as_uint(l), vb, 0x07060302u); // (H, L): low half = top of v, high half = top of l
+}
+// dword e (0..3) of bf16 MFMA u for lane (col, half) of the operand image of row `o` of Wq | Wk (pre-scaled by log2(e) like the fp32 image)
+__device__ __forceinline__ unsigned la_bf16_image_dword(const float* __restrict__ w_qkv, int C, int o, int half, int u, int e) {
+  const int dw = 4 * u + e, j = dw / 3, t = dw % 3;
+  if (j >= C / 2) return 0u;
+  const float w = w_qkv[o * C + la_chan(C, j, half)] * 1.4426950408889634f;
+  const unsigned hb = __float_as_uint(w) & 0xffff0000u;
+  const float r = w - __uint_as_float(hb);
+  const unsigned mb = __float_as_uint(r) & 0xffff0000u;
+  const unsigned lb = __float_as_uint(r - __uint_as_float(mb));
+  return t < 2 ? ((hb >> 16) | mb) : ((lb >> 16) | hb);              // (H, M) twice, then (L, H)
+}
+
+template <int C, int N, bool BF>
 __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
+  static_assert(!BF || (C <= 8 && N > 1), "the bf16 operand image of 12 / 16 channels does not fit the static LDS next to the other images");
+  constexpr int NU = la_nu(C);                // bf16 MFMAs per projection (BF)
   constexpr int NB = N >= 32 ? N / 32 : 1;    // 32-position blocks per row
   constexpr int RW = N >= 32 ? 1 : 32 / N;    // rows per wave
   constexpr int NJ = la_nj(C);                // x registers per lane (channel = la_chan(C, j, half))
@@ -54,7 +89,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   static_assert(NB <= 2, "rows longer than 64 take the two-pass path (k_la_long.hip)");
   static_assert(C % 4 == 0, "channel count must be a multiple of 4");
 
-  __shared__ __attribute__((aligned(16))) float w2_lds[1024];  // [head][c'][c] = sum_e Wo[c'][head*32+e] Wv[head*32+e][c] (4 C C floats used; sized for one 16-byte copy per thread)
+  __shared__ __attribute__((aligned(16))) float w2_lds[4 * C * C];  // [head][c'][c] = sum_e Wo[c'][head*32+e] Wv[head*32+e][c]
   __shared__ __attribute__((aligned(16))) float xs_lds[4][C * NP];  // per wave: xh as [c][n]
   constexpr int MS_ROW = C * 32 + 8;  // row stride of M: + 8 floats so that the rows of a unit start in different LDS banks
   __shared__ __attribute__((aligned(16))) float ms_lds[4][(SEGM ? RW : 1) * MS_ROW];  // per wave: M of the current head as [row][c][d]
@@ -105,7 +140,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
     }
   };
   float bflag = 0.f;
-  constexpr int WQ = 2 * 4 * NJ * 2 * 32;
+  constexpr int WQ = BF ? 2 * 4 * NU * 64 * 4 : 2 * 4 * NJ * 2 * 32;  // dwords of the Wq | Wk operand image (bf16: [q|k][head][u][lane][4])
   __shared__ __attribute__((aligned(16))) float wqk_lds[N > 1 ? (WQ + 1023) / 1024 * 1024 : 4];  // (WQ floats used; whole 16-byte copies per thread)
   if (a.prep) {
     // prepared images (k_linattn_prepare): linear 16-byte copies, one (w2) + one or two (q | k operands) per thread, NO guard -- a guarded
@@ -115,11 +150,11 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
     const float4 v2 = reinterpret_cast<const float4*>(a.prep)[threadIdx.x];
     float4 vq[NQ > 0 ? NQ : 1];
 #pragma unroll
-    for (int u = 0; u < NQ; ++u) vq[u] = reinterpret_cast<const float4*>(a.prep + 1024)[u * 256 + (int)threadIdx.x];
+    for (int u = 0; u < NQ; ++u) vq[u] = reinterpret_cast<const float4*>(a.prep + (BF ? LA_PREP_BF16 : 1024))[u * 256 + (int)threadIdx.x];
     bflag = a.prep[LA_PREP_BOUNDED];  // (also in front of x: read behind the barrier it was a full wait again)
     request_x();
     DQ_PSTAMP(300000 + C * 100 + N, 9);
-    reinterpret_cast<float4*>(w2_lds)[threadIdx.x] = v2;
+    if ((int)threadIdx.x < C * C) reinterpret_cast<float4*>(w2_lds)[threadIdx.x] = v2;  // (the LOAD above is unguarded: the slot holds 1024 floats whatever C is)
 #pragma unroll
     for (int u = 0; u < NQ; ++u) reinterpret_cast<float4*>(wqk_lds)[u * 256 + (int)threadIdx.x] = vq[u];
     DQ_PSTAMP(300000 + C * 100 + N, 10);
@@ -137,7 +172,12 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   // are zero.  The rows carry log2(e): both softmaxes then use exp2 (v_exp_f32) directly, which changes nothing
   // mathematically (softmax(x) = 2^(x*log2e - max) / sum).
   if (N > 1) {
-    if (!a.prep) {
+    if (!a.prep && BF) {
+      for (int i = threadIdx.x; i < WQ; i += blockDim.x) {
+        const int e = i & 3, ln = (i >> 2) & 63, u = (i >> 8) % NU, mh = i / (256 * NU);  // mh = (q | k) * 4 + head
+        wqk_lds[i] = __uint_as_float(la_bf16_image_dword(a.w_qkv, C, mh * 32 + (ln & 31), ln >> 5, u, e));
+      }
+    } else if (!a.prep) {
       for (int i = threadIdx.x; i < WQ; i += blockDim.x) {
         const int cc = i & 31, hh = (i >> 5) & 1, j = (i >> 6) % NJ, hd = (i / (64 * NJ)) & 3, m = i / (256 * NJ);
         const int c = la_chan(C, j, hh);
@@ -147,7 +187,9 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   }
   // Without prepared weights (the stand-alone entry point) the block also decides by itself whether the logits are bounded
   // (k_linattn_prepare's criterion, LA_PREP_BOUNDED): thread t = row t of Wq | Wk, the 256 row norms meet in LDS
-  __shared__ float bnd_lds[N > 1 ? 256 : 1];
+  float* bnd_lds = &ms_lds[0][0];  // (256 floats of the per-wave M staging, which nothing uses before the barrier below)
+  static_assert(sizeof(ms_lds) >= 256 * sizeof(float), "bnd_lds aliases ms_lds");
+  float bnd0 = 0.f;
   if (N > 1 && !a.prep) {
     float n2 = 0.f;
     for (int c = 0; c < C; ++c) { const float w = a.w_qkv[threadIdx.x * C + c]; n2 = fmaf(w, w, n2); }
@@ -157,6 +199,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
       if ((int)threadIdx.x < st) bnd_lds[threadIdx.x] = fmaxf(bnd_lds[threadIdx.x], bnd_lds[threadIdx.x + st]);
       __syncthreads();
     }
+    bnd0 = bnd_lds[0];  // (read in front of the barrier below: the staging area is the waves' M buffer afterwards)
   }
   // Workgroup barrier for the LDS images only.  __syncthreads() is a full fence: it waits for vmcnt(0), i.e. for the x loads requested above --
   // the barrier then cost a whole memory round trip (9,500 clocks at batch 512) whether or not anything was staged.
@@ -174,7 +217,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
   } else if (N > 1) {
     float gm = 0.f;
     for (int c = 0; c < C; ++c) gm = fmaxf(gm, fabsf(a.g_pre[c]));
-    bounded = 1.4426950408889634f * sqrtf(bnd_lds[0]) * sqC * gm <= 64.f;
+    bounded = 1.4426950408889634f * sqrtf(bnd0) * sqC * gm <= 64.f;
   } else {
     bounded = false;
   }
@@ -214,6 +257,20 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
     }
   }
   wave_fence();
+  // split-bf16 operand of this lane's xh values (head-independent: once per unit); it is the A operand of kT and the B operand of q
+  u32x4 xp[NB][BF ? NU : 1];
+  if (BF) {
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+      unsigned dw[4 * NU];
+#pragma unroll
+      for (int i = 0; i < 4 * NU; ++i) dw[i] = 0u;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) la_split_x(Xh[blk][j], dw[3 * j], dw[3 * j + 1], dw[3 * j + 2]);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) xp[blk][u] = u32x4{dw[4 * u], dw[4 * u + 1], dw[4 * u + 2], dw[4 * u + 3]};
+    }
+  }
 
   DQ_PSTAMP(300000 + C * 100 + N, 2);
   float yown[NB][NJ];  // (Wo out) of this lane's channels c' = la_chan(C, j, half)
@@ -263,19 +320,31 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
       continue;
     }
     // weight operands of this head: lane (col, half) supplies W[o_base + col][la_chan(C, j, half)]
-    float wq[NJ], wk[NJ];
+    float wq[BF ? 1 : NJ], wk[BF ? 1 : NJ];
+    u32x4 wkb[BF ? NU : 1];
+    if (BF) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      wq[j] = wqk_lds[(((0 * 4 + hd) * NJ + j) * 2 + half) * 32 + col];
-      wk[j] = wqk_lds[(((1 * 4 + hd) * NJ + j) * 2 + half) * 32 + col];
+      for (int u = 0; u < NU; ++u)  // one ds_read_b128 per MFMA and operand, consecutive lanes 16 bytes apart (the q operand: make_q)
+        wkb[u] = reinterpret_cast<const u32x4*>(wqk_lds)[((1 * 4 + hd) * NU + u) * 64 + lane];
+    } else {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        wq[j] = wqk_lds[(((0 * 4 + hd) * NJ + j) * 2 + half) * 32 + col];
+        wk[j] = wqk_lds[(((1 * 4 + hd) * NJ + j) * 2 + half) * 32 + col];
+      }
     }
     // ---------------- K^T (rows n, col d), softmax over the positions of each row
     f32x16 kT[NB];
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
       f32x16 ak = {0};
+      if (BF) {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) ak = mfma32(Xh[blk][j], wk[j], ak);
+        for (int u = 0; u < NU; ++u) ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(xp[blk][u]), as_bf16x8(wkb[u]), ak, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) ak = mfma32(Xh[blk][j], wk[j], ak);
+      }
       kT[blk] = ak;
     }
     float krs = 1.f;  // n >= 32: 1 / sum_n exp(k[d][n]) of this lane's d, applied to M instead of to the 32 x n tile
@@ -322,8 +391,16 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
     // q (rows d, col n): un-normalised exp; its 32^-0.5 / sum factor goes onto the C-row result
     auto make_q = [&](int blk, float& qs) {
       f32x16 q = {0};
+      if (BF) {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) q = mfma32(wq[j], Xh[blk][j], q);
+        for (int u = 0; u < NU; ++u) {
+          const u32x4 wqb = reinterpret_cast<const u32x4*>(wqk_lds)[((0 * 4 + hd) * NU + u) * 64 + lane];
+          q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wqb), as_bf16x8(xp[blk][u]), q, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) q = mfma32(wq[j], Xh[blk][j], q);
+      }
       float ssum = 0.f;
       if (bounded) {
 #pragma unroll
@@ -470,21 +547,35 @@ static int la_fwd_occ_cap() {  // DQ_LA_FWD_OCC = n > 0: the forward as ONE resi
   static const int v = [] { const char* e = std::getenv("DQ_LA_FWD_OCC"); return e ? std::atoi(e) : 0; }();
   return v;
 }
+// DQ_LA_PROJ=fp32: the K = C projections on v_mfma_f32_32x32x2_f32 as in rounds 1-3 (A-B switch; default: split-bf16 for 4 / 8 channels)
+bool la_proj_bf16() {
+  static const bool v = [] { const char* e = std::getenv("DQ_LA_PROJ"); return !(e && std::string(e) == "fp32"); }();
+  return v;
+}
 template <int C>
 static int linattn_fwd_n(const LinAttn& a, hipStream_t s) {
 #define DQ_LA(NN)                                                                      \
   case NN: {                                                                           \
     constexpr int RW = NN >= 32 ? 1 : 32 / NN;                                         \
+    constexpr bool CAN_BF = C <= 8 && NN > 1;                                          \
     const int units = cdiv(a.rows, RW);                                                \
-    static int occ = 0;                                                                \
-    if (!occ) {                                                                        \
-      int nb = 0;                                                                      \
-      DQ_HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_linattn_fwd<C, NN>, 256, 0)); \
-      occ = std::max(1, nb);                                                           \
-    }                                                                                  \
     const int cap = la_fwd_occ_cap();                                                  \
-    const int grid = cap <= 0 ? cdiv(units, 4) : std::min(cdiv(units, 4), std::min(occ, cap) * la_num_cus()); \
-    hipLaunchKernelGGL((k_linattn_fwd<C, NN>), dim3(grid), dim3(256), 0, s, a);        \
+    int grid = cdiv(units, 4);                                                         \
+    if (CAN_BF && la_proj_bf16()) {                                                    \
+      if (cap > 0) {                                                                   \
+        const int nb = occ_blocks_per_cu((const void*)k_linattn_fwd<C, NN, CAN_BF>, 256, 0); \
+        if (nb < 0) return 1;                                                          \
+        grid = std::min(grid, std::min(nb, cap) * la_num_cus());                       \
+      }                                                                                \
+      hipLaunchKernelGGL((k_linattn_fwd<C, NN, CAN_BF>), dim3(grid), dim3(256), 0, s, a); \
+    } else {                                                                           \
+      if (cap > 0) {                                                                   \
+        const int nb = occ_blocks_per_cu((const void*)k_linattn_fwd<C, NN, false>, 256, 0); \
+        if (nb < 0) return 1;                                                          \
+        grid = std::min(grid, std::min(nb, cap) * la_num_cus());                       \
+      }                                                                                \
+      hipLaunchKernelGGL((k_linattn_fwd<C, NN, false>), dim3(grid), dim3(256), 0, s, a); \
+    }                                                                                  \
     break;                                                                             \
   }
   switch (a.n) {
@@ -549,6 +640,22 @@ __global__ void __launch_bounds__(256) k_linattn_prepare(LaPrepMulti m) {
       const int hh = (i >> 5) & 1, j = (i >> 6) % NJ;
       const int c = la_chan(C, j, hh);
       if (i < WQ) it.prep[1024 + i] = c < C ? v[u] * 1.4426950408889634f : 0.f;
+    }
+  }
+  if (C <= 8) {  // split-bf16 operand image of Wq | Wk (k_linattn_fwd<C, N, true>): 2048 la_nu(C) dwords, [q|k][head][u][lane][4]
+    const int NU = la_nu(C);
+    unsigned v[24];
+#pragma unroll
+    for (int t = 0; t < 24; ++t) {
+      const int i = t * 256 + (int)threadIdx.x;
+      const int e = i & 3, ln = (i >> 2) & 63, u = (i >> 8) % NU, mh = (i / (256 * NU)) & 7;
+      v[t] = 0u;
+      if (t * 256 < 2048 * NU) v[t] = la_bf16_image_dword(it.w_qkv, C, mh * 32 + (ln & 31), ln >> 5, u, e);  // (wave-uniform guard)
+    }
+#pragma unroll
+    for (int t = 0; t < 24; ++t) {
+      const int i = t * 256 + (int)threadIdx.x;
+      if (i < 2048 * NU) it.prep[LA_PREP_BF16 + i] = __uint_as_float(v[t]);
     }
   }
   // LA_PREP_BOUNDED: are the softmax logits bounded for EVERY input?  xh = x / max(|x|, eps) * sqrt(C) * g_pre has |xh| <= sqrt(C)

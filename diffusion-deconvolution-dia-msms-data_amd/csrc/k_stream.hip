@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(256) k_adamw_clip(float* __restrict__ p, const
 __global__ void k_adamw_hyper(int* __restrict__ step, const float* __restrict__ lr_dev, double b1, double b2, double wd, float* __restrict__ hyp) {
   const int t = step[0] + 1;
   step[0] = t;
-  const double lr = (double)lr_dev[0];
+  const double lr = (double)lr_dev[0] + (double)lr_dev[1];  // (hi, lo) float pair: ~48 bits of the host's double lr
   const double bc1 = 1.0 - pow(b1, (double)t), bc2 = 1.0 - pow(b2, (double)t);
   hyp[0] = (float)(1.0 - lr * wd);
   hyp[1] = (float)(lr / bc1);
@@ -476,7 +476,9 @@ int launch_adamw_clip_dev(float* p, const float* g, float* m, float* v, int64_t 
 int launch_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, float* partials, float gscale, float max_norm,
                       double lr, double b1, double b2, double eps, double wd, int step, float* gnorm_out, hipStream_t s) {
   DQ_REQUIRE(n > 0 && step >= 1, "adamw: need n > 0 and step >= 1");
-  const int grid = (int)std::min<int64_t>(cdiv(n, 256), MSE_MAX_BLOCKS);
+  // (the same grid as the device-state variant above, which keeps 8 floats of the scratch for its scalars: the norm's partial sums are then
+  // taken in the same order by both, for any n)
+  const int grid = (int)std::min<int64_t>(cdiv(n, 256), MSE_MAX_BLOCKS - 8);
   hipLaunchKernelGGL(k_sumsq, dim3(grid), dim3(256), 0, s, g, n, gscale, partials);
   DQ_LAUNCH_CHECK();
   const double bc1 = 1.0 - std::pow(b1, step), bc2 = 1.0 - std::pow(b2, step);

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DQ_HIP_LIB", os.path.join(os.path.dirname(_HERE), "libdq_hip.so"))
 
 _lib = None
-ABI_VERSION = 8  # DQ_ABI_VERSION of include/dq_hip.h this table was written against
+ABI_VERSION = 9  # DQ_ABI_VERSION of include/dq_hip.h this table was written against
 PRED_TYPES = {"eps": 0, "x0": 1}  # DQ_PRED_EPS / DQ_PRED_X0
 PRECISIONS = {"fp32": 0, "bf16x3": 1}  # DQ_PRECISION_FP32 / DQ_PRECISION_BF16X3
 

@@ -131,11 +131,12 @@ class FlatAdamW(torch.optim.Optimizer):
         flat = self._buffers()
         if self._step_dev is None or self._step_dev.device != flat.device:
             self._step_dev = torch.tensor([self._step], dtype=torch.int32, device=flat.device)
-            self._lr_dev = torch.zeros(1, dtype=torch.float32, device=flat.device)
+            self._lr_dev = torch.zeros(2, dtype=torch.float32, device=flat.device)  # (hi, lo): the double lr as two floats
             self._lr_dev_value = None
         lr = float(self.param_groups[0]["lr"])
         if lr != self._lr_dev_value:
-            self._lr_dev.fill_(lr)
+            hi = float(np.float32(lr))
+            self._lr_dev.copy_(torch.tensor([hi, float(np.float32(lr - hi))], dtype=torch.float32), non_blocking=False)
             self._lr_dev_value = lr
         return flat
 
@@ -266,9 +267,22 @@ class TrainStepGraph:
         self.opt._step = snap[3]
         self.opt.sync_step_dev()
         torch.cuda.set_rng_state(snap[4], x_0.device)
+        # the replay dereferences RAW device pointers: every buffer the captured launches touch is held here for the graph's lifetime (the
+        # network's workspace cache may evict its entry when another training shape comes by -- this reference keeps the memory alive), and
+        # the ones whose identity carries the training state are part of matches(): a `.to()` / storage-replacing load re-creates the flat
+        # buffers, and a graph that still pointed at the old ones would train dead memory
+        B, RT = int(x_0.shape[0]), int(x_0.shape[1])
+        self._held = self._live_buffers() + (self.net.workspace(B, RT, True), self.opt._scratch, self.opt._gnorm, self.opt._lr_dev,
+                                             self.opt._step_dev, dm.alpha_bars)
+        self._ptrs = tuple(t.data_ptr() for t in self._live_buffers())
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._body(count=False)
+        if tuple(t.data_ptr() for t in self._live_buffers()) != self._ptrs or self.net.workspace(B, RT, True) is not self._held[4]:
+            raise RuntimeError("TrainStepGraph: a training buffer moved while the step was being captured")
+
+    def _live_buffers(self):
+        return (self.net.flat_params, self.net.flat_grads(), self.opt._m, self.opt._v)
 
     def _body(self, count):
         loss = self.dm.train_step_fused(self.x0, self.c2, self.c1, zero_grads=True, ms1_loss_weight=self.w)
@@ -276,17 +290,15 @@ class TrainStepGraph:
         return loss
 
     def matches(self, x_0, ms1_cond, ms1_loss_weight, grad_scale):
-        return self.key == (tuple(x_0.shape), tuple(ms1_cond.shape), float(ms1_loss_weight or 0.0), float(grad_scale))
+        return (self.key == (tuple(x_0.shape), tuple(ms1_cond.shape), float(ms1_loss_weight or 0.0), float(grad_scale))
+                and tuple(t.data_ptr() for t in self._live_buffers()) == self._ptrs)
 
     def step(self, x_0, ms2_cond, ms1_cond):
         self.x0.copy_(x_0); self.c2.copy_(ms2_cond); self.c1.copy_(ms1_cond)
         self.opt._dev_state()      # (a changed lr reaches its device copy here, outside the graph)
         self.opt._step += 1
         self.graph.replay()
-        return self.loss
-
-    def close(self):
-        N.check(N.lib().dq_plan_set_side_stream(self.net._plan, 1), "dq_plan_set_side_stream")
+        return self.loss.clone()   # a fresh tensor per step, as the eager path returns (the graph's own output is overwritten by the next replay)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -522,21 +534,27 @@ class ModelInterface(object):
         (dquartic_train_config.json:12), where a step is a chain of ~250 short launches and the host's launch rate is the limit.  Same
         kernels in the same order as the eager step (bit-identical given the same t / noise); single-process runs with drawn t / noise."""
         self.train_graph = bool(on)
-        if not on and getattr(self, "_train_graph_obj", None) is not None:
-            self._train_graph_obj.close()
-            self._train_graph_obj = None
+        if not on and getattr(self, "_train_graphs", None):
+            self._train_graphs = {}
+            N.check(N.lib().dq_plan_set_side_stream(self.model._plan, 1), "dq_plan_set_side_stream")  # eager steps fork their weight gradients again
 
     def _train_one_batch(self, x_0, ms2_cond=None, ms1_cond=None, noise=None, ms1_loss_weight=0.0, t=None, sync=True):
         """Reference :1090-1123.  Returns the loss as a float (``sync=False``: a 0-dim device tensor, no host sync)."""
         fused = self._native_net() and isinstance(self.optimizer, FlatAdamW) and x_0.is_cuda and hasattr(self, "train_step_fused")
-        if fused and getattr(self, "train_graph", False) and noise is None and t is None and _world() == 1 and hasattr(self.model, "_plan"):
-            # the whole step as one captured graph (enable_train_graph): drawn t / noise, single process
-            tg = getattr(self, "_train_graph_obj", None)
+        if (fused and getattr(self, "train_graph", False) and noise is None and t is None and _world() == 1 and hasattr(self.model, "_plan")
+                and ms2_cond is not None and ms1_cond is not None):
+            # the whole step as one captured graph (enable_train_graph): drawn t / noise, single process.  A few graphs are kept, keyed by
+            # shape: an epoch's short last batch does not throw the full-batch graph away (a capture costs two warm-up steps + state copies)
+            graphs = self.__dict__.setdefault("_train_graphs", {})
+            key = (tuple(x_0.shape), tuple(ms1_cond.shape), float(ms1_loss_weight or 0.0))
+            tg = graphs.get(key)
             if tg is None or not tg.matches(x_0, ms1_cond, ms1_loss_weight, 1.0):
-                if tg is not None:
-                    tg.close()
+                for k in [k for k, g in graphs.items() if not g.matches(g.x0, g.c1, g.w, 1.0)]:
+                    del graphs[k]   # (its flat buffers were re-created since: it can never match again)
+                while len(graphs) >= 4:
+                    del graphs[next(iter(graphs))]
                 self.optimizer.grad_scale = 1.0
-                tg = self._train_graph_obj = TrainStepGraph(self, x_0, ms2_cond, ms1_cond, ms1_loss_weight)
+                tg = graphs[key] = TrainStepGraph(self, x_0, ms2_cond, ms1_cond, ms1_loss_weight)
             loss = tg.step(x_0, ms2_cond, ms1_cond)
             self.last_grad_norm = self.optimizer.last_grad_norm
             return loss.item() if sync else loss

@@ -45,7 +45,7 @@ const char* dq_last_error(void);
  * dq_rope, dq_attn_*); dq_train_step takes ms1_loss_weight, dq_ms1_loss_fwd_bwd;
  * dq_tfm_set_precision, dq_gemm_bf16x3.  8: dq_tfm_bwd_buckets, dq_tfm_num_buckets, dq_tfm_bucket_info. */
 int dq_abi_version(void);
-#define DQ_ABI_VERSION 8
+#define DQ_ABI_VERSION 9
 
 /* DDIMDiffusionModel.pred_type (model.py:205-213, 269-280, 354-389); any other value is rejected ("Unknown pred_type"). */
 enum { DQ_PRED_EPS = 0, DQ_PRED_X0 = 1 };
@@ -114,7 +114,8 @@ int dq_mse_loss_weighted_fwd_bwd(const float* pred, const float* target, float t
 int dq_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float* scratch,
                        float grad_scale, float max_norm, double lr, double beta1, double beta2, double eps, double weight_decay,
                        int step, float* gnorm_out, void* stream);
-/* The same step with the learning rate (*lr_dev, fp32) and the step count (*step_dev, int32: incremented by the call, 0 before the first
+/* The same step with the learning rate (lr_dev[0] + lr_dev[1]: the host's double lr as a (hi, lo) fp32 pair, so the scalar factors formed
+ * from it in double match dq_adamw_clip_step's bit for bit) and the step count (*step_dev, int32: incremented by the call, 0 before the first
  * step) in device memory: the call's arguments do not change from step to step, so a captured graph of it can be replayed.  scratch as above. */
 int dq_adamw_clip_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float* scratch, float grad_scale,
                            float max_norm, const float* lr_dev, double beta1, double beta2, double eps, double weight_decay, int* step_dev,

@@ -4,6 +4,8 @@ import json
 import os
 import re
 
+import pytest
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -35,3 +37,40 @@ def test_bench_cli_surface():
     for flag in ("--gpus", "--steps", "--warmup"):
         assert re.search(r'add_argument\("%s", type=int' % flag, src), flag
     assert "init_process_group(\"nccl\"" in src and "127.0.0.1" in src and "ReduceOp.MAX" in src
+
+
+def test_single_rank_legs_issue_no_collective_alone():
+    """every collective between two barriers must be issued by all ranks -- the legs that call _train_one_batch (and with it the
+    flat gradient all-reduce) on rank 0 only must be gated on a single-process run."""
+    src = open(os.path.join(REPO, "bench.py")).read()
+    assert re.search(r"if rank == 0 and world == 1 and not args\.train_only:\s*\n\s*small = \{\}", src)
+    assert "cpu_baseline(net) if (rank == 0 and world == 1" in src and "if rank == 0 and world == 1 and not args.no_transformer" in src
+
+
+@pytest.mark.gpu
+def test_bench_train_leg_under_torch_distributed_run_with_one_rank():
+    """The driver's multi-GPU launch mode with the one GPU this box has: `python -m torch.distributed.run --nproc-per-node 1 bench.py
+    --train-only` (the launcher is a CHILD process started before it touches the GPU; this test process does not hand its GPU state over).
+    Checks that the `dist_on` path of the bench (RCCL process group, replica sync, flat all-reduce inside every step, barriers, MAX over
+    ranks) still produces the contract's JSON line."""
+    import json as _json
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(REPO, "bench.py"), "--gpus", "1", "--train-only", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = _json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["parallelism"] == "dp1" and d["steps"] == 3 and d["warmup"] == 1
+    assert d["value"] > 0 and d["last_loss"] == d["last_loss"] and abs(d["last_loss"]) < 1e3  # finite
+    assert d["small_batch"] is None and d["cpu_baseline"] is None  # --train-only

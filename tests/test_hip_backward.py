@@ -98,41 +98,53 @@ def test_whole_net_grads_golden(golden, tag, use_rope):
     (y * T(g["gout"]).cuda()).sum().backward()
     torch.cuda.synchronize()
     assert rel_err(x.grad, g[f"{tag}/dx"]) < 1e-4
-    worst, n = ("", 0.0), 0
     ref = sub(g, f"{tag}/grad/")
     # a gradient that is analytically zero (e.g. the key bias without RoPE: softmax is shift-invariant) is pure
     # round-off in the reference too, so errors are measured against max(|ref|, 1e-4 * the largest gradient)
     floor = 1e-4 * max(float(v.abs().max()) for v in ref.values())
     named = dict(net.named_parameters())
-    for k, v in ref.items():
-        e = float((named[k].grad.detach().cpu() - v).abs().max()) / max(float(v.abs().max()), floor)
-        n += 1
-        if e > worst[1]:
-            worst = (k, e)
-    assert n == 395
-    # The yardstick is the oracle evaluated in float64.  A few of these sums cancel heavily (the gain of a LinearAttention output norm:
-    # ups.5.2.fn.fn.to_out.1.g) and move by ~1e-4 of their value when one conv of the forward pass rounds differently: the REFERENCE's own
-    # fp32 result is 1.2e-4 off the float64 value on that tensor (5.7e-5 on the next one), the kernels' between 3e-5 and 1.2e-4 depending on
-    # which conv kernels ran.  So: within 2e-4 of the float64 value (the reference's own distance from it, with margin), and within 4e-4 of
-    # the reference's fp32 fixture (the two fp32 errors can add up).
+    assert len(ref) == 395
+    # The yardstick is the oracle evaluated in float64.  A few of these sums cancel heavily and move by ~1e-4 of their value when one conv of
+    # the forward pass rounds differently: the REFERENCE's own fp32 fixture is that far from the float64 value on them.  Those tensors are
+    # NAMED below with the reference's fp32-vs-float64 distance measured on this fixture (tools/whole_net_errs.py, round 4); the test
+    # re-measures that distance and requires it to be >= 2.5e-5 for every name on the list, so the list cannot grow into a blanket
+    # allowance.  Bounds: every tensor within 2e-4 of float64; vs the reference's fp32 fixture 1e-4 for every tensor that is not on the list,
+    # 4e-4 for the listed ones (two fp32 errors of ~1e-4 each can add up).
+    CANCELLING = {
+        "ups.5.2.fn.fn.to_out.1.g": 1.17e-4,    # gain of a LinearAttention output norm
+        "ups.4.0.block1.norm.g": 5.7e-5,
+        "downs.1.3.bias": 4.3e-5,
+        "ups.4.1.block1.norm.g": 3.8e-5,
+        "ups.4.1.block1.proj.bias": 3.3e-5,
+        "ups.4.1.block1.proj.weight": 3.1e-5,
+        "downs.1.2.fn.norm.g": 3.1e-5,
+    }
     from oracle import dq_oracle as O
     p64 = {k: v.double().clone().requires_grad_(not k.endswith("freqs")) for k, v in sub(g, "w/").items()}
     y64 = O.unet_forward(p64, O.UNetConfig(downsample_dim=64), T(g["x"]).double(), torch.as_tensor(np.asarray(g["t"])), T(g["init_cond"]).double(),
                          T(g["attn_cond"]).double(), use_rope=use_rope)
     (y64 * T(g["gout"]).double()).sum().backward()
-    worst64, ref64 = ("", 0.0), ("", 0.0)
+    worst, worst_listed, worst64, ref64 = ("", 0.0), ("", 0.0), ("", 0.0), ("", 0.0)
     for k, v in ref.items():
+        mine = named[k].grad.detach().cpu()
+        e = float((mine - v).abs().max()) / max(float(v.abs().max()), floor)
         t64 = p64[k].grad
         d = max(float(t64.abs().max()), floor)
-        e = float((named[k].grad.detach().cpu().double() - t64).abs().max()) / d
-        if e > worst64[1]:
-            worst64 = (k, e)
+        e64 = float((mine.double() - t64).abs().max()) / d
         er = float((v.double() - t64).abs().max()) / d
-        if er > ref64[1]:
-            ref64 = (k, er)
-    print("whole-net gradients:", tag, "vs the reference's fp32", worst, "| vs float64", worst64, "| the reference's fp32 vs float64", ref64)
+        if k in CANCELLING:
+            if not use_rope:  # (the distances above were measured on the norope fixture: the list is justified by measurement)
+                assert er >= 2.5e-5, (k, er)
+            worst_listed = max(worst_listed, (k, e), key=lambda q: q[1])
+        else:
+            worst = max(worst, (k, e), key=lambda q: q[1])
+        worst64 = max(worst64, (k, e64), key=lambda q: q[1])
+        ref64 = max(ref64, (k, er), key=lambda q: q[1])
+    print("whole-net gradients:", tag, "vs the reference's fp32", worst, "| listed", worst_listed, "| vs float64", worst64,
+          "| the reference's fp32 vs float64", ref64)
     assert worst64[1] < 2e-4, worst64
-    assert worst[1] < 4e-4, worst
+    assert worst[1] < 1e-4, worst
+    assert worst_listed[1] < 4e-4, worst_listed
 
 
 def _tiny_dm(g):

@@ -16,7 +16,7 @@ named = dict(net.named_parameters()); errs = []
 for k, v in ref.items():
     errs.append((float((named[k].grad.detach().cpu() - v).abs().max()) / max(float(v.abs().max()), floor), k, float(v.abs().max())))
 errs.sort(reverse=True)
-for e in errs[:6]: print(e)
+for e in errs[:12]: print(e)
 # ---- the same gradients against the oracle evaluated in float64 (the reference's own fp32 result is ~1e-4 off it on the worst tensor)
 from oracle import dq_oracle as O
 _orig = O.sinusoidal_emb
@@ -27,6 +27,6 @@ for k in p:
 y64 = O.unet_forward(p, O.UNetConfig(downsample_dim=64), T(g["x"]).double(), torch.as_tensor(g["t"]), T(g["init_cond"]).double(), T(g["attn_cond"]).double(), use_rope=False)
 (y64 * T(g["gout"]).double()).sum().backward()
 e2 = sorted(((float((named[k].grad.detach().cpu().double() - p[k].grad).abs().max()) / max(float(p[k].grad.abs().max()), floor), k) for k in ref), reverse=True)
-print("GPU vs oracle64:", e2[:4])
+print("GPU vs oracle64:", e2[:8])
 e3 = sorted(((float((ref[k].double() - p[k].grad).abs().max()) / max(float(p[k].grad.abs().max()), floor), k) for k in ref), reverse=True)
-print("reference fp32 (golden) vs oracle64:", e3[:2])
+print("reference fp32 (golden) vs oracle64:", e3[:8])
