@@ -43,6 +43,74 @@ def la_flops_fwd(C, n):
     return 2 * 384 * C * n + 2 * 2 * 4 * 32 * 32 * n + 2 * 128 * C * n
 
 
+# LinearAttention layers of the default network, (C, n) per m/z row: 7 down levels (dim_in, n = 64 .. 1), 7 up levels (dim_out, n = 1 .. 64)
+LA_LAYERS = [(4, 64), (4, 32), (8, 16), (8, 8), (12, 4), (12, 2), (16, 1), (16, 1), (16, 2), (12, 4), (12, 8), (8, 16), (8, 32), (4, 64)]
+
+
+def executed_flops_per_window(mz=MZ, rt=RT):
+    """FLOPs (2 x MAC, fp32-equivalent) the kernels EXECUTE per window: everything but LinearAttention runs the reference's association
+    (SURVEY 8d counts), LinearAttention runs the re-associated form: per (row, head) 4 products of 2*32*C*n forward,
+    12 backward, plus the C x C W2 products (1 forward, 3 backward); rows of one position take the closed form (W2 only).  The backward of
+    the non-LinearAttention part is priced at 2 x its forward, as the SURVEY count does.  Returns (forward, train step)."""
+    scale = mz // 64
+    la_alg = sum(la_flops_fwd(C, n * scale) for C, n in LA_LAYERS) * rt
+    la_fwd = sum(4 * ((4 * 2 * 32 * C * n * scale if n * scale > 1 else 0) + 2 * C * C * n * scale) for C, n in LA_LAYERS) * rt
+    la_bwd = sum(4 * ((12 * 2 * 32 * C * n * scale if n * scale > 1 else 0) + 3 * 2 * C * C * n * scale) for C, n in LA_LAYERS) * rt
+    if (mz, rt) == (MZ, RT):
+        fwd_alg = FLOPS_FWD
+    elif (mz, rt) == (256, 2000):
+        fwd_alg = 51_667_451_072  # SURVEY 8d, L
+    else:
+        raise ValueError("no algorithmic FLOP count for this window shape")
+    rest = fwd_alg - la_alg
+    return rest + la_fwd, 3 * rest + la_fwd + la_bwd
+
+
+def large_window_leg(device):
+    """BASELINE configs[4] on one GPU: windows of 2000 RT x 256 m/z (downsample_dim 256: rows of 256 .. 4 positions, 64-channel
+    bottleneck over 2000 positions), batch 8 per GPU, fp32, random-init weights, uniform random inputs: train step (the same
+    _train_one_batch as the headline) and one DDIM sampling step (hipGraph replay), timed over a handful of steps."""
+    from dquartic.model.model import DDIMDiffusionModel
+    from dquartic.model.unet1d import UNet1d
+
+    B, rt, mz = 8, 2000, 256
+    torch.manual_seed(0)
+    net = UNet1d(dim=4, channels=1, dim_mults=(1, 2, 2, 3, 3, 4, 4), conditional=True, init_cond_channels=1, attn_cond_channels=1,
+                 tfer_dim_mult=620, downsample_dim=mz, simple=True).to(device)
+    dm = DDIMDiffusionModel(model_class=net, num_timesteps=1000, beta_schedule_type="cosine", pred_type="eps", auto_normalize=True,
+                            ms1_loss_weight=0.0, device=device)
+    dm._set_optimizer(1e-5)
+    x0, c2, c1 = torch.rand(B, rt, mz, device=device), torch.rand(B, rt, mz, device=device), torch.rand(B, rt, device=device)
+    for _ in range(3):
+        dm._train_one_batch(x0, ms2_cond=c2, ms1_cond=c1, sync=False)
+    torch.cuda.synchronize()
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        loss = dm._train_one_batch(x0, ms2_cond=c2, ms1_cond=c1, sync=False)
+    torch.cuda.synchronize()
+    t_train = (time.perf_counter() - t0) / n
+    xT = torch.randn(B, rt, mz, device=device)
+    dm.sample(xT, c2, c1, num_steps=2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dm.sample(xT, c2, c1, num_steps=n)
+    torch.cuda.synchronize()
+    t_step = (time.perf_counter() - t0) / n
+    ex_f, ex_t = executed_flops_per_window(mz, rt)
+    out = {"workload": "BASELINE configs[4]: windows 2000 RT x 256 m/z, batch 8 per GPU, default UNet1d with downsample_dim 256 (197,103 params), fp32",
+           "batch": B, "params": int(net.flat_params.numel()),
+           "train": {"ms_per_step": round(t_train * 1e3, 3), "windows_per_s": round(B / t_train, 2), "loss": round(float(loss), 5),
+                     "flop_frac": round(B / t_train * 155_002_129_088 / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                     "executed_flop_frac": round(B / t_train * ex_t / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)},
+           "sample": {"ms_per_step": round(t_step * 1e3, 3), "windows_per_s_50_steps": round(B / (t_step * SAMPLE_STEPS), 3),
+                      "flop_frac": round(B / t_step * 51_667_451_072 / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                      "executed_flop_frac": round(B / t_step * ex_f / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}}
+    del net, dm, x0, c2, c1, xT
+    torch.cuda.empty_cache()
+    return out
+
+
 def build_model(device):
     from dquartic.model.model import DDIMDiffusionModel
     from dquartic.model.unet1d import UNet1d
@@ -80,7 +148,7 @@ def time_kernel(fn, iters=20):
     return e0.elapsed_time(e1) * 1e-3 / iters  # seconds per launch
 
 
-def pmc_traffic(kernel_prefix):
+def pmc_traffic(kernel_prefix, section="kernels"):
     """HBM bytes per launch of a kernel from the committed counter passes (profiles/pmc_linattn.json, written by
     tools/pmc_passes.sh on the GPU box) -- only if they were taken on THIS build of the native sources; a stale file gives null."""
     from dquartic import _native as N
@@ -92,13 +160,13 @@ def pmc_traffic(kernel_prefix):
         pmc = json.load(fh)
     if pmc.get("build_id") != N.build_id():
         return None, f"profiles/pmc_linattn.json is from build {pmc.get('build_id')}, this build is {N.build_id()}: stale, not quoted"
-    for name, v in pmc["kernels"].items():
+    for name, v in pmc.get(section, {}).items():
         if name.startswith(kernel_prefix):
             return float(v["hbm_bytes"]), f"profiles/pmc_linattn.json (2 x FETCH_SIZE + WRITE_SIZE, build {pmc['build_id']})"
     return None, f"{kernel_prefix} not in profiles/pmc_linattn.json"
 
 
-def pmc_sq(kernel_prefix, launch_seconds):
+def pmc_sq(kernel_prefix, launch_seconds, section="sq"):
     """Matrix-pipe busy fraction of a kernel from the SQ counter pass of the same file (stale file: null): SQ_VALU_MFMA_BUSY_CYCLES (summed
     over the SIMDs) / (launch duration x 2.4 GHz x 1,024 SIMDs)."""
     from dquartic import _native as N
@@ -110,7 +178,7 @@ def pmc_sq(kernel_prefix, launch_seconds):
         pmc = json.load(fh)
     if pmc.get("build_id") != N.build_id():
         return None
-    for name, v in pmc.get("sq", {}).items():
+    for name, v in pmc.get(section, {}).items():
         if name.startswith(kernel_prefix) and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
             return round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (launch_seconds * 2.4e9 * 1024), 4)
     return None
@@ -196,10 +264,15 @@ def roofline_linattn(device, rows=TRAIN_BATCH * RT, with_bwd=True):
     dw, dwo, dbo, dg1, dg2 = (torch.zeros_like(t) for t in (w, wo, bo, g1, g2))
     scratch = torch.empty(2 * x.numel() + 2048 * 512 * C, device=device)
     L = N.lib()
+    sampling = rows != TRAIN_BATCH * RT   # the sampling leg's launch (204,800 rows): its own counter passes (tools/pmc_passes.sh, "sample" mode)
+
+    # the network's code path: derived weights + operand images prepared once per parameter state (dq_linattn_prepare), every launch copies them
+    prep = torch.zeros(L.dq_linattn_prep_floats(), device=device)
+    N.check(L.dq_linattn_prepare(N.ptr(w), N.ptr(wo), N.ptr(g1), C, N.ptr(prep), N.stream_ptr()), "dq_linattn_prepare")
 
     def fwd():
-        N.check(L.dq_linattn_fwd(N.ptr(x), N.ptr(y), N.ptr(ypre), N.ptr(w), N.ptr(wo), N.ptr(bo), N.ptr(g1), N.ptr(g2), C, rows, n,
-                                 N.stream_ptr()), "dq_linattn_fwd")
+        N.check(L.dq_linattn_fwd_prepared(N.ptr(x), N.ptr(y), N.ptr(ypre), N.ptr(w), N.ptr(wo), N.ptr(bo), N.ptr(g1), N.ptr(g2), N.ptr(prep), C, rows, n,
+                                          N.stream_ptr()), "dq_linattn_fwd_prepared")
 
     def bwd():
         N.check(L.dq_linattn_bwd(N.ptr(x), N.ptr(ypre), N.ptr(dy), N.ptr(dx), N.ptr(w), N.ptr(wo), N.ptr(bo), N.ptr(g1), N.ptr(g2),
@@ -210,17 +283,18 @@ def roofline_linattn(device, rows=TRAIN_BATCH * RT, with_bwd=True):
     fl_f = la_flops_fwd(C, n) * rows
     ex_f = 4 * (4 * 2 * 32 * C * n + 2 * C * C * n) * rows
     by_f = 8 * C * n * rows  # x in, y out (inference; training adds the 4*C*n pre-norm save)
-    tr_f, src_f = pmc_traffic("k_linattn_fwd<4, 64>")
-    fwd_obj = {"bound": "mfma", "kernel": "k_linattn_fwd<4,64>", "rows": rows, "launch_us": round(t_f * 1e6, 2),
+    tr_f, src_f = pmc_traffic("k_linattn_fwd<4, 64,", "sample_kernels" if sampling else "kernels")
+    fwd_obj = {"bound": "mfma", "kernel": "k_linattn_fwd<4,64> (K = C projections: split-bf16 on v_mfma_f32_32x32x16_bf16, fp32-exact to ~2^-23)", "rows": rows,
+               "launch_us": round(t_f * 1e6, 2),
                "achieved": round(ex_f / t_f / 1e12, 3), "algorithmic_achieved": round(fl_f / t_f / 1e12, 3),
-               "algorithmic_frac": round(fl_f / t_f / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), "mfma_busy": pmc_sq("k_linattn_fwd<4, 64>", t_f) if rows == TRAIN_BATCH * RT else None,
+               "algorithmic_frac": round(fl_f / t_f / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), "mfma_busy": pmc_sq("k_linattn_fwd<4, 64,", t_f, "sample_sq" if sampling else "sq"),
                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                # the re-association removed work: the algorithmic rate can exceed the pipe's peak, so `frac` is stated on the FLOPs
                # the kernel executes; the algorithmic figure stays in `achieved`
                "frac": round(ex_f / t_f / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), "frac_basis": "executed FLOPs",
                "flops_per_launch": fl_f, "executed_flops_per_launch": ex_f,
                "hbm_frac": round(by_f / t_f / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": by_f,
-               "traffic": tr_f if rows == TRAIN_BATCH * RT else None, "traffic_source": src_f}
+               "traffic": tr_f, "traffic_source": src_f}
     if not with_bwd:
         return fwd_obj
     t_b = time_kernel(bwd)  # the fused backward launch + the ordered slot reduce (~3 % of it)
@@ -453,11 +527,12 @@ def main():
     ap.add_argument("--no-sample", action="store_true", help="skip the sampling leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-transformer", action="store_true", help="skip the CustomTransformer leg (rank 0, single-GPU runs only)")
+    ap.add_argument("--no-large-window", action="store_true", help="skip the configs[4] leg (2000 x 256 windows, batch 8; single-GPU runs only)")
     ap.add_argument("--train-only", action="store_true", help="only the train leg (clean per-kernel profiles of the train step)")
     ap.add_argument("--sample-batch", type=int, default=SAMPLE_BATCH)
     args = ap.parse_args()
     if args.train_only:
-        args.no_sample = args.no_cpu = args.no_transformer = True
+        args.no_sample = args.no_cpu = args.no_transformer = args.no_large_window = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -585,6 +660,7 @@ def main():
                   # whole-leg fractions per GPU: algorithmic FLOPs (50 forwards per window) against the f32 matrix peak, compulsory
                   # bytes (x_t, mixture, MS1 in; x_{t-1} out, per step) against the HBM peak
                   "whole_leg": {"flop_frac": round(swps / world * SAMPLE_STEPS * FLOPS_FWD / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                                "executed_flop_frac": round(swps / world * SAMPLE_STEPS * executed_flops_per_window()[0] / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                                 "hbm_frac": round(swps / world * SAMPLE_STEPS * BYTES_SAMPLE_STEP / 1e9 / HBM_PEAK_GBS, 6)}}
         if rank == 0:
             log("sampling roofline leg")
@@ -594,6 +670,10 @@ def main():
     roof = roofline_linattn(device) if (rank == 0 and not args.train_only) else None
     form = batch_formation(device) if (rank == 0 and not args.train_only) else None
     hbm = roofline_hbm_kernels(device) if (rank == 0 and not args.train_only) else None
+    large = None
+    if rank == 0 and world == 1 and not args.no_large_window:
+        log("large-window leg (configs[4])")
+        large = large_window_leg(device)
     log("cpu baseline leg")
     cpu = cpu_baseline(net) if (rank == 0 and world == 1 and not args.no_cpu) else None
     tfm = None
@@ -616,10 +696,13 @@ def main():
             "host_issue_ms_per_step": round(host_issue_ms, 3),
             "build_id": __import__("dquartic._native", fromlist=["x"]).build_id(),
             # whole-step fractions per GPU: algorithmic FLOPs of fwd + bwd against the f32 matrix peak; compulsory bytes against HBM
+            # (`flop_frac`: the reference's algorithmic count; `executed_flop_frac`: the FLOPs the kernels execute, executed_flops_per_window)
             "whole_step": {"flop_frac": round(train_wps / world * FLOPS_TRAIN / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                           "executed_flop_frac": round(train_wps / world * executed_flops_per_window()[1] / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                            "hbm_frac": round(train_wps / world * BYTES_TRAIN(TRAIN_BATCH) / 1e9 / HBM_PEAK_GBS, 6)},
             "sustained": sustained, "small_batch": small,
-            "sample": sample, "roofline": roof, "roofline_hbm": hbm, "cpu_baseline": cpu, "batch_formation": form, "transformer": tfm,
+            "sample": sample, "roofline": roof, "roofline_hbm": hbm, "cpu_baseline": cpu, "batch_formation": form, "large_window": large,
+            "transformer": tfm,
         }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

@@ -1448,6 +1448,21 @@ int dq_linattn_fwd(const float* x, float* y, float* ypre, const float* w_qkv, co
   return launch_linattn_fwd(a, (hipStream_t)stream);
 }
 
+int64_t dq_linattn_prep_floats(void) { return LA_PREP_FLOATS; }
+int dq_linattn_prepare(const float* w_qkv, const float* w_out, const float* g_pre, int C, float* prep, void* stream) {
+  DQ_REQUIRE(w_qkv && w_out && g_pre && prep && ((uintptr_t)prep & 15) == 0, "dq_linattn_prepare: null or unaligned argument (prep: 16-byte aligned)");
+  const LaPrepItem it{w_qkv, w_out, C, prep, g_pre};
+  return launch_linattn_prepare(&it, 1, (hipStream_t)stream);
+}
+int dq_linattn_fwd_prepared(const float* x, float* y, float* ypre, const float* w_qkv, const float* w_out, const float* b_out,
+                            const float* g_pre, const float* g_out, const float* prep, int C, int rows, int n, void* stream) {
+  DQ_REQUIRE(prep && ((uintptr_t)prep & 15) == 0 && la_short_row(n), "dq_linattn_fwd_prepared: prepared weights are used by rows of 1 .. 64 positions (powers of two)");
+  LinAttn a;
+  a.x = x; a.y = y; a.ypre = ypre; a.w_qkv = w_qkv; a.w_out = w_out; a.b_out = b_out; a.g_pre = g_pre; a.g_out = g_out; a.C = C; a.rows = rows; a.n = n;
+  a.prep = prep;
+  return launch_linattn_fwd(a, (hipStream_t)stream);
+}
+
 int dq_linattn_bwd(const float* x, const float* ypre, const float* dy, float* dx, const float* w_qkv, const float* w_out,
                    const float* b_out, const float* g_pre, const float* g_out, float* dw_qkv, float* dw_out, float* db_out,
                    float* dg_pre, float* dg_out, float* scratch, int C, int rows, int n, void* stream) {

@@ -110,7 +110,7 @@ __device__ __forceinline__ float half_sum(float v) {
 #endif
 constexpr bool la_two_waves(int C, int N) { return C == 4 || (C == 8 && (N == 32 || N == 16 || N == 8)) || (DQ_LA_12TW && C == 12 && N <= 8); }
 #ifndef DQ_LA_4_3W
-#define DQ_LA_4_3W 0  // build-time experiment: <4,64> at three waves per SIMD (168 registers by launch bound): 63 spilled registers, 281 -> 300 us
+#define DQ_LA_4_3W 0  // build-time experiment: <4,64> at three waves per SIMD (168 registers by launch bound).  Round 3: 63 spilled registers, 281 -> 300 us.  Round 4 (no tile carried across the phases, K^T recomputed in the k phase, x / dy re-read: 24 spilled registers): 278 -> 288 us stand-alone, the step unchanged -- the LDS pipe, not the wave count, is what the transposes and operand reads saturate
 #endif
 template <int C, int N>
 __global__ void __launch_bounds__(256, (DQ_LA_4_3W && C == 4 && N == 64) ? 3 : (la_two_waves(C, N) ? 2 : 1)) k_linattn_bwd(LinAttnBwdK a) {
@@ -126,6 +126,9 @@ __global__ void __launch_bounds__(256, (DQ_LA_4_3W && C == 4 && N == 64) ? 3 : (
   constexpr int MS_ROW = C * 32 + 8;        // one row's M as [c][d]; + 8 floats: the rows of a unit start in different LDS banks
   constexpr int MS_FLOATS = SEGM ? (RW * MS_ROW > 2 * C * 32 ? RW * MS_ROW : 2 * C * 32) : 2 * C * 32;  // M | dM ; SEGM: M_s, then dM_s over them
   constexpr bool PARTNER = N >= 8;
+  // three waves per SIMD (168 registers): K^T is not carried across the q phase (recomputed in the k phase: 2 NJ MFMAs + 32 exps per unit
+  // and head), and the raw x / dy the end of the unit needs are read again instead of held
+  constexpr bool LEAN = DQ_LA_4_3W && C == 4 && N == 64;
   // C = 4 runs two waves per SIMD instead (the partner wave hides the latency); C = 16 and the 64-position C = 12 variant have
   // no registers to spare
   constexpr bool PREFETCH = DQ_LA_PF4 ? (C <= 8 || (C == 12 && N < 64)) : ((C == 8 && !la_two_waves(C, N)) || (C == 12 && N < 64));
@@ -400,6 +403,7 @@ __global__ void __launch_bounds__(256, (DQ_LA_4_3W && C == 4 && N == 64) ? 3 : (
 
       // ---- K^T (rows n, col d): exps, then normalised in place (softmax over the positions of each row)
       f32x16 kT[NB];
+      float k_m = 0.f, k_rs = 1.f;  // LEAN: shift and 1 / sum of this lane's k-softmax row (d = col), for the recompute in the k phase
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         f32x16 ak = {0};
@@ -426,6 +430,7 @@ __global__ void __launch_bounds__(256, (DQ_LA_4_3W && C == 4 && N == 64) ? 3 : (
 #pragma unroll
             for (int r = s0; r < s0 + SEG; ++r) m = fmaxf(m, kT[b][r]);
           if (PARTNER) m = fmaxf(m, swp32(m));
+          if (LEAN) k_m = m;
 #pragma unroll
           for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -437,6 +442,7 @@ __global__ void __launch_bounds__(256, (DQ_LA_4_3W && C == 4 && N == 64) ? 3 : (
         }
         if (PARTNER) ssum += swp32(ssum);
         const float rs = 1.0f / ssum;
+        if (LEAN) k_rs = rs;
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -498,7 +504,12 @@ __global__ void __launch_bounds__(256, (DQ_LA_4_3W && C == 4 && N == 64) ? 3 : (
           }
         }
         wfence();
-        f32x16 qT[NB];  // Q^T (rows n, col d), kept for dM
+        // (Round 4: no tile is carried from one phase to the next any more.  Q^T of a block was kept for dM = sum_b dP_b Q_b^T and dK^T of
+        // both blocks for the k-softmax backward's sum over the row -- 64 registers at two blocks; now dM accumulates inside the block loop
+        // (same order of additions: bit-identical) and dK^T is formed twice (the sum, then the gradient: 2 NJ more K = C MFMAs per unit).)
+        f32x4 mtd[CG];  // dM^T[c][d] partial sums of this lane-half: sum over the blocks of dP Q^T
+#pragma unroll
+        for (int g = 0; g < CG; ++g) mtd[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           const f32x16 q = make_q(b);
@@ -521,47 +532,53 @@ __global__ void __launch_bounds__(256, (DQ_LA_4_3W && C == 4 && N == 64) ? 3 : (
           const f32x16 dq_raw = q_softmax_bwd(q, dq);
           add_dxh(b, 0, dq_raw);
           add_dw(gq, b, tr32(dq_raw, tile, col, half));
-          qT[b] = tr32(q, tile, col, half);
+          const f32x16 qT = tr32(q, tile, col, half);  // Q^T (rows n, col d); (the fences inside tr32 also complete this block's ps / dps stores)
+#pragma unroll
+          for (int g = 0; g < CG; ++g) mtd[g] += chain4(dps, NP, b * 32, g, qT);  // dM^T[c][d] += sum_(n in block b) dP[c][n] Q[d][n]
+          if (LEAN) __builtin_amdgcn_sched_barrier(0);  // (the scheduler interleaves the two blocks' streams otherwise: twice the live tiles)
         }
         wfence();  // ps / dps complete
         add_dw2();
-        // dM^T[c][d] = sum_n dP[c][n] Q[d][n] ; both halves ; its [c][d] image for the dXh chain
+        // dM: both halves ; its [c][d] image for the dXh chain
         float dMr[C];
 #pragma unroll
         for (int g = 0; g < CG; ++g) {
-          f32x4 mt = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int b = 0; b < NB; ++b) mt += chain4(dps, NP, b * 32, g, qT[b]);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            dMr[g * 4 + i] = mt[i] + swp32(mt[i]);
+            dMr[g * 4 + i] = mtd[g][i] + swp32(mtd[g][i]);
             if (half == 0) dms[(g * 4 + i) * 32 + col] = dMr[g * 4 + i];
           }
         }
         wfence();
-        // dK^T[n][d] = sum_c xh[c][n] dM[d][c] ; softmax backward over the positions (lane-local + partner)
-        f32x16 dkT[NB];
+        // dK^T[n][d] = sum_c xh[c][n] dM[d][c] ; softmax backward over the positions of the row.  Its sum over the row needs no tile:
+        // sum_n K[d][n] dK[d][n] = sum_c dM[d][c] sum_n K[d][n] xh[c][n] = sum_c dM[d][c] M[d][c]  (this lane's d; both halves hold M, dM)
         float dl = 0.f;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          f32x16 t = {0};
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) t = mfma32b(Xh[b][j], own(dMr, j), t);
-          dkT[b] = t;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) dl = fmaf(t[r], kT[b][r], dl);
-        }
-        dl += swp32(dl);
+        for (int c = 0; c < C; ++c) dl = fmaf(dMr[c], Mr[c], dl);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-          f32x16 dk_rawT;
+          f32x16 kTb;
+          if (LEAN) {  // K^T of this block again (it was not kept across the q phase: 16 registers per block)
+            f32x16 ak = {0};
 #pragma unroll
-          for (int r = 0; r < 16; ++r) dk_rawT[r] = kT[b][r] * (dkT[b][r] - dl);
+            for (int j = 0; j < NJ; ++j) ak = mfma32b(Xh[b][j], wk[j], ak);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ak[r] = __builtin_amdgcn_exp2f(ak[r] - k_m) * k_rs;
+            kTb = ak;
+          } else {
+            kTb = kT[b];
+          }
+          f32x16 dk_rawT = {0};
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) dk_rawT = mfma32b(Xh[b][j], own(dMr, j), dk_rawT);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dk_rawT[r] = kTb[r] * (dk_rawT[r] - dl);
           add_dw(gk, b, dk_rawT);
           add_dxh(b, 1, tr32(dk_rawT, tile, col, half));
-          const f32x16 Kd = tr32(kT[b], tile, col, half);  // rows d, col n
+          const f32x16 Kd = tr32(kTb, tile, col, half);  // rows d, col n
 #pragma unroll
           for (int g = 0; g < CG; ++g) part[b][g] += chain4(dms, 32, 0, g, Kd);  // dXh[c][n] += sum_d K[d][n] dM[d][c]
+          if (LEAN) __builtin_amdgcn_sched_barrier(0);
         }
       } else if (SEGM) {
         // ================= rows of 16 positions (two rows per unit): M / P form per ROW =================
@@ -662,52 +679,69 @@ __global__ void __launch_bounds__(256, (DQ_LA_4_3W && C == 4 && N == 64) ? 3 : (
         for (int g = 0; g < CG; ++g) part[0][g] += chain4(dms + rl * MS_ROW, 32, 0, g, Kd);  // dXh[c][n] += sum_d K[d][n] dM_row(n)[d][c]
       } else {
         // ================= 32/N rows per wave, one block: masked quadratic form =================
+        // One 32x32 tile chain at a time (round 4): S^T -> R, then S -> its dXh chain, then dS^T -> dQ and the whole q side, then dS -> dK^T.
+        // Each 16-deep chain runs back to back on one accumulator (this MFMA needs no interleaving with a second chain), the same sums in
+        // the same order as before -- but at most four tiles are live (q, K, K^T and the chain's accumulator) instead of nine.
         const f32x16 q = make_q(0);
-        const f32x16 qT = tr32(q, tile, col, half);
         const f32x16 Kd = tr32(kT[0], tile, col, half);
-        f32x16 st = {0}, sm = {0};
+        float dR[C];
+        {
+          f32x16 st = {0};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          st = mfma32b(Kd[r], q[r], st);  // S^T : rows n', col n
-          sm = mfma32b(q[r], Kd[r], sm);  // S   : rows n,  col n'
-        }
-        st = mask_same_row<N>(st, col, half);
-        sm = mask_same_row<N>(sm, col, half);
-        float dR[C], R[C];
-        make_dp(0, dR);
+          for (int r = 0; r < 16; ++r) st = mfma32b(Kd[r], q[r], st);  // S^T : rows n', col n
+          st = mask_same_row<N>(st, col, half);
+          float R[C];
 #pragma unroll
-        for (int g = 0; g < CG; ++g) {
-          const f32x4 rr = chain4(xs, NP, 0, g, st);  // R[c][n] = sum_n' xh[c][n'] S^T[n'][n]
+          for (int g = 0; g < CG; ++g) {
+            const f32x4 rr = chain4(xs, NP, 0, g, st);  // R[c][n] = sum_n' xh[c][n'] S^T[n'][n]
 #pragma unroll
-          for (int i = 0; i < 4; ++i) R[g * 4 + i] = rr[i] + swp32(rr[i]);
-        }
-        if (half == 0) {
+            for (int i = 0; i < 4; ++i) R[g * 4 + i] = rr[i] + swp32(rr[i]);
+          }
+          make_dp(0, dR);
+          if (half == 0) {
 #pragma unroll
-          for (int c = 0; c < C; ++c) { ps[c * NP + col] = R[c]; dps[c * NP + col] = dR[c]; }
+            for (int c = 0; c < C; ++c) { ps[c * NP + col] = R[c]; dps[c * NP + col] = dR[c]; }
+          }
         }
         wfence();
         add_dw2();
-        // dS^T[n'][n] = sum_c xh[c][n'] dR[c][n] and dS = its transpose (K = C products), masked to pairs of the same row
-        f32x16 dst = {0}, dsm = {0};
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          f32x16 sm = {0};
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          dst = mfma32b(Xh[0][j], own(dR, j), dst);
-          dsm = mfma32b(own(dR, j), Xh[0][j], dsm);
+          for (int r = 0; r < 16; ++r) sm = mfma32b(q[r], Kd[r], sm);  // S   : rows n,  col n'
+          sm = mask_same_row<N>(sm, col, half);
+          // dXh[c][n'] += sum_n S[n][n'] dR[c][n]
+#pragma unroll
+          for (int g = 0; g < CG; ++g) part[0][g] += chain4(dps, NP, 0, g, sm);
         }
-        dst = mask_same_row<N>(dst, col, half);
-        dsm = mask_same_row<N>(dsm, col, half);
-        // dXh[c][n'] += sum_n S[n][n'] dR[c][n]
+        __builtin_amdgcn_sched_barrier(0);
+        // dS^T[n'][n] = sum_c xh[c][n'] dR[c][n] (K = C product), masked to pairs of the same row ; dQ ; the q side
+        f32x16 qT;
+        {
+          f32x16 dst = {0};
 #pragma unroll
-        for (int g = 0; g < CG; ++g) part[0][g] += chain4(dps, NP, 0, g, sm);
-        f32x16 dq = {0}, dkT = {0};
+          for (int j = 0; j < NJ; ++j) dst = mfma32b(Xh[0][j], own(dR, j), dst);
+          dst = mask_same_row<N>(dst, col, half);
+          f32x16 dq = {0};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          dq = mfma32b(kT[0][r], dst[r], dq);    // rows d,  col n
-          dkT = mfma32b(dsm[r], qT[r], dkT);     // rows n', col d
+          for (int r = 0; r < 16; ++r) dq = mfma32b(kT[0][r], dst[r], dq);    // rows d,  col n
+          const f32x16 dq_raw = q_softmax_bwd(q, dq);
+          add_dxh(0, 0, dq_raw);
+          add_dw(gq, 0, tr32(dq_raw, tile, col, half));
+          qT = tr32(q, tile, col, half);  // (only now: one tile fewer is live across the S / dS products)
         }
-        const f32x16 dq_raw = q_softmax_bwd(q, dq);
-        add_dxh(0, 0, dq_raw);
-        add_dw(gq, 0, tr32(dq_raw, tile, col, half));
+        __builtin_amdgcn_sched_barrier(0);
+        // dS = the transpose of dS^T (the K = C product with the operands swapped) ; dK^T ; the k side
+        f32x16 dkT = {0};
+        {
+          f32x16 dsm = {0};
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) dsm = mfma32b(own(dR, j), Xh[0][j], dsm);
+          dsm = mask_same_row<N>(dsm, col, half);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dkT = mfma32b(dsm[r], qT[r], dkT);     // rows n', col d
+        }
         f32x16 dk_rawT;  // softmax over the positions of each row: a lane's own register segment (+ lane^32)
 #pragma unroll
         for (int s0 = 0; s0 < 16; s0 += SEG) {
@@ -737,6 +771,11 @@ __global__ void __launch_bounds__(256, (DQ_LA_4_3W && C == 4 && N == 64) ? 3 : (
           // (no registers to hold dx across the MFMA work in these variants: requested here, in front of the barrier)
           if (!PREFETCH && row_ok && c < C && last && !a.dx_store)
             pdx[b][j] = a.dx[((int64_t)row * C + c) * N + (N >= 32 ? b * 32 + col : col % N)];
+          if (LEAN && last) {  // the raw x / dy of this unit again (L2-hot: the four waves read them at the top of the unit)
+            const int64_t off = ((int64_t)row * C + c) * N + (N >= 32 ? b * 32 + col : col % N);
+            cx[b][j] = (row_ok && c < C) ? a.x[off] : 0.f;
+            cd[b][j] = (row_ok && c < C) ? a.dy[off] : 0.f;
+          }
         }
       }
       lds_barrier();  // (LDS-only: __syncthreads() would also wait for the dx values just requested and for a prefetched next unit)

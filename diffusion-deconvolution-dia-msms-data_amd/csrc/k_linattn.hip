@@ -44,8 +44,8 @@ __device__ __forceinline__ void wave_fence() {
 // ---- split-bf16 form of the K = C projections (kT = xh^T Wk^T, q = Wq xh): an fp32 value is EXACTLY the sum of three bf16 values
 // (H = its top 16 bits, M = the top 16 bits of v - H, L = the rest: 8 + 8 + 8 significant bits), so x w = sum of nine part products; the
 // six of them at or above 2^-16 of the largest -- HH, HM, MH, MM, HL, LH -- sit in six K slots of v_mfma_f32_32x32x16_bf16 (every bf16
-// product is exact in fp32, the accumulation is fp32), the three dropped ones are <= 3 * 2^-24 of |x||w| together: the error of one fp32
-// rounding.  A K = 4 projection is two 32-cycle bf16 MFMAs instead of two 64-cycle fp32 ones, a K = 8 projection three instead of four.
+// product is exact in fp32, the accumulation is fp32), the three dropped ones (M L, L M, L L) are < 2^-21 of |x||w| together in the worst
+// case and ~2^-23 typically: a few fp32 roundings (every forward fixture and trajectory tolerance holds unchanged, tests/test_hip_forward.py).  A K = 4 projection is two 32-cycle bf16 MFMAs instead of two 64-cycle fp32 ones, a K = 8 projection three instead of four.
 // Slot order inside a lane half: channel j of the half (la_chan) owns slots 6j .. 6j+5 = dwords 3j .. 3j+2:
 //   x parts (H, H | M, M | H, L)   weight parts (H, M | H, M | L, H)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -644,18 +644,26 @@ __global__ void __launch_bounds__(256) k_linattn_prepare(LaPrepMulti m) {
   }
   if (C <= 8) {  // split-bf16 operand image of Wq | Wk (k_linattn_fwd<C, N, true>): 2048 la_nu(C) dwords, [q|k][head][u][lane][4]
     const int NU = la_nu(C);
-    unsigned v[24];
+    // thread t owns dword e = t & 3 of lane t >> 2 of every (q|k, head, u) group of 256 dwords: its channel and part are the same in all
+    // groups of one u, so the weight column and the split are decoded once per u; eight loads in flight per pass
+#pragma unroll 1
+    for (int u = 0; u < NU; ++u) {
+      const int e = (int)threadIdx.x & 3, ln = (int)threadIdx.x >> 2, dw = 4 * u + e, j = dw / 3, t = dw % 3;
+      const bool live = j < C / 2;
+      const int c = live ? la_chan(C, j, ln >> 5) : 0;
+      float w[8];
 #pragma unroll
-    for (int t = 0; t < 24; ++t) {
-      const int i = t * 256 + (int)threadIdx.x;
-      const int e = i & 3, ln = (i >> 2) & 63, u = (i >> 8) % NU, mh = (i / (256 * NU)) & 7;
-      v[t] = 0u;
-      if (t * 256 < 2048 * NU) v[t] = la_bf16_image_dword(it.w_qkv, C, mh * 32 + (ln & 31), ln >> 5, u, e);  // (wave-uniform guard)
-    }
+      for (int mh = 0; mh < 8; ++mh) w[mh] = it.w_qkv[(mh * 32 + (ln & 31)) * C + c];
 #pragma unroll
-    for (int t = 0; t < 24; ++t) {
-      const int i = t * 256 + (int)threadIdx.x;
-      if (i < 2048 * NU) it.prep[LA_PREP_BF16 + i] = __uint_as_float(v[t]);
+      for (int mh = 0; mh < 8; ++mh) {
+        const float ws = w[mh] * 1.4426950408889634f;
+        const unsigned hb = __float_as_uint(ws) & 0xffff0000u;
+        const float r = ws - __uint_as_float(hb);
+        const unsigned mb = __float_as_uint(r) & 0xffff0000u;
+        const unsigned lb = __float_as_uint(r - __uint_as_float(mb));
+        const unsigned v = !live ? 0u : (t < 2 ? ((hb >> 16) | mb) : ((lb >> 16) | hb));
+        it.prep[LA_PREP_BF16 + (mh * NU + u) * 256 + (int)threadIdx.x] = __uint_as_float(v);
+      }
     }
   }
   // LA_PREP_BOUNDED: are the softmax logits bounded for EVERY input?  xh = x / max(|x|, eps) * sqrt(C) * g_pre has |xh| <= sqrt(C)

@@ -53,7 +53,9 @@ __device__ __forceinline__ void stage_res_weights(float* w2s, float* w1s, float*
   for (int u = 0; u < NR; ++u) { const int i = u * BS + (int)threadIdx.x; if (i < nr) wrs[i] = vr[u]; }
 }
 
-template <int C, int BS>
+// HB: the block has skip channels (cat(A, B)).  Without them (the bottleneck's blocks, the down path) the B-side registers do not exist:
+// <16, 512> held 255 registers + 60 spilled ones with them (two waves per SIMD at 512 threads).
+template <int C, int BS, bool HB>
 __global__ void __launch_bounds__(BS) k_res_fwd(ResFwd a) {
   __shared__ float sh[C][BS + 2];
   // the block's weights in LDS (broadcast reads): as scalar loads from memory inside the channel loops nothing overlapped their latency
@@ -75,7 +77,7 @@ __global__ void __launch_bounds__(BS) k_res_fwd(ResFwd a) {
   for (int co = 0; co < C; ++co) acc[co] = a.b1[co];
   // cat(A, B) has cinA == C channels from A (launcher-checked) and cinB <= C from B: every load of the thread is issued
   // up front from compile-time-unrolled loops -- a runtime ci loop serialised one exposed global latency per channel
-  float xa[C][3], xb[C][3];
+  float xa[C][3], xb[HB ? C : 1][3];
 #pragma unroll
   for (int ci = 0; ci < C; ++ci) {
     const float* src = a.inA + ((int64_t)row * C + ci) * a.n;
@@ -84,7 +86,7 @@ __global__ void __launch_bounds__(BS) k_res_fwd(ResFwd a) {
     xa[ci][2] = (live && p + 1 < a.n) ? src[p + 1] : 0.f;
   }
 #pragma unroll
-  for (int ci = 0; ci < C; ++ci) {
+  for (int ci = 0; ci < (HB ? C : 0); ++ci) {
     const bool ok = live && ci < a.cinB;
     const float* src = a.inB + ((int64_t)row * a.cinB + ci) * a.n;
     xb[ci][0] = (ok && p > 0) ? src[p - 1] : 0.f;
@@ -98,9 +100,9 @@ __global__ void __launch_bounds__(BS) k_res_fwd(ResFwd a) {
       const float* w = w1s + (co * cin + ci) * 3;
       acc[co] = fmaf(w[0], xa[ci][0], fmaf(w[1], xa[ci][1], fmaf(w[2], xa[ci][2], acc[co])));
     }
-  if (a.cinB) {
+  if (HB && a.cinB) {
 #pragma unroll
-    for (int ci = 0; ci < C; ++ci) {
+    for (int ci = 0; ci < (HB ? C : 0); ++ci) {
       if (ci < a.cinB) {
 #pragma unroll
         for (int co = 0; co < C; ++co) {
@@ -165,7 +167,7 @@ __global__ void __launch_bounds__(BS) k_res_fwd(ResFwd a) {
 #pragma unroll
       for (int co = 0; co < C; ++co) o[co] = fmaf(wrs[co * cin + ci], xa[ci][1], o[co]);
 #pragma unroll
-    for (int ci = 0; ci < C; ++ci) {
+    for (int ci = 0; ci < (HB ? C : 0); ++ci) {
       if (ci < a.cinB) {
 #pragma unroll
         for (int co = 0; co < C; ++co) o[co] = fmaf(wrs[co * cin + C + ci], xb[ci][1], o[co]);
@@ -204,8 +206,10 @@ int launch_res_fwd(const ResFwd& a, hipStream_t s) {
   dim3 grid(cdiv((int64_t)a.rows_per_sample * a.n, BS), B), block(BS);
 #define DQ_RF(CC)                                                                \
   case CC:                                                                       \
-    if (BS == 512) hipLaunchKernelGGL((k_res_fwd<CC, 512>), grid, block, 0, s, a); \
-    else hipLaunchKernelGGL((k_res_fwd<CC, 256>), grid, block, 0, s, a);          \
+    if (BS == 512 && a.cinB) hipLaunchKernelGGL((k_res_fwd<CC, 512, true>), grid, block, 0, s, a);  \
+    else if (BS == 512) hipLaunchKernelGGL((k_res_fwd<CC, 512, false>), grid, block, 0, s, a);      \
+    else if (a.cinB) hipLaunchKernelGGL((k_res_fwd<CC, 256, true>), grid, block, 0, s, a);          \
+    else hipLaunchKernelGGL((k_res_fwd<CC, 256, false>), grid, block, 0, s, a);                     \
     break;
   switch (a.C) { DQ_RF(4) DQ_RF(8) DQ_RF(12) DQ_RF(16) }
 #undef DQ_RF

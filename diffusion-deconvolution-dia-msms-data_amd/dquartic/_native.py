@@ -67,6 +67,9 @@ PROTOTYPES = {
     "dq_tfm_set_precision": (c_int, [c_void_p, c_int]),
     "dq_linattn_fwd": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p]),
     "dq_linattn_bwd": (c_int, [c_void_p] * 15 + [c_int, c_int, c_int, c_void_p]),
+    "dq_linattn_prep_floats": (c_int64, []),
+    "dq_linattn_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "dq_linattn_fwd_prepared": (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_void_p]),
     "dq_rmsnorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dq_time_mlp_fwd": (c_int, [c_void_p] * 8 + [c_int, c_void_p]),
     "dq_scale_shift_fwd": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),

@@ -239,6 +239,14 @@ int dq_gemm_bf16x3(const float* A, const float* B, float* C, const float* bias, 
 int dq_linattn_fwd(const float* x, float* y, float* ypre /* nullable: pre-norm output saved for the backward */,
                    const float* w_qkv, const float* w_out, const float* b_out, const float* g_pre, const float* g_out, int C,
                    int rows, int n, void* stream);
+/* The same block the way the network runs it: the layer's derived weights (W2 = Wo Wv per head, the MFMA operand images of Wq | Wk --
+ * fp32 and, for 4 / 8 channels, split-bf16 -- and the bounded-logit flag) are formed ONCE per parameter state by dq_linattn_prepare into
+ * `prep` (dq_linattn_prep_floats() floats, 16-byte aligned) and every forward launch copies them instead of deriving them per workgroup.
+ * n: a power of two <= 64. */
+int64_t dq_linattn_prep_floats(void);
+int dq_linattn_prepare(const float* w_qkv, const float* w_out, const float* g_pre, int C, float* prep, void* stream);
+int dq_linattn_fwd_prepared(const float* x, float* y, float* ypre, const float* w_qkv, const float* w_out, const float* b_out,
+                            const float* g_pre, const float* g_out, const float* prep, int C, int rows, int n, void* stream);
 /* Backward: dx += d/dx, parameter gradients +=.  ypre from the forward; scratch: 2*rows*C*n + 2048*512*C floats. */
 int dq_linattn_bwd(const float* x, const float* ypre, const float* dy, float* dx, const float* w_qkv, const float* w_out,
                    const float* b_out, const float* g_pre, const float* g_out, float* dw_qkv, float* dw_out, float* db_out,

@@ -47,6 +47,34 @@ def test_linattn_fwd_golden(N, golden, C, n):
     assert rel_err(y, g[pre + "y"]) < 1e-5  # fp32 tolerance: 1e-5 of the output scale
 
 
+@pytest.mark.parametrize("C,n", [(4, 64), (4, 32), (8, 16), (8, 8), (4, 2), (12, 4), (16, 1)])
+def test_linattn_fwd_prepared_equals_standalone(N, C, n):
+    """dq_linattn_prepare + dq_linattn_fwd_prepared (the network's path: derived weights and the split-bf16 / fp32 operand images formed once
+    per parameter state) == dq_linattn_fwd (every workgroup derives them itself), bit for bit; and against the oracle."""
+    from oracle import dq_oracle as O
+
+    gen = torch.Generator().manual_seed(7 * C + n)
+    rows = 203
+    x = torch.randn(rows, C, n, generator=gen)
+    p = {"la.fn.norm.g": torch.rand(1, C, 1, generator=gen) + 0.5, "la.fn.fn.to_qkv.weight": torch.randn(384, C, 1, generator=gen) * 0.4,
+         "la.fn.fn.to_out.0.weight": torch.randn(C, 128, 1, generator=gen) * 0.2, "la.fn.fn.to_out.0.bias": torch.randn(C, generator=gen) * 0.1,
+         "la.fn.fn.to_out.1.g": torch.rand(1, C, 1, generator=gen) + 0.5}
+    ref = O.linear_attention(p, "la", x)
+    d = {k: v.cuda().reshape(v.shape[0] if v.dim() == 1 else -1).contiguous() for k, v in p.items()}
+    xd = x.cuda()
+    y0, y1 = torch.empty_like(xd), torch.empty_like(xd)
+    L = N.lib()
+    args = (N.ptr(d["la.fn.fn.to_qkv.weight"]), N.ptr(d["la.fn.fn.to_out.0.weight"]), N.ptr(d["la.fn.fn.to_out.0.bias"]), N.ptr(d["la.fn.norm.g"]),
+            N.ptr(d["la.fn.fn.to_out.1.g"]))
+    N.check(L.dq_linattn_fwd(N.ptr(xd), N.ptr(y0), None, *args, C, rows, n, N.stream_ptr()), "dq_linattn_fwd")
+    prep = torch.zeros(L.dq_linattn_prep_floats(), device="cuda")
+    N.check(L.dq_linattn_prepare(args[0], args[1], args[3], C, N.ptr(prep), N.stream_ptr()), "dq_linattn_prepare")
+    N.check(L.dq_linattn_fwd_prepared(N.ptr(xd), N.ptr(y1), None, *args, N.ptr(prep), C, rows, n, N.stream_ptr()), "dq_linattn_fwd_prepared")
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    assert rel_err(y1, ref) < 1e-5
+
+
 @pytest.mark.parametrize("C,n,rows", [(4, 64, 401), (8, 32, 37), (8, 8, 13), (12, 4, 29), (16, 2, 50), (16, 1, 77), (12, 16, 5)])
 def test_linattn_fwd_oracle_ragged(N, C, n, rows):
     """row counts that do not fill the last wave / workgroup"""

@@ -18,6 +18,6 @@ cp "$(ls gpurun_out/prof_train/*/*_kernel_stats.csv | head -1)" gpurun_out/${TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_sample -- python3 tools/prof_sample.py 512 5 \
   > gpurun_out/prof_sample.log 2> gpurun_out/prof_sample.err
 cp "$(ls gpurun_out/prof_sample/*/*_kernel_stats.csv | head -1)" gpurun_out/${TAG}_sample_kernel_stats.csv
-rm -rf gpurun_out/prof_train gpurun_out/prof_sample gpurun_out/pmc/FETCH_SIZE gpurun_out/pmc/WRITE_SIZE gpurun_out/pmc/SQ   # (raw traces: not merged back)
+rm -rf gpurun_out/prof_train gpurun_out/prof_sample gpurun_out/pmc/FETCH_SIZE gpurun_out/pmc/WRITE_SIZE gpurun_out/pmc/SQ gpurun_out/pmc/S_FETCH_SIZE gpurun_out/pmc/S_WRITE_SIZE gpurun_out/pmc/S_SQ   # (raw traces: not merged back)
 python3 bench.py > gpurun_out/bench_${TAG}.json 2> gpurun_out/bench_${TAG}.err
 tail -c 1500 gpurun_out/bench_${TAG}.json

@@ -12,10 +12,10 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "diffusion-deconvolution-dia-msms-data_amd"))
 
 
-def counter_means(outdir, ctr):
-    """kernel name -> mean counter value per dispatch"""
+def counter_means(outdir, ctr, prefix=""):
+    """kernel name -> mean counter value per dispatch (prefix "S_": the sampling-size passes)"""
     acc = {}
-    for path in glob.glob(os.path.join(outdir, ctr if ctr in ("FETCH_SIZE", "WRITE_SIZE") else "SQ", "**", "*counter_collection.csv"), recursive=True):
+    for path in glob.glob(os.path.join(outdir, prefix + (ctr if ctr in ("FETCH_SIZE", "WRITE_SIZE") else "SQ"), "**", "*counter_collection.csv"), recursive=True):
         with open(path) as fh:
             for row in csv.DictReader(fh):
                 if row.get("Counter_Name") != ctr:
@@ -61,6 +61,23 @@ def main():
             if "k_linattn" in short:
                 sq.setdefault(short, {})[ctr] = v
     res["sq"] = sq
+    # the sampling-size launch (tools/pmc_linattn.py sample): k_linattn_fwd over 512 x 400 rows
+    sf, snf = counter_means(outdir, "FETCH_SIZE", "S_")
+    sw, _ = counter_means(outdir, "WRITE_SIZE", "S_")
+    res["sample_shape"] = {"C": 4, "n": 64, "rows": 512 * 400}
+    res["sample_kernels"], res["sample_sq"] = {}, {}
+    for name in sorted(set(sf) | set(sw)):
+        short = name.split("(")[0].replace("void ", "").replace("dq::", "")
+        if "k_linattn_fwd" in short:
+            f_kb, w_kb = sf.get(name, 0.0), sw.get(name, 0.0)
+            res["sample_kernels"][short] = {"fetch_kb": round(f_kb, 1), "write_kb": round(w_kb, 1), "dispatches": snf.get(name, 0),
+                                            "hbm_bytes": round((2 * f_kb + w_kb) * 1024)}
+    for ctr in ("SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_VALU_MFMA_BUSY_CYCLES"):
+        m, _ = counter_means(outdir, ctr, "S_")
+        for name, v in m.items():
+            short = name.split("(")[0].replace("void ", "").replace("dq::", "")
+            if "k_linattn_fwd" in short:
+                res["sample_sq"].setdefault(short, {})[ctr] = v
     with open(os.path.join(outdir, "pmc_linattn.json"), "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps(res, indent=1))
