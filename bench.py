@@ -99,7 +99,7 @@ def large_window_leg(device):
     t_step = (time.perf_counter() - t0) / n
     ex_f, ex_t = executed_flops_per_window(mz, rt)
     out = {"workload": "BASELINE configs[4]: windows 2000 RT x 256 m/z, batch 8 per GPU, default UNet1d with downsample_dim 256 (197,103 params), fp32",
-           "batch": B, "params": int(net.flat_params.numel()),
+           "batch": B, "params": int(sum(q.numel() for _, q in net.trainable_named())),
            "train": {"ms_per_step": round(t_train * 1e3, 3), "windows_per_s": round(B / t_train, 2), "loss": round(float(loss), 5),
                      "flop_frac": round(B / t_train * 155_002_129_088 / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                      "executed_flop_frac": round(B / t_train * ex_t / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)},

@@ -4,6 +4,7 @@
 // mid_block1, mid_attn, mid_block2, final_res_block, final_conv.  The non-trainable RoPE frequencies
 // (mid_attn.fn.fn.rotary_emb.freqs) are NOT part of the flat buffer.
 #include "dq_plan.h"
+#include <cstdlib>
 
 namespace dq {
 namespace {
@@ -80,9 +81,15 @@ std::string build_plan(Plan& p, int dim, int n_mults, const int* mults, int mz, 
     if (d > 16) return "channel widths above 16 are not built (dim*mult <= 16)";
   p.mid_n = mz >> (L - 1);
   p.mid_c = p.dims[L] * p.mid_n;
-  // 16 / 32 / 64 channels: the register-resident bottleneck kernels (the BASELINE shapes); anything else, e.g. the 10,000 of the
-  // reference's shipped downsample_dim 40000 (unet1d.py:1027-1029): the wide path
-  p.wide_mid = !(p.mid_c == 16 || p.mid_c == 32 || p.mid_c == 64);
+  // 16 / 32 channels: the register-resident bottleneck kernels; anything else -- the 64 channels of BASELINE configs[4] (256 x 2000 windows),
+  // the 10,000 of the reference's shipped downsample_dim 40000 (unet1d.py:1027-1029) -- the wide path (im2col + matrix-core GEMM + channel-axis
+  // norm, k_wide.hip).  Round 4 moved 64 channels there: a thread of the register-resident kernels ran 64 x 64 x 3 dependent FMAs per position
+  // (k_conv_fwd<64, 3, 0> 241 us per conv, k_block_bwd<64> with 596 spilled registers); measured at batch 8: train step 19.5 -> 18.0 ms,
+  // sampling step 4.7 -> 4.0 ms.  DQ_WIDE_MID64=0 keeps the old path (A-B switch).
+  p.wide_mid = !(p.mid_c == 16 || p.mid_c == 32);
+  if (const char* e = std::getenv("DQ_WIDE_MID64")) {
+    if (e[0] == '0' && p.mid_c == 64) p.wide_mid = false;
+  }
   if (p.wide_mid && p.mid_c % 4) return "bottleneck width dims[-1]*MZ/2**(L-1) must be a multiple of 4";
   p.cond_dim = 2 * dim;
   if (p.cond_dim != 8) return "attn_cond_init_dim (2*dim) must be 8";

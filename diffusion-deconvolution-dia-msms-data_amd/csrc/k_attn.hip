@@ -317,17 +317,23 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_kv(const float* __restrict_
     const f32x16 dlr = rows_scalar(dlb, RT, i0, half, 0.f);
     Qn = tile_ch_rows(qb, RT, min(i0 + 128, ilast), col, half, ATT_SCALE);
     dOn = tile_ch_rows(dob, RT, min(i0 + 128, ilast), col, half, 1.f);
-    const f32x16 Qx = transpose_tile(Qt, ttile, col, half);    // rows i, col d
-    const f32x16 dOx = transpose_tile(dOt, ttile, col, half);  // rows i, col e
+    // The P side first (S, P, dV), then the dS side (dP, dS, dK): each transposed tile is formed right in front of its product, so that
+    // Q / Q^T and dO / dO^T are not all live at once (the kernel held 6 registers more than its 256 and spilled them).
     f32x16 S = xty(Qt, Kt, f32x16{0});              // rows i, col j
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] = __builtin_amdgcn_exp2f((S[r] - lsr[r]) * LOG2E);  // P
+    {
+      const f32x16 dOx = transpose_tile(dOt, ttile, col, half);  // rows i, col e
+      dVa = xty(dOx, S, dVa);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 dP = xty(dOt, Vt, f32x16{0});            // rows i, col j
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      S[r] = __builtin_amdgcn_exp2f((S[r] - lsr[r]) * LOG2E);  // P
-      dP[r] = S[r] * (dP[r] - dlr[r]);                          // dS
+    for (int r = 0; r < 16; ++r) dP[r] = S[r] * (dP[r] - dlr[r]);  // dS
+    {
+      const f32x16 Qx = transpose_tile(Qt, ttile, col, half);    // rows i, col d
+      dKa = xty(Qx, dP, dKa);
     }
-    dVa = xty(dOx, S, dVa);
-    dKa = xty(Qx, dP, dKa);
   }
   if (wv > 0) {
 #pragma unroll

@@ -129,6 +129,7 @@ __global__ void __launch_bounds__(256, (DQ_LA_4_3W && C == 4 && N == 64) ? 3 : (
   // three waves per SIMD (168 registers): K^T is not carried across the q phase (recomputed in the k phase: 2 NJ MFMAs + 32 exps per unit
   // and head), and the raw x / dy the end of the unit needs are read again instead of held
   constexpr bool LEAN = DQ_LA_4_3W && C == 4 && N == 64;
+  constexpr bool SERIAL = la_two_waves(C, N);  // quadratic form: one tile chain at a time (fewer live tiles) instead of interleaved chains
   // C = 4 runs two waves per SIMD instead (the partner wave hides the latency); C = 16 and the 64-position C = 12 variant have
   // no registers to spare
   constexpr bool PREFETCH = DQ_LA_PF4 ? (C <= 8 || (C == 12 && N < 64)) : ((C == 8 && !la_two_waves(C, N)) || (C == 12 && N < 64));
@@ -679,81 +680,146 @@ __global__ void __launch_bounds__(256, (DQ_LA_4_3W && C == 4 && N == 64) ? 3 : (
         for (int g = 0; g < CG; ++g) part[0][g] += chain4(dms + rl * MS_ROW, 32, 0, g, Kd);  // dXh[c][n] += sum_d K[d][n] dM_row(n)[d][c]
       } else {
         // ================= 32/N rows per wave, one block: masked quadratic form =================
-        // One 32x32 tile chain at a time (round 4): S^T -> R, then S -> its dXh chain, then dS^T -> dQ and the whole q side, then dS -> dK^T.
+        // Two waves per SIMD (SERIAL): one 32x32 tile chain at a time (round 4): S^T -> R, then S -> its dXh chain, then dS^T -> dQ and the whole q side, then dS -> dK^T.
         // Each 16-deep chain runs back to back on one accumulator (this MFMA needs no interleaving with a second chain), the same sums in
         // the same order as before -- but at most four tiles are live (q, K, K^T and the chain's accumulator) instead of nine.
-        const f32x16 q = make_q(0);
-        const f32x16 Kd = tr32(kT[0], tile, col, half);
-        float dR[C];
-        {
-          f32x16 st = {0};
-#pragma unroll
-          for (int r = 0; r < 16; ++r) st = mfma32b(Kd[r], q[r], st);  // S^T : rows n', col n
+        // One wave per SIMD (12 / 16 channels) keeps the interleaved order: nothing else overlaps a chain's latencies there, and the serial
+        // order measured 2-6 % slower (<12,8> 151 -> 159 us, <12,2> 68 -> 73 us stand-alone).
+        if constexpr (SERIAL) {
+          const f32x16 q = make_q(0);
+          const f32x16 Kd = tr32(kT[0], tile, col, half);
+          float dR[C];
+          {
+            f32x16 st = {0};
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) st = mfma32b(Kd[r], q[r], st);  // S^T : rows n', col n
+            st = mask_same_row<N>(st, col, half);
+            float R[C];
+  #pragma unroll
+            for (int g = 0; g < CG; ++g) {
+              const f32x4 rr = chain4(xs, NP, 0, g, st);  // R[c][n] = sum_n' xh[c][n'] S^T[n'][n]
+  #pragma unroll
+              for (int i = 0; i < 4; ++i) R[g * 4 + i] = rr[i] + swp32(rr[i]);
+            }
+            make_dp(0, dR);
+            if (half == 0) {
+  #pragma unroll
+              for (int c = 0; c < C; ++c) { ps[c * NP + col] = R[c]; dps[c * NP + col] = dR[c]; }
+            }
+          }
+          wfence();
+          add_dw2();
+          __builtin_amdgcn_sched_barrier(0);
+          {
+            f32x16 sm = {0};
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) sm = mfma32b(q[r], Kd[r], sm);  // S   : rows n,  col n'
+            sm = mask_same_row<N>(sm, col, half);
+            // dXh[c][n'] += sum_n S[n][n'] dR[c][n]
+  #pragma unroll
+            for (int g = 0; g < CG; ++g) part[0][g] += chain4(dps, NP, 0, g, sm);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          // dS^T[n'][n] = sum_c xh[c][n'] dR[c][n] (K = C product), masked to pairs of the same row ; dQ ; the q side
+          f32x16 qT;
+          {
+            f32x16 dst = {0};
+  #pragma unroll
+            for (int j = 0; j < NJ; ++j) dst = mfma32b(Xh[0][j], own(dR, j), dst);
+            dst = mask_same_row<N>(dst, col, half);
+            f32x16 dq = {0};
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) dq = mfma32b(kT[0][r], dst[r], dq);    // rows d,  col n
+            const f32x16 dq_raw = q_softmax_bwd(q, dq);
+            add_dxh(0, 0, dq_raw);
+            add_dw(gq, 0, tr32(dq_raw, tile, col, half));
+            qT = tr32(q, tile, col, half);  // (only now: one tile fewer is live across the S / dS products)
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          // dS = the transpose of dS^T (the K = C product with the operands swapped) ; dK^T ; the k side
+          f32x16 dkT = {0};
+          {
+            f32x16 dsm = {0};
+  #pragma unroll
+            for (int j = 0; j < NJ; ++j) dsm = mfma32b(own(dR, j), Xh[0][j], dsm);
+            dsm = mask_same_row<N>(dsm, col, half);
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) dkT = mfma32b(dsm[r], qT[r], dkT);     // rows n', col d
+          }
+          f32x16 dk_rawT;  // softmax over the positions of each row: a lane's own register segment (+ lane^32)
+  #pragma unroll
+          for (int s0 = 0; s0 < 16; s0 += SEG) {
+            float dl = 0.f;
+  #pragma unroll
+            for (int r = s0; r < s0 + SEG; ++r) dl = fmaf(dkT[r], kT[0][r], dl);
+            if (PARTNER) dl += swp32(dl);
+  #pragma unroll
+            for (int r = s0; r < s0 + SEG; ++r) dk_rawT[r] = kT[0][r] * (dkT[r] - dl);
+          }
+          add_dw(gk, 0, dk_rawT);
+          add_dxh(0, 1, tr32(dk_rawT, tile, col, half));
+      
+        } else {
+          const f32x16 q = make_q(0);
+          const f32x16 qT = tr32(q, tile, col, half);
+          const f32x16 Kd = tr32(kT[0], tile, col, half);
+          f32x16 st = {0}, sm = {0};
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            st = mfma32b(Kd[r], q[r], st);  // S^T : rows n', col n
+            sm = mfma32b(q[r], Kd[r], sm);  // S   : rows n,  col n'
+          }
           st = mask_same_row<N>(st, col, half);
-          float R[C];
-#pragma unroll
+          sm = mask_same_row<N>(sm, col, half);
+          float dR[C], R[C];
+          make_dp(0, dR);
+  #pragma unroll
           for (int g = 0; g < CG; ++g) {
             const f32x4 rr = chain4(xs, NP, 0, g, st);  // R[c][n] = sum_n' xh[c][n'] S^T[n'][n]
-#pragma unroll
+  #pragma unroll
             for (int i = 0; i < 4; ++i) R[g * 4 + i] = rr[i] + swp32(rr[i]);
           }
-          make_dp(0, dR);
           if (half == 0) {
-#pragma unroll
+  #pragma unroll
             for (int c = 0; c < C; ++c) { ps[c * NP + col] = R[c]; dps[c * NP + col] = dR[c]; }
           }
-        }
-        wfence();
-        add_dw2();
-        __builtin_amdgcn_sched_barrier(0);
-        {
-          f32x16 sm = {0};
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sm = mfma32b(q[r], Kd[r], sm);  // S   : rows n,  col n'
-          sm = mask_same_row<N>(sm, col, half);
-          // dXh[c][n'] += sum_n S[n][n'] dR[c][n]
-#pragma unroll
-          for (int g = 0; g < CG; ++g) part[0][g] += chain4(dps, NP, 0, g, sm);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // dS^T[n'][n] = sum_c xh[c][n'] dR[c][n] (K = C product), masked to pairs of the same row ; dQ ; the q side
-        f32x16 qT;
-        {
-          f32x16 dst = {0};
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) dst = mfma32b(Xh[0][j], own(dR, j), dst);
+          wfence();
+          add_dw2();
+          // dS^T[n'][n] = sum_c xh[c][n'] dR[c][n] and dS = its transpose (K = C products), masked to pairs of the same row
+          f32x16 dst = {0}, dsm = {0};
+  #pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            dst = mfma32b(Xh[0][j], own(dR, j), dst);
+            dsm = mfma32b(own(dR, j), Xh[0][j], dsm);
+          }
           dst = mask_same_row<N>(dst, col, half);
-          f32x16 dq = {0};
-#pragma unroll
-          for (int r = 0; r < 16; ++r) dq = mfma32b(kT[0][r], dst[r], dq);    // rows d,  col n
+          dsm = mask_same_row<N>(dsm, col, half);
+          // dXh[c][n'] += sum_n S[n][n'] dR[c][n]
+  #pragma unroll
+          for (int g = 0; g < CG; ++g) part[0][g] += chain4(dps, NP, 0, g, sm);
+          f32x16 dq = {0}, dkT = {0};
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            dq = mfma32b(kT[0][r], dst[r], dq);    // rows d,  col n
+            dkT = mfma32b(dsm[r], qT[r], dkT);     // rows n', col d
+          }
           const f32x16 dq_raw = q_softmax_bwd(q, dq);
           add_dxh(0, 0, dq_raw);
           add_dw(gq, 0, tr32(dq_raw, tile, col, half));
-          qT = tr32(q, tile, col, half);  // (only now: one tile fewer is live across the S / dS products)
+          f32x16 dk_rawT;  // softmax over the positions of each row: a lane's own register segment (+ lane^32)
+  #pragma unroll
+          for (int s0 = 0; s0 < 16; s0 += SEG) {
+            float dl = 0.f;
+  #pragma unroll
+            for (int r = s0; r < s0 + SEG; ++r) dl = fmaf(dkT[r], kT[0][r], dl);
+            if (PARTNER) dl += swp32(dl);
+  #pragma unroll
+            for (int r = s0; r < s0 + SEG; ++r) dk_rawT[r] = kT[0][r] * (dkT[r] - dl);
+          }
+          add_dw(gk, 0, dk_rawT);
+          add_dxh(0, 1, tr32(dk_rawT, tile, col, half));
+      
         }
-        __builtin_amdgcn_sched_barrier(0);
-        // dS = the transpose of dS^T (the K = C product with the operands swapped) ; dK^T ; the k side
-        f32x16 dkT = {0};
-        {
-          f32x16 dsm = {0};
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) dsm = mfma32b(own(dR, j), Xh[0][j], dsm);
-          dsm = mask_same_row<N>(dsm, col, half);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) dkT = mfma32b(dsm[r], qT[r], dkT);     // rows n', col d
-        }
-        f32x16 dk_rawT;  // softmax over the positions of each row: a lane's own register segment (+ lane^32)
-#pragma unroll
-        for (int s0 = 0; s0 < 16; s0 += SEG) {
-          float dl = 0.f;
-#pragma unroll
-          for (int r = s0; r < s0 + SEG; ++r) dl = fmaf(dkT[r], kT[0][r], dl);
-          if (PARTNER) dl += swp32(dl);
-#pragma unroll
-          for (int r = s0; r < s0 + SEG; ++r) dk_rawT[r] = kT[0][r] * (dkT[r] - dl);
-        }
-        add_dw(gk, 0, dk_rawT);
-        add_dxh(0, 1, tr32(dk_rawT, tile, col, half));
       }
 
       // ---- d xh of this head: both halves' partial sums; each lane publishes its own channels to the block's exchange buffer, and

@@ -5,9 +5,10 @@
 set -e
 PKG=$(dirname "$0")/../diffusion-deconvolution-dia-msms-data_amd
 NAME=$1; SRC=$2; shift 2
+OUTSRC=${DQ_VARIANT_AS:-$SRC}
 mkdir -p $PKG/build/var_$NAME
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1"
 /opt/rocm/bin/hipcc $FLAGS "$@" -x hip -c $PKG/csrc/$SRC -o $PKG/build/var_$NAME/$SRC.o
-OBJS=$(ls $PKG/build/*.o | grep -v "/$SRC.o")
+OBJS=$(ls $PKG/build/*.o | grep -v "/$OUTSRC.o")   # (DQ_VARIANT_AS=<file.hip>: the variant source REPLACES that translation unit)
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $OBJS $PKG/build/var_$NAME/$SRC.o -o $PKG/build/var_$NAME/libdq_hip.so
 echo built $PKG/build/var_$NAME/libdq_hip.so
