@@ -22,6 +22,7 @@
 
 namespace dq {
 
+
 constexpr float ATT_SCALE = 0.17677669529663687f;  // 32^-0.5
 constexpr float LOG2E = 1.4426950408889634f;
 
@@ -116,6 +117,9 @@ __device__ __forceinline__ f32x16 rows_scalar(const float* __restrict__ v, int R
 // 18 / 27 / 36 us).  With a sampling batch the grid fills the SIMDs many times over and one wave per block (no merge) is the form.
 // ---- forward: NW waves = the same 32 queries of one (sample, head); their online-softmax partials (m, l, O^T) meet in LDS and are
 // merged by wave 0 in wave order (fixed order: repeatable)
+// (Round-4 measurements, batch 512: with every key block reading block 0's tiles -- L1-hot -- the launch takes 512 instead of 602 us, so the
+// tile loads are 15 % of it; two accumulation chains per product change nothing forward and spill backward; launch bounds of 4 / 5 waves per
+// SIMD spill 41 / 80 registers: 1,012 / 1,441 us.  The sweep runs at ~3,500 cycles per key block and SIMD against 2,048 cycles of MFMA.)
 template <int NW>
 __global__ void __launch_bounds__(64 * NW) k_attn_fwd(const float* __restrict__ q, int64_t q_bs, const float* __restrict__ k, int64_t k_bs,
                                                       const float* __restrict__ v, int64_t v_bs, float* __restrict__ o,
