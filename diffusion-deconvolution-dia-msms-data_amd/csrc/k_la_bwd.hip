@@ -314,9 +314,11 @@ __global__ void __launch_bounds__(256, (DQ_LA_4_3W && C == 4 && N == 64) ? 3 : (
         }
         ssq += swp32(ssq);
         usq += swp32(usq);
-        const float inv = sqC / fmaxf(sqrtf(ssq), RMS_EPS);
-        const float unrm = sqrtf(usq);
-        const float uinv = 1.0f / fmaxf(unrm, RMS_EPS);
+        // (v_sqrt / v_rcp, 1 ulp each, as the forward kernel: a correctly rounded division or square root is ~10 instructions, and this
+        // kernel issued 13 of them per unit and head)
+        const float inv = rms_inv(ssq, sqC);
+        const float unrm = fast_sqrt(usq);
+        const float uinv = fast_rcp(fmaxf(unrm, RMS_EPS));
         float dot = 0.f;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -442,7 +444,7 @@ __global__ void __launch_bounds__(256, (DQ_LA_4_3W && C == 4 && N == 64) ? 3 : (
             }
         }
         if (PARTNER) ssum += swp32(ssum);
-        const float rs = 1.0f / ssum;
+        const float rs = fast_rcp(ssum);
         if (LEAN) k_rs = rs;
 #pragma unroll
         for (int b = 0; b < NB; ++b)
@@ -473,7 +475,7 @@ __global__ void __launch_bounds__(256, (DQ_LA_4_3W && C == 4 && N == 64) ? 3 : (
           }
         }
         ssum += swp32(ssum);
-        const float qs = scale / ssum;
+        const float qs = scale * fast_rcp(ssum);
 #pragma unroll
         for (int r = 0; r < 16; ++r) q[r] *= qs;
         return q;
@@ -867,8 +869,8 @@ __global__ void __launch_bounds__(256, (DQ_LA_4_3W && C == 4 && N == 64) ? 3 : (
             ssq = fmaf(xv[j], xv[j], ssq);
           }
           ssq += swp32(ssq);
-          const float nrm = sqrtf(ssq);
-          const float inv = 1.0f / fmaxf(nrm, RMS_EPS);
+          const float nrm = fast_sqrt(ssq);
+          const float inv = fast_rcp(fmaxf(nrm, RMS_EPS));
           float dot = 0.f;
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
@@ -1038,10 +1040,10 @@ __global__ void __launch_bounds__(256) k_linattn_bwd1(LinAttnBwdK a) {
     // ---- pre-norm recompute; post-norm backward (same arithmetic as k_block_bwd) -> DY = dYpre
     ssq += swp32(ssq);
     usq += swp32(usq);
-    const float nrm = sqrtf(ssq);
-    const float inv = sqC / fmaxf(nrm, RMS_EPS);
-    const float unrm = sqrtf(usq);
-    const float uinv = 1.0f / fmaxf(unrm, RMS_EPS);
+    const float nrm = fast_sqrt(ssq);
+    const float inv = sqC * fast_rcp(fmaxf(nrm, RMS_EPS));
+    const float unrm = fast_sqrt(usq);
+    const float uinv = fast_rcp(fmaxf(unrm, RMS_EPS));
     float dot = 0.f;
     float gdv[NJ];
 #pragma unroll
@@ -1095,7 +1097,7 @@ __global__ void __launch_bounds__(256) k_linattn_bwd1(LinAttnBwdK a) {
       }
     }
     // ---- residual + pre-norm backward on dXh (own channels); dx += dy + d/dx
-    const float pinv = 1.0f / fmaxf(nrm, RMS_EPS);
+    const float pinv = fast_rcp(fmaxf(nrm, RMS_EPS));
     float tot[NJ], uh2[NJ];
     float dot2 = 0.f;
 #pragma unroll

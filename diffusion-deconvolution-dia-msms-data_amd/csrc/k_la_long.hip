@@ -55,7 +55,7 @@ __device__ __forceinline__ void prenorm(const float* x, const float* gpre, float
 #pragma unroll
   for (int j = 0; j < NJ; ++j) ssq = fmaf(x[j], x[j], ssq);
   ssq += swap_half(ssq);
-  const float inv = sqrtf((float)C) / fmaxf(sqrtf(ssq), RMS_EPS);
+  const float inv = rms_inv(ssq, sqrtf((float)C));
 #pragma unroll
   for (int j = 0; j < NJ; ++j) xh[j] = x[j] * inv * gpre[j];
 }
@@ -131,7 +131,7 @@ __device__ __forceinline__ f32x16 q_exp(f32x16 q, float& qs) {  // un-normalised
     s += q[r];
   }
   s += swap_half(s);
-  qs = L_SCALE / s;
+  qs = L_SCALE * fast_rcp(s);
   return q;
 }
 
@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd_long(LinAttn a) {
     }
 #pragma unroll
     for (int hd = 0; hd < 4; ++hd) {
-      const float rs = 1.0f / (ssum[hd] + swap_half(ssum[hd]));
+      const float rs = fast_rcp(ssum[hd] + swap_half(ssum[hd]));
 #pragma unroll
       for (int g = 0; g < CG; ++g)
 #pragma unroll
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd_long(LinAttn a) {
       ssq = fmaf(yv[j], yv[j], ssq);
     }
     ssq += swap_half(ssq);
-    const float inv = sqrtf((float)C) / fmaxf(sqrtf(ssq), RMS_EPS);
+    const float inv = rms_inv(ssq, sqrtf((float)C));
     float go[NJ];  // gains read before the first store of this position (a load behind a store waits for it)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) go[j] = la_chan(C, j, half) < C ? a.g_out[la_chan(C, j, half)] : 0.f;
@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(256, 2) k_linattn_bwd_long(LinAttnBwdLongK a) 
           online_m<CG>(kT, xs, m, ssum, mt, lane, half);
         }
         ssum += swap_half(ssum);
-        const float rs = 1.0f / ssum;
+        const float rs = fast_rcp(ssum);
         lfence();
 #pragma unroll
         for (int g = 0; g < CG; ++g)
@@ -505,7 +505,7 @@ __global__ void __launch_bounds__(256, 2) k_linattn_bwd_long(LinAttnBwdLongK a) 
           if (half == 0) dms[(g * 4 + i) * 32 + col] = dMr[g * 4 + i];
         }
       lfence();
-      const float rs = 1.0f / ssum;
+      const float rs = fast_rcp(ssum);
       // ---- sweep 3: k side
 #pragma unroll 1
       for (int b = 0; b < NB; ++b) {

@@ -129,7 +129,10 @@ __global__ void __launch_bounds__(256) k_level_images(LevelImgMulti mm, const fl
 // N64: rows of exactly 64 positions = one row per wave: the wave shifts' zero fill at lanes 0 / 63 IS the conv's zero padding, no masks
 template <int C, int PRE, int CP, bool N64>
 __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __restrict__ P, const float* __restrict__ ssb, int tiles_ps, int total_tiles,
-                                                   int ln, const float* __restrict__ img) {  // ssb: the per-sample scale / shift vectors; ln = log2(n)
+                                                   int ln_rt, const float* __restrict__ img) {  // ssb: the per-sample scale / shift vectors; ln_rt = log2(n)
+  // N64: the row length is a compile-time 64 -- a channel's plane offset (c * 256 bytes) then folds into the instructions' immediate offsets
+  // instead of costing a 64-bit address add per access (69 of them in <4, 2, 8>) and scalar registers for the per-channel bases
+  const int ln = N64 ? 6 : ln_rt;
   constexpr int G = C / 4;
   constexpr int KP = PRE == LEVEL_PRE_DOWN ? 4 : (PRE == LEVEL_PRE_INIT ? 7 : 3);
   extern __shared__ __attribute__((aligned(16))) float wl[];  // [job / 4][lane & 3][job % 4]
@@ -215,7 +218,7 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
   const int lane = threadIdx.x & 63, li = lane & 3;
   const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = gridDim.x * 4;
   const int b = blockIdx.y;
-  const int n = a.n;
+  const int n = N64 ? 64 : a.n;
   const int per_sample = a.rows_per_sample * n;
   const float sqC = sqrtf((float)C);
   const float* wlane = wl + li * 4;

@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) ssq = fmaf(X[blk][j], X[blk][j], ssq);
     ssq += swap32(ssq);
-    const float inv = sqC / fmaxf(sqrtf(ssq), RMS_EPS);
+    const float inv = rms_inv(ssq, sqC);  // (v_sqrt + v_rcp, 1 ulp each: the correctly rounded division / square root are ~20 instructions per use)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int c = la_chan(C, j, half);
@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
           }
       }
       if (PARTNER) ssum += swap32(ssum);
-      const float rs = 1.0f / ssum;
+      const float rs = fast_rcp(ssum);
       if (N >= 32) krs = rs;
       else if (SEGM) krs_seg[s0 / SEG] = rs;
       else {
@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
         }
       }
       ssum += swap32(ssum);
-      qs = scale / ssum;
+      qs = scale * fast_rcp(ssum);
       return q;
     };
 
@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
       ssq = fmaf(yv[j], yv[j], ssq);
     }
     ssq += swap32(ssq);
-    const float inv = sqC / fmaxf(sqrtf(ssq), RMS_EPS);
+    const float inv = rms_inv(ssq, sqC);  // (v_sqrt + v_rcp, 1 ulp each: the correctly rounded division / square root are ~20 instructions per use)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int c = la_chan(C, j, half);
