@@ -41,15 +41,22 @@ __device__ __forceinline__ void wfence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// 32x32 transpose of an accumulator tile through a wave-private LDS tile [32][33]
+// 32x32 transpose of an accumulator tile through a wave-private LDS tile [32][TRP]: written as 16 dwords per lane (a row's 32 lanes are
+// consecutive: conflict-free), read back as FOUR 16-byte reads -- registers 4 q .. 4 q + 3 are rows 8 q + 4 half .. + 3 of the transposed
+// tile, consecutive in memory; the row pitch of 36 floats keeps them 16-byte aligned and spreads a 16-lane phase over all 64 banks
+// (36 col mod 64 takes every multiple of 4 once).  With pitch 33 the reads were eight ds_read2_b32 per transpose.
+constexpr int TRP = 36;
 __device__ __forceinline__ f32x16 tr32(f32x16 a, float* tile, int col, int half) {
   wfence();
 #pragma unroll
-  for (int r = 0; r < 16; ++r) tile[rmap(r, half) * 33 + col] = a[r];
+  for (int r = 0; r < 16; ++r) tile[rmap(r, half) * TRP + col] = a[r];
   wfence();
   f32x16 o;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) o[r] = tile[col * 33 + rmap(r, half)];
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = *reinterpret_cast<const float4*>(tile + col * TRP + 8 * q + 4 * half);
+    o[4 * q + 0] = v.x; o[4 * q + 1] = v.y; o[4 * q + 2] = v.z; o[4 * q + 3] = v.w;
+  }
   return o;
 }
 
@@ -140,7 +147,7 @@ __global__ void __launch_bounds__(256, (DQ_LA_4_3W && C == 4 && N == 64) ? 3 : (
 
   __shared__ __attribute__((aligned(16))) float wp_lds[2 * 4 * 2 * C * 16];  // [q|k][head][half][c][r] = Wqkv[m*128 + head*32 + rmap(r,half)][c]
   __shared__ __attribute__((aligned(16))) float w2_lds[4 * C * C];           // [head][c'][c] = sum_e Wo[c'][head*32+e] Wv[head*32+e][c]
-  __shared__ float tiles[4][32 * 33];
+  __shared__ __attribute__((aligned(16))) float tiles[4][32 * TRP];
   // per wave: xh | dYpre | P (normalised) | dP as [c][n] ; M | dM as [c][d] ; dW2 of the head being flushed [c'][c] and [c][c']
   __shared__ __attribute__((aligned(16))) float stage[4][4 * C * NP + MS_FLOATS + 2 * C * C];
   // d xh of the four heads of one unit, [parity of the unit][head][c][n]: double-buffered so that ONE barrier per unit is enough (a
@@ -972,7 +979,7 @@ template <int C>
 __global__ void __launch_bounds__(256) k_linattn_bwd1(LinAttnBwdK a) {
   constexpr int NJ = la_nj(C), CG = C / 4, NP = 32;
   __shared__ __attribute__((aligned(16))) float w2_lds[4 * C * C];
-  __shared__ float tiles[4][32 * 33];
+  __shared__ __attribute__((aligned(16))) float tiles[4][32 * TRP];
   __shared__ __attribute__((aligned(16))) float stage[4][3 * C * NP + C * C];  // per wave: xh | dYpre | 32^-0.5 xh as [c][row] ; dW2
   if (a.prep) {
     for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) w2_lds[i] = a.prep[i];
