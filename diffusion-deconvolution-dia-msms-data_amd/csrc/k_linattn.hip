@@ -557,7 +557,8 @@ static int linattn_fwd_n(const LinAttn& a, hipStream_t s) {
 #define DQ_LA(NN)                                                                      \
   case NN: {                                                                           \
     constexpr int RW = NN >= 32 ? 1 : 32 / NN;                                         \
-    constexpr bool CAN_BF = C <= 8 && NN > 1;                                          \
+    /* 8 channels, rows of <= 8 positions: the 24 KB bf16 image costs the fourth workgroup per CU (278 -> 296 us at batch 512): fp32 form */ \
+    constexpr bool CAN_BF = C <= 8 && NN > 1 && !(C == 8 && NN <= 8);                  \
     const int units = cdiv(a.rows, RW);                                                \
     const int cap = la_fwd_occ_cap();                                                  \
     int grid = cdiv(units, 4);                                                         \
