@@ -502,7 +502,9 @@ int conv_plain_bwd(const Ctx& c, const ConvP& cp, int mode, const float* in, con
   wg.du = dout; wg.inA = in; wg.cinA = cp.cin; wg.cout = cp.cout; wg.K = cp.k; wg.mode = mode; wg.rows = rows; wg.n_in = n_in;
   wg.n_out = n_out; wg.dw = c.dprm(cp.w); wg.dbias = cp.b >= 0 ? c.dprm(cp.b) : nullptr;
   DQ_TRY(wgrad_async(c, wg));
-  if (din && conv_is_gemm(c, cp, mode, n_in, n_out) && (wslot >= 0 || ((uintptr_t)c.prm(cp.w) & 15) == 0)) {  // dX_b (cin x n) (+)= W^T (cin x cout) dY_b (cout x n)
+  ConvP nobias = cp;
+  nobias.b = -1;  // (a bias does not enter the DATA gradient: to_out's ran on the generic kernel because of it, 32 us against ~6 us on the GEMM)
+  if (din && conv_is_gemm(c, nobias, mode, n_in, n_out) && (wslot >= 0 || ((uintptr_t)c.prm(cp.w) & 15) == 0)) {  // dX_b (cin x n) (+)= W^T (cin x cout) dY_b (cout x n)
     Gemm g;
     DQ_TRY(gemm_weight(c, cp, &g.A, wslot));
     g.a_kmajor = 0; g.lda = cp.cin; g.B = dout; g.b_kmajor = 0; g.ldb = n_in; g.C = din; g.ldc = n_in;
@@ -934,14 +936,14 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
       // to_out (1x1 + bias) and the residual
       ConvP ao = proj(p.ao_w, p.mid_c, HID);
       ao.b = p.ao_b;
-      DQ_TRY(conv_plain_bwd(c, ao, CONV_S1, c.w(a.o), c.g(a.attn_out), c.g(a.o), B, RT, RT, 0));
+      const int ws_ok = (int)(p.downs.size() + p.ups.size()) <= LA_PREP_MAX ? 0 : -3;  // aligned weight slots as the forward of this step filled them (0: q|v, 1: k, 2: to_out)
+      DQ_TRY(conv_plain_bwd(c, ao, CONV_S1, c.w(a.o), c.g(a.attn_out), c.g(a.o), B, RT, RT, 0, ws_ok + 2));
       DQ_TRY(launch_axpy(c.g(a.mid1.out), c.g(a.attn_out), (int64_t)R * p.mid_c, c.s));
       DQ_TRY(launch_attn_bwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.g(a.o), c.w(a.lse), c.w(a.delta),
                              c.g(a.qv), qvbs, c.g(a.kk), kbs, c.g(a.qv) + kbs, qvbs, B, RT, c.s));
       if (rope) {
         DQ_TRY(launch_rope2(c.g(a.qv), (int64_t)2 * HID * RT, c.g(a.kk), (int64_t)HID * RT, rope, B, RT, -1.f, c.s));
       }
-      const int ws_ok = (int)(p.downs.size() + p.ups.size()) <= LA_PREP_MAX ? 0 : -2;  // slots as the forward of this step filled them
       DQ_TRY(conv_plain_bwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.g(a.kk), c.g(a.ms1f), B, RT, RT, 0, ws_ok + 1));
       DQ_TRY(conv_plain_bwd(c, proj(p.qv_w, 2 * HID, p.mid_c), CONV_S1, c.w(a.xn), c.g(a.qv), c.g(a.xn), B, RT, RT, 0, ws_ok));
       // PreNorm backward: xn = rmsnorm(mid1.out) * g  (pointwise kernel, no scale/shift, no activation)

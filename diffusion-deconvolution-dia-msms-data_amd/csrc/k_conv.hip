@@ -356,10 +356,14 @@ int launch_block_bwd(const BlockBwd& a, hipStream_t s) {
   const BlockBwd& a_ = a2;
   const int B = cdiv(a_.rows, a_.rows_per_sample);
   const int64_t per_sample = (int64_t)a_.rows_per_sample * a_.n;
-  // ~4 items per thread, at most 64 blocks per sample
-  const int bps = std::max(1, std::min(64, cdiv(per_sample, 1024)));
-  dim3 grid(bps, B), block(256);
+  // one item per thread while that stays within 64 blocks per sample (the bottleneck's PreNorm backward -- 12,800 items -- ran on 13
+  // workgroups at four items per thread: 19 us, a latency floor on 5 % of the CUs); larger tensors: 64 blocks per sample, a strided loop
+  int bps = std::max(1, std::min(64, cdiv(per_sample, 256)));
   const bool need_sums = a.dg || a.dss || a.dbias;
+  // (never more blocks than the caller's partial-sum slot holds: the arena sizes it for the per-sample grouping, the regrouped launches of
+  // short tensors can ask for more)
+  if (need_sums && a.part && a.part_floats >= (int64_t)B * 4 * a.C) bps = (int)std::min<int64_t>(bps, a.part_floats / ((int64_t)B * 4 * a.C));
+  dim3 grid(bps, B), block(256);
   DQ_REQUIRE(!need_sums || (a.part && a.part_floats >= (int64_t)bps * B * 4 * a.C), "block_bwd: partial-sum slot missing or too small");
   if (!need_sums) a2.part = nullptr;
 #define DQ_BB(CC)                                                     \
