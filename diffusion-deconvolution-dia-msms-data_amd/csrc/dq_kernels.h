@@ -177,6 +177,27 @@ int64_t level_img_floats(const LevelFwd& a);
 int launch_level_images(const LevelFwd* calls, int count, hipStream_t s);  // writes calls[i].img (must be set) for every call, ONE launch
 int launch_res_fwd(const ResFwd& a, hipStream_t s);
 int launch_res_bwd(const ResBwd& a, hipStream_t s);
+
+// k_tiny.hip: the levels with rows of 1 or 2 positions as a chain of dense layers on v_mfma_f32_32x32x2 (lane = (position | row half, row),
+// register = channel): [resample conv] -> ResnetBlock -> ResnetBlock in ONE launch like k_level_fwd and, at n == 1,
+// Residual(PreNorm(LinearAttention)) (linear over one position) and the last down level's k3 conv written in the bottleneck's
+// (B, C, RT) layout.  `lv` carries the stage and the blocks exactly as for launch_level_fwd (its img field is unused).
+struct TinyFwd {
+  LevelFwd lv;
+  int la = 0;  // n == 1: the level's LinearAttention rides along
+  const float* w_qkv = nullptr; const float* w_out = nullptr; const float* b_out = nullptr; const float* g_pre = nullptr; const float* g_out = nullptr;
+  float* la_y = nullptr; float* la_ypre = nullptr;  // (rows, C, 1); la_ypre nullable (training: the pre-norm output the backward reads)
+  const float* post_w = nullptr; const float* post_b = nullptr; float* post_out = nullptr;  // n == 1, behind the LinearAttention: k3 conv (C, C, 3) -> (B, C, RT)
+  int in_folded = 0;          // LEVEL_PRE_NONE, n == 1: lv.in is (B, C, RT)
+  float* in_copy = nullptr;   // nullable: the input again as (rows, C, 1) (training: the backward reads it in that layout)
+  const float* img = nullptr; // operand image (tiny_img_floats floats, 16-byte aligned) from launch_tiny_images on the SAME parameter values
+};
+constexpr int TINY_IMG_MAX = 4;
+constexpr int TINY_IMG_FLOATS = 12288;
+bool tiny_fwd_usable(const TinyFwd& t);
+int64_t tiny_img_floats(const TinyFwd& t);
+int launch_tiny_images(const TinyFwd* calls, int count, hipStream_t s);
+int launch_tiny_fwd(const TinyFwd& t, hipStream_t s);
 // k_res_wg.hip: ResnetBlock backward of the wide levels (C = 4 / 8, rows of 8..256 positions) with the block's weight gradients formed
 // in the same launch on the 4x4x1 matrix pipe.  Every workgroup leaves [c1.w | c1.b | g1 | c2.w | c2.b | g2 | res.w | res.b | dscale |
 // dshift] in its own slot of `part`; launch_res_wg_reduce adds the slots up in block order into the flat gradient buffer (the

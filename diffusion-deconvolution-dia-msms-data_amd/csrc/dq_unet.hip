@@ -153,6 +153,7 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
   a.la_part = take_nz(a.la_part_floats);
   a.la_prep = take_nz((int64_t)LA_PREP_MAX * LA_PREP_FLOATS);  // prepared LinearAttention weights, one slot per layer (downs, then ups)
   a.wimg = take_nz((int64_t)LEVEL_IMG_MAX * LEVEL_IMG_FLOATS);  // MFMA operand images of the level kernels' weights, one slot per launch (downs, then ups, then the head)
+  a.timg = take_nz((int64_t)TINY_IMG_MAX * TINY_IMG_FLOATS);  // operand images of the tiny-level launches (k_tiny.hip)
   a.bb_part_floats = (int64_t)64 * B * 4 * std::max(p.wide_mid ? 2 : p.mid_c, 2);  // partial sums of the PreNorm backward / the input affine
   a.bb_part = take_nz(a.bb_part_floats);
   a.ms1_scratch = take_nz(5 * R + B + 64);  // the MS1 loss term (ms1_loss_weight > 0): per-row sums / maxima and their gradients
@@ -765,6 +766,43 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
   // The launches that depend on the parameter values only -- W2 / the q | k operand images of the LinearAttention layers, the MFMA operand
   // images of the level kernels (slot = level on the way down, L + ui on the way up, 2 L = the head) -- run once per parameter state:
   // every forward in training, once per dq_ddim_sample call (its prologue calls this function with prepare_only).
+  // The levels with rows of 1 or 2 positions (k_tiny.hip): stage + both ResnetBlocks as a chain of dense layers; at n == 1 the (linear)
+  // LinearAttention rides along, the last down level also applies its k3 conv and writes the bottleneck's (B, C, RT) layout directly
+  // (no k_conv_fwd, no k_fold), and the first up level reads that layout (no k_fold behind the bottleneck either).
+  int tiny_dn[16], tiny_up[16], n_tiny = 0;
+  auto tiny_down = [&](int lv) {
+    TinyFwd t;
+    const LevelP& l = p.downs[lv];
+    t.lv = level_desc(c, down_call(lv));
+    if (l.n == 1 && lv == L - 1 && !p.wide_mid && p.mid_n == 1 && l.resample.k == 3 && l.resample.b >= 0 && l.resample.cout == l.la.C) {
+      t.la = 1; t.w_qkv = c.prm(l.la.qkv_w); t.w_out = c.prm(l.la.out_w); t.b_out = c.prm(l.la.out_b); t.g_pre = c.prm(l.la.g_pre); t.g_out = c.prm(l.la.g_out);
+      t.la_y = c.w(a.downs[lv].la); t.la_ypre = c.save ? c.w(a.downs[lv].la_pre) : nullptr;
+      t.post_w = c.prm(l.resample.w); t.post_b = c.prm(l.resample.b); t.post_out = c.w(a.mid_in);
+    }
+    return t;
+  };
+  auto tiny_upc = [&](int ui) {
+    TinyFwd t;
+    const LevelP& l = p.ups[ui];
+    t.lv = level_desc(c, up_call(ui));
+    if (l.n == 1 && ui == 0 && !p.wide_mid && p.mid_n == 1) {
+      t.la = 1; t.w_qkv = c.prm(l.la.qkv_w); t.w_out = c.prm(l.la.out_w); t.b_out = c.prm(l.la.out_b); t.g_pre = c.prm(l.la.g_pre); t.g_out = c.prm(l.la.g_out);
+      t.la_y = c.w(a.ups[ui].la); t.la_ypre = c.save ? c.w(a.ups[ui].la_pre) : nullptr;
+      t.in_folded = 1; t.lv.in = c.w(a.mid2.out); t.in_copy = c.save ? c.w(a.mid_back) : nullptr;
+    }
+    return t;
+  };
+  for (int lv = 0; lv < L && lv < 16; ++lv) {
+    tiny_dn[lv] = -1;
+    if (lv > 0 && L <= 16 && n_tiny < TINY_IMG_MAX && tiny_fwd_usable(tiny_down(lv))) tiny_dn[lv] = n_tiny++;
+  }
+  for (int ui = 0; ui < L && ui < 16; ++ui) {
+    tiny_up[ui] = -1;
+    if (L <= 16 && n_tiny < TINY_IMG_MAX && tiny_fwd_usable(tiny_upc(ui))) tiny_up[ui] = n_tiny++;
+  }
+  auto tiny_img = [&](int slot) -> const float* { return c.w(a.timg) + (int64_t)slot * TINY_IMG_FLOATS; };
+  auto is_tiny_dn = [&](int lv) { return lv < L && lv < 16 && tiny_dn[lv] >= 0; };
+  auto is_tiny_up = [&](int ui) { return ui < L && ui < 16 && tiny_up[ui] >= 0; };
   const bool imgs_ok = 2 * L + 1 <= LEVEL_IMG_MAX;
   auto img_slot = [&](int slot) -> const float* { return imgs_ok ? c.w(a.wimg) + (int64_t)slot * LEVEL_IMG_FLOATS : nullptr; };
   auto with_img = [&](const LevelCall& lc, int slot) {
@@ -778,10 +816,15 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     LevelFwd calls[LEVEL_IMG_MAX];
     int nc = 0;
     for (int lv = 0; lv < L; ++lv)
-      if (level_ok(c, down_call(lv))) { const LevelFwd f = with_img(down_call(lv), lv); if (f.img) calls[nc++] = f; }
+      if (!is_tiny_dn(lv) && level_ok(c, down_call(lv))) { const LevelFwd f = with_img(down_call(lv), lv); if (f.img) calls[nc++] = f; }
     for (int ui = 0; ui <= L; ++ui)
-      if (level_ok(c, up_call(ui))) { const LevelFwd f = with_img(up_call(ui), L + ui); if (f.img) calls[nc++] = f; }
+      if (!is_tiny_up(ui) && level_ok(c, up_call(ui))) { const LevelFwd f = with_img(up_call(ui), L + ui); if (f.img) calls[nc++] = f; }
     DQ_TRY(launch_level_images(calls, nc, c.s));
+    TinyFwd tc[TINY_IMG_MAX];
+    int nt = 0;
+    for (int lv = 0; lv < L; ++lv) if (is_tiny_dn(lv)) { tc[nt] = tiny_down(lv); tc[nt].img = tiny_img(tiny_dn[lv]); ++nt; }
+    for (int ui = 0; ui < L; ++ui) if (is_tiny_up(ui)) { tc[nt] = tiny_upc(ui); tc[nt].img = tiny_img(tiny_up[ui]); ++nt; }
+    DQ_TRY(launch_tiny_images(tc, nt, c.s));
   }
   if (c.prepare_only) return 0;
   // K1: time embedding + every scale/shift head (unet1d.py:1105, 315-318, 677)
@@ -803,19 +846,27 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
   }
   // down path (unet1d.py:1134-1142)
   const float* cur = c.w(a.h0);
+  bool mid_in_done = false;
   for (int lv = 0; lv < L; ++lv) {
     const LevelP& l = p.downs[lv];
     const LevelBuf& b = a.downs[lv];
     const int C = l.r0.cin;
     const LevelCall lc = down_call(lv);
-    if (level_ok(c, lc)) {
+    bool la_done = false;
+    if (is_tiny_dn(lv)) {
+      TinyFwd t = tiny_down(lv);
+      t.img = tiny_img(tiny_dn[lv]);
+      DQ_TRY(launch_tiny_fwd(t, c.s));
+      la_done = t.la != 0;
+      if (t.post_w) { mid_in_done = true; continue; }  // (the last level: its k3 conv went into the bottleneck's layout)
+    } else if (level_ok(c, lc)) {
       DQ_TRY(launch_level_fwd(with_img(lc, lv), c.s));
     } else {
       DQ_TRY(res_fwd(c, l.r0, b.r0, cur, C, nullptr, 0, R, l.n, RT));
       DQ_TRY(res_fwd(c, l.r1, b.r1, c.w(b.r0.out), C, nullptr, 0, R, l.n, RT));
     }
-    DQ_TRY(la_fwd(c, l.la, c.w(b.r1.out), c.w(b.la), c.save ? c.w(b.la_pre) : nullptr, R, l.n, prep_ok ? lv : -1));
-    if (lv + 1 < L && level_ok(c, down_call(lv + 1))) continue;  // the next level's launch applies this level's Downsample itself
+    if (!la_done) DQ_TRY(la_fwd(c, l.la, c.w(b.r1.out), c.w(b.la), c.save ? c.w(b.la_pre) : nullptr, R, l.n, prep_ok ? lv : -1));
+    if (lv + 1 < L && (is_tiny_dn(lv + 1) || level_ok(c, down_call(lv + 1)))) continue;  // the next level's launch applies this level's Downsample itself
     DQ_TRY(conv_plain_fwd(c, l.resample, l.last ? CONV_S1 : CONV_DOWN, c.w(b.la), c.w(b.rs), R, l.n, l.n_next));
     cur = c.w(b.rs);
   }
@@ -823,7 +874,7 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
   if (p.wide_mid) {
     DQ_TRY(mid_forward_wide(c, rope, cur));
   } else {
-    DQ_TRY(launch_fold(cur, c.w(a.mid_in), B, RT, p.mid_c, 1, 0, c.s));
+    if (!mid_in_done) DQ_TRY(launch_fold(cur, c.w(a.mid_in), B, RT, p.mid_c, 1, 0, c.s));
     DQ_TRY(res_fwd(c, p.mid1, a.mid1, c.w(a.mid_in), p.mid_c, nullptr, 0, B, RT, 1));
     {
       // Residual(PreNorm(Attention(use_xattn))) (unet1d.py:552-567)
@@ -855,7 +906,7 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
       }
     }
     DQ_TRY(res_fwd(c, p.mid2, a.mid2, c.w(a.attn_out), p.mid_c, nullptr, 0, B, RT, 1));
-    DQ_TRY(launch_fold(c.w(a.mid2.out), c.w(a.mid_back), B, RT, p.mid_c, 0, 0, c.s));
+    if (!(is_tiny_up(0) && tiny_upc(0).in_folded)) DQ_TRY(launch_fold(c.w(a.mid2.out), c.w(a.mid_back), B, RT, p.mid_c, 0, 0, c.s));
   }
   cur = c.w(a.mid_back);
   for (int ui = 0; ui < L; ++ui) {
@@ -864,14 +915,20 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     const int lv = L - 1 - ui;
     const int cx = l.r0.cout, cs = l.r0.cin - l.r0.cout;
     const LevelCall lc = up_call(ui);
-    if (level_ok(c, lc)) {
+    bool la_done = false;
+    if (is_tiny_up(ui)) {
+      TinyFwd t = tiny_upc(ui);
+      t.img = tiny_img(tiny_up[ui]);
+      DQ_TRY(launch_tiny_fwd(t, c.s));
+      la_done = t.la != 0;
+    } else if (level_ok(c, lc)) {
       DQ_TRY(launch_level_fwd(with_img(lc, L + ui), c.s));
     } else {
       DQ_TRY(res_fwd(c, l.r0, b.r0, cur, cx, c.w(a.downs[lv].la), cs, R, l.n, RT));
       DQ_TRY(res_fwd(c, l.r1, b.r1, c.w(b.r0.out), cx, c.w(a.downs[lv].r0.out), cs, R, l.n, RT));
     }
-    DQ_TRY(la_fwd(c, l.la, c.w(b.r1.out), c.w(b.la), c.save ? c.w(b.la_pre) : nullptr, R, l.n, prep_ok ? L + ui : -1));
-    if (level_ok(c, up_call(ui + 1))) continue;  // the next launch applies this level's Upsample / k3 conv itself
+    if (!la_done) DQ_TRY(la_fwd(c, l.la, c.w(b.r1.out), c.w(b.la), c.save ? c.w(b.la_pre) : nullptr, R, l.n, prep_ok ? L + ui : -1));
+    if (is_tiny_up(ui + 1) || level_ok(c, up_call(ui + 1))) continue;  // the next launch applies this level's Upsample / k3 conv itself
     DQ_TRY(conv_plain_fwd(c, l.resample, l.last ? CONV_S1 : CONV_UP, c.w(b.la), c.w(b.rs), R, l.n, l.n_next));
     cur = c.w(b.rs);
   }

@@ -1,0 +1,444 @@
+// The levels whose m/z rows are 1 or 2 positions long (reference dquartic/model/unet1d.py:1134-1142, 1150-1158 at the bottom of the
+// pyramid): a row's whole state is n * C <= 32 floats, so every convolution over it is a DENSE layer on that vector -- a k3 conv over two
+// positions sees both of them from either one, a k3 conv over one position is its centre tap, Downsample / Upsample are (2 C_in x C)
+// matrices.  The level then is a chain of small matrix products over rows, and runs on v_mfma_f32_32x32x2_f32 with
+//   lane = (half, slot):  n == 2: half = position, slot = row of the tile (32 rows per wave)
+//                         n == 1: half * 32 + slot = row of the tile (64 rows per wave)
+//   register c = channel c of the lane's (row, position)                                  (16 registers, zero above C)
+// This IS the MFMA accumulator layout (dq_mfma.h: register r of half h holds output row (r & 3) + 8 (r >> 2) + 4 h) when output row m
+// is read as (position (m >> 2) & 1, channel (m & 3) + 4 (m >> 3)); and register c of the two halves is one K = 2 slice of the B operand.
+// A layer's output tile therefore feeds the next layer register by register -- no data movement between layers -- and everything that
+// acts per position (RMSNorm over the channels, scale / shift, SiLU, the residual) is plain per-lane arithmetic over 16 registers.
+// The A operands (weights placed by the position structure of each layer; zero where a tap does not exist) are built once per
+// parameter state by k_tiny_images and copied to LDS by every workgroup.
+//
+// One launch = [resample conv producing the level's input] -> ResnetBlock -> ResnetBlock
+//              (-> Residual(PreNorm(LinearAttention)) at n == 1, where it is linear: k.softmax over one position is 1, q.softmax
+//                  sums to 1, so out = scale * Wo Wv xhat + b, unet1d.py:466-496)
+//              (-> the last down level's k3 conv, written straight in the bottleneck's (B, C, RT) layout, unet1d.py:1144-1148)
+// replacing k_level_fwd + k_linattn_fwd (+ k_conv_fwd + k_fold) at those levels: at batch 32 they were latency floors of 20-34 us each
+// (one 64-position wave per tile walking ~1,000 dependent 4x4x1 MFMAs at one wave per SIMD).
+#include "dq_common.h"
+#include "dq_kernels.h"
+#include "dq_mfma.h"
+#include "dq_plan.h"
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+namespace dq {
+
+namespace {
+
+enum { TL_CONV3_N2 = 0, TL_DIAG = 1, TL_DOWN_N2 = 2, TL_DOWN_N1 = 3, TL_UP_N2 = 4, TL_LA1 = 5 };
+// One dense layer of the chain = `steps` MFMAs.  Element (step s, lane) of its operand image:
+//   m = lane & 31 -> output (position pm = (m >> 2) & 1, channel co = (m & 3) + 4 (m >> 3)); k = lane >> 5 = the half that supplies B
+struct TinyLayer {
+  int kind;
+  int w;      // weight offset in the flat parameter buffer (TL_LA1: to_qkv)
+  int w2;     // TL_LA1: to_out.0.weight
+  int cin;    // input channels of the conv (row pitch of the weight tensor)
+  int K;      // kernel width of the weight tensor
+  int c0;     // first input channel this layer's steps walk (the skip half of cat(x, skip) starts at C)
+  int steps, cout;
+};
+constexpr int TINY_MAX_LAYERS = 12;
+struct TinyImgItem { TinyLayer L[TINY_MAX_LAYERS]; int nl, total_steps; float* dst; };
+struct TinyImgMulti { TinyImgItem it[TINY_IMG_MAX]; };
+
+__device__ __forceinline__ float tiny_img_value(const TinyLayer& L, int s, int lane, const float* __restrict__ P) {
+  const int m = lane & 31, k = lane >> 5;
+  const int pm = (m >> 2) & 1, co = (m & 3) + 4 * (m >> 3);
+  if (co >= L.cout) return 0.f;
+  switch (L.kind) {
+    case TL_CONV3_N2: {  // k3 over two positions: input position k reaches output position pm through tap k - pm + 1
+      const int ci = L.c0 + s, t = k - pm + 1;
+      return P[L.w + (co * L.cin + ci) * 3 + t];
+    }
+    case TL_DIAG: {  // per (row, position): the centre tap of a k3 conv over one position, or a 1x1 conv
+      const int ci = L.c0 + s;
+      return pm == k ? P[L.w + (co * L.cin + ci) * L.K + L.K / 2] : 0.f;
+    }
+    case TL_DOWN_N2: {  // k4 s2 p1, 4 -> 2 positions: half k holds in[2 k], in[2 k + 1]; step = (ci, j)
+      const int ci = s >> 1, j = s & 1, t = 2 * k + j - 2 * pm + 1;
+      return (t >= 0 && t < 4) ? P[L.w + (co * L.cin + ci) * 4 + t] : 0.f;
+    }
+    case TL_DOWN_N1: {  // k4 s2 p1, 2 -> 1 positions: out = w[1] in[0] + w[2] in[1]
+      const int ci = s >> 1, j = s & 1;
+      return pm == k ? P[L.w + (co * L.cin + ci) * 4 + j + 1] : 0.f;
+    }
+    case TL_UP_N2: {  // nearest x2 of one position, then k3: out[0] = (w1 + w2) in, out[1] = (w0 + w1) in, as two groups of steps
+      const int g = s / L.cin, ci = s - g * L.cin;
+      const int t = g == 0 ? 1 : (pm == 0 ? 2 : 0);
+      return pm == k ? P[L.w + (co * L.cin + ci) * 3 + t] : 0.f;
+    }
+    default: {  // TL_LA1: scale * (Wo Wv)[co][ci]  (to_qkv (3 HID, C, 1): the v rows start at 2 HID; to_out.0 (C, HID, 1))
+      if (pm != k) return 0.f;
+      const int ci = s;
+      float acc = 0.f;
+      for (int j = 0; j < HID; ++j) acc = fmaf(P[L.w2 + co * HID + j], P[L.w + (2 * HID + j) * L.cin + ci], acc);
+      return acc * 0.17677669529663687f;  // 32^-0.5
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_tiny_images(TinyImgMulti mm, const float* __restrict__ P) {
+  const TinyImgItem& it = mm.it[blockIdx.y];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= it.total_steps * 64) return;
+  int s = idx >> 6, l = 0;
+  while (l + 1 < it.nl && s >= it.L[l].steps) { s -= it.L[l].steps; ++l; }
+  it.dst[idx] = tiny_img_value(it.L[l], s, idx & 63, P);
+}
+
+struct TinyBlkK {
+  int b1, g1, b2, g2, br;  // offsets in P (br < 0: identity residual)
+  int ss_off;
+  const float* inB; float* u1; float* a1; float* u2; float* out;
+};
+struct TinyFwdK {
+  const float* in; float* pre_out; float* in_copy;
+  int pb, rows_per_sample, ss_stride, in_folded, total_steps;
+  TinyBlkK blk[2];
+  int la, la_gpre, la_bo, la_go; float* la_y; float* la_ypre;
+  int post, post_b; float* post_out;
+};
+
+constexpr int NPRM = 20;  // 16-float parameter vectors in LDS: stage bias | per block: b1 g1 b2 g2 br scale+1 shift | g_pre b_out g_out | post bias
+
+// C: the level's channels; N: row length; PRE: input stage; CP: its input channels; CS: skip channels of cat(x, skip) (0: none, identity residual)
+template <int C, int N, int PRE, int CP, int CS>
+__global__ void __launch_bounds__(256) k_tiny_fwd(TinyFwdK a, const float* __restrict__ P, const float* __restrict__ ssb, const float* __restrict__ img,
+                                                 int tiles_ps) {
+  constexpr int RPT = 64 / N;
+  constexpr bool WR = CS > 0;
+  constexpr int S_PRE = (PRE == LEVEL_PRE_DOWN || PRE == LEVEL_PRE_UP) ? 2 * CP : 0;
+  constexpr int S_C1 = C + CS, S_C2 = C, S_RS = WR ? C + CS : 0;
+  constexpr int BLK = S_C1 + S_C2 + S_RS;
+  constexpr int B_LA = S_PRE + 2 * BLK, B_POST = B_LA + C;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* wl = lds;                                  // [total_steps][64]
+  float* prm = lds + (size_t)a.total_steps * 64;    // [NPRM][16]
+  {
+    const int total4 = a.total_steps * 16;
+    const float4* src = reinterpret_cast<const float4*>(img);
+    float4* dst = reinterpret_cast<float4*>(wl);
+    for (int base = threadIdx.x; base < total4; base += 256 * 4) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = src[base + u * 256 < total4 ? base + u * 256 : 0];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (base + u * 256 < total4) dst[base + u * 256] = v[u];
+    }
+  }
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < NPRM * 16; i += 256) {
+    const int what = i >> 4, c = i & 15;
+    float v = 0.f;
+    if (c < C) {
+      if (what == 0) { v = S_PRE ? P[a.pb + c] : 0.f; }
+      else if (what <= 14) {
+        const int bi = (what - 1) / 7, k = (what - 1) % 7;
+        const TinyBlkK& r = a.blk[bi];
+        const float* ss = ssb + (int64_t)b * a.ss_stride + r.ss_off;
+        v = k == 0 ? P[r.b1 + c] : k == 1 ? P[r.g1 + c] : k == 2 ? P[r.b2 + c] : k == 3 ? P[r.g2 + c] : k == 4 ? (WR ? P[r.br + c] : 0.f)
+          : k == 5 ? ss[c] + 1.0f : ss[C + c];
+      } else if (what <= 17) {
+        if (a.la) v = what == 15 ? P[a.la_gpre + c] : what == 16 ? P[a.la_bo + c] : P[a.la_go + c];
+      } else if (what == 18) {
+        if (a.post) v = P[a.post_b + c];
+      }
+    }
+    prm[i] = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, half = lane >> 5, slot = lane & 31;
+  const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int RT = a.rows_per_sample;
+  const float sqC = sqrtf((float)C);
+  const float* wlane = wl + lane;
+  auto prmv = [&](int what, int c) -> float { return prm[what * 16 + c]; };
+  // one dense layer: STEPS MFMAs, B operand = breg[0 .. STEPS) in image order
+  auto dense = [&](int base, const float* breg, auto steps_c, f32x16 acc) __attribute__((always_inline)) -> f32x16 {
+    constexpr int STEPS = decltype(steps_c)::value;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) acc = mfma_f32(wlane[(base + s) * 64], breg[s], acc);
+    return acc;
+  };
+  const int rowl = N == 2 ? slot : lane, p = N == 2 ? half : 0;
+
+#pragma unroll 1
+  for (int tile = wid; tile < tiles_ps; tile += nwaves) {
+    const int r_in_s = tile * RPT + rowl;
+    const bool live = r_in_s < RT;
+    const int rs_c = live ? r_in_s : RT - 1;
+    const int64_t row = (int64_t)b * RT + rs_c;
+    // (rows, CH, N) tensors: element (row, c, p)
+    auto ldrow = [&](const float* base, int CH, float* dst, int cnt) __attribute__((always_inline)) {
+      const float* q = base + (row * CH) * N + p;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) dst[c] = c < cnt ? q[c * N] : 0.f;
+    };
+    auto strow = [&](float* base, const float* v) __attribute__((always_inline)) {
+      if (base && live) {
+        float* q = base + (row * C) * N + p;
+#pragma unroll
+        for (int c = 0; c < C; ++c) q[c * N] = v[c];
+      }
+    };
+    float x[16], xb0[16], xb1[16];
+    // ---------------------------------------------------------------- input stage (every global read of the tile is requested up front)
+    if constexpr (PRE == LEVEL_PRE_DOWN) {
+      // input (rows, CP, 2 N): the lane holds in[ci][2 p], in[ci][2 p + 1]
+      float v[2 * CP];
+      const float* q = a.in + (row * CP) * (2 * N) + 2 * p;
+#pragma unroll
+      for (int ci = 0; ci < CP; ++ci) {
+        const float2 t = *reinterpret_cast<const float2*>(q + ci * 2 * N);
+        v[2 * ci] = t.x; v[2 * ci + 1] = t.y;
+      }
+      if (CS) { ldrow(a.blk[0].inB, CS, xb0, CS); ldrow(a.blk[1].inB, CS, xb1, CS); }
+      f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      acc = dense(0, v, std::integral_constant<int, 2 * CP>{}, acc);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) x[c] = c < C ? acc[c] + prmv(0, c) : 0.f;
+      strow(a.pre_out, x);
+    } else if constexpr (PRE == LEVEL_PRE_UP) {
+      // input (rows, CP, 1): both positions of the row read the row's one input position
+      float v[2 * CP];
+      const float* q = a.in + row * CP;
+#pragma unroll
+      for (int ci = 0; ci < CP; ++ci) { v[ci] = q[ci]; v[CP + ci] = v[ci]; }
+      if (CS) { ldrow(a.blk[0].inB, CS, xb0, CS); ldrow(a.blk[1].inB, CS, xb1, CS); }
+      f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      acc = dense(0, v, std::integral_constant<int, 2 * CP>{}, acc);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) x[c] = c < C ? acc[c] + prmv(0, c) : 0.f;
+      strow(a.pre_out, x);
+    } else {
+      if (a.in_folded) {  // (B, C, RT): the bottleneck's layout (N == 1)
+        const float* q = a.in + (int64_t)b * C * RT + rs_c;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) x[c] = c < C ? q[(int64_t)c * RT] : 0.f;
+      } else {
+        ldrow(a.in, C, x, C);
+      }
+      if (CS) { ldrow(a.blk[0].inB, CS, xb0, CS); ldrow(a.blk[1].inB, CS, xb1, CS); }
+      strow(a.in_copy, x);
+    }
+    // ---------------------------------------------------------------- the level's ResnetBlocks (unet1d.py:302-323)
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi) {
+      const TinyBlkK& r = a.blk[bi];
+      const int base = S_PRE + bi * BLK, pq = 1 + 7 * bi;
+      const float* xs = bi == 0 ? xb0 : xb1;
+      f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      acc = dense(base, x, std::integral_constant<int, C>{}, acc);
+      if constexpr (CS > 0) acc = dense(base + C, xs, std::integral_constant<int, CS>{}, acc);
+      float u[16], h[16];
+      float ssq = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) { u[c] = acc[c] + prmv(pq + 0, c); ssq = fmaf(u[c], u[c], ssq); }
+      strow(r.u1, u);
+      {
+        const float inv = rms_inv(ssq, sqC);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) h[c] = c < C ? silu_f(fmaf(u[c] * inv * prmv(pq + 1, c), prmv(pq + 5, c), prmv(pq + 6, c))) : 0.f;
+      }
+      strow(r.a1, h);
+      f32x16 acc2 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      acc2 = dense(base + S_C1, h, std::integral_constant<int, C>{}, acc2);
+      ssq = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) { u[c] = acc2[c] + prmv(pq + 2, c); ssq = fmaf(u[c], u[c], ssq); }
+      strow(r.u2, u);
+      float res[16];
+      if constexpr (WR) {
+        f32x16 ar = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        ar = dense(base + S_C1 + S_C2, x, std::integral_constant<int, C>{}, ar);
+        ar = dense(base + S_C1 + S_C2 + C, xs, std::integral_constant<int, CS>{}, ar);
+#pragma unroll
+        for (int c = 0; c < C; ++c) res[c] = ar[c] + prmv(pq + 4, c);
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) res[c] = x[c];
+      }
+      {
+        const float inv = rms_inv(ssq, sqC);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) x[c] = c < C ? silu_f(u[c] * inv * prmv(pq + 3, c)) + res[c] : 0.f;
+      }
+      strow(r.out, x);
+    }
+    if constexpr (N == 1) {
+      // ------------------------------------------------------------ Residual(PreNorm(LinearAttention)) over one position: linear
+      if (a.la) {
+        float xh[16];
+        float ssq = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) ssq = fmaf(x[c], x[c], ssq);
+        const float inv = rms_inv(ssq, sqC);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) xh[c] = c < C ? x[c] * inv * prmv(15, c) : 0.f;
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc = dense(B_LA, xh, std::integral_constant<int, C>{}, acc);
+        float yp[16];
+        ssq = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { yp[c] = acc[c] + prmv(16, c); ssq = fmaf(yp[c], yp[c], ssq); }
+        strow(a.la_ypre, yp);
+        const float inv2 = rms_inv(ssq, sqC);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) x[c] = c < C ? fmaf(yp[c] * inv2, prmv(17, c), x[c]) : 0.f;
+        strow(a.la_y, x);
+      }
+      // ------------------------------------------------------------ the last down level's k3 conv, stored as (B, C, RT)
+      if (a.post) {
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc = dense(B_POST, x, std::integral_constant<int, C>{}, acc);
+        if (live) {
+          float* q = a.post_out + (int64_t)b * C * RT + rs_c;
+#pragma unroll
+          for (int c = 0; c < C; ++c) q[(int64_t)c * RT] = acc[c] + prmv(18, c);
+        }
+      }
+    }
+  }
+}
+
+// the layer list of a launch, in image order (the kernel's step bases follow the same formulas)
+int tiny_layers(const TinyFwd& t, TinyLayer* L) {
+  const LevelFwd& a = t.lv;
+  auto poff = [&](const float* ptr) -> int { return ptr ? (int)(ptr - a.params) : -1; };
+  int nl = 0;
+  const int C = a.C, N = a.n;
+  if (a.pre == LEVEL_PRE_DOWN) L[nl++] = TinyLayer{N == 2 ? TL_DOWN_N2 : TL_DOWN_N1, poff(a.pw), 0, a.cp, 4, 0, 2 * a.cp, C};
+  if (a.pre == LEVEL_PRE_UP) L[nl++] = TinyLayer{TL_UP_N2, poff(a.pw), 0, a.cp, 3, 0, 2 * a.cp, C};
+  for (int b = 0; b < 2; ++b) {
+    const ResFwd& r = a.blk[b];
+    const int cs = r.cinB, cin = C + cs, kind = N == 2 ? TL_CONV3_N2 : TL_DIAG;
+    L[nl++] = TinyLayer{kind, poff(r.w1), 0, cin, 3, 0, C, C};
+    if (cs) L[nl++] = TinyLayer{kind, poff(r.w1), 0, cin, 3, C, cs, C};
+    L[nl++] = TinyLayer{kind, poff(r.w2), 0, C, 3, 0, C, C};
+    if (cs) {
+      L[nl++] = TinyLayer{TL_DIAG, poff(r.wr), 0, cin, 1, 0, C, C};
+      L[nl++] = TinyLayer{TL_DIAG, poff(r.wr), 0, cin, 1, C, cs, C};
+    }
+  }
+  if (t.la) L[nl++] = TinyLayer{TL_LA1, poff(t.w_qkv), poff(t.w_out), C, 1, 0, C, C};
+  if (t.post_w) L[nl++] = TinyLayer{TL_DIAG, poff(t.post_w), 0, C, 3, 0, C, C};  // (only behind the LinearAttention: tiny_fwd_usable)
+  return nl;
+}
+
+bool tiny_enabled() {
+  static const bool on = [] { const char* e = std::getenv("DQ_NO_TINY"); return !(e && e[0] == '1'); }();  // A-B switch
+  return on;
+}
+
+}  // namespace
+
+bool tiny_fwd_usable(const TinyFwd& t) {
+  const LevelFwd& a = t.lv;
+  if (!tiny_enabled()) return false;
+  if (a.nblocks != 2 || a.rows_per_sample <= 1 || !a.params) return false;
+  const int cs = a.blk[0].cinB;
+  if (a.blk[1].cinB != cs) return false;
+  for (int b = 0; b < 2; ++b) if ((cs > 0) != (a.blk[b].wr != nullptr)) return false;
+  const bool extras = t.la || t.post_w || t.in_folded;
+  if (extras && a.n != 1) return false;
+  if (t.post_w && !t.la) return false;  // (the post conv's steps sit behind the LinearAttention's in the image)
+  if (a.C == 12 && a.n == 2 && a.pre == LEVEL_PRE_DOWN && a.cp == 12 && cs == 0) return true;
+  if (a.C == 16 && a.n == 1 && a.pre == LEVEL_PRE_DOWN && a.cp == 12 && cs == 0) return true;
+  if (a.C == 16 && a.n == 1 && a.pre == LEVEL_PRE_NONE && cs == 16) return true;
+  if (a.C == 16 && a.n == 2 && a.pre == LEVEL_PRE_UP && a.cp == 16 && cs == 12) return true;
+  return false;
+}
+
+int64_t tiny_img_floats(const TinyFwd& t) {
+  TinyLayer L[TINY_MAX_LAYERS];
+  const int nl = tiny_layers(t, L);
+  int64_t steps = 0;
+  for (int i = 0; i < nl; ++i) steps += L[i].steps;
+  return steps * 64;
+}
+
+int launch_tiny_images(const TinyFwd* calls, int count, hipStream_t s) {
+  if (count == 0) return 0;
+  DQ_REQUIRE(count <= TINY_IMG_MAX, "tiny images: too many launches");
+  TinyImgMulti mm;
+  int64_t mx = 0;
+  for (int i = 0; i < count; ++i) {
+    const TinyFwd& t = calls[i];
+    DQ_REQUIRE(t.img && ((uintptr_t)t.img & 15) == 0 && t.lv.params, "tiny images: missing / misaligned image buffer");
+    DQ_REQUIRE(tiny_fwd_usable(t), "tiny images: unsupported shape");
+    DQ_REQUIRE(t.lv.params == calls[0].lv.params, "tiny images: the launches must share one parameter buffer");
+    TinyImgItem& it = mm.it[i];
+    it.nl = tiny_layers(t, it.L);
+    it.total_steps = 0;
+    for (int l = 0; l < it.nl; ++l) it.total_steps += it.L[l].steps;
+    it.dst = const_cast<float*>(t.img);
+    DQ_REQUIRE((int64_t)it.total_steps * 64 <= TINY_IMG_FLOATS, "tiny images: image larger than its slot");
+    mx = std::max<int64_t>(mx, (int64_t)it.total_steps * 64);
+  }
+  hipLaunchKernelGGL(k_tiny_images, dim3(cdiv(mx, 256), count), dim3(256), 0, s, mm, calls[0].lv.params);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+static int tiny_num_cus() {
+  static const int v = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+  return v;
+}
+
+int launch_tiny_fwd(const TinyFwd& t, hipStream_t s) {
+  const LevelFwd& a = t.lv;
+  DQ_REQUIRE(tiny_fwd_usable(t), "tiny_fwd: unsupported shape");
+  DQ_REQUIRE(a.rows % a.rows_per_sample == 0 && a.in && t.img, "tiny_fwd: bad rows / missing input or operand image");
+  DQ_REQUIRE(a.pre == LEVEL_PRE_NONE || (a.pw && a.pb), "tiny_fwd: the input stage needs its conv weight and bias");
+  DQ_REQUIRE(!t.la || (t.w_qkv && t.w_out && t.b_out && t.g_pre && t.g_out && t.la_y), "tiny_fwd: incomplete LinearAttention operands");
+  DQ_REQUIRE(!t.post_w || (t.post_b && t.post_out), "tiny_fwd: incomplete post conv");
+  auto poff = [&](const float* ptr) -> int { return ptr ? (int)(ptr - a.params) : -1; };
+  TinyFwdK k;
+  k.in = a.in; k.pre_out = a.pre_out; k.in_copy = t.in_copy; k.pb = poff(a.pb); k.rows_per_sample = a.rows_per_sample; k.in_folded = t.in_folded;
+  const float* ssb = a.blk[0].ss;
+  k.ss_stride = a.blk[0].ss_stride;
+  for (int b = 0; b < 2; ++b) {
+    const ResFwd& r = a.blk[b];
+    DQ_REQUIRE(r.w1 && r.b1 && r.g1 && r.w2 && r.b2 && r.g2 && r.ss && (r.cinB == 0 || (r.inB && r.wr && r.br)), "tiny_fwd: missing block operand");
+    DQ_REQUIRE(r.ss_stride == k.ss_stride && r.ss >= ssb - (1 << 20) && r.ss <= ssb + (1 << 20), "tiny_fwd: the blocks' scale / shift vectors must share one buffer");
+    for (const float* q : {r.w1, r.b1, r.g1, r.w2, r.b2, r.g2, r.wr, r.br})
+      DQ_REQUIRE(!q || (q >= a.params && q - a.params < (1ll << 31)), "tiny_fwd: a parameter lies outside the flat parameter buffer");
+    TinyBlkK& d = k.blk[b];
+    d.b1 = poff(r.b1); d.g1 = poff(r.g1); d.b2 = poff(r.b2); d.g2 = poff(r.g2); d.br = poff(r.br);
+    d.ss_off = (int)(r.ss - ssb);
+    d.inB = r.inB; d.u1 = r.u1; d.a1 = r.a1; d.u2 = r.u2; d.out = r.out;
+  }
+  k.la = t.la; k.la_gpre = poff(t.g_pre); k.la_bo = poff(t.b_out); k.la_go = poff(t.g_out); k.la_y = t.la_y; k.la_ypre = t.la_ypre;
+  k.post = t.post_w ? 1 : 0; k.post_b = poff(t.post_b); k.post_out = t.post_out;
+  k.total_steps = (int)(tiny_img_floats(t) / 64);
+  const int B = a.rows / a.rows_per_sample;
+  const int rpt = 64 / a.n;
+  const int tiles_ps = cdiv(a.rows_per_sample, rpt);
+  const size_t lds = (size_t)k.total_steps * 256 + NPRM * 16 * 4;
+  DQ_REQUIRE(lds <= 96 * 1024, "tiny_fwd: weight image too large");
+  const int cs = a.blk[0].cinB;
+#define DQ_TINY(CC, NN, PP, PC, SS)                                                                                           \
+  if (a.C == CC && a.n == NN && a.pre == PP && (PP == LEVEL_PRE_NONE || a.cp == PC) && cs == SS) {                            \
+    const int nb = occ_blocks_per_cu((const void*)k_tiny_fwd<CC, NN, PP, PC, SS>, 256, lds);                                  \
+    if (nb < 0) return 1;                                                                                                     \
+    const int gx = std::max(1, std::min(nb * tiny_num_cus() / B, (tiles_ps + 3) / 4));                                        \
+    hipLaunchKernelGGL((k_tiny_fwd<CC, NN, PP, PC, SS>), dim3(gx, B), dim3(256), lds, s, k, a.params, ssb, t.img, tiles_ps);  \
+    DQ_LAUNCH_CHECK();                                                                                                        \
+    return 0;                                                                                                                 \
+  }
+  DQ_TINY(12, 2, LEVEL_PRE_DOWN, 12, 0)
+  DQ_TINY(16, 1, LEVEL_PRE_DOWN, 12, 0)
+  DQ_TINY(16, 1, LEVEL_PRE_NONE, 0, 16)
+  DQ_TINY(16, 2, LEVEL_PRE_UP, 16, 12)
+#undef DQ_TINY
+  set_error("tiny_fwd: unsupported (C, n, stage, stage input width, skip width)");
+  return 2;
+}
+
+}  // namespace dq
