@@ -213,6 +213,9 @@ int wgrad_async(const Ctx& c, const ConvWgrad& w);
 int wgrad_async_multi(const Ctx& c, ConvWgrad* w, int count);  // <= 3 stride-1 convs over the same rows: one launch + one reduce
 int join_side(const Ctx& c);
 int side_flush(const Ctx& c);
+int fork_side(const Ctx& c);                      // the side stream continues from this point of the main stream
+int side_mark(const Ctx& c, hipEvent_t* ev);      // an event behind what the side stream has been given so far
+
 // flush after every second level (measured, ms per step: every level 4.876, the three widest + every second deeper one 4.858, every
 // second 4.836, every third 4.90 -- the side stream then starts too late); level 0 always flushes
 static inline bool side_flush_here(int lv) { return (lv & 1) == 0; }
@@ -404,7 +407,7 @@ int la_fwd(const Ctx& c, const LAP& l, const float* x, float* y, float* ypre, in
 }
 // W2 = Wo Wv and the MFMA operand image of Wq | Wk of every LinearAttention layer, once per forward (one launch) instead of once
 // per block of every layer's kernel
-int la_prepare_all(const Ctx& c) {
+int la_prepare_all(const Ctx& c, hipStream_t ps) {
   const Plan& p = c.p;
   LaPrepItem items[LA_PREP_MAX];
   int count = 0;
@@ -423,7 +426,7 @@ int la_prepare_all(const Ctx& c) {
   const int wn[3] = {2 * HID * p.mid_c, HID * p.cond_dim, p.mid_c * HID};
   for (int i = 0; i < 3; ++i)
     if (((uintptr_t)c.prm(wsrc[i]) & 15) != 0 && wn[i] <= WTMP_SLOT) cps[nc++] = PrepCopy{c.prm(wsrc[i]), c.w(c.ar.wtmp) + i * WTMP_SLOT, wn[i]};
-  return launch_linattn_prepare(items, count, c.s, cps, nc);
+  return launch_linattn_prepare(items, count, ps, cps, nc);
 }
 
 // the collected slot reductions, one launch
@@ -811,8 +814,19 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     if (f.img && level_img_floats(f) > LEVEL_IMG_FLOATS) f.img = nullptr;
     return f;
   };
+  // Training steps (dq_train_step: side stream + gradient twin at hand): what the first level does not wait for runs on the side stream --
+  // the LinearAttention / tiny-level operand preparation, the MS1 feature path (needed at the bottleneck) and the clearing of the
+  // gradient twin's accumulated-into region (needed by the backward) were ~55 us at the head of the main queue, in front of or between
+  // launches that do not depend on them.  One event forks; the main stream waits for `ev_prep` in front of the first LinearAttention and
+  // for `ev_rest` in front of the first launch that reads the MS1 features.
+  static const bool fwd_fork_on = [] { const char* e = std::getenv("DQ_NO_FWD_FORK"); return !(e && e[0] == '1'); }();  // A-B switch
+  const bool fwd_fork = fwd_fork_on && c.owner && c.save && c.G && !c.step_io && !c.prepare_only;
+  hipStream_t ps = c.s;
+  hipEvent_t ev_prep = nullptr, ev_rest = nullptr;
+  bool wait_prep = false, wait_rest = false;
+  if (fwd_fork) { DQ_TRY(fork_side(c)); ps = c.owner->side_stream; }
   if (!(c.step_io && c.step_io->prepared)) {
-    DQ_TRY(la_prepare_all(c));
+    DQ_TRY(la_prepare_all(c, ps));
     LevelFwd calls[LEVEL_IMG_MAX];
     int nc = 0;
     for (int lv = 0; lv < L; ++lv)
@@ -824,25 +838,36 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     int nt = 0;
     for (int lv = 0; lv < L; ++lv) if (is_tiny_dn(lv)) { tc[nt] = tiny_down(lv); tc[nt].img = tiny_img(tiny_dn[lv]); ++nt; }
     for (int ui = 0; ui < L; ++ui) if (is_tiny_up(ui)) { tc[nt] = tiny_upc(ui); tc[nt].img = tiny_img(tiny_up[ui]); ++nt; }
-    DQ_TRY(launch_tiny_images(tc, nt, c.s));
+    DQ_TRY(launch_tiny_images(tc, nt, ps));
   }
   if (c.prepare_only) return 0;
+  if (fwd_fork) { DQ_TRY(side_mark(c, &ev_prep)); wait_prep = true; }
   // K1: time embedding + every scale/shift head (unet1d.py:1105, 315-318, 677)
   DQ_TRY(launch_time_embed_fwd(p, dt, c.P, t, t_scalar, c.w(a.tbuf), c.w(a.ss), B, step_tab, step_ptr, c.s));
   // K2: mixture conditioning + concat (unet1d.py:1107-1115), then init_conv k7 (:1117)
   if (init_fused) {
     if (!skip_ms1) DQ_TRY(launch_ms1_norm(attn_cond, cm, ca, c.w(a.ms1n), (int64_t)B * RT, c.s));
   } else {
-    DQ_TRY(launch_prep_inputs(x, init_cond, attn_cond, c.w(a.ss), p.ss_total, p.ss_init, cm, ca, c.w(a.cat0), c.w(a.ms1n), B, RT, p.mz, c.s));
+    // (forked: the MS1 normalisation goes with the MS1 path to the side stream)
+    DQ_TRY(launch_prep_inputs(x, init_cond, attn_cond, c.w(a.ss), p.ss_total, p.ss_init, cm, ca, c.w(a.cat0), fwd_fork ? nullptr : c.w(a.ms1n), B, RT, p.mz, c.s));
     DQ_TRY(conv_plain_fwd(c, p.init_conv, CONV_S1, c.w(a.cat0), c.w(a.h0), R, p.mz, p.mz));
   }
   // K3: MS1 features (unet1d.py:1120-1130): (B,1,RT) -> conv k7 -> GELU -> conv k1
   if (!skip_ms1) {
+    Ctx cs = c;
+    cs.s = ps;
+    if (fwd_fork && !init_fused) DQ_TRY(launch_ms1_norm(attn_cond, cm, ca, c.w(a.ms1n), (int64_t)B * RT, ps));
     ConvFwd f;
     f.inA = c.w(a.ms1n); f.cinA = 1; f.w = c.prm(p.ms1_c0.w); f.bias = c.prm(p.ms1_c0.b); f.cout = p.cond_dim; f.K = 7;
     f.rows = B; f.n_in = RT; f.n_out = RT; f.u_out = c.save ? c.w(a.ms1_u) : nullptr; f.y_out = c.w(a.ms1_a); f.act = ACT_GELU;
-    DQ_TRY(launch_conv_fwd(f, c.s));
-    DQ_TRY(conv_plain_fwd(c, p.ms1_c1, CONV_S1, c.w(a.ms1_a), c.w(a.ms1f), B, RT, RT));
+    DQ_TRY(launch_conv_fwd(f, ps));
+    DQ_TRY(conv_plain_fwd(cs, p.ms1_c1, CONV_S1, c.w(a.ms1_a), c.w(a.ms1f), B, RT, RT));
+  }
+  if (fwd_fork) {
+    DQ_TRY(launch_zero(c.G, a.zero_floats, ps));  // (unet_backward skips its own clearing: dq_plan::twin_zeroed)
+    c.owner->twin_zeroed = c.G;
+    DQ_TRY(side_mark(c, &ev_rest));
+    wait_rest = true;
   }
   // down path (unet1d.py:1134-1142)
   const float* cur = c.w(a.h0);
@@ -865,12 +890,14 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
       DQ_TRY(res_fwd(c, l.r0, b.r0, cur, C, nullptr, 0, R, l.n, RT));
       DQ_TRY(res_fwd(c, l.r1, b.r1, c.w(b.r0.out), C, nullptr, 0, R, l.n, RT));
     }
+    if (wait_prep) { DQ_HIP_OK(hipStreamWaitEvent(c.s, ev_prep, 0)); wait_prep = false; }  // (in front of lv 0's LinearAttention: the tiny levels come later)
     if (!la_done) DQ_TRY(la_fwd(c, l.la, c.w(b.r1.out), c.w(b.la), c.save ? c.w(b.la_pre) : nullptr, R, l.n, prep_ok ? lv : -1));
     if (lv + 1 < L && (is_tiny_dn(lv + 1) || level_ok(c, down_call(lv + 1)))) continue;  // the next level's launch applies this level's Downsample itself
     DQ_TRY(conv_plain_fwd(c, l.resample, l.last ? CONV_S1 : CONV_DOWN, c.w(b.la), c.w(b.rs), R, l.n, l.n_next));
     cur = c.w(b.rs);
   }
   // bottleneck (unet1d.py:1144-1148)
+  if (wait_rest) { DQ_HIP_OK(hipStreamWaitEvent(c.s, ev_rest, 0)); wait_rest = false; c.owner->side_used = false; }
   if (p.wide_mid) {
     DQ_TRY(mid_forward_wide(c, rope, cur));
   } else {
@@ -961,7 +988,9 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
   const Plan& p = c.p;
   const Arena& a = c.ar;
   const int B = c.B, RT = c.RT, R = B * RT, L = p.levels;
-  DQ_TRY(launch_zero(c.G, a.zero_floats, c.s));  // only the accumulated-into region of the twin (offsets are multiples of 64 floats)
+  // only the accumulated-into region of the twin (offsets are multiples of 64 floats); a forked forward of the same step cleared it already
+  if (c.owner && c.owner->twin_zeroed == c.G) c.owner->twin_zeroed = nullptr;
+  else DQ_TRY(launch_zero(c.G, a.zero_floats, c.s));
   // head
   DQ_TRY(conv_plain_bwd(c, p.final_conv, CONV_S1, c.w(a.fin.out), grad_out, c.g(a.fin.out), R, p.mz, p.mz, 0));
   const LevelBuf& lastup = a.ups[L - 1];
@@ -1061,6 +1090,34 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
   return launch_time_embed_bwd(p, dt, c.P, c.dP, c.w(a.tbuf), c.g(a.ss), B, c.s);
 }
 
+int ensure_side(dq_plan* pl) {
+  if (pl->side_stream) return 0;
+    // Own priority class => own hardware queue.  Normal-priority streams share a small round-robin pool of HSA queues,
+    // and once RCCL has taken its streams from that pool a plain stream can land on the caller's queue, which serialises
+    // the weight-gradient kernels behind the main chain (measured: 15.7 vs 13.0 ms/step under torch.distributed.run).
+    int prio_least = 0, prio_greatest = 0;
+    DQ_HIP_OK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    static const bool low = [] { const char* e = std::getenv("DQ_SIDE_PRIO"); return e && e[0] == 'l'; }();  // A-B switch
+    DQ_HIP_OK(hipStreamCreateWithPriority(&pl->side_stream, hipStreamNonBlocking, low ? prio_least : prio_greatest));
+    for (auto& e : pl->events) DQ_HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return 0;
+}
+int fork_side(const Ctx& c) {
+  dq_plan* pl = c.owner;
+  DQ_TRY(ensure_side(pl));
+  hipEvent_t ev = pl->events[pl->ev_next++ % dq_plan::NUM_EVENTS];
+  DQ_HIP_OK(hipEventRecord(ev, c.s));
+  DQ_HIP_OK(hipStreamWaitEvent(pl->side_stream, ev, 0));
+  pl->side_used = true;
+  return 0;
+}
+int side_mark(const Ctx& c, hipEvent_t* ev) {
+  dq_plan* pl = c.owner;
+  *ev = pl->events[pl->ev_next++ % dq_plan::NUM_EVENTS];
+  DQ_HIP_OK(hipEventRecord(*ev, pl->side_stream));
+  return 0;
+}
+
 int wgrad_async(const Ctx& c, const ConvWgrad& w) {
   dq_plan* pl = c.owner;
   if (!pl) return launch_conv_wgrad(w, c.s);
@@ -1070,16 +1127,7 @@ int wgrad_async(const Ctx& c, const ConvWgrad& w) {
     c.side_defer->push_back(it);
     return 0;
   }
-  if (!pl->side_stream) {
-    // Own priority class => own hardware queue.  Normal-priority streams share a small round-robin pool of HSA queues,
-    // and once RCCL has taken its streams from that pool a plain stream can land on the caller's queue, which serialises
-    // the weight-gradient kernels behind the main chain (measured: 15.7 vs 13.0 ms/step under torch.distributed.run).
-    int prio_least = 0, prio_greatest = 0;
-    DQ_HIP_OK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    static const bool low = [] { const char* e = std::getenv("DQ_SIDE_PRIO"); return e && e[0] == 'l'; }();  // A-B switch
-    DQ_HIP_OK(hipStreamCreateWithPriority(&pl->side_stream, hipStreamNonBlocking, low ? prio_least : prio_greatest));
-    for (auto& e : pl->events) DQ_HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  }
+  DQ_TRY(ensure_side(pl));
   hipEvent_t ev = pl->events[pl->ev_next++ % dq_plan::NUM_EVENTS];
   DQ_HIP_OK(hipEventRecord(ev, c.s));
   DQ_HIP_OK(hipStreamWaitEvent(pl->side_stream, ev, 0));

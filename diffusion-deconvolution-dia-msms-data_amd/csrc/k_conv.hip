@@ -919,7 +919,7 @@ __global__ void __launch_bounds__(256) k_prep_inputs(const float* __restrict__ x
                                                      float* __restrict__ ms1n, int B, int RT, int MZ) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)B * RT * MZ;
-  if (i < (int64_t)B * RT) ms1n[i] = fmaf(ms1[i], cm, ca);
+  if (ms1n && i < (int64_t)B * RT) ms1n[i] = fmaf(ms1[i], cm, ca);
   if (i >= total) return;
   const int mz = (int)(i % MZ);
   const int64_t row = i / MZ;

@@ -119,38 +119,54 @@ __global__ void __launch_bounds__(256) k_tiny_fwd(TinyFwdK a, const float* __res
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* wl = lds;                                  // [total_steps][64]
   float* prm = lds + (size_t)a.total_steps * 64;    // [NPRM][16]
+  // Preamble in ONE memory round trip: every 16-byte load of the image and the thread's (<= 2) parameter values are requested before the
+  // first LDS store (as a load -> store loop plus a branchy parameter gather it was three to four dependent round trips, ~5 us of a
+  // ~16 us launch at the training batch).
+  const int b = blockIdx.y;
   {
+    constexpr int MAXS = B_POST + C;                  // upper bound of total_steps
+    constexpr int NLD = (MAXS * 16 + 255) / 256;
     const int total4 = a.total_steps * 16;
     const float4* src = reinterpret_cast<const float4*>(img);
-    float4* dst = reinterpret_cast<float4*>(wl);
-    for (int base = threadIdx.x; base < total4; base += 256 * 4) {
-      float4 v[4];
+    float4 v[NLD];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = src[base + u * 256 < total4 ? base + u * 256 : 0];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (base + u * 256 < total4) dst[base + u * 256] = v[u];
+    for (int u = 0; u < NLD; ++u) {
+      const int i = u * 256 + (int)threadIdx.x;
+      v[u] = src[i < total4 ? i : 0];
     }
-  }
-  const int b = blockIdx.y;
-  for (int i = threadIdx.x; i < NPRM * 16; i += 256) {
-    const int what = i >> 4, c = i & 15;
-    float v = 0.f;
-    if (c < C) {
-      if (what == 0) { v = S_PRE ? P[a.pb + c] : 0.f; }
+    float pvv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = u * 256 + (int)threadIdx.x;       // NPRM * 16 = 320 values
+      const int what = (i >> 4) < NPRM ? (i >> 4) : 0, c = i & 15;
+      const int bi = what >= 8 ? 1 : 0, k = what == 0 ? 7 : (what - 1) % 7;
+      const TinyBlkK& r0 = a.blk[0];
+      const TinyBlkK& r1 = a.blk[1];
+      const int b1 = bi ? r1.b1 : r0.b1, g1 = bi ? r1.g1 : r0.g1, b2 = bi ? r1.b2 : r0.b2, g2 = bi ? r1.g2 : r0.g2, br = bi ? r1.br : r0.br;
+      const int sso = bi ? r1.ss_off : r0.ss_off;
+      int off = -1;      // offset into P, or
+      int soff = -1;     // offset into this sample's scale / shift vector
+      if (what == 0) off = S_PRE ? a.pb : -1;
       else if (what <= 14) {
-        const int bi = (what - 1) / 7, k = (what - 1) % 7;
-        const TinyBlkK& r = a.blk[bi];
-        const float* ss = ssb + (int64_t)b * a.ss_stride + r.ss_off;
-        v = k == 0 ? P[r.b1 + c] : k == 1 ? P[r.g1 + c] : k == 2 ? P[r.b2 + c] : k == 3 ? P[r.g2 + c] : k == 4 ? (WR ? P[r.br + c] : 0.f)
-          : k == 5 ? ss[c] + 1.0f : ss[C + c];
-      } else if (what <= 17) {
-        if (a.la) v = what == 15 ? P[a.la_gpre + c] : what == 16 ? P[a.la_bo + c] : P[a.la_go + c];
-      } else if (what == 18) {
-        if (a.post) v = P[a.post_b + c];
-      }
+        off = k == 0 ? b1 : k == 1 ? g1 : k == 2 ? b2 : k == 3 ? g2 : (k == 4 && WR) ? br : -1;
+        soff = k == 5 ? sso : (k == 6 ? sso + C : -1);
+      } else if (what <= 17) { off = a.la ? (what == 15 ? a.la_gpre : what == 16 ? a.la_bo : a.la_go) : -1; }
+      else if (what == 18) { off = a.post ? a.post_b : -1; }
+      const bool use = c < C && (off >= 0 || soff >= 0);
+      const float* q = soff >= 0 ? ssb + (int64_t)b * a.ss_stride + soff : P + (off >= 0 ? off : 0);
+      const float val = q[use ? c : 0];
+      pvv[u] = use ? (what <= 14 && k == 5 ? val + 1.0f : val) : 0.f;
     }
-    prm[i] = v;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int i = u * 256 + (int)threadIdx.x;
+      if (i < total4) reinterpret_cast<float4*>(wl)[i] = v[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = u * 256 + (int)threadIdx.x;
+      if (i < NPRM * 16) prm[i] = pvv[u];
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, half = lane >> 5, slot = lane & 31;
