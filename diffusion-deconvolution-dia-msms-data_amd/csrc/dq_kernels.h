@@ -20,7 +20,10 @@ int launch_sample_finish(const float* x, const float* ms2_cond, float* out_x, fl
                          hipStream_t s);
 int launch_mse_fwd_bwd(const float* eps, const float* noise, float* loss_out, float* grad_out, float* partials, int64_t n,
                        hipStream_t s, const float* lw = nullptr, const int64_t* t = nullptr, int64_t per_sample = 0, float tm = 1.f,
-                       float ta = 0.f);  // lw: per-timestep loss weights (x0 objective); target' = target*tm + ta
+                       float ta = 0.f, int* defer_sum = nullptr);  // lw: per-timestep loss weights (x0 objective); target' = target*tm + ta
+// defer_sum: the kernel leaves its per-block partials, *defer_sum receives their count and loss_out is NOT written -- the caller runs
+// launch_sum_partials(partials, count, 1 / n, loss_out, stream) when it suits (dq_train_step: on the side stream)
+int launch_sum_partials(const float* partials, int count, float scale, float* out, hipStream_t s);
 // the MS1 term of train_step with ms1_loss_weight = w > 0 (k_stream.hip): on entry loss_out / grad hold the MSE part, on exit the
 // combined loss (1 - w) * MSE + w * additional and its gradient w.r.t. the network output; x_t null = x0 objective;
 // scratch: 5 * B * RT + B floats

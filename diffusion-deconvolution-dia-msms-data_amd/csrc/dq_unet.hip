@@ -8,6 +8,7 @@
 #include "../../include/dq_hip.h"
 
 #include <algorithm>
+#include <functional>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -168,6 +169,10 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
 
 namespace {
 
+bool tail_fork_enabled() {
+  static const bool on = [] { const char* e = std::getenv("DQ_NO_TAIL_FORK"); return !(e && e[0] == '1'); }();  // A-B switch
+  return on;
+}
 bool side_stream_enabled() {
   static const bool on = [] { const char* e = std::getenv("DQ_NO_SIDE_STREAM"); return !(e && e[0] == '1'); }();
   return on;
@@ -189,7 +194,7 @@ struct Ctx {
   // set by unet_backward: the side-stream launches (weight gradients, norm-gain reduces) are collected and issued by side_flush
   // behind ONE event per group instead of one per ResnetBlock / conv (an event record costs ~4 us on the main stream: 29 + 14
   // of them were 0.13 ms per step); everything they read is final when it is queued and stays untouched until the join
-  struct SideItem { int kind; ConvWgrad w[3]; int count; PartReduce red; };
+  struct SideItem { int kind; ConvWgrad w[3]; int count; PartReduce red; std::function<int(hipStream_t)> fn; };  // kind 3: fn(side stream)
   std::vector<SideItem>* side_defer = nullptr;
   // set by unet_backward: the slot reductions of the ResnetBlock backwards that form their own weight gradients (k_res_bwd_wg),
   // collected for ONE launch at the end of the pass (null: each is reduced right behind its launch)
@@ -201,6 +206,9 @@ struct Ctx {
                   bool prepared = false; };  // prepared: the once-per-parameter-state launches (la_prepare_all, operand images) ran before the loop
   StepIO* step_io = nullptr;
   bool prepare_only = false;  // unet_forward: run just those launches and return
+  // dq_train_step: the scalar loss (sum of the MSE kernel's partials) is needed by nobody on the gradient chain: it rides on the side stream
+  struct LossSum { const float* partials = nullptr; int count = 0; float scale = 0.f; float* out = nullptr; };
+  LossSum loss_sum;
   float* w(int64_t off) const { return W + off; }
   float* g(int64_t off) const { return G + off; }
   const float* prm(int64_t off) const { return P + off; }
@@ -985,6 +993,16 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
   c.la_defer = &la_defer;
   c.wg_defer = &wg_items;
   if (c.owner) c.side_defer = &side_items;
+  if (c.loss_sum.out) {
+    const Ctx::LossSum ls = c.loss_sum;
+    if (c.side_defer) {
+      Ctx::SideItem it{};
+      it.kind = 3; it.fn = [ls](hipStream_t ss) { return launch_sum_partials(ls.partials, ls.count, ls.scale, ls.out, ss); };
+      side_items.push_back(it);
+    } else {
+      DQ_TRY(launch_sum_partials(ls.partials, ls.count, ls.scale, ls.out, c.s));
+    }
+  }
   const Plan& p = c.p;
   const Arena& a = c.ar;
   const int B = c.B, RT = c.RT, R = B * RT, L = p.levels;
@@ -1043,6 +1061,26 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     DQ_TRY(res_bwd(c, p.mid1, a.mid1, c.w(a.mid_in), c.g(a.mid_in), p.mid_c, nullptr, nullptr, 0, B, RT, 1));
     DQ_TRY(launch_fold(c.g(a.mid_in), c.g(a.downs[L - 1].rs), B, RT, p.mid_c, 0, 0, c.s));  // first and only writer: store
   }
+  // MS1 feature path (unet1d.py:1120-1130): its gradient d ms1f is final behind the bottleneck (to_k is its only consumer) and nothing on
+  // the main chain reads what it produces -- data path and weight gradients go to the side stream with the next flush, instead of standing
+  // at the end of the pass in front of the join (~24 us of the main queue and ~35 us of the side queue's tail)
+  auto ms1_bwd = [&p, &a, B, RT](const Ctx& cc) -> int {
+    DQ_TRY(conv_plain_bwd(cc, p.ms1_c1, CONV_S1, cc.w(a.ms1_a), cc.g(a.ms1f), cc.g(a.ms1_a), B, RT, RT, 0));
+    BlockBwd gb;
+    gb.u = cc.w(a.ms1_u); gb.dy = cc.g(a.ms1_a); gb.du = cc.g(a.ms1_u); gb.C = p.cond_dim; gb.rows = B; gb.n = RT; gb.rows_per_sample = 1;
+    gb.act = ACT_GELU;
+    DQ_TRY(launch_block_bwd(gb, cc.s));
+    return conv_plain_bwd(cc, p.ms1_c0, CONV_S1, cc.w(a.ms1n), cc.g(a.ms1_u), nullptr, B, RT, RT, 0);
+  };
+  if (c.owner && c.side_defer && tail_fork_enabled()) {
+    Ctx sc = c;
+    sc.owner = nullptr; sc.side_defer = nullptr;
+    Ctx::SideItem it{};
+    it.kind = 3; it.fn = [sc, ms1_bwd](hipStream_t ss) mutable { sc.s = ss; return ms1_bwd(sc); };
+    side_items.push_back(it);
+  } else {
+    DQ_TRY(ms1_bwd(c));
+  }
   // down path, reversed
   for (int lv = L - 1; lv >= 0; --lv) {
     const LevelP& l = p.downs[lv];
@@ -1059,19 +1097,23 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     DQ_TRY(res_bwd(c, l.r0, b.r0, c.w(in_off), c.g(in_off), C, nullptr, nullptr, 0, R, l.n, RT, lv > 0 ? 1 : 0, 0));  // (d h0 has the final block's part already)
     if (side_flush_here(lv)) DQ_TRY(side_flush(c));
   }
-  // MS1 feature path
-  DQ_TRY(conv_plain_bwd(c, p.ms1_c1, CONV_S1, c.w(a.ms1_a), c.g(a.ms1f), c.g(a.ms1_a), B, RT, RT, 0));
-  {
-    BlockBwd gb;
-    gb.u = c.w(a.ms1_u); gb.dy = c.g(a.ms1_a); gb.du = c.g(a.ms1_u); gb.C = p.cond_dim; gb.rows = B; gb.n = RT; gb.rows_per_sample = 1;
-    gb.act = ACT_GELU;
-    DQ_TRY(launch_block_bwd(gb, c.s));
-    DQ_TRY(conv_plain_bwd(c, p.ms1_c0, CONV_S1, c.w(a.ms1n), c.g(a.ms1_u), nullptr, B, RT, RT, 0));
+  // init conv + mixture conditioning: d h0 is final here and only d(scale, shift) of init_cond_proj (read by the time-embedding backward
+  // behind the join) and the init_conv weight gradient depend on it -- on the side stream when nobody asked for d loss / d x, under the
+  // LinearAttention / ResnetBlock slot reductions of the main stream
+  auto init_bwd = [&p, &a, init_cond, cm, ca, B, RT, R](const Ctx& cc) -> int {
+    DQ_TRY(conv_plain_bwd(cc, p.init_conv, CONV_S1, cc.w(a.cat0), cc.g(a.h0), cc.g(a.cat0), R, p.mz, p.mz, 0));
+    return launch_prep_inputs_bwd(cc.g(a.cat0), init_cond, cm, ca, cc.g(a.ss), p.ss_total, p.ss_init, B, RT, p.mz, cc.w(a.bb_part),
+                                  a.bb_part_floats, cc.s);
+  };
+  if (c.owner && c.side_defer && !grad_x && tail_fork_enabled()) {
+    Ctx sc = c;
+    sc.owner = nullptr; sc.side_defer = nullptr;
+    Ctx::SideItem it{};
+    it.kind = 3; it.fn = [sc, init_bwd](hipStream_t ss) mutable { sc.s = ss; return init_bwd(sc); };
+    side_items.push_back(it);
+  } else {
+    DQ_TRY(init_bwd(c));
   }
-  // init conv + mixture conditioning
-  DQ_TRY(conv_plain_bwd(c, p.init_conv, CONV_S1, c.w(a.cat0), c.g(a.h0), c.g(a.cat0), R, p.mz, p.mz, 0));
-  DQ_TRY(launch_prep_inputs_bwd(c.g(a.cat0), init_cond, cm, ca, c.g(a.ss), p.ss_total, p.ss_init, B, RT, p.mz, c.w(a.bb_part),
-                                a.bb_part_floats, c.s));
   if (grad_x) {
     // channel 1 of d(cat0) is d loss / d x
     DQ_HIP_OK(hipMemcpy2DAsync(grad_x, sizeof(float) * p.mz, c.g(a.cat0) + p.mz, sizeof(float) * 2 * p.mz, sizeof(float) * p.mz, R,
@@ -1171,15 +1213,10 @@ int side_flush(const Ctx& c) {
       DQ_TRY(launch_part_reduce(it.red, rs));
       continue;
     }
-    if (first || !pl->side_stream) {  // one event for the whole group (wgrad_async also creates the stream on first use)
-      if (it.kind == 0) DQ_TRY(wgrad_async(now, it.w[0]));
-      else DQ_TRY(wgrad_async_multi(now, it.w, it.count));
-      first = false;
-    } else {
-      pl->side_used = true;
-      if (it.kind == 0) DQ_TRY(launch_conv_wgrad(it.w[0], pl->side_stream));
-      else DQ_TRY(launch_conv_wgrad_multi(it.w, it.count, pl->side_stream));
-    }
+    if (first) { DQ_TRY(fork_side(now)); first = false; }  // one event for the whole group (creates the stream on first use)
+    if (it.kind == 0) DQ_TRY(launch_conv_wgrad(it.w[0], pl->side_stream));
+    else if (it.kind == 1) DQ_TRY(launch_conv_wgrad_multi(it.w, it.count, pl->side_stream));
+    else DQ_TRY(it.fn(pl->side_stream));
   }
   return 0;
 }
@@ -1379,7 +1416,11 @@ int dq_train_step(dq_plan* plan, const float* params, const float* rope_freqs, c
   // the gradient twin is zeroed inside unet_backward, so the loss gradient goes to a forward-arena buffer (xb)
   if (pred_type == DQ_PRED_X0)  // model.py:372-376, 404: target = normalised x0, per-sample weight loss_weight[t_b]
     DQ_TRY(launch_mse_fwd_bwd(c.w(a.eps), x0, loss_out, c.w(a.xb), c.w(a.partials), B * per, s, loss_weight_dev, t, per, cm, ca));
-  else
+  else if (c.owner && ms1_loss_weight == 0.f && tail_fork_enabled()) {
+    int nparts = 0;  // (the sum of the partials -> loss_out rides on the side stream: unet_backward)
+    DQ_TRY(launch_mse_fwd_bwd(c.w(a.eps), noise, loss_out, c.w(a.xb), c.w(a.partials), B * per, s, nullptr, nullptr, 0, 1.f, 0.f, &nparts));
+    c.loss_sum.partials = c.w(a.partials); c.loss_sum.count = nparts; c.loss_sum.scale = 1.0f / (float)(B * per); c.loss_sum.out = loss_out;
+  } else
     DQ_TRY(launch_mse_fwd_bwd(c.w(a.eps), noise, loss_out, c.w(a.xb), c.w(a.partials), B * per, s));         // model.py:361
   if (ms1_loss_weight > 0.f)  // model.py:364-371 / 379-386, 398-402 (semantics: DESIGN.md section 12)
     DQ_TRY(launch_ms1_loss(c.w(a.eps), pred_type == DQ_PRED_X0 ? nullptr : c.w(a.xa), ms1_cond, cm, ca,

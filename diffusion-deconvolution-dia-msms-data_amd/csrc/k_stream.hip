@@ -195,8 +195,14 @@ int launch_axpy(float* dst, const float* src, int64_t n, hipStream_t s) {
   return 0;
 }
 
+int launch_sum_partials(const float* partials, int count, float scale, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, s, partials, count, scale, out);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_mse_fwd_bwd(const float* eps, const float* noise, float* loss_out, float* grad_out, float* partials, int64_t n,
-                       hipStream_t s, const float* lw, const int64_t* t, int64_t per_sample, float tm, float ta) {
+                       hipStream_t s, const float* lw, const int64_t* t, int64_t per_sample, float tm, float ta, int* defer_sum) {
   DQ_REQUIRE(n % 4 == 0 && n > 0, "mse: element count must be a positive multiple of 4");
   DQ_REQUIRE(!lw || (t && per_sample > 0 && per_sample % 4 == 0 && n % per_sample == 0),
              "mse: the weighted form needs t and a per-sample element count that is a multiple of 4");
@@ -204,9 +210,8 @@ int launch_mse_fwd_bwd(const float* eps, const float* noise, float* loss_out, fl
   hipLaunchKernelGGL(k_mse_fwd_bwd, dim3(grid), dim3(256), 0, s, eps, noise, grad_out, partials, n / 4, 2.0f / (float)n, lw, t,
                      lw ? per_sample / 4 : (int64_t)1, tm, ta);
   DQ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, s, partials, grid, 1.0f / (float)n, loss_out);
-  DQ_LAUNCH_CHECK();
-  return 0;
+  if (defer_sum) { *defer_sum = grid; return 0; }  // the caller sums the partials later (launch_sum_partials(partials, grid, 1 / n, loss_out))
+  return launch_sum_partials(partials, grid, 1.0f / (float)n, loss_out, s);
 }
 
 // ---- the MS1 term of train_step (reference model.py:364-371, 379-386, 398-402; semantics chosen in DESIGN.md section 12 because
