@@ -292,9 +292,15 @@ struct LinAttn {
   const float* prep = nullptr;
 };
 int launch_linattn_fwd(const LinAttn& a, hipStream_t s);
+// k_la_small.hip: rows of 2 / 4 (/ 8) positions at 8 / 12 / 16 channels with a prepared image (LinAttn::prep): every product on
+// v_mfma_f32_32x32x2 with lane = (channel half, row) and one group of registers per position (launch_linattn_fwd dispatches to it)
+bool la_small_usable(int C, int n);
+int la_small_min_rows();  // launch_linattn_fwd takes this path from that many rows on
+int launch_la_small_fwd(const LinAttn& a, hipStream_t s);
 constexpr int LA_PREP_BOUNDED = 1024 + 4096;          // 1.0f when the layer's softmax logits are bounded by 64 for every input (k_linattn_prepare)
 constexpr int LA_PREP_BF16 = 1024 + 4096 + 8;         // split-bf16 operand image of Wq | Wk for 4 / 8 channels: 2048 la_nu(C) <= 6144 dwords (k_linattn.hip)
-constexpr int LA_PREP_FLOATS = 1024 + 4096 + 8 + 6144;  // [w2: 4 * 16 * 16][wqk: 2 * 4 * 8 * 2 * 32][bounded, 7 unused][bf16 image]
+constexpr int LA_PREP_SMALL = 1024 + 4096 + 8 + 6144;  // operand image of k_la_small (rows of <= 8 positions, C = 8 / 12 / 16): [q | k | W2][head][step < C / 2][64 lanes] <= 6144 floats
+constexpr int LA_PREP_FLOATS = 1024 + 4096 + 8 + 6144 + 6144;  // [w2: 4 * 16 * 16][wqk: 2 * 4 * 8 * 2 * 32][bounded, 7 unused][bf16 image][small-row image]
 struct LaPrepItem { const float* w_qkv; const float* w_out; int C; float* prep; const float* g_pre; };
 constexpr int LA_PREP_MAX = 16;
 struct PrepCopy { const float* src; float* dst; int n; };  // plain copies riding in the same launch (aligned weight slots)

@@ -21,6 +21,10 @@ __host__ __device__ __forceinline__ constexpr int la_nj(int C) { return C == 4 ?
 __device__ __forceinline__ constexpr int la_chan(int C, int j, int half) {
   return C == 4 ? 2 * half + j : (C == 12 ? 6 * half + j : rmap(j, half));
 }
+// k_la_small: the channel that half `half` supplies in K-step i of a projection (C / 2 steps).  C = 8 / 16: the accumulator row map, so
+// that a projection operand register IS the residual / output register of the same index; C = 12: i + 6 half (six full steps instead of
+// eight with a third of the slots empty; the residual is then read a second time in the row-map layout).
+__host__ __device__ __forceinline__ constexpr int sm_chan(int C, int i, int half) { return C == 12 ? i + 6 * half : (i & 3) + 8 * (i >> 2) + 4 * half; }
 // value of lane ^ 32 (ds_bpermute).  gfx950's v_permlane32_swap_b32 (tools/probe/permlane32.hip) was tried here: with the
 // two register copies and the select it needs it is four VALU instructions, and the VALU-bound forward kernel got 4 % slower
 // (the LDS pipe that serves ds_bpermute is otherwise idle there); the latency-bound backward did not change.

@@ -688,6 +688,20 @@ __global__ void __launch_bounds__(256) k_linattn_prepare(LaPrepMulti m) {
       it.prep[LA_PREP_BOUNDED] = (bound <= 64.f) ? 1.f : 0.f;  // (a NaN anywhere compares false: the shifted form)
     }
   }
+  // operand image of k_la_small (k_la_small.hip): [q | k][head][step][lane] = W[(q|k) head row lane & 31][sm_chan(step, lane >> 5)] log2(e),
+  // then [head][step][lane] = W2_head[out channel lane & 31][sm_chan(step, lane >> 5)] (zero above C).  W2 was written to prep[] above by
+  // this workgroup (the barriers of the reduction stand between).
+  if (C >= 8) {
+    const int S = C / 2;
+    for (int i = threadIdx.x; i < 12 * S * 64; i += 256) {
+      const int l = i & 63, st = (i >> 6) % S, g = i / (64 * S);  // g: 0..3 q heads, 4..7 k heads, 8..11 W2 heads
+      const int mrow = l & 31, c = sm_chan(C, st, l >> 5);
+      float v = 0.f;
+      if (g < 8) v = c < C ? it.w_qkv[((g >> 2) * 128 + (g & 3) * 32 + mrow) * C + c] * 1.4426950408889634f : 0.f;
+      else v = (mrow < C && c < C) ? it.prep[((g - 8) * C + mrow) * C + c] : 0.f;
+      it.prep[LA_PREP_SMALL + i] = v;
+    }
+  }
 }
 int launch_linattn_prepare(const LaPrepItem* items, int count, hipStream_t s, const PrepCopy* copies, int n_copies) {
   if (count + n_copies == 0) return 0;
@@ -708,6 +722,7 @@ int launch_linattn_fwd(const LinAttn& a, hipStream_t s) {
   DQ_REQUIRE(a.x && a.y && a.w_qkv && a.w_out && a.b_out && a.g_pre && a.g_out, "linattn_fwd: missing operand");
   if (a.rows == 0) return 0;
   if (a.n > 64 || (a.n & (a.n - 1)) != 0) return launch_linattn_fwd_long(a, s);  // long rows, and lengths that are not a power of two
+  if (a.prep && la_small_usable(a.C, a.n) && a.rows >= la_small_min_rows()) return launch_la_small_fwd(a, s);
   switch (a.C) {
     case 4: return linattn_fwd_n<4>(a, s);
     case 8: return linattn_fwd_n<8>(a, s);
