@@ -196,7 +196,7 @@ struct TinyFwd {
   const float* img = nullptr; // operand image (tiny_img_floats floats, 16-byte aligned) from launch_tiny_images on the SAME parameter values
 };
 constexpr int TINY_IMG_MAX = 4;
-constexpr int TINY_IMG_FLOATS = 12288;
+constexpr int TINY_IMG_FLOATS = 16384;  // (whole rounds of 256 x 16 bytes: the kernels copy a slot without guards)
 bool tiny_fwd_usable(const TinyFwd& t);
 int64_t tiny_img_floats(const TinyFwd& t);
 int launch_tiny_images(const TinyFwd* calls, int count, hipStream_t s);

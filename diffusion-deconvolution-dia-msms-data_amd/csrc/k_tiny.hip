@@ -22,6 +22,7 @@
 #include "dq_kernels.h"
 #include "dq_mfma.h"
 #include "dq_plan.h"
+#include "dq_probe.h"
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -104,7 +105,8 @@ struct TinyFwdK {
   int post, post_b; float* post_out;
 };
 
-constexpr int NPRM = 20;  // 16-float parameter vectors in LDS: stage bias | per block: b1 g1 b2 g2 br scale+1 shift | g_pre b_out g_out | post bias
+__host__ __device__ constexpr int tiny_rounds(int steps) { return (steps * 16 + 255) / 256; }
+constexpr int NPRM = 20;  // 16-float parameter vectors in LDS (the table is padded to 32 vectors: two unguarded stores per thread): stage bias | per block: b1 g1 b2 g2 br scale+1 shift | g_pre b_out g_out | post bias
 
 // C: the level's channels; N: row length; PRE: input stage; CP: its input channels; CS: skip channels of cat(x, skip) (0: none, identity residual)
 template <int C, int N, int PRE, int CP, int CS>
@@ -116,59 +118,58 @@ __global__ void __launch_bounds__(256) k_tiny_fwd(TinyFwdK a, const float* __res
   constexpr int S_C1 = C + CS, S_C2 = C, S_RS = WR ? C + CS : 0;
   constexpr int BLK = S_C1 + S_C2 + S_RS;
   constexpr int B_LA = S_PRE + 2 * BLK, B_POST = B_LA + C;
+  constexpr int PID = 300000 + C * 1000 + N * 100 + PRE * 10 + (CS ? 1 : 0);  // tools/probe_step.py id
+  DQ_PSTAMP(PID, 0);
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* wl = lds;                                  // [total_steps][64]
-  float* prm = lds + (size_t)a.total_steps * 64;    // [NPRM][16]
+  constexpr int NLD = tiny_rounds(B_POST + C);       // 16-byte loads per thread that cover the largest image of this instantiation
+  float* wl = lds;                                  // [total_steps][64], padded to NLD * 1024 floats
+  float* prm = lds + NLD * 1024;                    // [NPRM][16]
   // Preamble in ONE memory round trip: every 16-byte load of the image and the thread's (<= 2) parameter values are requested before the
   // first LDS store (as a load -> store loop plus a branchy parameter gather it was three to four dependent round trips, ~5 us of a
   // ~16 us launch at the training batch).
   const int b = blockIdx.y;
   {
-    constexpr int MAXS = B_POST + C;                  // upper bound of total_steps
-    constexpr int NLD = (MAXS * 16 + 255) / 256;
-    const int total4 = a.total_steps * 16;
+    // (no guards: the image slot and the LDS region are padded to whole rounds of 256 x 16 bytes -- a guarded store made the compiler sink
+    // each load under its store's branch, i.e. one memory round trip per round: 14,000 clocks of a 60,000-clock launch)
+    // the thread's two parameter values (vectors 0..15 and 16..31 of the padded table): one unconditional load from P and one from the
+    // sample's scale / shift vector each, selected after the barrier below
+    int offs[2], soffs[2], kk[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = u * 256 + (int)threadIdx.x;
+      const int what = (i >> 4) < NPRM ? (i >> 4) : 19, c = i & 15;
+      const int bi = what >= 8 ? 1 : 0, k = (what >= 1 && what <= 14) ? (what - 1) % 7 : 7;
+      const int b1 = bi ? a.blk[1].b1 : a.blk[0].b1, g1 = bi ? a.blk[1].g1 : a.blk[0].g1, b2 = bi ? a.blk[1].b2 : a.blk[0].b2;
+      const int g2 = bi ? a.blk[1].g2 : a.blk[0].g2, br = bi ? a.blk[1].br : a.blk[0].br, sso = bi ? a.blk[1].ss_off : a.blk[0].ss_off;
+      int off = k == 0 ? b1 : k == 1 ? g1 : k == 2 ? b2 : k == 3 ? g2 : (k == 4 && WR) ? br : -1;
+      off = what == 0 ? (S_PRE ? a.pb : -1) : off;
+      off = what == 15 ? (a.la ? a.la_gpre : -1) : what == 16 ? (a.la ? a.la_bo : -1) : what == 17 ? (a.la ? a.la_go : -1) : off;
+      off = what == 18 ? (a.post ? a.post_b : -1) : off;
+      const int soff = k == 5 ? sso : (k == 6 ? sso + C : -1);
+      const bool inC = c < C;
+      kk[u] = k;
+      offs[u] = (off >= 0 && inC) ? off + c : -1;
+      soffs[u] = (soff >= 0 && inC) ? soff + c : -1;
+    }
+    float pv[2], sv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      pv[u] = P[offs[u] >= 0 ? offs[u] : 0];
+      sv[u] = ssb[(int64_t)b * a.ss_stride + (soffs[u] >= 0 ? soffs[u] : 0)];
+    }
     const float4* src = reinterpret_cast<const float4*>(img);
     float4 v[NLD];
 #pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      const int i = u * 256 + (int)threadIdx.x;
-      v[u] = src[i < total4 ? i : 0];
-    }
-    float pvv[2];
+    for (int u = 0; u < NLD; ++u) v[u] = src[u * 256 + (int)threadIdx.x];
+    __builtin_amdgcn_sched_barrier(0);  // every load of the preamble is in flight here
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int i = u * 256 + (int)threadIdx.x;       // NPRM * 16 = 320 values
-      const int what = (i >> 4) < NPRM ? (i >> 4) : 0, c = i & 15;
-      const int bi = what >= 8 ? 1 : 0, k = what == 0 ? 7 : (what - 1) % 7;
-      const TinyBlkK& r0 = a.blk[0];
-      const TinyBlkK& r1 = a.blk[1];
-      const int b1 = bi ? r1.b1 : r0.b1, g1 = bi ? r1.g1 : r0.g1, b2 = bi ? r1.b2 : r0.b2, g2 = bi ? r1.g2 : r0.g2, br = bi ? r1.br : r0.br;
-      const int sso = bi ? r1.ss_off : r0.ss_off;
-      int off = -1;      // offset into P, or
-      int soff = -1;     // offset into this sample's scale / shift vector
-      if (what == 0) off = S_PRE ? a.pb : -1;
-      else if (what <= 14) {
-        off = k == 0 ? b1 : k == 1 ? g1 : k == 2 ? b2 : k == 3 ? g2 : (k == 4 && WR) ? br : -1;
-        soff = k == 5 ? sso : (k == 6 ? sso + C : -1);
-      } else if (what <= 17) { off = a.la ? (what == 15 ? a.la_gpre : what == 16 ? a.la_bo : a.la_go) : -1; }
-      else if (what == 18) { off = a.post ? a.post_b : -1; }
-      const bool use = c < C && (off >= 0 || soff >= 0);
-      const float* q = soff >= 0 ? ssb + (int64_t)b * a.ss_stride + soff : P + (off >= 0 ? off : 0);
-      const float val = q[use ? c : 0];
-      pvv[u] = use ? (what <= 14 && k == 5 ? val + 1.0f : val) : 0.f;
-    }
+    for (int u = 0; u < NLD; ++u) reinterpret_cast<float4*>(wl)[u * 256 + (int)threadIdx.x] = v[u];
 #pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      const int i = u * 256 + (int)threadIdx.x;
-      if (i < total4) reinterpret_cast<float4*>(wl)[i] = v[u];
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int i = u * 256 + (int)threadIdx.x;
-      if (i < NPRM * 16) prm[i] = pvv[u];
-    }
+    for (int u = 0; u < 2; ++u)
+      prm[u * 256 + (int)threadIdx.x] = soffs[u] >= 0 ? (kk[u] == 5 ? sv[u] + 1.0f : sv[u]) : (offs[u] >= 0 ? pv[u] : 0.f);
   }
   __syncthreads();
+  DQ_PSTAMP(PID, 1);
   const int lane = threadIdx.x & 63, half = lane >> 5, slot = lane & 31;
   const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = gridDim.x * 4;
   const int RT = a.rows_per_sample;
@@ -215,6 +216,7 @@ __global__ void __launch_bounds__(256) k_tiny_fwd(TinyFwdK a, const float* __res
         v[2 * ci] = t.x; v[2 * ci + 1] = t.y;
       }
       if (CS) { ldrow(a.blk[0].inB, CS, xb0, CS); ldrow(a.blk[1].inB, CS, xb1, CS); }
+      __builtin_amdgcn_sched_barrier(0);  // (every global read of the tile is in flight before the first product: left alone the scheduler sinks the skip loads to their use)
       f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       acc = dense(0, v, std::integral_constant<int, 2 * CP>{}, acc);
 #pragma unroll
@@ -227,6 +229,7 @@ __global__ void __launch_bounds__(256) k_tiny_fwd(TinyFwdK a, const float* __res
 #pragma unroll
       for (int ci = 0; ci < CP; ++ci) { v[ci] = q[ci]; v[CP + ci] = v[ci]; }
       if (CS) { ldrow(a.blk[0].inB, CS, xb0, CS); ldrow(a.blk[1].inB, CS, xb1, CS); }
+      __builtin_amdgcn_sched_barrier(0);  // (every global read of the tile is in flight before the first product: left alone the scheduler sinks the skip loads to their use)
       f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       acc = dense(0, v, std::integral_constant<int, 2 * CP>{}, acc);
 #pragma unroll
@@ -241,8 +244,10 @@ __global__ void __launch_bounds__(256) k_tiny_fwd(TinyFwdK a, const float* __res
         ldrow(a.in, C, x, C);
       }
       if (CS) { ldrow(a.blk[0].inB, CS, xb0, CS); ldrow(a.blk[1].inB, CS, xb1, CS); }
+      __builtin_amdgcn_sched_barrier(0);
       strow(a.in_copy, x);
     }
+    DQ_PSTAMP(PID, 2);
     // ---------------------------------------------------------------- the level's ResnetBlocks (unet1d.py:302-323)
 #pragma unroll
     for (int bi = 0; bi < 2; ++bi) {
@@ -286,6 +291,7 @@ __global__ void __launch_bounds__(256) k_tiny_fwd(TinyFwdK a, const float* __res
         for (int c = 0; c < 16; ++c) x[c] = c < C ? silu_f(u[c] * inv * prmv(pq + 3, c)) + res[c] : 0.f;
       }
       strow(r.out, x);
+      DQ_PSTAMP(PID, 3 + bi);
     }
     if constexpr (N == 1) {
       // ------------------------------------------------------------ Residual(PreNorm(LinearAttention)) over one position: linear
@@ -320,7 +326,9 @@ __global__ void __launch_bounds__(256) k_tiny_fwd(TinyFwdK a, const float* __res
         }
       }
     }
+    DQ_PSTAMP(PID, 5);
   }
+  DQ_PSTAMP(PID, 6);
 }
 
 // the layer list of a launch, in image order (the kernel's step bases follow the same formulas)
@@ -436,7 +444,10 @@ int launch_tiny_fwd(const TinyFwd& t, hipStream_t s) {
   const int B = a.rows / a.rows_per_sample;
   const int rpt = 64 / a.n;
   const int tiles_ps = cdiv(a.rows_per_sample, rpt);
-  const size_t lds = (size_t)k.total_steps * 256 + NPRM * 16 * 4;
+  // (image region padded to whole rounds of 256 threads x 16 bytes over the instantiation's largest image: steps + the optional LinearAttention / post conv)
+  const int max_steps = k.total_steps + (t.la ? 0 : a.C) + (t.post_w ? 0 : a.C);
+  const size_t lds = (size_t)tiny_rounds(max_steps) * 4096 + 32 * 16 * 4;
+  DQ_REQUIRE((int64_t)tiny_rounds(max_steps) * 1024 <= TINY_IMG_FLOATS, "tiny_fwd: image slot too small for the padded copy");
   DQ_REQUIRE(lds <= 96 * 1024, "tiny_fwd: weight image too large");
   const int cs = a.blk[0].cinB;
 #define DQ_TINY(CC, NN, PP, PC, SS)                                                                                           \
