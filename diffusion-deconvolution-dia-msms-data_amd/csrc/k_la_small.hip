@@ -34,6 +34,12 @@ __global__ void __launch_bounds__(256, 2) k_la_small(LaSmallK a) {
   constexpr int NR = C == 8 ? 4 : 8;  // output / residual registers per lane: channel rmap(j, half), valid below C
   __shared__ __attribute__((aligned(16))) float img[12 * S * 64];
   __shared__ float prm[3 * 16];
+  // wave-private x tile (32 rows x (C N + 1) floats): the rows are read as contiguous 16-byte runs and stay here for the residual; y (and
+  // y_pre) leave through it the same way.  As per-lane 4-byte accesses at a row pitch of C N floats every load / store instruction touched
+  // 32..64 cache lines: ~90 such instructions per tile were a third of the launch at the sampling batch.
+  constexpr int E = C * N, EP = E + 1;
+  __shared__ float xt_all[4 * 32 * EP];
+  float* xt = xt_all + (threadIdx.x >> 6) * 32 * EP;
   {
     constexpr int T4 = 12 * S * 16, NLD = (T4 + 255) / 256;
     const float4* src = reinterpret_cast<const float4*>(a.prep + LA_PREP_SMALL);
@@ -69,7 +75,25 @@ __global__ void __launch_bounds__(256, 2) k_la_small(LaSmallK a) {
   for (int tile = wid; tile < a.ntiles; tile += nwaves) {
     const int row = tile * 32 + col;
     const bool live = row < a.rows;
-    const float* xp = a.x + (int64_t)(live ? row : a.rows - 1) * C * N;
+    const int valid = a.rows - tile * 32 < 32 ? a.rows - tile * 32 : 32;
+    auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    {
+      const float4* g4 = reinterpret_cast<const float4*>(a.x + (int64_t)tile * 32 * E);  // (32 E floats from a 128-byte aligned tile start)
+      const int lim4 = valid * E / 4;  // E is a multiple of 4
+      float4 raw[E / 8];
+#pragma unroll
+      for (int k = 0; k < E / 8; ++k) { const int i4 = k * 64 + lane; raw[k] = g4[i4 < lim4 ? i4 : lim4 - 1]; }
+      __builtin_amdgcn_sched_barrier(0);
+      wsync();  // (the previous tile's readers of xt are done)
+#pragma unroll
+      for (int k = 0; k < E / 8; ++k) {
+        const int lin = (k * 64 + lane) * 4, r = lin / E, e = lin - r * E;  // four consecutive floats of one row (E % 4 == 0)
+        float* d = xt + r * EP + e;
+        d[0] = raw[k].x; d[1] = raw[k].y; d[2] = raw[k].z; d[3] = raw[k].w;
+      }
+      wsync();
+    }
+    const float* xp = xt + col * EP;  // the lane's row: element (c, m) at c * N + m
     float xh[N][S];
 #pragma unroll
     for (int m = 0; m < N; ++m)
@@ -164,33 +188,50 @@ __global__ void __launch_bounds__(256, 2) k_la_small(LaSmallK a) {
         for (int j = 0; j < NR; ++j) yp[n][j] += t16[j];
       }
     }
-    // to_out bias, RMSNorm, residual (unet1d.py:470-473, 495, 79)
-    float* yo = a.y + (int64_t)row * C * N;
-    float* po = a.ypre ? a.ypre + (int64_t)row * C * N : nullptr;
+    // to_out bias, RMSNorm, residual (unet1d.py:470-473, 495, 79): y replaces x in the staging tile element by element (every (row, c, n) is
+    // read and written by exactly one lane), then the tile leaves as contiguous 16-byte runs; y_pre (training) takes the same way first
+    float yv[N][NR];
 #pragma unroll
     for (int n = 0; n < N; ++n) {
-      float v[NR];
       float ssq = 0.f;
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
         const int co = rmap(j, half);
         const bool ok = co < C;
-        v[j] = ok ? yp[n][j] + prm[16 + (ok ? co : 0)] : 0.f;
-        ssq = fmaf(v[j], v[j], ssq);
+        yp[n][j] = ok ? yp[n][j] + prm[16 + (ok ? co : 0)] : 0.f;
+        ssq = fmaf(yp[n][j], yp[n][j], ssq);
       }
       ssq += swap_half(ssq);
       const float inv = rms_inv(ssq, sqC);
-      if (live) {
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const int co = rmap(j, half);
+        yv[n][j] = co < C ? fmaf(yp[n][j] * inv, prm[32 + co], xp[co * N + n]) : 0.f;
+      }
+    }
+    auto flush = [&](float* dst, float (&val)[N][NR]) __attribute__((always_inline)) {
+      wsync();
+#pragma unroll
+      for (int n = 0; n < N; ++n)
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
           const int co = rmap(j, half);
-          if (co < C) {
-            if (po) po[co * N + n] = v[j];
-            yo[co * N + n] = fmaf(v[j] * inv, prm[32 + co], xp[co * N + n]);  // (the residual is read again: L1 / L2, the row was loaded above)
-          }
+          if (co < C) xt[col * EP + co * N + n] = val[n][j];
         }
+      wsync();
+      float4* g4 = reinterpret_cast<float4*>(dst + (int64_t)tile * 32 * E);
+      const int lim4 = valid * E / 4;
+#pragma unroll
+      for (int k = 0; k < E / 8; ++k) {
+        const int i4 = k * 64 + lane, lin = i4 * 4, r = lin / E, e = lin - r * E;
+        const float* sp = xt + r * EP + e;
+        const float4 o = make_float4(sp[0], sp[1], sp[2], sp[3]);
+        if (i4 < lim4) g4[i4] = o;
       }
-    }
+    };
+    if (a.ypre) flush(a.ypre, yp);
+    flush(a.y, yv);
+    (void)live;
   }
 }
 
@@ -215,7 +256,7 @@ int la_small_min_rows() {
 
 int launch_la_small_fwd(const LinAttn& a, hipStream_t s) {
   DQ_REQUIRE(a.x && a.y && a.prep && a.b_out && a.g_pre && a.g_out && la_small_usable(a.C, a.n), "la_small: missing operand / unsupported shape");
-  DQ_REQUIRE(((uintptr_t)a.prep & 15) == 0, "la_small: misaligned prepared-weights buffer");
+  DQ_REQUIRE((((uintptr_t)a.prep | (uintptr_t)a.x | (uintptr_t)a.y | (uintptr_t)a.ypre) & 15) == 0, "la_small: misaligned tensor / prepared-weights buffer");
   if (a.rows == 0) return 0;
   LaSmallK k{a.x, a.y, a.ypre, a.prep, a.b_out, a.g_pre, a.g_out, a.rows, cdiv(a.rows, 32)};
   static const int cus = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();

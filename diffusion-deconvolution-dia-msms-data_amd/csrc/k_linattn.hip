@@ -722,7 +722,9 @@ int launch_linattn_fwd(const LinAttn& a, hipStream_t s) {
   DQ_REQUIRE(a.x && a.y && a.w_qkv && a.w_out && a.b_out && a.g_pre && a.g_out, "linattn_fwd: missing operand");
   if (a.rows == 0) return 0;
   if (a.n > 64 || (a.n & (a.n - 1)) != 0) return launch_linattn_fwd_long(a, s);  // long rows, and lengths that are not a power of two
-  if (a.prep && la_small_usable(a.C, a.n) && a.rows >= la_small_min_rows()) return launch_la_small_fwd(a, s);
+  if (a.prep && la_small_usable(a.C, a.n) && a.rows >= la_small_min_rows() &&
+      (((uintptr_t)a.x | (uintptr_t)a.y | (uintptr_t)a.ypre) & 15) == 0)  // (its tiles move as 16-byte runs)
+    return launch_la_small_fwd(a, s);
   switch (a.C) {
     case 4: return linattn_fwd_n<4>(a, s);
     case 8: return linattn_fwd_n<8>(a, s);

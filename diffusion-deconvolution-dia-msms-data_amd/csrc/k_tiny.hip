@@ -105,6 +105,8 @@ struct TinyFwdK {
   int post, post_b; float* post_out;
 };
 
+__host__ __device__ constexpr int tiny_max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+__host__ __device__ constexpr int tiny_stg_floats(int N, int e_in, int C, int CS) { return N == 1 ? 0 : (64 / N) * (tiny_max3(e_in, C * N, CS * N) + 1); }
 __host__ __device__ constexpr int tiny_rounds(int steps) { return (steps * 16 + 255) / 256; }
 constexpr int NPRM = 20;  // 16-float parameter vectors in LDS (the table is padded to 32 vectors: two unguarded stores per thread): stage bias | per block: b1 g1 b2 g2 br scale+1 shift | g_pre b_out g_out | post bias
 
@@ -124,6 +126,12 @@ __global__ void __launch_bounds__(256) k_tiny_fwd(TinyFwdK a, const float* __res
   constexpr int NLD = tiny_rounds(B_POST + C);       // 16-byte loads per thread that cover the largest image of this instantiation
   float* wl = lds;                                  // [total_steps][64], padded to NLD * 1024 floats
   float* prm = lds + NLD * 1024;                    // [NPRM][16]
+  // wave-private staging tile (RPT rows x (E + 1) floats): global tensors are read and written as contiguous runs of whole rows (4 bytes per
+  // lane, 256 bytes per instruction) and transposed to / from the lane = (position, row) layout here.  As direct accesses every instruction
+  // touched 32 cache lines with 4..8 bytes each: the 2-position levels spent 170 clocks per store instruction (probe), 64 of them per block.
+  constexpr int E_IN = PRE == LEVEL_PRE_DOWN ? CP * 2 * N : (PRE == LEVEL_PRE_UP ? CP : 0);
+  constexpr int STG = tiny_stg_floats(N, E_IN, C, CS);
+  float* stg = prm + 32 * 16 + (threadIdx.x >> 6) * STG;
   // Preamble in ONE memory round trip: every 16-byte load of the image and the thread's (<= 2) parameter values are requested before the
   // first LDS store (as a load -> store loop plus a branchy parameter gather it was three to four dependent round trips, ~5 us of a
   // ~16 us launch at the training batch).
@@ -191,32 +199,86 @@ __global__ void __launch_bounds__(256) k_tiny_fwd(TinyFwdK a, const float* __res
     const bool live = r_in_s < RT;
     const int rs_c = live ? r_in_s : RT - 1;
     const int64_t row = (int64_t)b * RT + rs_c;
-    // (rows, CH, N) tensors: element (row, c, p)
+    const int valid = RT - tile * RPT < RPT ? RT - tile * RPT : RPT;          // rows of this tile that exist
+    const int64_t trow = (int64_t)b * RT + (int64_t)tile * RPT;                // the tile's first row
+    auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    // (rows, CH, N) tensors, E = CH * N floats per row.  lin_load: the tile's E * RPT floats as E * RPT / 64 contiguous 256-byte reads
+    // (rows beyond the sample re-read its last element); to_lanes: through the staging tile into dst[c] = element (row, c, p) of the lane
+    auto lin_load = [&](const float* base, auto e_c, float* raw) __attribute__((always_inline)) {
+      constexpr int E = decltype(e_c)::value;
+      const float* g = base + trow * E;
+      const int lim = valid * E;
+#pragma unroll
+      for (int k = 0; k < E * RPT / 64; ++k) { const int lin = k * 64 + lane; raw[k] = g[lin < lim ? lin : lim - 1]; }
+    };
+    auto lin_to_stg = [&](auto e_c, const float* raw) __attribute__((always_inline)) {
+      constexpr int E = decltype(e_c)::value;
+      wsync();
+#pragma unroll
+      for (int k = 0; k < E * RPT / 64; ++k) { const int lin = k * 64 + lane; stg[lin + lin / E] = raw[k]; }
+      wsync();
+    };
+    auto to_lanes = [&](auto ch_c, const float* raw, float* dst) __attribute__((always_inline)) {
+      constexpr int CH = decltype(ch_c)::value, E = CH * N;
+      if constexpr (N == 1) {  // (lin_load_rows read the lane's own row: nothing to transpose)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) dst[c] = c < CH ? raw[c] : 0.f;
+        return;
+      }
+      lin_to_stg(std::integral_constant<int, E>{}, raw);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) dst[c] = c < CH ? stg[rowl * (E + 1) + c * N + p] : 0.f;
+    };
+    // direct form (the LEVEL_PRE_NONE input when it is not the bottleneck's layout)
     auto ldrow = [&](const float* base, int CH, float* dst, int cnt) __attribute__((always_inline)) {
       const float* q = base + (row * CH) * N + p;
 #pragma unroll
       for (int c = 0; c < 16; ++c) dst[c] = c < cnt ? q[c * N] : 0.f;
     };
     auto strow = [&](float* base, const float* v) __attribute__((always_inline)) {
-      if (base && live) {
-        float* q = base + (row * C) * N + p;
+      if constexpr (N == 1) {  // lane = row: neighbouring lanes share cache lines already, and the staged form measured slower (5,200 -> 10,100 clocks per block)
+        if (base && live) {
+          float* q = base + row * C;
 #pragma unroll
-        for (int c = 0; c < C; ++c) q[c * N] = v[c];
+          for (int c = 0; c < C; ++c) q[c] = v[c];
+        }
+      } else if (base) {  // (wave-uniform)
+        constexpr int E = C * N;
+        wsync();
+#pragma unroll
+        for (int c = 0; c < C; ++c) stg[rowl * (E + 1) + c * N + p] = v[c];
+        wsync();
+        float* g = base + trow * E;
+        const int lim = valid * E;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+          const int lin = k * 64 + lane;
+          const float val = stg[lin + lin / E];
+          if (lin < lim) g[lin] = val;
+        }
       }
     };
     float x[16], xb0[16], xb1[16];
     // ---------------------------------------------------------------- input stage (every global read of the tile is requested up front)
     if constexpr (PRE == LEVEL_PRE_DOWN) {
       // input (rows, CP, 2 N): the lane holds in[ci][2 p], in[ci][2 p + 1]
-      float v[2 * CP];
-      const float* q = a.in + (row * CP) * (2 * N) + 2 * p;
+      static_assert(PRE != LEVEL_PRE_DOWN || CS == 0, "a Downsample stage in front of blocks with skip channels is not built");
+      float v[2 * CP], raw[2 * CP];
+      if constexpr (N == 1) {
+        const float* q = a.in + row * (CP * 2);
 #pragma unroll
-      for (int ci = 0; ci < CP; ++ci) {
-        const float2 t = *reinterpret_cast<const float2*>(q + ci * 2 * N);
-        v[2 * ci] = t.x; v[2 * ci + 1] = t.y;
+        for (int ci = 0; ci < CP; ++ci) { const float2 t = *reinterpret_cast<const float2*>(q + ci * 2); v[2 * ci] = t.x; v[2 * ci + 1] = t.y; }
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        lin_load(a.in, std::integral_constant<int, E_IN>{}, raw);
+        __builtin_amdgcn_sched_barrier(0);
+        lin_to_stg(std::integral_constant<int, E_IN>{}, raw);
+#pragma unroll
+        for (int ci = 0; ci < CP; ++ci) {
+          v[2 * ci] = stg[rowl * (E_IN + 1) + ci * 2 * N + 2 * p];
+          v[2 * ci + 1] = stg[rowl * (E_IN + 1) + ci * 2 * N + 2 * p + 1];
+        }
       }
-      if (CS) { ldrow(a.blk[0].inB, CS, xb0, CS); ldrow(a.blk[1].inB, CS, xb1, CS); }
-      __builtin_amdgcn_sched_barrier(0);  // (every global read of the tile is in flight before the first product: left alone the scheduler sinks the skip loads to their use)
       f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       acc = dense(0, v, std::integral_constant<int, 2 * CP>{}, acc);
 #pragma unroll
@@ -224,12 +286,14 @@ __global__ void __launch_bounds__(256) k_tiny_fwd(TinyFwdK a, const float* __res
       strow(a.pre_out, x);
     } else if constexpr (PRE == LEVEL_PRE_UP) {
       // input (rows, CP, 1): both positions of the row read the row's one input position
-      float v[2 * CP];
-      const float* q = a.in + row * CP;
+      float v[2 * CP], raw[CP * RPT / 64], rb0[CS > 0 ? CS : 1], rb1[CS > 0 ? CS : 1];
+      lin_load(a.in, std::integral_constant<int, E_IN>{}, raw);
+      if constexpr (CS > 0) { lin_load(a.blk[0].inB, std::integral_constant<int, CS * N>{}, rb0); lin_load(a.blk[1].inB, std::integral_constant<int, CS * N>{}, rb1); }
+      __builtin_amdgcn_sched_barrier(0);  // (every global read of the tile is in flight before the first product)
+      lin_to_stg(std::integral_constant<int, E_IN>{}, raw);
 #pragma unroll
-      for (int ci = 0; ci < CP; ++ci) { v[ci] = q[ci]; v[CP + ci] = v[ci]; }
-      if (CS) { ldrow(a.blk[0].inB, CS, xb0, CS); ldrow(a.blk[1].inB, CS, xb1, CS); }
-      __builtin_amdgcn_sched_barrier(0);  // (every global read of the tile is in flight before the first product: left alone the scheduler sinks the skip loads to their use)
+      for (int ci = 0; ci < CP; ++ci) { v[ci] = stg[rowl * (E_IN + 1) + ci]; v[CP + ci] = v[ci]; }
+      if constexpr (CS > 0) { to_lanes(std::integral_constant<int, CS>{}, rb0, xb0); to_lanes(std::integral_constant<int, CS>{}, rb1, xb1); }
       f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       acc = dense(0, v, std::integral_constant<int, 2 * CP>{}, acc);
 #pragma unroll
@@ -243,8 +307,19 @@ __global__ void __launch_bounds__(256) k_tiny_fwd(TinyFwdK a, const float* __res
       } else {
         ldrow(a.in, C, x, C);
       }
-      if (CS) { ldrow(a.blk[0].inB, CS, xb0, CS); ldrow(a.blk[1].inB, CS, xb1, CS); }
+      float rb0[CS > 0 ? CS : 1], rb1[CS > 0 ? CS : 1];
+      if constexpr (CS > 0) {
+        if constexpr (N == 1) {
+          const float* q0 = a.blk[0].inB + row * CS;
+          const float* q1 = a.blk[1].inB + row * CS;
+#pragma unroll
+          for (int c = 0; c < CS; ++c) { rb0[c] = q0[c]; rb1[c] = q1[c]; }
+        } else {
+          lin_load(a.blk[0].inB, std::integral_constant<int, CS * N>{}, rb0); lin_load(a.blk[1].inB, std::integral_constant<int, CS * N>{}, rb1);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (CS > 0) { to_lanes(std::integral_constant<int, CS>{}, rb0, xb0); to_lanes(std::integral_constant<int, CS>{}, rb1, xb1); }
       strow(a.in_copy, x);
     }
     DQ_PSTAMP(PID, 2);
@@ -446,7 +521,8 @@ int launch_tiny_fwd(const TinyFwd& t, hipStream_t s) {
   const int tiles_ps = cdiv(a.rows_per_sample, rpt);
   // (image region padded to whole rounds of 256 threads x 16 bytes over the instantiation's largest image: steps + the optional LinearAttention / post conv)
   const int max_steps = k.total_steps + (t.la ? 0 : a.C) + (t.post_w ? 0 : a.C);
-  const size_t lds = (size_t)tiny_rounds(max_steps) * 4096 + 32 * 16 * 4;
+  const int e_in = a.pre == LEVEL_PRE_DOWN ? a.cp * 2 * a.n : (a.pre == LEVEL_PRE_UP ? a.cp : 0);
+  const size_t lds = (size_t)tiny_rounds(max_steps) * 4096 + 32 * 16 * 4 + (size_t)4 * tiny_stg_floats(a.n, e_in, a.C, a.blk[0].cinB) * 4;
   DQ_REQUIRE((int64_t)tiny_rounds(max_steps) * 1024 <= TINY_IMG_FLOATS, "tiny_fwd: image slot too small for the padded copy");
   DQ_REQUIRE(lds <= 96 * 1024, "tiny_fwd: weight image too large");
   const int cs = a.blk[0].cinB;
