@@ -144,21 +144,19 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
   // 16-byte load of a thread in flight at once.  Without one (the stand-alone entry point) the workgroup gathers it from the parameter
   // tensors: element offsets formed without control flow, four loads in flight -- ~12 us per workgroup at 16 channels, which at training
   // batch sizes (one or two tiles per wave at the deep levels) was a third of the launch.
+  constexpr int MAXJ = pad4(G * CP * KP) + 2 * (pad4(G * 2 * C * 3) + pad4(G * C * 3) + pad4(G * 2 * C));
+  constexpr int NLD = (MAXJ + 255) / 256;  // rounds of 256 x 16 bytes that cover the largest image of this instantiation
   if (img) {
-    const int total4 = J.total;  // 16-byte units
-    constexpr int MAXJ = pad4(G * CP * KP) + 2 * (pad4(G * 2 * C * 3) + pad4(G * C * 3) + pad4(G * 2 * C));
-    constexpr int NLD = (MAXJ + 255) / 256;
+    // NO guards: the image slot (LEVEL_IMG_FLOATS) and the LDS region (level_img_rounds x 4 KB) hold whole rounds.  With `if (i < total4) wl[i] = v[u]`
+    // the compiler sank every load under its store's branch -- `global_load_dwordx4; s_waitcnt vmcnt(0); ds_write_b128` four to six times in a
+    // row, one memory round trip per 4 KB of image at the head of every workgroup (ISA of every instantiation, round 4), the opposite of what this
+    // block was written for.
     float4 v[NLD];
 #pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      const int i = u * 256 + (int)threadIdx.x;
-      v[u] = reinterpret_cast<const float4*>(img)[i < total4 ? i : 0];
-    }
+    for (int u = 0; u < NLD; ++u) v[u] = reinterpret_cast<const float4*>(img)[u * 256 + (int)threadIdx.x];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      const int i = u * 256 + (int)threadIdx.x;
-      if (i < total4) reinterpret_cast<float4*>(wl)[i] = v[u];
-    }
+    for (int u = 0; u < NLD; ++u) reinterpret_cast<float4*>(wl)[u * 256 + (int)threadIdx.x] = v[u];
   } else {
     LevelImgSrc m;
     m.pre = PRE; m.G = G; m.C = C; m.cp = CP; m.kp = KP; m.nblocks = a.nblocks; m.pw = a.pw;
@@ -181,36 +179,37 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
   // [stage bias C][per block: b1 | g1 | b2 | g2 | br | scale + 1 | shift] -- read back as 16-byte broadcasts.  Inside the tile loop a
   // wave then waits on nothing but its own tile's loads and LDS reads (as scalar loads from memory, re-issued per tile under
   // scalar-register pressure, they cost a full wait each: the launch time did not move with the instruction count).
-  float* prm = wl + J.total * 4;
+  float* prm = wl + (img ? NLD * 1024 : J.total * 4);  // (the unguarded image copy fills whole rounds)
   DQ_PSTAMP(C * 1000 + PRE * 100 + CP, 1);
   {
+    // ONE value per thread (C * 15 + 8 <= 248), no control flow: the source offset -- into P, or into this sample's scale / shift vector -- is a
+    // chain of selects, both loads are unconditional, the store is unguarded (the table holds 256 floats).  As `for (i ...) { if (what == 0) ...
+    // else if (k == 0) v = P[...] ...; prm[i] = v; }` every arm kept its own load and its own s_waitcnt vmcnt(0), and a wave -- whose 64 threads
+    // span ~5 of the 15 vectors -- walked them one after the other: 5+ memory round trips in series at the head of every workgroup (ISA, round 4).
     const int b = blockIdx.y;
-    if (threadIdx.x < 8) {  // [C * 15 ..): final_conv weight (4) | bias | this sample's init_cond_proj scale + 1 | shift  (C == 4 launches only)
-      const int i = threadIdx.x;
-      float v = 0.f;
-      if (C == 4 && a.ep_w >= 0 && i < 4) v = P[a.ep_w + i];
-      if (C == 4 && a.ep_w >= 0 && i == 4) v = P[a.ep_b];
-      if (PRE == LEVEL_PRE_INIT && (i == 5 || i == 6)) {
-        const float* ssi = ssb + (int64_t)b * a.ss_stride + a.ss_init;
-        v = i == 5 ? ssi[0] + 1.0f : ssi[1];
-      }
-      prm[C * 15 + i] = v;
+    const int i = threadIdx.x;
+    const int what = i / C, c = i - what * C, t = i - C * 15;  // t >= 0: [final_conv weight (4) | bias | init scale + 1 | init shift | 0]
+    const int bi = what >= 8 ? 1 : 0, k = (what >= 1 && what <= 14) ? (what - 1) % 7 : 7;
+    const bool on = what >= 1 && what <= 14 && bi < a.nblocks;
+    const int b1 = bi ? a.blk[1].b1 : a.blk[0].b1, g1 = bi ? a.blk[1].g1 : a.blk[0].g1, b2 = bi ? a.blk[1].b2 : a.blk[0].b2;
+    const int g2 = bi ? a.blk[1].g2 : a.blk[0].g2, br = bi ? a.blk[1].br : a.blk[0].br, wrr = bi ? a.blk[1].wr : a.blk[0].wr;
+    const int sso = bi ? a.blk[1].ss_off : a.blk[0].ss_off;
+    int offP = -1, offS = 0;   // (offsets into the scale / shift vector are relative to block 0's and may be NEGATIVE: hasS says whether one is meant)
+    bool plus1 = false, hasS = false;
+    if (what == 0) offP = PRE != LEVEL_PRE_NONE ? a.pb + c : -1;
+    offP = on ? (k == 0 ? b1 + c : k == 1 ? g1 + c : k == 2 ? b2 + c : k == 3 ? g2 + c : (k == 4 && wrr >= 0) ? br + c : -1) : offP;
+    hasS = on && (k == 5 || k == 6);
+    offS = hasS ? (k == 5 ? sso + c : sso + C + c) : 0;
+    plus1 = on && k == 5;
+    if (t >= 0) {
+      offP = (C == 4 && a.ep_w >= 0 && t < 4) ? a.ep_w + t : ((C == 4 && a.ep_w >= 0 && t == 4) ? a.ep_b : -1);
+      hasS = PRE == LEVEL_PRE_INIT && (t == 5 || t == 6);
+      offS = hasS ? a.ss_init + (t - 5) : 0;
+      plus1 = PRE == LEVEL_PRE_INIT && t == 5;
     }
-    for (int i = threadIdx.x; i < C * 15; i += 256) {
-      const int what = i / C, c = i % C;
-      float v = 0.f;
-      if (what == 0) { v = (PRE != LEVEL_PRE_NONE) ? P[a.pb + c] : 0.f; }
-      else {
-        const int bi = (what - 1) / 7, k = (what - 1) % 7;
-        const LevelBlkK& r = a.blk[bi];
-        if (bi < a.nblocks) {
-          const float* ss = ssb + (int64_t)b * a.ss_stride + r.ss_off;
-          v = k == 0 ? P[r.b1 + c] : k == 1 ? P[r.g1 + c] : k == 2 ? P[r.b2 + c] : k == 3 ? P[r.g2 + c] : k == 4 ? (r.wr >= 0 ? P[r.br + c] : 0.f)
-            : k == 5 ? ss[c] + 1.0f : ss[C + c];
-        }
-      }
-      prm[i] = v;
-    }
+    const float pv = P[offP >= 0 ? offP : 0];
+    const float sv = ssb[(int64_t)b * a.ss_stride + offS];
+    prm[i] = hasS ? (plus1 ? sv + 1.0f : sv) : (offP >= 0 ? pv : 0.f);
   }
   __syncthreads();
   DQ_PSTAMP(C * 1000 + PRE * 100 + CP, 2);
@@ -686,7 +685,14 @@ int launch_level_fwd(const LevelFwd& a, hipStream_t s) {
   const int cin[2] = {a.C + a.blk[0].cinB, a.C + a.blk[1].cinB};
   const bool wr[2] = {a.blk[0].wr != nullptr, a.blk[1].wr != nullptr};
   const int cp = a.pre == LEVEL_PRE_NONE ? 4 : a.cp;
-  const size_t lds = (size_t)level_jobs(a.C, a.pre, cp, a.nblocks, cin, wr).total * 16 + ((size_t)a.C * 15 + 8) * 4;
+  size_t lds = (size_t)level_jobs(a.C, a.pre, cp, a.nblocks, cin, wr).total * 16 + 256 * 4;  // + the parameter table: one value per thread
+  if (a.img) {  // the kernel copies the image in whole rounds of 256 x 16 bytes (no guards): LDS region and slot must hold them
+    const int G = a.C / 4, kp = a.pre == LEVEL_PRE_DOWN ? 4 : (a.pre == LEVEL_PRE_INIT ? 7 : 3);
+    const int maxj = pad4(G * cp * kp) + 2 * (pad4(G * 2 * a.C * 3) + pad4(G * a.C * 3) + pad4(G * 2 * a.C));
+    const int rounds = (maxj + 255) / 256;
+    DQ_REQUIRE((int64_t)rounds * 1024 <= LEVEL_IMG_FLOATS, "level_fwd: image slot too small for the padded copy");
+    lds = (size_t)rounds * 4096 + 256 * 4;
+  }
   DQ_REQUIRE(lds <= 64 * 1024, "level_fwd: weight image too large");
   // one resident round: blocks per CU from the occupancy query, capped at 6 (at this kernel's ~106 scalar registers the hardware admits six
   // 256-thread blocks per CU where the query can say seven: MI355X_MICROARCH.md, Residency), never more blocks than tiles need

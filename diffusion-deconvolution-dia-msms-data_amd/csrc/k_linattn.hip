@@ -154,7 +154,14 @@ __global__ void __launch_bounds__(256) k_linattn_fwd(LinAttn a) {
     bflag = a.prep[LA_PREP_BOUNDED];  // (also in front of x: read behind the barrier it was a full wait again)
     request_x();
     DQ_PSTAMP(300000 + C * 100 + N, 9);
-    if ((int)threadIdx.x < C * C) reinterpret_cast<float4*>(w2_lds)[threadIdx.x] = v2;  // (the LOAD above is unguarded: the slot holds 1024 floats whatever C is)
+    // (the LOAD above is unguarded: the slot holds 1024 floats whatever C is.  The STORE is unguarded too -- threads beyond the 4 C C floats of W2
+    // write into the per-wave M staging, which nothing reads before the barrier below: with `if (tid < C * C) w2_lds[tid] = v2` the compiler sank
+    // the load under the branch, BEHIND the x requests, and its wait became s_waitcnt vmcnt(0): a full memory round trip, with the operand-image
+    // loads issued only after it -- two round trips in series at the head of every launch (ISA of every instantiation, round 4))
+    static_assert(sizeof(ms_lds) >= 64 * sizeof(float4), "the dump area of the W2 copy aliases ms_lds");
+    float4* w2dst = (int)threadIdx.x < C * C ? reinterpret_cast<float4*>(w2_lds) + threadIdx.x
+                                              : reinterpret_cast<float4*>(&ms_lds[0][0]) + (threadIdx.x & 63);
+    *w2dst = v2;
 #pragma unroll
     for (int u = 0; u < NQ; ++u) reinterpret_cast<float4*>(wqk_lds)[u * 256 + (int)threadIdx.x] = vq[u];
     DQ_PSTAMP(300000 + C * 100 + N, 10);

@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(256) k_tiny_fwd(TinyFwdK a, const float* __res
     // the thread's two parameter values (vectors 0..15 and 16..31 of the padded table): one unconditional load from P and one from the
     // sample's scale / shift vector each, selected after the barrier below
     int offs[2], soffs[2], kk[2];
+    bool hasS[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int i = u * 256 + (int)threadIdx.x;
@@ -153,17 +154,17 @@ __global__ void __launch_bounds__(256) k_tiny_fwd(TinyFwdK a, const float* __res
       off = what == 0 ? (S_PRE ? a.pb : -1) : off;
       off = what == 15 ? (a.la ? a.la_gpre : -1) : what == 16 ? (a.la ? a.la_bo : -1) : what == 17 ? (a.la ? a.la_go : -1) : off;
       off = what == 18 ? (a.post ? a.post_b : -1) : off;
-      const int soff = k == 5 ? sso : (k == 6 ? sso + C : -1);
       const bool inC = c < C;
       kk[u] = k;
       offs[u] = (off >= 0 && inC) ? off + c : -1;
-      soffs[u] = (soff >= 0 && inC) ? soff + c : -1;
+      hasS[u] = (k == 5 || k == 6) && inC;  // (an offset into the scale / shift vector is relative to block 0's and may be negative)
+      soffs[u] = hasS[u] ? (k == 5 ? sso : sso + C) + c : 0;
     }
     float pv[2], sv[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       pv[u] = P[offs[u] >= 0 ? offs[u] : 0];
-      sv[u] = ssb[(int64_t)b * a.ss_stride + (soffs[u] >= 0 ? soffs[u] : 0)];
+      sv[u] = ssb[(int64_t)b * a.ss_stride + soffs[u]];
     }
     const float4* src = reinterpret_cast<const float4*>(img);
     float4 v[NLD];
@@ -174,7 +175,7 @@ __global__ void __launch_bounds__(256) k_tiny_fwd(TinyFwdK a, const float* __res
     for (int u = 0; u < NLD; ++u) reinterpret_cast<float4*>(wl)[u * 256 + (int)threadIdx.x] = v[u];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
-      prm[u * 256 + (int)threadIdx.x] = soffs[u] >= 0 ? (kk[u] == 5 ? sv[u] + 1.0f : sv[u]) : (offs[u] >= 0 ? pv[u] : 0.f);
+      prm[u * 256 + (int)threadIdx.x] = hasS[u] ? (kk[u] == 5 ? sv[u] + 1.0f : sv[u]) : (offs[u] >= 0 ? pv[u] : 0.f);
   }
   __syncthreads();
   DQ_PSTAMP(PID, 1);
