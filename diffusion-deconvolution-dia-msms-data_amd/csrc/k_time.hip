@@ -109,6 +109,8 @@ int launch_time_embed_fwd(const Plan& p, const DevTables& dt, const float* param
 }
 
 // ---- backward ----
+constexpr int TIME_MAX_B = 128;  // samples whose silu(temb) k_time_bwd_rows stages in LDS (larger batches read them from memory)
+constexpr int TIME_RPT = 3;      // rows per thread and pass of k_time_bwd_sample
 // (1) per ss row r: dW[r][:] += sum_b dss[b][r] * silu(temb_b) ; db[r] += sum_b dss[b][r]
 // (launched together with (3): the last block of the launch is the time_mlp block below -- (1) does not depend on (2), (3) does, so the
 // order is (2), then (1) + (3) in one launch)
@@ -122,48 +124,92 @@ __global__ void __launch_bounds__(256) k_time_bwd_rows(float* __restrict__ G, co
     time_bwd_mlp_block(G, tbuf, B, t1w, t1b, t2w, t2b, dim);
     return;
   }
+  // silu(temb) of every sample in LDS (B x 16 floats), then the batch loop with EIGHT samples' dss loads in flight: as `for (b) { d = dss[b][r];
+  // st = tbuf + ...; fma x 16 }` over a run-time B the loop was 32 dependent memory round trips per thread -- 13 us at the very end of the step
+  // (nothing overlaps the time-embedding backward: it waits for every d(scale, shift) sum and the optimiser waits for it).
+  __shared__ float st_lds[TIME_MAX_B * 16];
   const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= ss_total) return;
+  const int rc = r < ss_total ? r : ss_total - 1;
+  const bool staged = B <= TIME_MAX_B;
+  if (staged) {
+    for (int i = threadIdx.x; i < B * 16; i += 256) st_lds[i] = tbuf[(int64_t)(i >> 4) * TBUF_FLOATS + 52 + (i & 15)];
+    __syncthreads();
+  }
+  const int64_t wo = ss_w_off[rc], bo = ss_b_off[rc];
   float dw[16], db = 0.f;
 #pragma unroll
   for (int i = 0; i < 16; ++i) dw[i] = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float d = dss[(int64_t)b * ss_total + r];
-    const float* st = tbuf + (int64_t)b * TBUF_FLOATS + 52;
-    db += d;
+  for (int b0 = 0; b0 < B; b0 += 8) {
+    float d[8];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) dw[i] = fmaf(d, st[i], dw[i]);
+    for (int u = 0; u < 8; ++u) d[u] = b0 + u < B ? dss[(int64_t)(b0 + u) * ss_total + rc] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (b0 + u < B) {  // (wave-uniform)
+        const float* st = staged ? st_lds + (b0 + u) * 16 : tbuf + (int64_t)(b0 + u) * TBUF_FLOATS + 52;
+        db += d[u];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dw[i] = fmaf(d[u], st[i], dw[i]);
+      }
+    }
   }
-  float* gw = G + ss_w_off[r];
+  if (r >= ss_total) return;
+  float* gw = G + wo;
 #pragma unroll
   for (int i = 0; i < 16; ++i) gw[i] += dw[i];
-  G[ss_b_off[r]] += db;
+  G[bo] += db;
 }
 
 // (2) per sample: d silu(temb) = sum_r dss[b][r] W[r][:] -> dtemb -> dh_act -> dh_pre (stored in tbuf)
-__global__ void __launch_bounds__(64) k_time_bwd_sample(const float* __restrict__ P, float* __restrict__ tbuf,
-                                                        const float* __restrict__ dss, int ss_total,
-                                                        const int64_t* __restrict__ ss_w_off, int64_t t2w) {
+__global__ void __launch_bounds__(256) k_time_bwd_sample(const float* __restrict__ P, float* __restrict__ tbuf,
+                                                         const float* __restrict__ dss, int ss_total,
+                                                         const int64_t* __restrict__ ss_w_off, int64_t t2w) {
+  // 256 threads per sample, up to TIME_RPT rows each with every load in flight (offset table + dss, then the 16 weights of each row): two memory
+  // round trips.  (64 threads walking ss_total / 64 rows one after the other, offset -> weights -> next row, were ~20 dependent round trips: 14 us.)
   const int b = blockIdx.x, tid = threadIdx.x;
   float* tb = tbuf + (int64_t)b * TBUF_FLOATS;
   float acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  for (int r = tid; r < ss_total; r += 64) {
-    const float d = dss[(int64_t)b * ss_total + r];
-    const float* w = P + ss_w_off[r];
+  for (int r0 = 0; r0 < ss_total; r0 += 256 * TIME_RPT) {
+    float d[TIME_RPT];
+    int64_t wo[TIME_RPT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = fmaf(d, w[i], acc[i]);
+    for (int u = 0; u < TIME_RPT; ++u) {
+      const int r = r0 + u * 256 + tid;
+      const int rc = r < ss_total ? r : ss_total - 1;
+      d[u] = r < ss_total ? dss[(int64_t)b * ss_total + rc] : 0.f;
+      wo[u] = ss_w_off[rc];
+    }
+    float4 w[TIME_RPT][4];
+#pragma unroll
+    for (int u = 0; u < TIME_RPT; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {  // (the rows of the flat parameter buffer are not 16-byte aligned in general: four scalar loads each)
+        const float* wp = P + wo[u] + 4 * q;
+        w[u][q] = make_float4(wp[0], wp[1], wp[2], wp[3]);
+      }
+#pragma unroll
+    for (int u = 0; u < TIME_RPT; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc[4 * q + 0] = fmaf(d[u], w[u][q].x, acc[4 * q + 0]); acc[4 * q + 1] = fmaf(d[u], w[u][q].y, acc[4 * q + 1]);
+        acc[4 * q + 2] = fmaf(d[u], w[u][q].z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(d[u], w[u][q].w, acc[4 * q + 3]);
+      }
   }
+  __shared__ float part[4][16];
   __shared__ float dtemb[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const float v = wave_sum(acc[i]);
-    if (tid == i) {
-      const float dt = v * silu_grad_f(tb[36 + i]);
-      dtemb[i] = dt;
-      tb[68 + i] = dt;
-    }
+    if ((tid & 63) == 0) part[tid >> 6][i] = v;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const float v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);  // fixed order
+    const float dt = v * silu_grad_f(tb[36 + tid]);
+    dtemb[tid] = dt;
+    tb[68 + tid] = dt;
   }
   __syncthreads();
   if (tid < 16) {
@@ -179,12 +225,30 @@ __device__ __forceinline__ void time_bwd_mlp_block(float* __restrict__ G, const 
                                                    int64_t t2b, int dim) {
   const int tid = threadIdx.x, o = tid >> 4, i = tid & 15;
   float dw2 = 0.f, db2 = 0.f, dw1 = 0.f, db1 = 0.f;
+  // the four 16-vectors of every sample this block reads (x | h_act | d temb | d h_pre) staged in LDS with eight loads in flight per thread;
+  // as a loop over the samples with four dependent loads each it was the longest block of the launch (~10 us)
+  __shared__ float sv[TIME_MAX_B * 64];
+  const bool staged = B <= TIME_MAX_B;
+  if (staged) {
+    for (int base = 0; base < B * 64; base += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = base + u * 256 + tid, ec = e < B * 64 ? e : 0;
+        const int bb = ec >> 6, q = (ec >> 4) & 3, j = ec & 15;
+        v[u] = tbuf[(int64_t)bb * TBUF_FLOATS + (q == 0 ? 0 : q == 1 ? 20 : q == 2 ? 68 : 84) + j];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int e = base + u * 256 + tid; if (e < B * 64) sv[e] = v[u]; }
+    }
+    __syncthreads();
+  }
   for (int b = 0; b < B; ++b) {
     const float* tb = tbuf + (int64_t)b * TBUF_FLOATS;
-    const float dt = tb[68 + o], dh = tb[84 + o];
-    dw2 = fmaf(dt, tb[20 + i], dw2);
+    const float dt = staged ? sv[b * 64 + 32 + o] : tb[68 + o], dh = staged ? sv[b * 64 + 48 + o] : tb[84 + o];
+    dw2 = fmaf(dt, staged ? sv[b * 64 + 16 + i] : tb[20 + i], dw2);
     db2 += dt;
-    if (i < dim) dw1 = fmaf(dh, tb[i], dw1);
+    if (i < dim) dw1 = fmaf(dh, staged ? sv[b * 64 + i] : tb[i], dw1);
     db1 += dh;
   }
   G[t2w + o * 16 + i] += dw2;
@@ -195,7 +259,7 @@ __device__ __forceinline__ void time_bwd_mlp_block(float* __restrict__ G, const 
 int launch_time_embed_bwd(const Plan& p, const DevTables& dt, const float* params, float* grads, float* tbuf, const float* dss,
                           int B, hipStream_t s) {
   if (B == 0) return 0;
-  hipLaunchKernelGGL(k_time_bwd_sample, dim3(B), dim3(64), 0, s, params, tbuf, dss, p.ss_total, dt.ss_w_off, p.t2_w);
+  hipLaunchKernelGGL(k_time_bwd_sample, dim3(B), dim3(256), 0, s, params, tbuf, dss, p.ss_total, dt.ss_w_off, p.t2_w);
   DQ_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_time_bwd_rows, dim3(cdiv(p.ss_total, 256) + 1), dim3(256), 0, s, grads, tbuf, dss, p.ss_total, B, dt.ss_w_off, dt.ss_b_off,
                      p.t1_w, p.t1_b, p.t2_w, p.t2_b, p.dim);
