@@ -21,7 +21,8 @@ __device__ __forceinline__ float ss_head_row(const float* __restrict__ w, float 
   return v;
 }
 
-__global__ void __launch_bounds__(64) k_time_fwd(const float* __restrict__ P, const int64_t* __restrict__ t, int t_scalar,
+constexpr int TIME_FWD_RPT = 3;  // head rows per thread and pass of k_time_fwd (256 threads: 768 rows per pass)
+__global__ void __launch_bounds__(256) k_time_fwd(const float* __restrict__ P, const int64_t* __restrict__ t, int t_scalar,
                                                  float* __restrict__ tbuf, float* __restrict__ ss, int ss_total,
                                                  const int64_t* __restrict__ ss_w_off, const int64_t* __restrict__ ss_b_off,
                                                  const float* __restrict__ t1w, const float* __restrict__ t1b,
@@ -30,6 +31,24 @@ __global__ void __launch_bounds__(64) k_time_fwd(const float* __restrict__ P, co
   const int b = blockIdx.x, tid = threadIdx.x;
   float* tb = tbuf + (int64_t)b * TBUF_FLOATS;
   __shared__ float sinu[4], hact[16], st[16];
+  // The first pass of head rows (offset table -> 16 weights + bias per row) is requested HERE, in front of the time MLP it does not depend on:
+  // the MLP's three dependent steps run under those two memory round trips.  (64 threads walking ss_total / 64 rows one after the other behind
+  // the MLP were ~20 round trips in series: 11 us at the head of every forward, 15 us per sampling step.)
+  float hw[TIME_FWD_RPT][16], hb[TIME_FWD_RPT];
+  if (ss) {
+    int64_t wo[TIME_FWD_RPT], bo[TIME_FWD_RPT];
+#pragma unroll
+    for (int u = 0; u < TIME_FWD_RPT; ++u) {
+      const int r = u * 256 + tid, rc = r < ss_total ? r : ss_total - 1;
+      wo[u] = ss_w_off[rc]; bo[u] = ss_b_off[rc];
+    }
+#pragma unroll
+    for (int u = 0; u < TIME_FWD_RPT; ++u) {
+      hb[u] = P[bo[u]];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) hw[u][i] = P[wo[u] + i];
+    }
+  }
   // timestep: per-sample tensor, or a scalar, or (graph replay) table[*step] read on the device
   const float tv = (float)(t ? t[b] : (int64_t)(step_tab ? step_tab[*step_ptr] : t_scalar));  // int64 * fp32 -> fp32 (unet1d.py:215)
   const int half = dim / 2;
@@ -62,7 +81,13 @@ __global__ void __launch_bounds__(64) k_time_fwd(const float* __restrict__ P, co
     st[tid] = sv;
   }
   __syncthreads();
-  for (int r = tid; r < ss_total; r += 64) ss[(int64_t)b * ss_total + r] = ss_head_row(P + ss_w_off[r], P[ss_b_off[r]], st);
+  if (!ss) return;
+#pragma unroll
+  for (int u = 0; u < TIME_FWD_RPT; ++u) {
+    const int r = u * 256 + tid;
+    if (r < ss_total) ss[(int64_t)b * ss_total + r] = ss_head_row(hw[u], hb[u], st);
+  }
+  for (int r = TIME_FWD_RPT * 256 + tid; r < ss_total; r += 256) ss[(int64_t)b * ss_total + r] = ss_head_row(P + ss_w_off[r], P[ss_b_off[r]], st);  // (networks with more than 768 head rows)
 }
 
 // stand-alone heads (dq_scale_shift_fwd): ss[b][r] = Linear(SiLU(temb_b))[r] for a caller-supplied temb
@@ -93,7 +118,7 @@ int launch_ss_heads(const float* temb, const float* w, const float* bias, float*
 int launch_time_mlp_fwd(const float* w1, const float* b1, const float* w2, const float* b2, const int64_t* t, float* tbuf, int B,
                         hipStream_t s) {
   if (B == 0) return 0;
-  hipLaunchKernelGGL(k_time_fwd, dim3(B), dim3(64), 0, s, (const float*)nullptr, t, 0, tbuf, (float*)nullptr, 0, (const int64_t*)nullptr,
+  hipLaunchKernelGGL(k_time_fwd, dim3(B), dim3(256), 0, s, (const float*)nullptr, t, 0, tbuf, (float*)nullptr, 0, (const int64_t*)nullptr,
                      (const int64_t*)nullptr, w1, b1, w2, b2, 4, 10000.0f, (const int*)nullptr, (const int*)nullptr);
   DQ_LAUNCH_CHECK();
   return 0;
@@ -102,7 +127,7 @@ int launch_time_mlp_fwd(const float* w1, const float* b1, const float* w2, const
 int launch_time_embed_fwd(const Plan& p, const DevTables& dt, const float* params, const int64_t* t, int t_scalar, float* tbuf,
                           float* ss, int B, const int* step_tab, const int* step_ptr, hipStream_t s) {
   if (B == 0) return 0;
-  hipLaunchKernelGGL(k_time_fwd, dim3(B), dim3(64), 0, s, params, t, t_scalar, tbuf, ss, p.ss_total, dt.ss_w_off, dt.ss_b_off,
+  hipLaunchKernelGGL(k_time_fwd, dim3(B), dim3(256), 0, s, params, t, t_scalar, tbuf, ss, p.ss_total, dt.ss_w_off, dt.ss_b_off,
                      params + p.t1_w, params + p.t1_b, params + p.t2_w, params + p.t2_b, p.dim, 10000.0f, step_tab, step_ptr);
   DQ_LAUNCH_CHECK();
   return 0;
