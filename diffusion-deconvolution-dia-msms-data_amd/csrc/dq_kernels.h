@@ -195,12 +195,40 @@ struct TinyFwd {
   float* in_copy = nullptr;   // nullable: the input again as (rows, C, 1) (training: the backward reads it in that layout)
   const float* img = nullptr; // operand image (tiny_img_floats floats, 16-byte aligned) from launch_tiny_images on the SAME parameter values
 };
-constexpr int TINY_IMG_MAX = 4;
+constexpr int TINY_IMG_MAX = 6;  // four forward launches + two backward ones
 constexpr int TINY_IMG_FLOATS = 16384;  // (whole rounds of 256 x 16 bytes: the kernels copy a slot without guards)
 bool tiny_fwd_usable(const TinyFwd& t);
 int64_t tiny_img_floats(const TinyFwd& t);
 int launch_tiny_images(const TinyFwd* calls, int count, hipStream_t s);
 int launch_tiny_fwd(const TinyFwd& t, hipStream_t s);
+
+// k_tiny.hip, backward: the DATA path of a level with rows of one position in one launch ([last down level's k3 conv] -> LinearAttention ->
+// ResnetBlock 1 -> ResnetBlock 0 -> [Downsample]); weight gradients stay with the side-stream kernels, which read the d u1 / d u2 / d rs /
+// d out tensors this launch writes; norm gains and per-sample d(scale, shift) leave as ResBwd::gpart partials (*gblocks = blocks per
+// sample), the LinearAttention's gradients as one k_linattn_bwd1-format slot per workgroup (tiny_bwd_slots of them).
+struct TinyBwd {
+  const float* params = nullptr; const float* img = nullptr;
+  int C = 0, rows = 0, rows_per_sample = 1, pre = LEVEL_PRE_NONE, cp = 0, cs = 0;
+  const float* x = nullptr; const float* ypre = nullptr; const float* dy = nullptr;      // block-1 output, saved pre-norm LinearAttention output, d la
+  const float* w_qkv = nullptr; const float* w_out = nullptr; const float* g_pre = nullptr; const float* g_out = nullptr;
+  float* la_part = nullptr; int64_t la_part_floats = 0;
+  const float* post_w = nullptr; const float* dmid = nullptr; float* drs_out = nullptr;   // LEVEL_PRE_DOWN (last down level): its k3 conv, d mid_in (B, C, RT), d rs (rows, C) out
+  float* dfold = nullptr;                                                                 // LEVEL_PRE_NONE: input gradient as (B, C, RT)
+  float* din_rows = nullptr; float* dprev = nullptr; const float* stage_w = nullptr;      // LEVEL_PRE_DOWN: input gradient (rows, C); previous level's d la (rows, cp, 2) +=; Downsample weight
+  const float* r0out_g = nullptr;                                                         // nullable: skip gradient already in d r0.out
+  struct Blk {
+    const float* w1 = nullptr; const float* w2 = nullptr; const float* wr = nullptr; const float* g1 = nullptr; const float* g2 = nullptr;
+    const float* ss = nullptr; int ss_stride = 0;
+    const float* u1 = nullptr; const float* u2 = nullptr; float* du1 = nullptr; float* du2 = nullptr;
+    float* dB = nullptr; int dB_acc = 0; float* dout_st = nullptr; float* gpart = nullptr; int64_t gpart_floats = 0;
+  } blk[2];
+  int* gblocks = nullptr;
+};
+bool tiny_bwd_usable(const TinyBwd& t);
+int tiny_bwd_slots(const TinyBwd& t);
+int64_t tiny_bwd_img_floats(const TinyBwd& t);
+int launch_tiny_bwd_images(const TinyBwd* calls, int count, hipStream_t s);
+int launch_tiny_bwd(const TinyBwd& t, hipStream_t s);
 // k_res_wg.hip: ResnetBlock backward of the wide levels (C = 4 / 8, rows of 8..256 positions) with the block's weight gradients formed
 // in the same launch on the 4x4x1 matrix pipe.  Every workgroup leaves [c1.w | c1.b | g1 | c2.w | c2.b | g2 | res.w | res.b | dscale |
 // dshift] in its own slot of `part`; launch_res_wg_reduce adds the slots up in block order into the flat gradient buffer (the

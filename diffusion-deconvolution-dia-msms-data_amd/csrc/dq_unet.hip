@@ -270,6 +270,48 @@ int res_fwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, int 
   return 0;
 }
 
+// the side-stream part of a fused ResnetBlock backward: the block's weight gradients from the d u1 / d u2 / d out tensors the data-path launch
+// left, and the ordered sums of its per-workgroup [d g2 | d g1 | d scale | d shift] partials (gblocks workgroups per sample)
+int res_bwd_side(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, int cinA, const float* inB, int cinB, int rows, int n,
+                 int rows_per_sample, int gblocks) {
+  const float* dout = c.g(b.out);
+  // the block's three weight gradients (conv2, conv1, res_conv) in ONE launch + one reduce; each gets a third of the scratch
+  ConvWgrad w[3];
+  const int64_t third = c.ar.wg_floats / 3 / 64 * 64;
+  ConvWgrad& w2 = w[0];
+  w2.scratch = c.w(c.ar.wg); w2.scratch_floats = third;
+  w2.du = c.g(b.u2); w2.inA = c.w(b.a1); w2.cinA = r.cout; w2.cout = r.cout; w2.K = 3; w2.mode = CONV_S1;
+  w2.rows = rows; w2.n_in = n; w2.n_out = n; w2.dw = c.dprm(r.c2.w); w2.dbias = c.dprm(r.c2.b);
+  w[1] = w2;
+  ConvWgrad& w1 = w[1];
+  w1.scratch = c.w(c.ar.wg) + third;
+  w1.du = c.g(b.u1); w1.inA = inA; w1.inB = inB; w1.cinA = cinA; w1.cinB = cinB; w1.dw = c.dprm(r.c1.w); w1.dbias = c.dprm(r.c1.b);
+  int count = 2;
+  if (r.res.cout) {
+    w[2] = w1;
+    w[2].scratch = c.w(c.ar.wg) + 2 * third;
+    w[2].du = dout; w[2].K = 1; w[2].dw = c.dprm(r.res.w); w[2].dbias = c.dprm(r.res.b);
+    count = 3;
+  }
+  DQ_TRY(wgrad_async_multi(c, w, count));
+  // the ordered sums of the per-block partials (norm gains, this block's d(scale), d(shift) of every sample): behind the
+  // weight gradients on the side stream (which has waited for the event recorded after k_res_bwd), or on the main stream
+  // without one.  The time-embedding backward, which reads d(scale, shift), runs after the join.
+  if (gblocks > 0) {
+    const PartReduce red = res_part_reduce(c.w(b.gpart), gblocks, rows / rows_per_sample, r.cout, c.dprm(r.g2), c.dprm(r.g1),
+                                           c.g(c.ar.ss) + r.ss_off, c.p.ss_total);
+    if (c.side_defer && c.owner) {
+      Ctx::SideItem it{};
+      it.kind = 2; it.red = red;
+      c.side_defer->push_back(it);
+    } else {
+      hipStream_t rs = (c.owner && c.owner->side_stream) ? c.owner->side_stream : c.s;
+      DQ_TRY(launch_part_reduce(red, rs));
+    }
+  }
+  return 0;
+}
+
 // ResnetBlock backward: d(out) is complete in the twin of b.out; adds into dA / dB (twins of the inputs; null => skipped)
 // storeA / storeB: this block is the first writer of dA / dB in the backward pass (fused path only; the step-by-step path
 // below accumulates into the cleared buffers as before)
@@ -312,41 +354,7 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
     int gblocks = 0;
     k.gpart = c.w(b.gpart); k.gpart_floats = b.gpart_floats; k.gblocks = &gblocks;
     DQ_TRY(launch_res_bwd(k, c.s));
-    // the block's three weight gradients (conv2, conv1, res_conv) in ONE launch + one reduce; each gets a third of the scratch
-    ConvWgrad w[3];
-    const int64_t third = c.ar.wg_floats / 3 / 64 * 64;
-    ConvWgrad& w2 = w[0];
-    w2.scratch = c.w(c.ar.wg); w2.scratch_floats = third;
-    w2.du = c.g(b.u2); w2.inA = c.w(b.a1); w2.cinA = r.cout; w2.cout = r.cout; w2.K = 3; w2.mode = CONV_S1;
-    w2.rows = rows; w2.n_in = n; w2.n_out = n; w2.dw = c.dprm(r.c2.w); w2.dbias = c.dprm(r.c2.b);
-    w[1] = w2;
-    ConvWgrad& w1 = w[1];
-    w1.scratch = c.w(c.ar.wg) + third;
-    w1.du = c.g(b.u1); w1.inA = inA; w1.inB = inB; w1.cinA = cinA; w1.cinB = cinB; w1.dw = c.dprm(r.c1.w); w1.dbias = c.dprm(r.c1.b);
-    int count = 2;
-    if (r.res.cout) {
-      w[2] = w1;
-      w[2].scratch = c.w(c.ar.wg) + 2 * third;
-      w[2].du = dout; w[2].K = 1; w[2].dw = c.dprm(r.res.w); w[2].dbias = c.dprm(r.res.b);
-      count = 3;
-    }
-    DQ_TRY(wgrad_async_multi(c, w, count));
-    // the ordered sums of the per-block partials (norm gains, this block's d(scale), d(shift) of every sample): behind the
-    // weight gradients on the side stream (which has waited for the event recorded after k_res_bwd), or on the main stream
-    // without one.  The time-embedding backward, which reads d(scale, shift), runs after the join.
-    if (gblocks > 0) {
-      const PartReduce red = res_part_reduce(c.w(b.gpart), gblocks, rows / rows_per_sample, r.cout, c.dprm(r.g2), c.dprm(r.g1),
-                                             c.g(c.ar.ss) + r.ss_off, c.p.ss_total);
-      if (c.side_defer && c.owner) {
-        Ctx::SideItem it{};
-        it.kind = 2; it.red = red;
-        c.side_defer->push_back(it);
-      } else {
-        hipStream_t rs = (c.owner && c.owner->side_stream) ? c.owner->side_stream : c.s;
-        DQ_TRY(launch_part_reduce(red, rs));
-      }
-    }
-    return 0;
+    return res_bwd_side(c, r, b, inA, cinA, inB, cinB, rows, n, rows_per_sample, gblocks);
   }
   // block2: norm -> silu
   BlockBwd bb;
@@ -400,6 +408,59 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
     DQ_TRY(launch_axpy(dA, dout, (int64_t)rows * r.cout * n, c.s));
   }
   return 0;
+}
+
+
+// The tiny backward (k_tiny.hip) of the two levels with rows of one position: `up` = the first up level (its input gradient goes straight into
+// the bottleneck's layout), otherwise the last down level (with its k3 conv and the Downsample in front of it).  Image slots 4 / 5 of the
+// tiny-image region.  Gradient-arena pointers are filled only when the context has one (the forward builds the images from the weights alone).
+bool tiny_bwd_desc(const Ctx& c, bool up, TinyBwd* out) {
+  const Plan& p = c.p;
+  const Arena& a = c.ar;
+  const int L = p.levels;
+  if (L < 2 || p.wide_mid || p.mid_n != 1) return false;
+  const LevelP& l = up ? p.ups[0] : p.downs[L - 1];
+  const LevelBuf& b = up ? a.ups[0] : a.downs[L - 1];
+  if (l.n != 1 || l.la.C != 16 || l.r0.cout != 16 || l.r1.cout != 16) return false;
+  TinyBwd t;
+  t.params = c.P; t.img = c.w(a.timg) + (int64_t)(up ? 4 : 5) * TINY_IMG_FLOATS;
+  t.C = 16; t.rows = c.B * c.RT; t.rows_per_sample = c.RT;
+  t.pre = up ? LEVEL_PRE_NONE : LEVEL_PRE_DOWN;
+  t.cs = l.r0.cin - l.r0.cout;
+  if (l.r1.cin != l.r0.cin) return false;
+  t.w_qkv = c.prm(l.la.qkv_w); t.w_out = c.prm(l.la.out_w); t.g_pre = c.prm(l.la.g_pre); t.g_out = c.prm(l.la.g_out);
+  t.x = c.w(b.r1.out); t.ypre = c.w(b.la_pre);
+  const ResP* rp[2] = {&l.r0, &l.r1};
+  const ResBuf* rb[2] = {&b.r0, &b.r1};
+  for (int i = 0; i < 2; ++i) {
+    TinyBwd::Blk& k = t.blk[i];
+    const ResP& r = *rp[i];
+    k.w1 = c.prm(r.c1.w); k.w2 = c.prm(r.c2.w); k.wr = r.res.cout ? c.prm(r.res.w) : nullptr; k.g1 = c.prm(r.g1); k.g2 = c.prm(r.g2);
+    k.ss = c.w(a.ss) + r.ss_off; k.ss_stride = p.ss_total;
+    k.u1 = c.w(rb[i]->u1); k.u2 = c.w(rb[i]->u2);
+    k.gpart = c.w(rb[i]->gpart); k.gpart_floats = rb[i]->gpart_floats;
+    if (c.G) { k.du1 = c.g(rb[i]->u1); k.du2 = c.g(rb[i]->u2); k.dout_st = r.res.cout ? c.g(rb[i]->out) : nullptr; }
+  }
+  if (up) {
+    if (c.G) {
+      t.dy = c.g(b.la); t.dfold = c.g(a.mid2.out);
+      t.blk[1].dB = c.g(a.downs[L - 1].r0.out); t.blk[1].dB_acc = 0;  // the up path is the first writer of the skip gradients (unet_backward)
+      t.blk[0].dB = c.g(a.downs[L - 1].la); t.blk[0].dB_acc = 0;
+    }
+  } else {
+    const LevelP& lp = p.downs[L - 2];
+    if (l.resample.k != 3 || l.resample.cout != 16 || l.resample.cin != 16 || lp.resample.k != 4 || lp.resample.cout != 16 || lp.n != 2) return false;
+    t.cp = lp.resample.cin;
+    t.post_w = c.prm(l.resample.w); t.stage_w = c.prm(lp.resample.w);
+    if (c.G) {
+      t.dy = c.g(b.la); t.dmid = c.g(a.mid_in); t.drs_out = c.g(b.rs);
+      t.din_rows = c.g(a.downs[L - 2].rs); t.dprev = c.g(a.downs[L - 2].la);
+      t.r0out_g = c.g(b.r0.out);
+    }
+  }
+  if (!tiny_bwd_usable(t)) return false;
+  *out = t;
+  return true;
 }
 
 // rows the register-resident kernels handle (k_linattn.hip / k_la_bwd.hip); anything else goes through the sweep kernels (k_la_long.hip)
@@ -470,6 +531,53 @@ int la_bwd(const Ctx& c, const LAP& l, const LevelBuf& b, const float* x, const 
   if (waves > 0) {
     d->items[d->count++] = LaReduceItem{a.part, waves, l.C, a.dw_qkv, a.dw_out, a.dg_out, a.db_out, a.dg_pre, w2sum, a.f.w_qkv, a.f.w_out};
     d->cursor += need;
+  }
+  return 0;
+}
+
+
+// launches the tiny backward of one level and queues what stays on the side stream / in the deferred reductions: the LinearAttention slot
+// reduce, both blocks' weight gradients + partial-sum reduces, and (down level) the weight gradients of its k3 conv and of the Downsample
+int tiny_bwd_run(const Ctx& c, TinyBwd t, bool up) {
+  const Plan& p = c.p;
+  const Arena& a = c.ar;
+  const int L = p.levels, R = c.B * c.RT;
+  const LevelP& l = up ? p.ups[0] : p.downs[L - 1];
+  const LevelBuf& b = up ? a.ups[0] : a.downs[L - 1];
+  Ctx::LaDefer* d = c.la_defer;
+  DQ_REQUIRE(d, "tiny_bwd_run: needs the deferred LinearAttention reduction");
+  const int64_t need = la_part_reserve(l.la.C);
+  if (d->count == LA_REDUCE_MAX || d->cursor + need > a.la_part_floats) DQ_TRY(la_flush(c));
+  t.la_part = c.w(a.la_part) + d->cursor; t.la_part_floats = a.la_part_floats - d->cursor;
+  int gblocks = 0;
+  t.gblocks = &gblocks;
+  DQ_TRY(launch_tiny_bwd(t, c.s));
+  const int slots = tiny_bwd_slots(t), C = l.la.C;
+  const int64_t slot_floats = 256 * C + 4 * C * C + 3 * C;  // la_slot(C), k_la_bwd.hip
+  DQ_REQUIRE((int64_t)slots * slot_floats + 4 * C * C <= need, "tiny_bwd_run: more LinearAttention slots than a layer's reservation holds");
+  d->items[d->count++] = LaReduceItem{t.la_part, slots, C, c.dprm(l.la.qkv_w), c.dprm(l.la.out_w), c.dprm(l.la.g_out), c.dprm(l.la.out_b),
+                                      c.dprm(l.la.g_pre), t.la_part + (int64_t)slots * slot_floats, c.prm(l.la.qkv_w), c.prm(l.la.out_w)};
+  d->cursor += need;
+  if (up) {
+    const int cs = l.r0.cin - l.r0.cout;
+    DQ_TRY(res_bwd_side(c, l.r1, b.r1, c.w(b.r0.out), l.r1.cout, c.w(a.downs[L - 1].r0.out), cs, R, l.n, c.RT, gblocks));
+    DQ_TRY(res_bwd_side(c, l.r0, b.r0, c.w(a.mid_back), l.r0.cout, c.w(a.downs[L - 1].la), cs, R, l.n, c.RT, gblocks));
+  } else {
+    const LevelP& lp = p.downs[L - 2];
+    const LevelBuf& bp = a.downs[L - 2];
+    // the level's k3 conv (centre tap at one position) and the Downsample in front of the level: weight gradients from the d rs tensors
+    ConvWgrad wg;
+    wg.scratch = c.w(a.wg); wg.scratch_floats = a.wg_floats;
+    wg.du = c.g(b.rs); wg.inA = c.w(b.la); wg.cinA = l.resample.cin; wg.cout = l.resample.cout; wg.K = l.resample.k; wg.mode = CONV_S1;
+    wg.rows = R; wg.n_in = l.n; wg.n_out = l.n_next; wg.dw = c.dprm(l.resample.w); wg.dbias = l.resample.b >= 0 ? c.dprm(l.resample.b) : nullptr;
+    DQ_TRY(wgrad_async(c, wg));
+    DQ_TRY(res_bwd_side(c, l.r1, b.r1, c.w(b.r0.out), l.r1.cin, nullptr, 0, R, l.n, c.RT, gblocks));
+    DQ_TRY(res_bwd_side(c, l.r0, b.r0, c.w(bp.rs), l.r0.cin, nullptr, 0, R, l.n, c.RT, gblocks));
+    ConvWgrad wd;
+    wd.scratch = c.w(a.wg); wd.scratch_floats = a.wg_floats;
+    wd.du = c.g(bp.rs); wd.inA = c.w(bp.la); wd.cinA = lp.resample.cin; wd.cout = lp.resample.cout; wd.K = lp.resample.k; wd.mode = CONV_DOWN;
+    wd.rows = R; wd.n_in = lp.n; wd.n_out = lp.n_next; wd.dw = c.dprm(lp.resample.w); wd.dbias = lp.resample.b >= 0 ? c.dprm(lp.resample.b) : nullptr;
+    DQ_TRY(wgrad_async(c, wd));
   }
   return 0;
 }
@@ -805,11 +913,11 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
   };
   for (int lv = 0; lv < L && lv < 16; ++lv) {
     tiny_dn[lv] = -1;
-    if (lv > 0 && L <= 16 && n_tiny < TINY_IMG_MAX && tiny_fwd_usable(tiny_down(lv))) tiny_dn[lv] = n_tiny++;
+    if (lv > 0 && L <= 16 && n_tiny < 4 && tiny_fwd_usable(tiny_down(lv))) tiny_dn[lv] = n_tiny++;  // (slots 4, 5: the backward's images)
   }
   for (int ui = 0; ui < L && ui < 16; ++ui) {
     tiny_up[ui] = -1;
-    if (L <= 16 && n_tiny < TINY_IMG_MAX && tiny_fwd_usable(tiny_upc(ui))) tiny_up[ui] = n_tiny++;
+    if (L <= 16 && n_tiny < 4 && tiny_fwd_usable(tiny_upc(ui))) tiny_up[ui] = n_tiny++;
   }
   auto tiny_img = [&](int slot) -> const float* { return c.w(a.timg) + (int64_t)slot * TINY_IMG_FLOATS; };
   auto is_tiny_dn = [&](int lv) { return lv < L && lv < 16 && tiny_dn[lv] >= 0; };
@@ -847,6 +955,13 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     for (int lv = 0; lv < L; ++lv) if (is_tiny_dn(lv)) { tc[nt] = tiny_down(lv); tc[nt].img = tiny_img(tiny_dn[lv]); ++nt; }
     for (int ui = 0; ui < L; ++ui) if (is_tiny_up(ui)) { tc[nt] = tiny_upc(ui); tc[nt].img = tiny_img(tiny_up[ui]); ++nt; }
     DQ_TRY(launch_tiny_images(tc, nt, ps));
+    if (c.save) {  // the transposed images of the tiny backward (same parameter state)
+      TinyBwd tb[2];
+      int nb = 0;
+      if (is_tiny_up(0) && tiny_bwd_desc(c, true, &tb[nb])) ++nb;
+      if (is_tiny_dn(L - 1) && tiny_bwd_desc(c, false, &tb[nb])) ++nb;
+      DQ_TRY(launch_tiny_bwd_images(tb, nb, ps));
+    }
   }
   if (c.prepare_only) return 0;
   if (fwd_fork) { DQ_TRY(side_mark(c, &ev_prep)); wait_prep = true; }
@@ -1009,6 +1124,9 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
   // only the accumulated-into region of the twin (offsets are multiples of 64 floats); a forked forward of the same step cleared it already
   if (c.owner && c.owner->twin_zeroed == c.G) c.owner->twin_zeroed = nullptr;
   else DQ_TRY(launch_zero(c.G, a.zero_floats, c.s));
+  // the two levels with rows of one position: their backward data path in one launch each (k_tiny.hip), when their forward ran there
+  TinyBwd tb_up, tb_dn;
+  const bool use_tb_up = tiny_bwd_desc(c, true, &tb_up), use_tb_dn = tiny_bwd_desc(c, false, &tb_dn);
   // head
   DQ_TRY(conv_plain_bwd(c, p.final_conv, CONV_S1, c.w(a.fin.out), grad_out, c.g(a.fin.out), R, p.mz, p.mz, 0));
   const LevelBuf& lastup = a.ups[L - 1];
@@ -1021,10 +1139,14 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     const int cx = l.r0.cout, cs = l.r0.cin - l.r0.cout;
     const int64_t in_off = ui == 0 ? a.mid_back : a.ups[ui - 1].rs;
     DQ_TRY(resample_bwd(c, l.resample, l.last ? LEVEL_PRE_S1 : LEVEL_PRE_UP, b, l.n, l.n_next, 0));  // only writer of d la (up): store
+    if (ui == 0 && use_tb_up) {
+      DQ_TRY(tiny_bwd_run(c, tb_up, true));  // LinearAttention + both ResnetBlocks; the input gradient lands in the bottleneck's layout
+    } else {
     DQ_TRY(la_bwd(c, l.la, b, c.w(b.r1.out), c.g(b.la), c.g(b.r1.out), R, l.n, L + ui));
     // the up path is the first writer of its own tensors AND of the skip tensors (the down path accumulates into them later)
     DQ_TRY(res_bwd(c, l.r1, b.r1, c.w(b.r0.out), c.g(b.r0.out), cx, c.w(a.downs[lv].r0.out), c.g(a.downs[lv].r0.out), cs, R, l.n, RT, 1, 1));
     DQ_TRY(res_bwd(c, l.r0, b.r0, c.w(in_off), c.g(in_off), cx, c.w(a.downs[lv].la), c.g(a.downs[lv].la), cs, R, l.n, RT, 1, 1));
+    }
     // the resample-conv and ResnetBlock weight gradients of two levels behind one event: an event record holds the main queue for ~6 us
     // (kernel trace)
     if (side_flush_here(lv)) DQ_TRY(side_flush(c));
@@ -1033,7 +1155,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
   if (p.wide_mid) {
     DQ_TRY(mid_backward_wide(c, rope));
   } else {
-    DQ_TRY(launch_fold(c.g(a.mid_back), c.g(a.mid2.out), B, RT, p.mid_c, 1, 1, c.s));
+    if (!use_tb_up) DQ_TRY(launch_fold(c.g(a.mid_back), c.g(a.mid2.out), B, RT, p.mid_c, 1, 1, c.s));  // (the tiny backward wrote d mid2.out itself)
     DQ_TRY(res_bwd(c, p.mid2, a.mid2, c.w(a.attn_out), c.g(a.attn_out), p.mid_c, nullptr, nullptr, 0, B, RT, 1));
     {
       const int64_t qvbs = (int64_t)2 * HID * RT, kbs = (int64_t)HID * RT;
@@ -1059,7 +1181,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
       DQ_TRY(launch_axpy(c.g(a.mid1.out), c.g(a.xn), (int64_t)R * p.mid_c, c.s));
     }
     DQ_TRY(res_bwd(c, p.mid1, a.mid1, c.w(a.mid_in), c.g(a.mid_in), p.mid_c, nullptr, nullptr, 0, B, RT, 1));
-    DQ_TRY(launch_fold(c.g(a.mid_in), c.g(a.downs[L - 1].rs), B, RT, p.mid_c, 0, 0, c.s));  // first and only writer: store
+    if (!use_tb_dn) DQ_TRY(launch_fold(c.g(a.mid_in), c.g(a.downs[L - 1].rs), B, RT, p.mid_c, 0, 0, c.s));  // first and only writer: store (the tiny backward reads d mid_in itself)
   }
   // MS1 feature path (unet1d.py:1120-1130): its gradient d ms1f is final behind the bottleneck (to_k is its only consumer) and nothing on
   // the main chain reads what it produces -- data path and weight gradients go to the side stream with the next flush, instead of standing
@@ -1087,6 +1209,12 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     const LevelBuf& b = a.downs[lv];
     const int C = l.r0.cin;
     const int64_t in_off = lv == 0 ? a.h0 : a.downs[lv - 1].rs;
+    if (lv == L - 1 && use_tb_dn) {  // k3 conv, LinearAttention, both ResnetBlocks and the Downsample in front of the level: one launch
+      DQ_TRY(tiny_bwd_run(c, tb_dn, false));
+      if (side_flush_here(lv)) DQ_TRY(side_flush(c));
+      continue;
+    }
+    if (!(lv == L - 2 && use_tb_dn))  // (that Downsample's backward rode in the launch above)
     DQ_TRY(resample_bwd(c, l.resample, l.last ? LEVEL_PRE_S1 : LEVEL_PRE_DOWN, b, l.n, l.n_next, 1));
     if (lv == 0) DQ_TRY(side_flush(c));  // (last level: the resample conv's weight gradient under the LinearAttention backward, not in the tail)
     DQ_TRY(la_bwd(c, l.la, b, c.w(b.r1.out), c.g(b.la), c.g(b.r1.out), R, l.n, lv));

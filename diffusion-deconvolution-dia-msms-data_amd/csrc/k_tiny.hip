@@ -23,6 +23,7 @@
 #include "dq_mfma.h"
 #include "dq_plan.h"
 #include "dq_probe.h"
+#include "k_res_common.h"
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -31,7 +32,8 @@ namespace dq {
 
 namespace {
 
-enum { TL_CONV3_N2 = 0, TL_DIAG = 1, TL_DOWN_N2 = 2, TL_DOWN_N1 = 3, TL_UP_N2 = 4, TL_LA1 = 5 };
+enum { TL_CONV3_N2 = 0, TL_DIAG = 1, TL_DOWN_N2 = 2, TL_DOWN_N1 = 3, TL_UP_N2 = 4, TL_LA1 = 5,
+       TL_DIAG_T = 6, TL_LA1_T = 7, TL_DOWN_N1_T = 8 };  // transposed forms of the backward data path (n == 1): step = output channel of the conv
 // One dense layer of the chain = `steps` MFMAs.  Element (step s, lane) of its operand image:
 //   m = lane & 31 -> output (position pm = (m >> 2) & 1, channel co = (m & 3) + 4 (m >> 3)); k = lane >> 5 = the half that supplies B
 struct TinyLayer {
@@ -72,6 +74,18 @@ __device__ __forceinline__ float tiny_img_value(const TinyLayer& L, int s, int l
       const int g = s / L.cin, ci = s - g * L.cin;
       const int t = g == 0 ? 1 : (pm == 0 ? 2 : 0);
       return pm == k ? P[L.w + (co * L.cin + ci) * 3 + t] : 0.f;
+    }
+    case TL_DIAG_T: {  // d in[ci = idx] = sum_co W[co = s][c0 + ci][centre] d out[co]; `cout` = number of valid ci
+      return pm == k ? P[L.w + (s * L.cin + L.c0 + co) * L.K + L.K / 2] : 0.f;
+    }
+    case TL_DOWN_N1_T: {  // d in[ci][j] = sum_co W[co = s][ci][1 + j] d out[co]; j = L.w2
+      return pm == k ? P[L.w + (s * L.cin + co) * 4 + 1 + L.w2] : 0.f;
+    }
+    case TL_LA1_T: {  // d xhat[ci = idx] = scale * sum_c' (Wo Wv)[c' = s][ci] d ypre[c']
+      if (pm != k) return 0.f;
+      float acc = 0.f;
+      for (int j = 0; j < HID; ++j) acc = fmaf(P[L.w2 + s * HID + j], P[L.w + (2 * HID + j) * L.cin + co], acc);
+      return acc * 0.17677669529663687f;
     }
     default: {  // TL_LA1: scale * (Wo Wv)[co][ci]  (to_qkv (3 HID, C, 1): the v rows start at 2 HID; to_out.0 (C, HID, 1))
       if (pm != k) return 0.f;
@@ -407,6 +421,330 @@ __global__ void __launch_bounds__(256) k_tiny_fwd(TinyFwdK a, const float* __res
   DQ_PSTAMP(PID, 6);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Backward DATA path of a level with rows of ONE position, one launch (autograd of the chain above; reference: unet1d.py:302-323, 446-496,
+// 1134-1158):  [the last down level's k3 conv] -> Residual(PreNorm(LinearAttention)) (linear at n = 1) -> ResnetBlock 1 -> ResnetBlock 0
+// -> [Downsample that produced the level's input], every transposed conv a chain of dense layers exactly as in the forward (lane = row,
+// register = channel), everything per position in-lane.  It writes what the weight-gradient kernels on the side stream read (d u1, d u2 of
+// both blocks, d rs), the skip gradients, the level's input gradient (the first up level: straight into the bottleneck's (B, C, RT)
+// layout), the blocks' [d g2 | d g1 | d scale | d shift] sums per workgroup (ResBwd::gpart format) and ONE LinearAttention slot per
+// workgroup in k_linattn_bwd1's format (d Wq = d Wk = 0 at one position; d W2 the same for the four heads).  d W2 = sum_rows dYpre xhat^T
+// runs over the lanes: both operands go through a wave-private LDS tile [c][row] and 32 MFMAs per tile.
+// Replaces k_fold + k_conv_bwd_wg + k_linattn_bwd1 + 2 k_res_bwd_cp (+ the previous level's k_conv_bwd_wg data path) per level.
+struct TinyBwdBlkK {
+  int g1, g2, ss_off;                  // gains (offsets in P), this block's [scale | shift] in the sample's vector
+  const float* u1; const float* u2;    // saved pre-norm conv outputs (rows, C)
+  float* du1; float* du2;              // their gradients (written: the weight-gradient kernels read them)
+  float* dB; int dB_acc;               // gradient of the skip input (rows, CS): stored, or accumulated into
+  float* dout_st;                      // nullable: the block's OUTPUT gradient (rows, C), stored for the res_conv weight gradient
+  float* gpart;                        // [b * gridDim.x + x][4 C] = [d g2 | d g1 | d scale | d shift]
+};
+struct TinyBwdK {
+  const float* x; const float* ypre; const float* dy;  // r1.out (forward), la_pre (forward), d la (rows, C); with a post conv: its skip part
+  int la_gpre, la_go;
+  float* la_part;                                      // [workgroup][la_slot(C)]
+  const float* dmid; float* drs_out;                   // post conv: d mid_in (B, C, RT); the same as (rows, C) for its weight gradient
+  float* dfold;                                        // LEVEL_PRE_NONE: the level's input gradient as (B, C, RT)
+  float* din_rows; float* dprev;                       // LEVEL_PRE_DOWN: the input gradient as (rows, C); the Downsample's data gradient += (rows, CP, 2)
+  const float* r0out_g;                                // nullable: d r0.out already holds a skip gradient (down path): added to block 0's d out
+  TinyBwdBlkK blk[2];                                  // [0] = ResnetBlock 0, [1] = ResnetBlock 1
+  int rows_per_sample, ss_stride;
+};
+constexpr int tiny_la_slot(int C) { return 256 * C + 4 * C * C + 3 * C; }  // = la_slot(C) of k_la_bwd.hip
+
+template <int C, int PRE, int CP, int CS>
+__global__ void __launch_bounds__(256) k_tiny_bwd(TinyBwdK a, const float* __restrict__ P, const float* __restrict__ ssb, const float* __restrict__ img,
+                                                 int tiles_ps) {
+  static_assert(C == 16, "built for 16 channels");
+  constexpr bool WR = CS > 0, POST = PRE == LEVEL_PRE_DOWN;
+  constexpr int BLKT = 2 * C + (CS ? C : 0) + (WR ? 2 * C : 0);
+  constexpr int B_POST = 0, B_LA = POST ? C : 0, B_R1 = B_LA + C, B_R0 = B_R1 + BLKT, B_ST = B_R0 + BLKT;
+  constexpr int TOTAL = B_ST + (PRE == LEVEL_PRE_DOWN ? 2 * C : 0);
+  constexpr int NLD = tiny_rounds(TOTAL);
+  constexpr int NACC = 3 * C + 8 * C;  // per-lane sums: d g_out | d b_out | d g_pre | per block d g2 | d g1 | d scale | d shift
+  constexpr int PIDB = 400000 + PRE * 10 + (CS ? 1 : 0);  // tools/probe_step.py id
+  DQ_PSTAMP(PIDB, 0);
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* wl = lds;                       // [TOTAL][64] padded to NLD rounds
+  float* prm = lds + NLD * 1024;         // [16 vectors][16]: g_out | g_pre | blk0: g1 g2 scale shift | blk1: g1 g2 scale shift
+  float* tr = prm + 256 + (threadIdx.x >> 6) * (2 * C * 65);   // per wave: dYpre | scale-free xhat as [c][row]
+  float* comb = prm + 256 + 4 * (2 * C * 65);                  // [4 waves][4 lane rows][NACC], then [4 waves][C * C]
+  float* w2c = comb + 16 * NACC;
+  const int b = blockIdx.y;
+  {
+    const int i = threadIdx.x;
+    const int what = i >> 4, c = i & 15;
+    const int bi = what >= 6 ? 1 : 0, k = what >= 2 ? (what - 2) & 3 : 4;   // k: 0 g1, 1 g2, 2 scale, 3 shift
+    const int g1o = bi ? a.blk[1].g1 : a.blk[0].g1, g2o = bi ? a.blk[1].g2 : a.blk[0].g2, sso = bi ? a.blk[1].ss_off : a.blk[0].ss_off;
+    const bool isS = what >= 2 && what < 10 && (k == 2 || k == 3);
+    int offP = what == 0 ? a.la_go : what == 1 ? a.la_gpre : (what < 10 ? (k == 0 ? g1o : k == 1 ? g2o : -1) : -1);
+    const int offS = isS ? sso + (k == 3 ? C : 0) + c : 0;
+    const float pv = P[offP >= 0 ? offP + c : 0];
+    const float sv = ssb[(int64_t)b * a.ss_stride + offS];
+    float4 v[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) v[u] = reinterpret_cast<const float4*>(img)[u * 256 + (int)threadIdx.x];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) reinterpret_cast<float4*>(wl)[u * 256 + (int)threadIdx.x] = v[u];
+    prm[i] = isS ? sv : (offP >= 0 ? pv : 0.f);
+  }
+  __syncthreads();
+  DQ_PSTAMP(PIDB, 1);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wv), nwaves = gridDim.x * 4;
+  const int RT = a.rows_per_sample;
+  const float sqC = 4.0f;  // sqrt(16)
+  const float* wlane = wl + lane;
+  // (scheduling fences around every layer: left alone the scheduler hoists the operand reads of ALL ~180 layers' steps to the top of the tile --
+  // 512 + 256 registers and 60-110 spilled ones)
+  auto dense = [&](int base, const float* breg, f32x16 acc) __attribute__((always_inline)) -> f32x16 {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < C; ++s) acc = mfma_f32(wlane[(base + s) * 64], breg[s], acc);
+    __builtin_amdgcn_sched_barrier(0);
+    return acc;
+  };
+  auto zero16 = []() __attribute__((always_inline)) -> f32x16 { f32x16 z; for (int r = 0; r < 16; ++r) z[r] = 0.f; return z; };
+  auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+  // Sums over the rows (norm gains, bias, per-sample d scale / d shift): 176 values per tile.  Kept per lane across the tiles they cost 176
+  // registers (the kernel sat at 512 + 256 with ~100 spilled); added into an LDS table value by value they were 64 dependent LDS round trips
+  // per block (21,700 clocks per block, probe).  Now: four DPP adds give every lane its 16-lane row's sum of value i, and lane (i mod 16) of
+  // each row keeps the running sum of value i -- 11 registers per lane, two VALU instructions per value, a fixed order, no LDS in the loop.
+  float racc[NACC / 16];
+#pragma unroll
+  for (int i = 0; i < NACC / 16; ++i) racc[i] = 0.f;
+  auto flush_vals = [&](const float* v, auto n_c, auto off_c) __attribute__((always_inline)) {
+    constexpr int NV = decltype(n_c)::value, OFF = decltype(off_c)::value;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float t = v[i];
+      t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+      t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+      t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x141, 0xF, 0xF, false));  // row_half_mirror
+      t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x140, 0xF, 0xF, false));  // row_mirror
+      racc[(OFF + i) / 16] += (lane & 15) == ((OFF + i) & 15) ? t : 0.f;
+      if ((i & 15) == 15) __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from carrying dozens of row sums around)
+    }
+  };
+  f32x16 w2acc = zero16();
+
+#pragma unroll 1
+  for (int tile = wid; tile < tiles_ps; tile += nwaves) {
+    const int r_in_s = tile * 64 + lane;
+    const bool live = r_in_s < RT;
+    const int rs_c = live ? r_in_s : RT - 1;
+    const int64_t row = (int64_t)b * RT + rs_c;
+    auto ld16 = [&](const float* base, float* dst) __attribute__((always_inline)) {
+      const float4* q = reinterpret_cast<const float4*>(base + row * C);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const float4 t = q[u]; dst[4 * u] = t.x; dst[4 * u + 1] = t.y; dst[4 * u + 2] = t.z; dst[4 * u + 3] = t.w; }
+    };
+    auto st16 = [&](float* base, const float* v) __attribute__((always_inline)) {
+      if (base && live) {
+        float4* q = reinterpret_cast<float4*>(base + row * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = make_float4(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
+      }
+    };
+    // ---- loads of the whole tile up front
+    float xv[16], uv[16], dv[16], dm[16], u2a[16], u1a[16], u2b[16], u1b[16], r0g[16];
+    ld16(a.x, xv); ld16(a.ypre, uv); ld16(a.dy, dv);
+    if constexpr (POST) {
+      const float* q = a.dmid + (int64_t)b * C * RT + rs_c;
+#pragma unroll
+      for (int c = 0; c < C; ++c) dm[c] = q[(int64_t)c * RT];
+    }
+    ld16(a.blk[1].u2, u2a); ld16(a.blk[1].u1, u1a);
+    __builtin_amdgcn_sched_barrier(0);  // (block 0's tensors are requested behind the LinearAttention part: 48 registers less at the peak)
+    // ---- the last down level's k3 conv (centre tap): d la += W^T d mid_in; d rs in row layout for its weight gradient
+    if constexpr (POST) {
+      st16(a.drs_out, dm);
+      const f32x16 t = dense(B_POST, dm, zero16());
+#pragma unroll
+      for (int c = 0; c < C; ++c) dv[c] += t[c];
+    }
+    DQ_PSTAMP(PIDB, 2);
+    // ---- Residual(PreNorm(LinearAttention)) at one position (arithmetic of k_linattn_bwd1)
+    float dout[16];
+    {
+      float ssq = 0.f, usq = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) { ssq = fmaf(xv[c], xv[c], ssq); usq = fmaf(uv[c], uv[c], usq); }
+      const float nrm = fast_sqrt(ssq), unrm = fast_sqrt(usq);
+      const float inv = sqC * fast_rcp(fmaxf(nrm, RMS_EPS)), uinv = fast_rcp(fmaxf(unrm, RMS_EPS));
+      float xh[16], DY[16], gdv[16], lacc[3 * C];
+#pragma unroll
+      for (int i = 0; i < 3 * C; ++i) lacc[i] = 0.f;
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        xh[c] = xv[c] * inv * prm[16 + c];
+        const float uh = uv[c] * uinv;
+        if (live) lacc[c] = dv[c] * (uh * sqC);  // d g_out
+        gdv[c] = dv[c] * prm[c] * sqC;
+        uv[c] = uh;
+        dot = fmaf(gdv[c], uh, dot);
+      }
+      const bool uclamped = unrm < RMS_EPS;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        DY[c] = uclamped ? gdv[c] * uinv : uinv * (gdv[c] - uv[c] * dot);
+        DY[c] = live ? DY[c] : 0.f;
+        lacc[C + c] = DY[c];  // d b_out
+      }
+      // d W2[c'][c] += sum_rows dYpre[c'][row] xhat[c][row] (the 32^-0.5 is applied at the flush): K = rows = lanes, through the [c][row] tile
+      wsync();
+#pragma unroll
+      for (int c = 0; c < C; ++c) { tr[c * 65 + lane] = DY[c]; tr[(C + c) * 65 + lane] = live ? xh[c] : 0.f; }
+      wsync();
+#pragma unroll
+      for (int sgm = 0; sgm < 32; ++sgm) {
+        const float av = tr[(lane & 15) * 65 + 2 * sgm + (lane >> 5)];
+        const float bv = tr[(C + (lane & 15)) * 65 + 2 * sgm + (lane >> 5)];
+        w2acc = mfma_f32(av, bv, w2acc);
+      }
+      const f32x16 dr = dense(B_LA, DY, zero16());  // 32^-0.5 (Wo Wv)^T dYpre
+      const float pinv = fast_rcp(fmaxf(nrm, RMS_EPS));
+      float tot[16], uh2[16];
+      float dot2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float dxh = dr[c];
+        uh2[c] = xv[c] * pinv;
+        lacc[2 * C + c] = dxh * (uh2[c] * sqC);  // d g_pre  (dxh is 0 for dead lanes: DY is)
+        tot[c] = dxh * prm[16 + c] * sqC;
+        dot2 = fmaf(tot[c], uh2[c], dot2);
+      }
+      const bool clamped = nrm < RMS_EPS;
+#pragma unroll
+      for (int c = 0; c < C; ++c) dout[c] = dv[c] + (clamped ? tot[c] * pinv : pinv * (tot[c] - uh2[c] * dot2));
+      flush_vals(lacc, std::integral_constant<int, 3 * C>{}, std::integral_constant<int, 0>{});
+    }
+    DQ_PSTAMP(PIDB, 3);
+    ld16(a.blk[0].u2, u2b); ld16(a.blk[0].u1, u1b);
+    if (a.r0out_g) ld16(a.r0out_g, r0g);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- ResnetBlock 1, then ResnetBlock 0
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int bi = 1 - pass;
+      const TinyBwdBlkK& r = a.blk[bi];
+      const int base = bi ? B_R1 : B_R0, pq = 2 + 4 * bi;
+      float bacc[4 * C];
+#pragma unroll
+      for (int i = 0; i < 4 * C; ++i) bacc[i] = 0.f;
+      if (bi == 0 && a.r0out_g) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) dout[c] += r0g[c];
+      }
+      if (!live) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) dout[c] = 0.f;
+      }
+      st16(r.dout_st, dout);
+      float d[16], dsum_dummy[16];
+      float* u2 = bi ? u2a : u2b;
+      float* u1 = bi ? u1a : u1b;
+#pragma unroll
+      for (int c = 0; c < C; ++c) d[c] = dout[c];
+      norm_act_bwd<C, false>(u2, d, prm + (pq + 1) * 16, nullptr, bacc, dsum_dummy, dsum_dummy);   // block2: d u2 ; d g2
+      st16(r.du2, d);
+      const f32x16 da1 = dense(base, d, zero16());                                               // conv2^T
+      float e[16];
+#pragma unroll
+      for (int c = 0; c < C; ++c) e[c] = da1[c];
+      norm_act_bwd<C, true>(u1, e, prm + pq * 16, prm + (pq + 2) * 16, bacc + C, bacc + 2 * C, bacc + 3 * C);  // block1: d u1 ; d g1, d scale, d shift
+      st16(r.du1, e);
+      if (bi) flush_vals(bacc, std::integral_constant<int, 4 * C>{}, std::integral_constant<int, 3 * C + 4 * C>{});
+      else flush_vals(bacc, std::integral_constant<int, 4 * C>{}, std::integral_constant<int, 3 * C>{});
+      f32x16 dxa = dense(base + C, e, zero16());                                                 // conv1^T, x part
+      if constexpr (CS > 0) {
+        f32x16 dsk = dense(base + 2 * C, e, zero16());                                           // conv1^T, skip part
+        if constexpr (WR) {
+          dxa = dense(base + 3 * C, dout, dxa);                                                  // res_conv^T
+          dsk = dense(base + 4 * C, dout, dsk);
+        }
+        if (r.dB && live) {
+          float4* q = reinterpret_cast<float4*>(r.dB + row * CS);
+#pragma unroll
+          for (int u = 0; u < CS / 4; ++u) {
+            float4 o = make_float4(dsk[4 * u], dsk[4 * u + 1], dsk[4 * u + 2], dsk[4 * u + 3]);
+            if (r.dB_acc) { const float4 p0 = q[u]; o.x += p0.x; o.y += p0.y; o.z += p0.z; o.w += p0.w; }
+            q[u] = o;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) dout[c] = dxa[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) dout[c] = dxa[c] + dout[c];                                  // identity residual
+      }
+    }
+    DQ_PSTAMP(PIDB, 4);
+    // ---- the level's input gradient
+    if constexpr (PRE == LEVEL_PRE_NONE) {
+      if (live) {
+        float* q = a.dfold + (int64_t)b * C * RT + rs_c;
+#pragma unroll
+        for (int c = 0; c < C; ++c) q[(int64_t)c * RT] = dout[c];
+      }
+    } else {
+      st16(a.din_rows, dout);
+      // Downsample k4 s2 p1 from two positions: d in[ci][j] += sum_co w[co][ci][1 + j] d out[co]
+      const f32x16 t0 = dense(B_ST, dout, zero16()), t1 = dense(B_ST + C, dout, zero16());
+      if (live) {
+        float2* q = reinterpret_cast<float2*>(a.dprev + row * (CP * 2));
+#pragma unroll
+        for (int ci = 0; ci < CP; ++ci) { float2 o = q[ci]; o.x += t0[ci]; o.y += t1[ci]; q[ci] = o; }
+      }
+    }
+  }
+  DQ_PSTAMP(PIDB, 5);
+  // ---- flush: the waves' row tables and d W2 tiles -> workgroup sums (fixed order), then the block's slots
+  {
+    float* crow = comb + (wv * 4) * NACC;  // [lane row][value]: lane (row, j) holds the row sums of the values i = j (mod 16)
+#pragma unroll
+    for (int sl = 0; sl < NACC / 16; ++sl) crow[(lane >> 4) * NACC + sl * 16 + (lane & 15)] = racc[sl];
+  }
+  {
+    // the d W2 tile: register j of lane (half, col) holds [c' = rmap(j, half)][c = col]; rows / columns 16..31 are duplicates
+    const int half = lane >> 5, col = lane & 31;
+    float* cw = w2c + wv * (C * C);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int cp = rmap(j, half);
+      if (col < C) cw[cp * C + col] = w2acc[j];
+    }
+  }
+  __syncthreads();
+  const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+  float* slot = a.la_part + (int64_t)wg * tiny_la_slot(C);
+  for (int i = threadIdx.x; i < 256 * C; i += 256) slot[i] = 0.f;  // d Wq | d Wk
+  for (int i = threadIdx.x; i < NACC + C * C; i += 256) {
+    float v = 0.f;
+    if (i < NACC) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v += comb[q * NACC + i];  // (wave, lane row) order
+    } else {
+      const int e = i - NACC;
+      v = (w2c[e] + w2c[C * C + e]) + (w2c[2 * C * C + e] + w2c[3 * C * C + e]);
+    }
+    if (i < 3 * C) slot[256 * C + 4 * C * C + i] = v;                                   // d g_out | d b_out | d g_pre
+    else if (i < NACC) {
+      const int bi = (i - 3 * C) / (4 * C), e = (i - 3 * C) % (4 * C), what = e / C, c = e % C;
+      // order per block: d g2 | d g1 | d scale | d shift  == ResBwd::gpart order
+      a.blk[bi].gpart[(int64_t)wg * (4 * C) + what * C + c] = v;
+    } else {
+      const float w = v * 0.17677669529663687f;
+#pragma unroll
+      for (int hd = 0; hd < 4; ++hd) slot[256 * C + hd * C * C + (i - NACC)] = w;
+    }
+  }
+  DQ_PSTAMP(PIDB, 6);
+}
+
 // the layer list of a launch, in image order (the kernel's step bases follow the same formulas)
 int tiny_layers(const TinyFwd& t, TinyLayer* L) {
   const LevelFwd& a = t.lv;
@@ -429,6 +767,36 @@ int tiny_layers(const TinyFwd& t, TinyLayer* L) {
   if (t.la) L[nl++] = TinyLayer{TL_LA1, poff(t.w_qkv), poff(t.w_out), C, 1, 0, C, C};
   if (t.post_w) L[nl++] = TinyLayer{TL_DIAG, poff(t.post_w), 0, C, 3, 0, C, C};  // (only behind the LinearAttention: tiny_fwd_usable)
   return nl;
+}
+
+
+// the backward's transposed layers, in image order (k_tiny_bwd's step bases follow the same formulas)
+int tiny_bwd_layers(const TinyBwd& t, TinyLayer* L) {
+  auto poff = [&](const float* ptr) -> int { return ptr ? (int)(ptr - t.params) : -1; };
+  int nl = 0;
+  const int C = t.C, cs = t.cs, cin = C + cs;
+  if (t.pre == LEVEL_PRE_DOWN) L[nl++] = TinyLayer{TL_DIAG_T, poff(t.post_w), 0, C, 3, 0, C, C};
+  L[nl++] = TinyLayer{TL_LA1_T, poff(t.w_qkv), poff(t.w_out), C, 1, 0, C, C};
+  for (int b = 1; b >= 0; --b) {
+    const TinyBwd::Blk& r = t.blk[b];
+    L[nl++] = TinyLayer{TL_DIAG_T, poff(r.w2), 0, C, 3, 0, C, C};
+    L[nl++] = TinyLayer{TL_DIAG_T, poff(r.w1), 0, cin, 3, 0, C, C};
+    if (cs) {
+      L[nl++] = TinyLayer{TL_DIAG_T, poff(r.w1), 0, cin, 3, C, C, cs};
+      L[nl++] = TinyLayer{TL_DIAG_T, poff(r.wr), 0, cin, 1, 0, C, C};
+      L[nl++] = TinyLayer{TL_DIAG_T, poff(r.wr), 0, cin, 1, C, C, cs};
+    }
+  }
+  if (t.pre == LEVEL_PRE_DOWN) {
+    L[nl++] = TinyLayer{TL_DOWN_N1_T, poff(t.stage_w), 0, t.cp, 4, 0, C, t.cp};
+    L[nl++] = TinyLayer{TL_DOWN_N1_T, poff(t.stage_w), 1, t.cp, 4, 0, C, t.cp};
+  }
+  return nl;
+}
+
+bool tiny_bwd_enabled() {
+  static const bool on = [] { const char* e = std::getenv("DQ_NO_TINY_BWD"); return !(e && e[0] == '1'); }();  // A-B switch
+  return on;
 }
 
 bool tiny_enabled() {
@@ -542,6 +910,93 @@ int launch_tiny_fwd(const TinyFwd& t, hipStream_t s) {
   DQ_TINY(16, 2, LEVEL_PRE_UP, 16, 12)
 #undef DQ_TINY
   set_error("tiny_fwd: unsupported (C, n, stage, stage input width, skip width)");
+  return 2;
+}
+
+
+bool tiny_bwd_usable(const TinyBwd& t) {
+  if (!tiny_enabled() || !tiny_bwd_enabled()) return false;
+  if (t.C != 16 || t.rows_per_sample <= 1 || !t.params) return false;
+  if (t.pre == LEVEL_PRE_DOWN) return t.cp == 12 && t.cs == 0;
+  if (t.pre == LEVEL_PRE_NONE) return t.cs == 16;
+  return false;
+}
+static int tiny_bwd_gx(const TinyBwd& t) {
+  const int B = t.rows / t.rows_per_sample, tiles_ps = cdiv(t.rows_per_sample, 64);
+  return std::max(1, std::min(tiny_num_cus() / std::max(1, B), (tiles_ps + 3) / 4));
+}
+int tiny_bwd_slots(const TinyBwd& t) { return tiny_bwd_gx(t) * (t.rows / t.rows_per_sample); }
+int64_t tiny_bwd_img_floats(const TinyBwd& t) {
+  TinyLayer L[TINY_MAX_LAYERS + 4];
+  const int nl = tiny_bwd_layers(t, L);
+  int64_t steps = 0;
+  for (int i = 0; i < nl; ++i) steps += L[i].steps;
+  return steps * 64;
+}
+int launch_tiny_bwd_images(const TinyBwd* calls, int count, hipStream_t s) {
+  if (count == 0) return 0;
+  DQ_REQUIRE(count <= TINY_IMG_MAX, "tiny bwd images: too many launches");
+  TinyImgMulti mm;
+  int64_t mx = 0;
+  for (int i = 0; i < count; ++i) {
+    const TinyBwd& t = calls[i];
+    DQ_REQUIRE(t.img && ((uintptr_t)t.img & 15) == 0 && tiny_bwd_usable(t), "tiny bwd images: missing image buffer / unsupported shape");
+    DQ_REQUIRE(t.params == calls[0].params, "tiny bwd images: the launches must share one parameter buffer");
+    TinyImgItem& it = mm.it[i];
+    TinyLayer L[TINY_MAX_LAYERS + 4];
+    it.nl = tiny_bwd_layers(t, L);
+    DQ_REQUIRE(it.nl <= TINY_MAX_LAYERS, "tiny bwd images: too many layers");
+    it.total_steps = 0;
+    for (int l = 0; l < it.nl; ++l) { it.L[l] = L[l]; it.total_steps += L[l].steps; }
+    it.dst = const_cast<float*>(t.img);
+    DQ_REQUIRE((int64_t)tiny_rounds(it.total_steps) * 1024 <= TINY_IMG_FLOATS, "tiny bwd images: image larger than its slot");
+    mx = std::max<int64_t>(mx, (int64_t)it.total_steps * 64);
+  }
+  hipLaunchKernelGGL(k_tiny_images, dim3(cdiv(mx, 256), count), dim3(256), 0, s, mm, calls[0].params);
+  DQ_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_tiny_bwd(const TinyBwd& t, hipStream_t s) {
+  DQ_REQUIRE(tiny_bwd_usable(t), "tiny_bwd: unsupported shape");
+  DQ_REQUIRE(t.rows % t.rows_per_sample == 0 && t.img && t.x && t.ypre && t.dy && t.w_qkv && t.w_out && t.g_pre && t.g_out && t.la_part, "tiny_bwd: missing operand");
+  DQ_REQUIRE(t.pre != LEVEL_PRE_DOWN || (t.post_w && t.dmid && t.drs_out && t.din_rows && t.dprev && t.stage_w), "tiny_bwd: incomplete down-level operands");
+  DQ_REQUIRE(t.pre != LEVEL_PRE_NONE || t.dfold, "tiny_bwd: missing input-gradient tensor");
+  auto poff = [&](const float* ptr) -> int { return ptr ? (int)(ptr - t.params) : -1; };
+  const int C = t.C, B = t.rows / t.rows_per_sample, gx = tiny_bwd_gx(t);
+  TinyBwdK k;
+  k.x = t.x; k.ypre = t.ypre; k.dy = t.dy; k.la_gpre = poff(t.g_pre); k.la_go = poff(t.g_out); k.la_part = t.la_part;
+  k.dmid = t.dmid; k.drs_out = t.drs_out; k.dfold = t.dfold; k.din_rows = t.din_rows; k.dprev = t.dprev; k.r0out_g = t.r0out_g;
+  k.rows_per_sample = t.rows_per_sample;
+  const float* ssb = t.blk[0].ss;
+  k.ss_stride = t.blk[0].ss_stride;
+  DQ_REQUIRE(t.la_part_floats >= (int64_t)gx * B * tiny_la_slot(C) + 4 * C * C, "tiny_bwd: LinearAttention slot region too small");
+  for (int b = 0; b < 2; ++b) {
+    const TinyBwd::Blk& r = t.blk[b];
+    DQ_REQUIRE(r.w1 && r.w2 && r.g1 && r.g2 && r.ss && r.u1 && r.u2 && r.du1 && r.du2 && r.gpart && (t.cs == 0 || r.wr), "tiny_bwd: missing block operand");
+    DQ_REQUIRE(r.ss_stride == k.ss_stride && r.gpart_floats >= (int64_t)gx * B * 4 * C, "tiny_bwd: scale / shift stride or partial-sum slot");
+    TinyBwdBlkK& d = k.blk[b];
+    d.g1 = poff(r.g1); d.g2 = poff(r.g2); d.ss_off = (int)(r.ss - ssb);
+    d.u1 = r.u1; d.u2 = r.u2; d.du1 = r.du1; d.du2 = r.du2; d.dB = r.dB; d.dB_acc = r.dB_acc; d.dout_st = r.dout_st; d.gpart = r.gpart;
+  }
+  if (t.gblocks) *t.gblocks = gx;
+  const int tiles_ps = cdiv(t.rows_per_sample, 64);
+  const int blkt = 2 * C + (t.cs ? C : 0) + (t.cs ? 2 * C : 0);
+  const int total = (t.pre == LEVEL_PRE_DOWN ? C : 0) + C + 2 * blkt + (t.pre == LEVEL_PRE_DOWN ? 2 * C : 0);
+  DQ_REQUIRE((int64_t)total * 64 == tiny_bwd_img_floats(t), "tiny_bwd: image layout mismatch");
+  const size_t lds = (size_t)tiny_rounds(total) * 4096 + 256 * 4 + (size_t)4 * (2 * C * 65) * 4 + (size_t)(16 * 11 * C + 4 * C * C) * 4;
+#define DQ_TINYB(PP, PC, SS)                                                                                                  \
+  if (t.pre == PP && t.cs == SS) {                                                                                            \
+    const int nb = occ_blocks_per_cu((const void*)k_tiny_bwd<16, PP, PC, SS>, 256, lds);                                      \
+    if (nb < 0) return 1;                                                                                                     \
+    hipLaunchKernelGGL((k_tiny_bwd<16, PP, PC, SS>), dim3(gx, B), dim3(256), lds, s, k, t.params, ssb, t.img, tiles_ps);      \
+    DQ_LAUNCH_CHECK();                                                                                                        \
+    return 0;                                                                                                                 \
+  }
+  DQ_TINYB(LEVEL_PRE_DOWN, 12, 0)
+  DQ_TINYB(LEVEL_PRE_NONE, 0, 16)
+#undef DQ_TINYB
+  set_error("tiny_bwd: unsupported (stage, skip width)");
   return 2;
 }
 
