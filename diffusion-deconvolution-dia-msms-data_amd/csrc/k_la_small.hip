@@ -29,7 +29,7 @@ struct LaSmallK {
 };
 
 template <int C, int N>
-__global__ void __launch_bounds__(256, 2) k_la_small(LaSmallK a) {
+__global__ void __launch_bounds__(256, N <= 4 ? 2 : 1) k_la_small(LaSmallK a) {  // (N = 8: 128 registers of k tiles alone -- one wave per SIMD)
   constexpr int S = C / 2;
   constexpr int NR = C == 8 ? 4 : 8;  // output / residual registers per lane: channel rmap(j, half), valid below C
   __shared__ __attribute__((aligned(16))) float img[12 * S * 64];
@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256, 2) k_la_small(LaSmallK a) {
   // y_pre) leave through it the same way.  As per-lane 4-byte accesses at a row pitch of C N floats every load / store instruction touched
   // 32..64 cache lines: ~90 such instructions per tile were a third of the launch at the sampling batch.
   constexpr int E = C * N, EP = E + 1;
-  __shared__ float xt_all[4 * 32 * EP];
+  extern __shared__ __attribute__((aligned(16))) float xt_all[];  // 4 x 32 x EP floats (dynamic: with the image it passes 64 KB at N = 8)
   float* xt = xt_all + (threadIdx.x >> 6) * 32 * EP;
   {
     constexpr int T4 = 12 * S * 16, NLD = (T4 + 255) / 256;
@@ -235,6 +235,10 @@ __global__ void __launch_bounds__(256, 2) k_la_small(LaSmallK a) {
   }
 }
 
+bool la_small8_enabled() {
+  static const bool on = [] { const char* e = std::getenv("DQ_NO_LA_SMALL8"); return !(e && e[0] == '1'); }();  // A-B switch (rows of 8 positions)
+  return on;
+}
 bool la_small_enabled() {
   static const bool on = [] { const char* e = std::getenv("DQ_NO_LA_SMALL"); return !(e && e[0] == '1'); }();  // A-B switch
   return on;
@@ -244,7 +248,7 @@ bool la_small_enabled() {
 
 bool la_small_usable(int C, int n) {
   if (!la_small_enabled()) return false;
-  return (n == 2 || n == 4) && (C == 12 || C == 16);
+  return ((n == 2 || n == 4) && (C == 12 || C == 16)) || (n == 8 && C == 12 && la_small8_enabled());  // (8 channels at 8 positions measured slower than the register-resident kernel: 297 vs 276 us at batch 512; 12 channels: 371 vs 429)
 }
 // Below this many rows the launch is a latency chain (a training batch of 32 windows: 400 tiles for 1,024 SIMDs) and the register-resident
 // kernel's shorter prologue wins (measured at 12,800 rows: 4 launches +35 us per step); above it the matrix pipe is the limit and this
@@ -262,14 +266,15 @@ int launch_la_small_fwd(const LinAttn& a, hipStream_t s) {
   static const int cus = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
 #define DQ_LAS(CC, NN)                                                                                        \
   if (a.C == CC && a.n == NN) {                                                                               \
-    const int nb = occ_blocks_per_cu((const void*)k_la_small<CC, NN>, 256, 0);                                \
+    const size_t lds = (size_t)4 * 32 * (CC * NN + 1) * 4;                                                   \
+    const int nb = occ_blocks_per_cu((const void*)k_la_small<CC, NN>, 256, lds);                              \
     if (nb < 0) return 1;                                                                                     \
     const int grid = std::max(1, std::min(nb * cus, (k.ntiles + 3) / 4));                                     \
-    hipLaunchKernelGGL((k_la_small<CC, NN>), dim3(grid), dim3(256), 0, s, k);                                 \
+    hipLaunchKernelGGL((k_la_small<CC, NN>), dim3(grid), dim3(256), lds, s, k);                               \
     DQ_LAUNCH_CHECK();                                                                                        \
     return 0;                                                                                                 \
   }
-  DQ_LAS(12, 2) DQ_LAS(16, 2) DQ_LAS(12, 4) DQ_LAS(16, 4)
+  DQ_LAS(12, 2) DQ_LAS(16, 2) DQ_LAS(12, 4) DQ_LAS(16, 4) DQ_LAS(12, 8)
 #undef DQ_LAS
   set_error("la_small: unsupported (C, n)");
   return 2;

@@ -47,11 +47,11 @@ def test_linattn_fwd_golden(N, golden, C, n):
     assert rel_err(y, g[pre + "y"]) < 1e-5  # fp32 tolerance: 1e-5 of the output scale
 
 
-@pytest.mark.parametrize("C,n", [(4, 64), (4, 32), (8, 16), (8, 8), (4, 2), (12, 4), (16, 1), (12, 2), (16, 2), (16, 4)])
+@pytest.mark.parametrize("C,n", [(4, 64), (4, 32), (8, 16), (8, 8), (4, 2), (12, 4), (16, 1), (12, 2), (16, 2), (16, 4), (12, 8)])
 def test_linattn_fwd_prepared_equals_standalone(N, C, n):
     """dq_linattn_prepare + dq_linattn_fwd_prepared (the network's path: derived weights and the split-bf16 / fp32 operand images formed once
     per parameter state) == dq_linattn_fwd (every workgroup derives them itself), bit for bit; and against the oracle.
-    Rows of 2 / 4 positions at 12 / 16 channels: the prepared path is another kernel (k_la_small: one group of registers per position, every
+    Rows of 2 / 4 positions at 12 / 16 channels and of 8 positions at 12: the prepared path is another kernel (k_la_small: one group of registers per position, every
     product on the 32x32x2 matrix pipe) -- same fp32 tolerance against the oracle, and against the stand-alone kernel instead of bit equality."""
     from oracle import dq_oracle as O
 
@@ -73,7 +73,7 @@ def test_linattn_fwd_prepared_equals_standalone(N, C, n):
     N.check(L.dq_linattn_prepare(args[0], args[1], args[3], C, N.ptr(prep), N.stream_ptr()), "dq_linattn_prepare")
     N.check(L.dq_linattn_fwd_prepared(N.ptr(xd), N.ptr(y1), None, *args, N.ptr(prep), C, rows, n, N.stream_ptr()), "dq_linattn_fwd_prepared")
     torch.cuda.synchronize()
-    if n in (2, 4) and C in (12, 16):
+    if (n in (2, 4) and C in (12, 16)) or (n == 8 and C == 12):
         assert rel_err(y1, y0.cpu()) < 1e-5
     else:
         assert torch.equal(y0, y1)
