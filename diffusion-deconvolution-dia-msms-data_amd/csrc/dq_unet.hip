@@ -507,6 +507,23 @@ int la_flush(const Ctx& c) {
   return 0;
 }
 
+// The slot reductions collected so far as ONE side-stream item (unet_backward, in front of the last two levels of the down path): every layer
+// reduces into its own parameters' gradients, the slots are final when the item is queued, and the side queue has room there -- at the end of
+// the pass the reduce of all fourteen layers stood on the main queue in front of the join (~22 us + k_linattn_dwvo); the two levels that are
+// left take a third of that.  The slot cursor keeps running (every layer has its own reservation), so nothing the queued reduce reads is reused.
+int la_flush_side(const Ctx& c) {
+  Ctx::LaDefer* d = c.la_defer;
+  static const bool off = [] { const char* e = std::getenv("DQ_NO_LA_FLUSH_SIDE"); return e && e[0] == '1'; }();  // A-B switch
+  if (off || !d || d->count == 0 || !c.owner || !c.side_defer || !tail_fork_enabled()) return 0;
+  std::vector<LaReduceItem> items(d->items, d->items + d->count);
+  Ctx::SideItem it{};
+  it.kind = 3;
+  it.fn = [items](hipStream_t ss) { return launch_linattn_dw_reduce_multi(items.data(), (int)items.size(), ss); };
+  c.side_defer->push_back(it);
+  d->count = 0;
+  return 0;
+}
+
 int la_bwd(const Ctx& c, const LAP& l, const LevelBuf& b, const float* x, const float* dy, float* dx, int rows, int n, int slot = -1) {
   LinAttnBwd a;
   a.ypre = c.w(b.la_pre); a.dyp = c.g(b.la_pre); a.dxh = c.g(b.la_tmp);
@@ -1223,6 +1240,23 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     // r1's run under r0's data path instead of behind it)
     if (lv == 0) DQ_TRY(side_flush(c));
     DQ_TRY(res_bwd(c, l.r0, b.r0, c.w(in_off), c.g(in_off), C, nullptr, nullptr, 0, R, l.n, RT, lv > 0 ? 1 : 0, 0));  // (d h0 has the final block's part already)
+    if (lv == 2 && p.mz <= 64) {  // (short rows only: the sweep kernels of longer rows use the whole slot buffer per layer)
+      DQ_TRY(la_flush_side(c));
+      // the ResnetBlock / resample-conv slot reductions collected so far ride along (every block has its own slots and its own parameters)
+      static const bool wg_off = [] { const char* e = std::getenv("DQ_NO_LA_FLUSH_SIDE"); return e && e[0] == '1'; }();
+      if (!wg_off && c.owner && c.side_defer && tail_fork_enabled() && !wg_items.empty()) {
+        std::vector<ResWgReduce> part(wg_items);
+        Ctx::SideItem it{};
+        it.kind = 3;
+        it.fn = [part](hipStream_t ss) {
+          for (size_t i = 0; i < part.size(); i += RES_WG_REDUCE_MAX)
+            if (int rc = launch_res_wg_reduce(part.data() + i, (int)std::min<size_t>(RES_WG_REDUCE_MAX, part.size() - i), ss)) return rc;
+          return 0;
+        };
+        side_items.push_back(it);
+        wg_items.clear();
+      }
+    }
     if (side_flush_here(lv)) DQ_TRY(side_flush(c));
   }
   // init conv + mixture conditioning: d h0 is final here and only d(scale, shift) of init_cond_proj (read by the time-embedding backward
