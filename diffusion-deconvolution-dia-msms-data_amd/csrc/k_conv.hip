@@ -622,7 +622,7 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(ConvWgrad a, int n_cib, int 
 
 template <int COB, int CIB, int K>
 __device__ __forceinline__ void wgrad_body_v4(const ConvWgrad& a, int n_cib, int nelem_w, int gx, int by) {
-  static_assert(K == 1 || K == 3, "vectorised weight gradient: K = 1 or 3");
+  static_assert(K == 1 || K == 3 || K == 7, "vectorised weight gradient: K = 1, 3 or 7");
   constexpr int H = (K - 1) / 2;
   const int cin = a.cinA + a.cinB;
   const int co0 = (by / n_cib) * COB, ci0 = (by % n_cib) * CIB;
@@ -657,9 +657,11 @@ __device__ __forceinline__ void wgrad_body_v4(const ConvWgrad& a, int n_cib, int
       const float4 xm = *reinterpret_cast<const float4*>(src + p);
       float win[4 + 2 * H];
       win[H + 0] = xm.x; win[H + 1] = xm.y; win[H + 2] = xm.z; win[H + 3] = xm.w;
-      if (H) {
-        win[0] = p > 0 ? src[p - 1] : 0.f;
-        win[4 + H] = p + 4 < n ? src[p + 4] : 0.f;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {  // the halo: H positions either side (zero padding at the row ends)
+        const int ql = p - H + h, qr = p + 4 + h;
+        win[h] = ql >= 0 ? src[ql] : 0.f;
+        win[4 + H + h] = qr < n ? src[qr] : 0.f;
       }
 #pragma unroll
       for (int k = 0; k < K; ++k)
@@ -812,13 +814,16 @@ int launch_conv_wgrad(const ConvWgrad& a, hipStream_t s) {
   const int n_cob = cdiv(a.cout, COB), n_cib = cdiv(cin, CIB);
   const int nelem_w = a.cout * cin * a.K;
   // <= WGRAD_MAX_PARTS partial blocks per element; ~4 items per thread, ~2048 blocks in flight where the problem allows it
-  const bool vec4 = a.mode == CONV_S1 && (a.K == 1 || a.K == 3) && a.n_out % 4 == 0 && a.n_in == a.n_out;
+  // (K = 7 -- init_conv and the first MS1 conv -- joined in round 4: as one position per thread and step the init_conv launch was six dependent
+  // memory round trips per thread, 25 us at the tail of the side queue, which the end of the backward waits for)
+  const bool vec4 = a.mode == CONV_S1 && (a.K == 1 || a.K == 3 || a.K == 7) && a.n_out % 4 == 0 && a.n_in == a.n_out;
   const int gx = std::max(1, std::min({cdiv(total, 256 * (vec4 ? 8 : 4)), WGRAD_MAX_PARTS, std::max(1, wgrad_blocks() / (n_cob * n_cib))}));
   DQ_REQUIRE((int64_t)gx * (nelem_w + a.cout) <= a.scratch_floats, "conv_wgrad: scratch too small");
   dim3 grid(gx, n_cob * n_cib), block(256);
   if (vec4) {
     if (a.K == 1) hipLaunchKernelGGL((k_conv_wgrad_v4<COB, CIB, 1>), grid, block, 0, s, a, n_cib, nelem_w);
-    else hipLaunchKernelGGL((k_conv_wgrad_v4<COB, CIB, 3>), grid, block, 0, s, a, n_cib, nelem_w);
+    else if (a.K == 3) hipLaunchKernelGGL((k_conv_wgrad_v4<COB, CIB, 3>), grid, block, 0, s, a, n_cib, nelem_w);
+    else hipLaunchKernelGGL((k_conv_wgrad_v4<COB, CIB, 7>), grid, block, 0, s, a, n_cib, nelem_w);
     DQ_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(nelem_w + a.cout, 16)), dim3(256), 0, s, a.scratch, gx, nelem_w, a.cout, a.dw, a.dbias);
     DQ_LAUNCH_CHECK();
