@@ -253,6 +253,16 @@ __global__ void __launch_bounds__(256) k_res_bwd_cp(ResBwd a) {
   const int64_t obase = ((int64_t)row * C + ch) * N;
   const int64_t oload = ((int64_t)row * C + (ch < C ? ch : 0)) * N;  // (loads of the padding lanes)
 
+  // Every per-lane input of the launch is requested HERE, in front of the weight staging: d out, u2, u1, the gains and this sample's scale /
+  // shift.  Read where they are used (behind the first and the second barrier) they were two more memory round trips in series per launch --
+  // and a launch is one short dependent chain per workgroup (10 of them per train step at the deep levels).
+  float dvp[N], u2p[N], u1p[N];
+#pragma unroll
+  for (int p = 0; p < N; ++p) { dvp[p] = a.dout[oload + p]; u2p[p] = a.u2[oload + p]; u1p[p] = a.u1[oload + p]; }
+  const int chc = ch < C ? ch : 0;
+  const float g2p = a.g2[chc], g1p = a.g1[chc];
+  const float scp = (a.ss + (int64_t)b * a.ss_stride)[chc], shp = (a.ss + (int64_t)b * a.ss_stride)[C + chc];
+  __builtin_amdgcn_sched_barrier(0);
   stage_wt<3>(w2t, a.w2, C, C);
   stage_wt<3>(w1t, a.w1, C, cin);
   if (a.wr) stage_wt<1>(wrt, a.wr, C, cin);
@@ -263,10 +273,10 @@ __global__ void __launch_bounds__(256) k_res_bwd_cp(ResBwd a) {
   // ---- block2: dU2 = norm/act backward of d out (this lane's channel)
   float dout[N], d2[N];
   {
-    const float g2 = ch < C ? a.g2[ch] : 0.f;
+    const float g2 = ch < C ? g2p : 0.f;
 #pragma unroll
     for (int p = 0; p < N; ++p) {
-      const float dv = a.dout[oload + p], uv = a.u2[oload + p];  // (not predicated: padding lanes re-read channel 0 / row 0 and are zeroed)
+      const float dv = dvp[p], uv = u2p[p];  // (not predicated: padding lanes re-read channel 0 / row 0 and are zeroed)
       dout[p] = act ? dv : 0.f;
       const float u = act ? uv : 0.f;
       float z0 = 0.f, z1 = 0.f;
@@ -302,12 +312,11 @@ __global__ void __launch_bounds__(256) k_res_bwd_cp(ResBwd a) {
   }
   // ---- block1: dU1
   {
-    const float g1 = ch < C ? a.g1[ch] : 0.f;
-    const float* ss = a.ss + (int64_t)b * a.ss_stride;
-    const float sc = ch < C ? ss[ch] + 1.0f : 0.f, sh = ch < C ? ss[C + ch] : 0.f;
+    const float g1 = ch < C ? g1p : 0.f;
+    const float sc = ch < C ? scp + 1.0f : 0.f, sh = ch < C ? shp : 0.f;
 #pragma unroll
     for (int p = 0; p < N; ++p) {
-      const float uv = a.u1[oload + p];
+      const float uv = u1p[p];
       const float u = act ? uv : 0.f;
       da1[p] = norm_act_bwd_cp<C, true>(u, da1[p], g1, sc, sh, act, dg1, dsc, dsh);
       if (!act) da1[p] = 0.f;
