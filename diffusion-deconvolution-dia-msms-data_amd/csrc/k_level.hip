@@ -278,10 +278,10 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
       for (int c = 0; c < C; ++c) xb[bi][c] = 0.f;
       if (bi < a.nblocks && r.cinB > 0) {  // ONE wave-uniform branch around the group; inside it no load is predicated (channels beyond cinB re-read channel 0)
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-          const float v = ld(r.inB, c < r.cinB ? c : 0, boff);
-          xb[bi][c] = c < r.cinB ? v : 0.f;
-        }
+        for (int c = 0; c < C; ++c) xb[bi][c] = ld(r.inB, c < r.cinB ? c : 0, boff);
+        // (NO masking here: the consumers below take whole quads of channels under `4 * cq < cinB`, so a value beyond cinB is never used -- and
+        // `c < cinB ? v : 0` was a USE of every loaded value right behind its load: eleven s_waitcnt in a row in the middle of the tile, one
+        // full memory latency per tile with block 1's skip channels supposedly "travelling while block 0 computes" (ISA, round 4))
       }
     };
     // ---------------------------------------------------------------- input stage
