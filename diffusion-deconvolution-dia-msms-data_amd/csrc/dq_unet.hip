@@ -960,6 +960,7 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
   if (fwd_fork) { DQ_TRY(fork_side(c)); ps = c.owner->side_stream; }
   if (!(c.step_io && c.step_io->prepared)) {
     DQ_TRY(la_prepare_all(c, ps));
+    if (fwd_fork) { DQ_TRY(side_mark(c, &ev_prep)); wait_prep = true; }  // (level 0's LinearAttention waits for THIS; the tiny images below are needed five levels later: ev_rest)
     LevelFwd calls[LEVEL_IMG_MAX];
     int nc = 0;
     for (int lv = 0; lv < L; ++lv)
@@ -981,7 +982,7 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     }
   }
   if (c.prepare_only) return 0;
-  if (fwd_fork) { DQ_TRY(side_mark(c, &ev_prep)); wait_prep = true; }
+  if (fwd_fork && !wait_prep) { DQ_TRY(side_mark(c, &ev_prep)); wait_prep = true; }  // (a prepared sampling loop does not come here with a fork)
   // K1: time embedding + every scale/shift head (unet1d.py:1105, 315-318, 677)
   DQ_TRY(launch_time_embed_fwd(p, dt, c.P, t, t_scalar, c.w(a.tbuf), c.w(a.ss), B, step_tab, step_ptr, c.s));
   // K2: mixture conditioning + concat (unet1d.py:1107-1115), then init_conv k7 (:1117)
@@ -1019,6 +1020,7 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     const LevelCall lc = down_call(lv);
     bool la_done = false;
     if (is_tiny_dn(lv)) {
+      if (wait_rest) { DQ_HIP_OK(hipStreamWaitEvent(c.s, ev_rest, 0)); wait_rest = false; c.owner->side_used = false; }  // (its operand image came from the side stream)
       TinyFwd t = tiny_down(lv);
       t.img = tiny_img(tiny_dn[lv]);
       DQ_TRY(launch_tiny_fwd(t, c.s));
