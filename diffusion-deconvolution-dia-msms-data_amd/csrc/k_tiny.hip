@@ -914,9 +914,13 @@ int launch_tiny_fwd(const TinyFwd& t, hipStream_t s) {
 }
 
 
+static int tiny_bwd_gx(const TinyBwd& t);
 bool tiny_bwd_usable(const TinyBwd& t) {
   if (!tiny_enabled() || !tiny_bwd_enabled()) return false;
-  if (t.C != 16 || t.rows_per_sample <= 1 || !t.params) return false;
+  if (t.C != 16 || t.rows_per_sample <= 1 || !t.params || t.rows <= 0 || t.rows % t.rows_per_sample) return false;
+  // one LinearAttention slot per workgroup: a layer's reservation (la_part_reserve: 1024 slots at 16 channels) must hold them -- batches
+  // beyond ~1000 samples keep the per-kernel backward
+  if ((int64_t)tiny_bwd_gx(t) * (t.rows / t.rows_per_sample) > 1000) return false;
   if (t.pre == LEVEL_PRE_DOWN) return t.cp == 12 && t.cs == 0;
   if (t.pre == LEVEL_PRE_NONE) return t.cs == 16;
   return false;

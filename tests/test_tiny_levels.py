@@ -27,9 +27,9 @@ with torch.no_grad():
         p.add_(torch.randn_like(p) * 0.05)  # biases / gains off their initial 0 / 1
 dm = DDIMDiffusionModel(model_class=net, device="cuda")
 g = torch.Generator().manual_seed(11)
-B, RT, MZ = 3, 70, 64
+B, RT, MZ = (int(sys.argv[3]), int(sys.argv[4]), 64) if len(sys.argv) > 4 else (3, 70, 64)
 x0 = torch.rand(B, RT, MZ, generator=g).cuda(); c2 = torch.rand(B, RT, MZ, generator=g).cuda(); c1 = torch.rand(B, RT, generator=g).cuda()
-t = torch.tensor([999, 417, 3], dtype=torch.long).cuda(); noise = torch.randn(B, RT, MZ, generator=g).cuda()
+t = torch.tensor([999, 417, 3] * ((B + 2) // 3), dtype=torch.long)[:B].cuda(); noise = torch.randn(B, RT, MZ, generator=g).cuda()
 with torch.no_grad():
     eps = net(dm.q_sample(dm.normalize(x0), t, noise), t, dm.normalize(c2), dm.normalize(c1))
 loss = dm.train_step_fused(x0, c2, c1, t=t, noise=noise, zero_grads=True)
@@ -39,12 +39,12 @@ np.savez(sys.argv[2], eps=eps.cpu().numpy(), loss=float(loss), grads=net.flat_gr
 """
 
 
-def _run(tmp_path, tag, env):
+def _run(tmp_path, tag, env, shape=()):
     out = str(tmp_path / f"{tag}.npz")
     e = dict(os.environ)
     e.update(env)
     e.setdefault("DQ_LA_SMALL_MIN_ROWS", "0")
-    r = subprocess.run([sys.executable, "-c", CHILD, os.path.join(REPO, "diffusion-deconvolution-dia-msms-data_amd"), out], env=e, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", CHILD, os.path.join(REPO, "diffusion-deconvolution-dia-msms-data_amd"), out] + [str(v) for v in shape], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     return dict(np.load(out))
 
@@ -69,3 +69,12 @@ def test_side_stream_schedule_is_bitwise_neutral(tmp_path):
     b = _run(tmp_path, "chain", {"DQ_NO_FWD_FORK": "1", "DQ_NO_TAIL_FORK": "1"})
     assert a["loss"] == b["loss"]
     assert np.array_equal(a["grads"], b["grads"]) and np.array_equal(a["eps"], b["eps"])
+
+
+def test_large_batch_keeps_the_per_kernel_backward(tmp_path):
+    """More samples than a LinearAttention layer's slot reservation holds workgroups of the tiny backward (one slot each): the launch is declined
+    and the per-kernel backward runs -- same loss, gradients within the fp32 tolerance of the small-batch comparison."""
+    new = _run(tmp_path, "big_new", {}, shape=(1100, 4))
+    old = _run(tmp_path, "big_old", {"DQ_NO_TINY_BWD": "1"}, shape=(1100, 4))
+    assert abs(new["loss"] - old["loss"]) < 2e-6 * abs(old["loss"])
+    assert _rel(new["grads"], old["grads"]) < 1e-4
