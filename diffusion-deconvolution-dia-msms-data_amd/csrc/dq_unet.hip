@@ -1303,7 +1303,11 @@ int ensure_side(dq_plan* pl) {
     // the weight-gradient kernels behind the main chain (measured: 15.7 vs 13.0 ms/step under torch.distributed.run).
     int prio_least = 0, prio_greatest = 0;
     DQ_HIP_OK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    static const bool low = [] { const char* e = std::getenv("DQ_SIDE_PRIO"); return e && e[0] == 'l'; }();  // A-B switch
+    // LOWEST priority since round 4: the side queue carries what the main chain does not wait for, so it should fill the main queue's gaps, not take
+    // compute units from it (three same-call pairs at batch 32: 3.695 / 3.681 / 3.679 ms against 3.697 / 3.696 / 3.954 with the highest priority, whose
+    // occasional slow run is the side queue's kernels winning the arbitration against a resident-round grid of the main chain).  Either class is a
+    // queue of its own.  DQ_SIDE_PRIO=h: the old setting (A-B switch).
+    static const bool low = [] { const char* e = std::getenv("DQ_SIDE_PRIO"); return !(e && e[0] == 'h'); }();
     DQ_HIP_OK(hipStreamCreateWithPriority(&pl->side_stream, hipStreamNonBlocking, low ? prio_least : prio_greatest));
     for (auto& e : pl->events) DQ_HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   return 0;
