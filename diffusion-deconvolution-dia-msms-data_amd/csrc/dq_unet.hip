@@ -1242,6 +1242,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     // r1's run under r0's data path instead of behind it)
     if (lv == 0) DQ_TRY(side_flush(c));
     DQ_TRY(res_bwd(c, l.r0, b.r0, c.w(in_off), c.g(in_off), C, nullptr, nullptr, 0, R, l.n, RT, lv > 0 ? 1 : 0, 0));  // (d h0 has the final block's part already)
+    // (a second early flush in front of the last level measured neutral at batch 32 and +25 us at batch 1 / 4, where the host's launch count is the limit)
     if (lv == 2 && p.mz <= 64) {  // (short rows only: the sweep kernels of longer rows use the whole slot buffer per layer)
       DQ_TRY(la_flush_side(c));
       // the ResnetBlock / resample-conv slot reductions collected so far ride along (every block has its own slots and its own parameters)
