@@ -1193,11 +1193,11 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
       DQ_TRY(conv_plain_bwd(c, proj(p.qv_w, 2 * HID, p.mid_c), CONV_S1, c.w(a.xn), c.g(a.qv), c.g(a.xn), B, RT, RT, 0, ws_ok));
       // PreNorm backward: xn = rmsnorm(mid1.out) * g  (pointwise kernel, no scale/shift, no activation)
       BlockBwd nb;
-      nb.u = c.w(a.mid1.out); nb.dy = c.g(a.xn); nb.du = c.g(a.xn); nb.C = p.mid_c; nb.rows = B; nb.n = RT; nb.rows_per_sample = 1;
+      // (du accumulates straight into d mid1.out -- the residual branch's gradient is there already: was a separate k_axpy launch behind this one)
+      nb.u = c.w(a.mid1.out); nb.dy = c.g(a.xn); nb.du = c.g(a.mid1.out); nb.accumulate = 1; nb.C = p.mid_c; nb.rows = B; nb.n = RT; nb.rows_per_sample = 1;
       nb.g = c.prm(p.ag); nb.dg = c.dprm(p.ag);
       nb.part = c.w(a.bb_part); nb.part_floats = a.bb_part_floats;
       DQ_TRY(launch_block_bwd(nb, c.s));
-      DQ_TRY(launch_axpy(c.g(a.mid1.out), c.g(a.xn), (int64_t)R * p.mid_c, c.s));
     }
     DQ_TRY(res_bwd(c, p.mid1, a.mid1, c.w(a.mid_in), c.g(a.mid_in), p.mid_c, nullptr, nullptr, 0, B, RT, 1));
     if (!use_tb_dn) DQ_TRY(launch_fold(c.g(a.mid_in), c.g(a.downs[L - 1].rs), B, RT, p.mid_c, 0, 0, c.s));  // first and only writer: store (the tiny backward reads d mid_in itself)
