@@ -75,6 +75,7 @@ struct BlockBwd {
   // per-block partial sums [dg | dscale | dshift | dbias] (needed when any of dg / dss / dbias is set): >= 64 * groups * 4 C
   // floats; the launcher sums them in block order right behind the kernel (no float atomics: repeatable to the bit)
   float* part = nullptr; int64_t part_floats = 0;
+  struct PartReduce* defer_reduce = nullptr;  // nullable: the launcher hands the reduction of `part` back instead of launching it (the caller runs it, e.g. on a side stream)
 };
 int launch_block_bwd(const BlockBwd& a, hipStream_t s);
 

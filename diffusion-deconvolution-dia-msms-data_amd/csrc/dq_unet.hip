@@ -1197,7 +1197,17 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
       nb.u = c.w(a.mid1.out); nb.dy = c.g(a.xn); nb.du = c.g(a.mid1.out); nb.accumulate = 1; nb.C = p.mid_c; nb.rows = B; nb.n = RT; nb.rows_per_sample = 1;
       nb.g = c.prm(p.ag); nb.dg = c.dprm(p.ag);
       nb.part = c.w(a.bb_part); nb.part_floats = a.bb_part_floats;
+      // (the gain's slot reduction feeds nothing on the chain: with the next side-stream flush; the slot's other user, the input-affine backward
+      // at the end of the pass, runs on the same stream behind it)
+      PartReduce gred;
+      const bool defer = c.owner && c.side_defer && !grad_x && tail_fork_enabled();
+      if (defer) nb.defer_reduce = &gred;
       DQ_TRY(launch_block_bwd(nb, c.s));
+      if (defer && gred.part) {
+        Ctx::SideItem it{};
+        it.kind = 3; it.fn = [gred](hipStream_t ss) { return launch_part_reduce(gred, ss); };  // (kind 3: behind the flush's fork event whatever precedes it)
+        c.side_defer->push_back(it);
+      }
     }
     DQ_TRY(res_bwd(c, p.mid1, a.mid1, c.w(a.mid_in), c.g(a.mid_in), p.mid_c, nullptr, nullptr, 0, B, RT, 1));
     if (!use_tb_dn) DQ_TRY(launch_fold(c.g(a.mid_in), c.g(a.downs[L - 1].rs), B, RT, p.mid_c, 0, 0, c.s));  // first and only writer: store (the tiny backward reads d mid_in itself)

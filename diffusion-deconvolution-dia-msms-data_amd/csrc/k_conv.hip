@@ -385,6 +385,7 @@ int launch_block_bwd(const BlockBwd& a, hipStream_t s) {
   if (a.dg) { r.seg_start[r.nseg] = 0; r.seg_len[r.nseg] = a.C; r.seg_dst[r.nseg] = a.dg; ++r.nseg; }
   if (a.dbias) { r.seg_start[r.nseg] = 3 * a.C; r.seg_len[r.nseg] = a.C; r.seg_dst[r.nseg] = a.dbias; ++r.nseg; }
   if (a.dss) { r.s0 = a.C; r.sn = 2 * a.C; r.sdst = a.dss; r.sstride = a.ss_stride; }
+  if (a.defer_reduce) { *a.defer_reduce = r; return 0; }
   return launch_part_reduce(r, s);
 }
 
