@@ -72,6 +72,7 @@ struct BlockBwd {
   int act = ACT_NONE;
   float* dbias = nullptr;  // optional: sum of du over rows and positions (+=)
   int accumulate = 0;      // 1: du += instead of du =
+  const float* add_src = nullptr;  // accumulate: the addend is read from HERE instead of du (du = add_src + d; du itself is only written)
   // per-block partial sums [dg | dscale | dshift | dbias] (needed when any of dg / dss / dbias is set): >= 64 * groups * 4 C
   // floats; the launcher sums them in block order right behind the kernel (no float atomics: repeatable to the bit)
   float* part = nullptr; int64_t part_floats = 0;

@@ -1183,7 +1183,8 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
       ao.b = p.ao_b;
       const int ws_ok = (int)(p.downs.size() + p.ups.size()) <= LA_PREP_MAX ? 0 : -3;  // aligned weight slots as the forward of this step filled them (0: q|v, 1: k, 2: to_out)
       DQ_TRY(conv_plain_bwd(c, ao, CONV_S1, c.w(a.o), c.g(a.attn_out), c.g(a.o), B, RT, RT, 0, ws_ok + 2));
-      DQ_TRY(launch_axpy(c.g(a.mid1.out), c.g(a.attn_out), (int64_t)R * p.mid_c, c.s));
+      // (d mid1.out = d attn_out [the residual] + the PreNorm path: formed by the PreNorm backward below, which reads d attn_out as its addend --
+      // was a k_axpy launch here plus one behind that kernel)
       DQ_TRY(launch_attn_bwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.g(a.o), c.w(a.lse), c.w(a.delta),
                              c.g(a.qv), qvbs, c.g(a.kk), kbs, c.g(a.qv) + kbs, qvbs, B, RT, c.s));
       if (rope) {
@@ -1194,7 +1195,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
       // PreNorm backward: xn = rmsnorm(mid1.out) * g  (pointwise kernel, no scale/shift, no activation)
       BlockBwd nb;
       // (du accumulates straight into d mid1.out -- the residual branch's gradient is there already: was a separate k_axpy launch behind this one)
-      nb.u = c.w(a.mid1.out); nb.dy = c.g(a.xn); nb.du = c.g(a.mid1.out); nb.accumulate = 1; nb.C = p.mid_c; nb.rows = B; nb.n = RT; nb.rows_per_sample = 1;
+      nb.u = c.w(a.mid1.out); nb.dy = c.g(a.xn); nb.du = c.g(a.mid1.out); nb.accumulate = 1; nb.add_src = c.g(a.attn_out); nb.C = p.mid_c; nb.rows = B; nb.n = RT; nb.rows_per_sample = 1;
       nb.g = c.prm(p.ag); nb.dg = c.dprm(p.ag);
       nb.part = c.w(a.bb_part); nb.part_floats = a.bb_part_floats;
       // (the gain's slot reduction feeds nothing on the chain: with the next side-stream flush; the slot's other user, the input-affine backward

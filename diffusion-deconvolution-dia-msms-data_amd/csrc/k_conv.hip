@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(256) k_block_bwd(BlockBwd a) {
     }
     float oldv[C];  // an accumulating launch reads all C old values before its first store
 #pragma unroll
-    for (int c = 0; c < C; ++c) oldv[c] = a.accumulate ? a.du[base + (int64_t)c * a.n] : 0.f;
+    for (int c = 0; c < C; ++c) oldv[c] = a.accumulate ? (a.add_src ? a.add_src : a.du)[base + (int64_t)c * a.n] : 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       dbs[c] += d[c];
