@@ -633,12 +633,14 @@ int conv_plain_fwd(const Ctx& c, const ConvP& cp, int mode, const float* in, flo
 }
 
 int conv_plain_bwd(const Ctx& c, const ConvP& cp, int mode, const float* in, const float* dout, float* din, int rows, int n_in,
-                   int n_out, int accumulate, int wslot = -1) {
-  ConvWgrad wg;
-  wg.scratch = c.w(c.ar.wg); wg.scratch_floats = c.ar.wg_floats;
-  wg.du = dout; wg.inA = in; wg.cinA = cp.cin; wg.cout = cp.cout; wg.K = cp.k; wg.mode = mode; wg.rows = rows; wg.n_in = n_in;
-  wg.n_out = n_out; wg.dw = c.dprm(cp.w); wg.dbias = cp.b >= 0 ? c.dprm(cp.b) : nullptr;
-  DQ_TRY(wgrad_async(c, wg));
+                   int n_out, int accumulate, int wslot = -1, bool with_wgrad = true) {
+  if (with_wgrad) {
+    ConvWgrad wg;
+    wg.scratch = c.w(c.ar.wg); wg.scratch_floats = c.ar.wg_floats;
+    wg.du = dout; wg.inA = in; wg.cinA = cp.cin; wg.cout = cp.cout; wg.K = cp.k; wg.mode = mode; wg.rows = rows; wg.n_in = n_in;
+    wg.n_out = n_out; wg.dw = c.dprm(cp.w); wg.dbias = cp.b >= 0 ? c.dprm(cp.b) : nullptr;
+    DQ_TRY(wgrad_async(c, wg));
+  }
   ConvP nobias = cp;
   nobias.b = -1;  // (a bias does not enter the DATA gradient: to_out's ran on the generic kernel because of it, 32 us against ~6 us on the GEMM)
   if (din && conv_is_gemm(c, nobias, mode, n_in, n_out) && (wslot >= 0 || ((uintptr_t)c.prm(cp.w) & 15) == 0)) {  // dX_b (cin x n) (+)= W^T (cin x cout) dY_b (cout x n)
@@ -1143,6 +1145,21 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
   // only the accumulated-into region of the twin (offsets are multiples of 64 floats); a forked forward of the same step cleared it already
   if (c.owner && c.owner->twin_zeroed == c.G) c.owner->twin_zeroed = nullptr;
   else DQ_TRY(launch_zero(c.G, a.zero_floats, c.s));
+  // the ResnetBlock / resample-conv slot reductions collected so far as one side-stream item
+  auto wg_to_side = [&c, &wg_items, &side_items]() {
+    static const bool wg_off = [] { const char* e = std::getenv("DQ_NO_LA_FLUSH_SIDE"); return e && e[0] == '1'; }();
+    if (wg_off || !c.owner || !c.side_defer || !tail_fork_enabled() || wg_items.empty()) return;
+    std::vector<ResWgReduce> part(wg_items);
+    Ctx::SideItem it{};
+    it.kind = 3;
+    it.fn = [part](hipStream_t ss) {
+      for (size_t i = 0; i < part.size(); i += RES_WG_REDUCE_MAX)
+        if (int rc = launch_res_wg_reduce(part.data() + i, (int)std::min<size_t>(RES_WG_REDUCE_MAX, part.size() - i), ss)) return rc;
+      return 0;
+    };
+    side_items.push_back(it);
+    wg_items.clear();
+  };
   // the two levels with rows of one position: their backward data path in one launch each (k_tiny.hip), when their forward ran there
   TinyBwd tb_up, tb_dn;
   const bool use_tb_up = tiny_bwd_desc(c, true, &tb_up), use_tb_dn = tiny_bwd_desc(c, false, &tb_dn);
@@ -1257,19 +1274,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     if (lv == 2 && p.mz <= 64) {  // (short rows only: the sweep kernels of longer rows use the whole slot buffer per layer)
       DQ_TRY(la_flush_side(c));
       // the ResnetBlock / resample-conv slot reductions collected so far ride along (every block has its own slots and its own parameters)
-      static const bool wg_off = [] { const char* e = std::getenv("DQ_NO_LA_FLUSH_SIDE"); return e && e[0] == '1'; }();
-      if (!wg_off && c.owner && c.side_defer && tail_fork_enabled() && !wg_items.empty()) {
-        std::vector<ResWgReduce> part(wg_items);
-        Ctx::SideItem it{};
-        it.kind = 3;
-        it.fn = [part](hipStream_t ss) {
-          for (size_t i = 0; i < part.size(); i += RES_WG_REDUCE_MAX)
-            if (int rc = launch_res_wg_reduce(part.data() + i, (int)std::min<size_t>(RES_WG_REDUCE_MAX, part.size() - i), ss)) return rc;
-          return 0;
-        };
-        side_items.push_back(it);
-        wg_items.clear();
-      }
+      wg_to_side();
     }
     if (side_flush_here(lv)) DQ_TRY(side_flush(c));
   }
@@ -1281,6 +1286,31 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     return launch_prep_inputs_bwd(cc.g(a.cat0), init_cond, cm, ca, cc.g(a.ss), p.ss_total, p.ss_init, B, RT, p.mz, cc.w(a.bb_part),
                                   a.bb_part_floats, cc.s);
   };
+  static const bool tail_swap = [] { const char* e = std::getenv("DQ_NO_TAIL_SWAP"); return !(e && e[0] == '1'); }();  // A-B switch
+  if (tail_swap && c.owner && c.side_defer && !grad_x && tail_fork_enabled()) {
+    // The chain that ends the pass is  d h0 -> d cat0 (init conv, data) -> d(scale, shift) of init_cond_proj -> time-embedding backward -> norm -> update;
+    // the LinearAttention slot reductions and the init conv's weight gradient only have to be there for the norm.  So the MAIN queue runs that chain and
+    // the side queue those (they stood on the main queue in front of the join, the chain's first half on the side queue behind the
+    // weight gradient: the main queue idled ~50 us in front of the time-embedding backward).  That backward needs the side queue only up to
+    // HERE (the per-sample scale / shift sums of the ResnetBlocks): one event marks the place.
+    DQ_TRY(side_flush(c));
+    hipEvent_t ev_ss = nullptr;
+    if (c.owner->side_used) DQ_TRY(side_mark(c, &ev_ss));
+    DQ_TRY(conv_plain_bwd(c, p.init_conv, CONV_S1, c.w(a.cat0), c.g(a.h0), nullptr, R, p.mz, p.mz, 0));  // (weight gradient only: queued)
+    DQ_TRY(la_flush_side(c));
+    DQ_TRY(side_flush(c));
+    // (the ResnetBlock slot reduce stays on this queue: it also forms those blocks' per-sample d(scale, shift), which the time-embedding backward reads)
+    DQ_TRY(conv_plain_bwd(c, p.init_conv, CONV_S1, c.w(a.cat0), c.g(a.h0), c.g(a.cat0), R, p.mz, p.mz, 0, -1, false));
+    // (the wait stands in front of the input affine's backward already: its partial-sum scratch is the PreNorm backward's, whose reduce is on the side queue)
+    if (ev_ss) DQ_HIP_OK(hipStreamWaitEvent(c.s, ev_ss, 0));
+    DQ_TRY(launch_prep_inputs_bwd(c.g(a.cat0), init_cond, cm, ca, c.g(a.ss), p.ss_total, p.ss_init, B, RT, p.mz, c.w(a.bb_part), a.bb_part_floats,
+                                  c.s));
+    DQ_TRY(la_flush(c));  // (nothing left unless DQ_NO_LA_FLUSH_SIDE)
+    for (size_t i = 0; i < wg_items.size(); i += RES_WG_REDUCE_MAX)
+      DQ_TRY(launch_res_wg_reduce(wg_items.data() + i, (int)std::min<size_t>(RES_WG_REDUCE_MAX, wg_items.size() - i), c.s));
+    DQ_TRY(launch_time_embed_bwd(p, dt, c.P, c.dP, c.w(a.tbuf), c.g(a.ss), B, c.s));
+    return join_side(c);
+  }
   if (c.owner && c.side_defer && !grad_x && tail_fork_enabled()) {
     Ctx sc = c;
     sc.owner = nullptr; sc.side_defer = nullptr;
