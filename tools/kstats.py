@@ -14,7 +14,7 @@ def group(n):
     return "other"
 calls = 0
 for r in rows:
-    n = re.sub(r"\(.*", "", r["Name"]).replace("void ", "").replace("dq::", "").replace("(anonymous namespace)::", "")
+    n = re.sub(r"\(.*", "", r["Name"].replace("(anonymous namespace)::", "")).replace("void ", "").replace("dq::", "")
     r["n"] = n
     g = group(n); t = float(r["TotalDurationNs"]); grp[g] = grp.get(g, [0, 0]); grp[g][0] += t; grp[g][1] += int(r["Calls"]); calls += int(r["Calls"])
 for r in rows[:a.top]:
