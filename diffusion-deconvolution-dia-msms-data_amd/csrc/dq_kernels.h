@@ -169,6 +169,12 @@ struct LevelFwd {
   // x_t set the DDIM update of model.py:265-289 into x_out (coef: [sa, sb, sap, sbp] rows; step_ptr nullable: row index on the device)
   const float* ew = nullptr; const float* eb = nullptr; float* eps_out = nullptr;
   const float* x_t = nullptr; float* x_out = nullptr; const float* coef = nullptr; const int* step_ptr = nullptr; int pred_x0 = 0;
+  // training head (with ew / eb; the block's output is still written): loss_z = the regression target (rows, n).  d = eps - z; the squared-error
+  // sums go to loss_part, one float per WAVE of the grid (*loss_parts_out receives their number: sum them in index order); grad_out (rows, n) =
+  // d * loss_gscale (= d loss / d eps) and dout (rows, 4, n) = ew[c] * grad_out (final_conv's backward data path): what k_conv_fwd<1,1,0>,
+  // k_mse_fwd_bwd and k_conv_bwd_data<4,1,0> did in three launches behind this one
+  const float* loss_z = nullptr; float* loss_part = nullptr; float* grad_out = nullptr; float* dout = nullptr; float loss_gscale = 0.f;
+  int* loss_parts_out = nullptr;
   int C = 0, rows = 0, n = 0, rows_per_sample = 1;
   // nullable: this launch's MFMA operand image (level_img_floats floats, 16-byte aligned) as launch_level_images built it from the SAME
   // parameter values -- the kernel's workgroups then copy it to LDS instead of gathering it from the parameter tensors themselves
@@ -176,6 +182,7 @@ struct LevelFwd {
 };
 bool level_fwd_usable(int C, int n, int rows_per_sample, int pre_mode, int cp, int nblocks, const ResFwd* blk);
 int launch_level_fwd(const LevelFwd& a, hipStream_t s);
+constexpr int LEVEL_LOSS_PARTS = 8192;     // floats behind LevelFwd::loss_part (one per wave of a resident round: 6 x 256 workgroups x 4)
 constexpr int LEVEL_IMG_MAX = 20;          // launches per launch_level_images call
 constexpr int LEVEL_IMG_FLOATS = 8192;     // upper bound of level_img_floats over the built instantiations (16 channels, 32-channel blocks)
 int64_t level_img_floats(const LevelFwd& a);

@@ -41,7 +41,7 @@ struct Arena {
   int64_t zero_floats = 0;  // prefix whose gradient twin must be zeroed before a backward (the accumulated-into tensors)
   int64_t tbuf, ss, cat0, ms1n, ms1_u, ms1_a, ms1f, h0;
   std::vector<LevelBuf> downs, ups;
-  int64_t mid_in, xn, qv, kk, o, lse, delta, attn_out, mid_back, eps, partials, loss, coef, xa, xb, wg, wg_floats, la_part, la_part_floats, ts_tab, step, c2_stage, c1_stage, wtmp, la_prep, wimg, timg, bb_part, bb_part_floats, ms1_scratch;
+  int64_t mid_in, xn, qv, kk, o, lse, delta, attn_out, mid_back, eps, partials, head_part, loss, coef, xa, xb, wg, wg_floats, la_part, la_part_floats, ts_tab, step, c2_stage, c1_stage, wtmp, la_prep, wimg, timg, bb_part, bb_part_floats, ms1_scratch;
   ResBuf mid1, mid2, fin;
   // wide bottleneck (Plan::wide_mid): P = RT padded to a multiple of 4; every tensor below is (B, channels, P)
   int P = 0;

@@ -139,6 +139,7 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
   a.xa = take_nz(R * p.mz);   // sampling ping-pong / train-step x_t
   a.xb = take_nz(R * p.mz);
   a.partials = take_nz(MSE_MAX_BLOCKS);
+  a.head_part = take_nz(LEVEL_LOSS_PARTS);  // per-wave squared-error sums of the training head (k_level_fwd)
   a.loss = take_nz(64);
   a.coef = take_nz(4 * 1024);  // DDIM coefficient table (<= 1024 steps)
   // (the wide bottleneck's weight gradients are GEMMs into the gradient buffer itself: no partial sums)
@@ -209,6 +210,10 @@ struct Ctx {
   // dq_train_step: the scalar loss (sum of the MSE kernel's partials) is needed by nobody on the gradient chain: it rides on the side stream
   struct LossSum { const float* partials = nullptr; int count = 0; float scale = 0.f; float* out = nullptr; };
   LossSum loss_sum;
+  // dq_train_step: final_conv, the squared error against `z` and the first two steps of the backward (d eps -> grad_out, d fin.out) ride in
+  // the final block's launch when it can take them (k_level_fwd's training head); `done` / `nparts` tell the caller
+  struct HeadLoss { const float* z = nullptr; float* grad_out = nullptr; float* part = nullptr; float gscale = 0.f; int nparts = 0; bool done = false; };
+  HeadLoss* head_loss = nullptr;
   float* w(int64_t off) const { return W + off; }
   float* g(int64_t off) const { return G + off; }
   const float* prm(int64_t off) const { return P + off; }
@@ -1106,8 +1111,18 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
   // head (unet1d.py:1160-1166)
   {
     LevelCall lh = up_call(L);
-    const bool head_fused = !c.save && p.dim == 4 && p.final_conv.cout == 1 && p.final_conv.cin == 4 && p.final_conv.k == 1 && p.final_conv.b >= 0 &&
-                            level_ok(c, lh);
+    const bool head_shape = p.dim == 4 && p.final_conv.cout == 1 && p.final_conv.cin == 4 && p.final_conv.k == 1 && p.final_conv.b >= 0 && level_ok(c, lh);
+    const bool head_fused = !c.save && head_shape;
+    if (c.save && c.head_loss && c.G && head_shape && lh.pre == LEVEL_PRE_S1 && lh.pc && lh.pc->cin == 4) {
+      // train step: final_conv, loss and d fin.out in the final block's launch (its output IS stored); built for the (4, k3 conv, 4) launch
+      lh.head = &p.final_conv; lh.eps_out = nullptr;
+      LevelFwd f = with_img(lh, 2 * L);
+      Ctx::HeadLoss& hl = *c.head_loss;
+      f.loss_z = hl.z; f.grad_out = hl.grad_out; f.dout = c.g(a.fin.out); f.loss_part = hl.part; f.loss_gscale = hl.gscale; f.loss_parts_out = &hl.nparts;
+      DQ_TRY(launch_level_fwd(f, c.s));
+      hl.done = true;
+      return 0;
+    }
     if (head_fused) {  // inference: final_conv (and, while sampling, the DDIM update) in the final block's launch; its output is not stored
       lh.head = &p.final_conv; lh.eps_out = out; lh.write_out[0] = false;
       if (c.step_io && c.step_io->x_t) c.step_io->fused_update = true;
@@ -1164,7 +1179,8 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
   TinyBwd tb_up, tb_dn;
   const bool use_tb_up = tiny_bwd_desc(c, true, &tb_up), use_tb_dn = tiny_bwd_desc(c, false, &tb_dn);
   // head
-  DQ_TRY(conv_plain_bwd(c, p.final_conv, CONV_S1, c.w(a.fin.out), grad_out, c.g(a.fin.out), R, p.mz, p.mz, 0));
+  // (d fin.out came with the forward's last launch when the training head ran: only the weight gradient is left)
+  DQ_TRY(conv_plain_bwd(c, p.final_conv, CONV_S1, c.w(a.fin.out), grad_out, (c.head_loss && c.head_loss->done) ? nullptr : c.g(a.fin.out), R, p.mz, p.mz, 0));
   const LevelBuf& lastup = a.ups[L - 1];
   DQ_TRY(res_bwd(c, p.fin, a.fin, c.w(lastup.rs), c.g(lastup.rs), p.dim, c.w(a.h0), c.g(a.h0), p.dim, R, p.mz, RT, 1, 1));  // first writers of d rs, d h0
   // up path, reversed
@@ -1622,9 +1638,17 @@ int dq_train_step(dq_plan* plan, const float* params, const float* rope_freqs, c
   const int64_t per = (int64_t)RT * plan->plan.mz;
   const float cm = auto_normalize ? 2.f : 1.f, ca = auto_normalize ? -1.f : 0.f;
   DQ_TRY(launch_q_sample(alpha_bars_dev, x0, t, noise, c.w(a.xa), B, per, auto_normalize, s));               // model.py:349-352
+  static const bool head_loss_on = [] { const char* e = std::getenv("DQ_NO_HEAD_LOSS"); return !(e && e[0] == '1'); }();  // A-B switch
+  Ctx::HeadLoss hl;
+  if (head_loss_on && pred_type == DQ_PRED_EPS && ms1_loss_weight == 0.f) {
+    hl.z = noise; hl.grad_out = c.w(a.xb); hl.part = c.w(a.head_part); hl.gscale = 2.0f / (float)(B * per);  // (launch_mse_fwd_bwd's scale)
+    c.head_loss = &hl;
+  }
   DQ_TRY(unet_forward(c, rope_freqs, c.w(a.xa), t, 0, ms2_cond, ms1_cond, cm, ca, plan->dev, c.w(a.eps)));   // model.py:359
   // the gradient twin is zeroed inside unet_backward, so the loss gradient goes to a forward-arena buffer (xb)
-  if (pred_type == DQ_PRED_X0)  // model.py:372-376, 404: target = normalised x0, per-sample weight loss_weight[t_b]
+  if (hl.done) {  // (loss and its gradient came with the forward's last launch; the sum of the partials rides on the side stream: unet_backward)
+    c.loss_sum.partials = hl.part; c.loss_sum.count = hl.nparts; c.loss_sum.scale = 1.0f / (float)(B * per); c.loss_sum.out = loss_out;
+  } else if (pred_type == DQ_PRED_X0)  // model.py:372-376, 404: target = normalised x0, per-sample weight loss_weight[t_b]
     DQ_TRY(launch_mse_fwd_bwd(c.w(a.eps), x0, loss_out, c.w(a.xb), c.w(a.partials), B * per, s, loss_weight_dev, t, per, cm, ca));
   else if (c.owner && ms1_loss_weight == 0.f && tail_fork_enabled()) {
     int nparts = 0;  // (the sum of the partials -> loss_out rides on the side stream: unet_backward)

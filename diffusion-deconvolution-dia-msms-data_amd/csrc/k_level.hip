@@ -70,6 +70,8 @@ struct LevelFwdK {
   // head epilogue (ep_w >= 0): final_conv weight / bias offsets in P; eps_out nullable; DDIM update when x_t is set
   int ep_w, ep_b, pred_x0;
   float* eps_out; const float* x_t; float* x_out; const float* coef; const int* step_ptr;
+  // training head: target, per-wave squared-error sums, d loss / d eps, d loss / d (block output)
+  const float* loss_z; float* loss_part; float* grad_out; float* dout; float loss_gscale;
 };
 
 }  // namespace
@@ -127,7 +129,9 @@ __global__ void __launch_bounds__(256) k_level_images(LevelImgMulti mm, const fl
 // with the channel quads walked in a run-time load -> use loop a wave exposed one memory latency per quad and the launch ran at a
 // third of the rate its loads in flight allow)
 // N64: rows of exactly 64 positions = one row per wave: the wave shifts' zero fill at lanes 0 / 63 IS the conv's zero padding, no masks
-template <int C, int PRE, int CP, bool N64>
+// TH: the training head (LevelFwd::loss_z) is compiled in -- its own instantiation, so that the inference kernels keep their registers (with a
+// run-time branch every C = 4 kernel went from 77 to 87: five instead of six workgroups per CU)
+template <int C, int PRE, int CP, bool N64, bool TH = false>
 __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __restrict__ P, const float* __restrict__ ssb, int tiles_ps, int total_tiles,
                                                    int ln_rt, const float* __restrict__ img) {  // ssb: the per-sample scale / shift vectors; ln_rt = log2(n)
   // N64: the row length is a compile-time 64 -- a channel's plane offset (c * 256 bytes) then folds into the instructions' immediate offsets
@@ -252,6 +256,7 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
   // wave-uniform channel base pointers (the launcher checks every tensor stays below 2^31 elements), and NO load is predicated -- the
   // lanes beyond a sample's last position read its last position instead (their values reach no live lane: a sample ends at a row end)
   // -- so the only control flow is one branch around each group of stores.
+  float lacc = 0.f;  // training head: this lane's sum of squared errors
 #pragma unroll 1
   for (int tile = wid; tile < tiles_ps; tile += nwaves) {  // the workgroups of a sample share its tiles; the grid is one resident round
     const int it = tile * 64 + lane;
@@ -577,12 +582,26 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
             }
             if (a.eps_out) *reinterpret_cast<float*>(reinterpret_cast<char*>(a.eps_out) + eoff) = ep;
           }
+          if constexpr (TH) {  // training: model.py:361 and the first two steps of its backward, k_mse_fwd_bwd's arithmetic per element
+            const float z = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.loss_z) + eoff);  // (not predicated: a clamped position)
+            const float d = ev - z;
+            if (live) {
+              lacc += d * d;
+              const float gv = d * a.loss_gscale;
+              *reinterpret_cast<float*>(reinterpret_cast<char*>(a.grad_out) + eoff) = gv;
+              st(a.dout, 0, obase, w4.x * gv); st(a.dout, 1, obase, w4.y * gv); st(a.dout, 2, obase, w4.z * gv); st(a.dout, 3, obase, w4.w * gv);
+            }
+          }
         }
       }
 #pragma unroll
       for (int c = 0; c < C; ++c) x[c] = o[c];
     }
     DQ_PSTAMP(C * 1000 + PRE * 100 + CP, 5);
+  }
+  if constexpr (TH) {  // one partial sum per wave (fixed order inside the wave; the caller sums the waves in index order)
+    const float t = wave_sum(lacc);
+    if (lane == 0) a.loss_part[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = t;
   }
   DQ_PSTAMP(C * 1000 + PRE * 100 + CP, 6);
 }
@@ -657,7 +676,9 @@ int launch_level_fwd(const LevelFwd& a, hipStream_t s) {
   LevelFwdK k;
   auto poff = [&](const float* ptr) -> int { return ptr ? (int)(ptr - a.params) : -1; };
   DQ_REQUIRE(a.pre != LEVEL_PRE_INIT || (a.cond && a.ss_init && a.pre_out), "level_fwd: the first-layer stage needs the mixture, its scale / shift and h0");
-  DQ_REQUIRE(!a.ew || (a.C == 4 && a.eb && (a.eps_out || a.x_t) && (!a.x_t || (a.x_out && a.coef))), "level_fwd: incomplete head epilogue");
+  DQ_REQUIRE(!a.ew || (a.C == 4 && a.eb && (a.eps_out || a.x_t || a.loss_z) && (!a.x_t || (a.x_out && a.coef))), "level_fwd: incomplete head epilogue");
+  DQ_REQUIRE(!a.loss_z || (a.ew && !a.x_t && a.loss_part && a.grad_out && a.dout && a.loss_parts_out), "level_fwd: incomplete training head");
+  k.loss_z = a.loss_z; k.loss_part = a.loss_part; k.grad_out = a.grad_out; k.dout = a.dout; k.loss_gscale = a.loss_gscale;
   k.cond = a.cond; k.cm = a.cm; k.ca = a.ca; k.ss_init = a.ss_init ? (int)(a.ss_init - a.blk[0].ss) : 0;
   k.ep_w = poff(a.ew); k.ep_b = poff(a.eb); k.pred_x0 = a.pred_x0; k.eps_out = a.eps_out; k.x_t = a.x_t; k.x_out = a.x_out; k.coef = a.coef;
   k.step_ptr = a.step_ptr;
@@ -696,13 +717,18 @@ int launch_level_fwd(const LevelFwd& a, hipStream_t s) {
   DQ_REQUIRE(lds <= 64 * 1024, "level_fwd: weight image too large");
   // one resident round: blocks per CU from the occupancy query, capped at 6 (at this kernel's ~106 scalar registers the hardware admits six
   // 256-thread blocks per CU where the query can say seven: MI355X_MICROARCH.md, Residency), never more blocks than tiles need
-#define DQ_LVN(CC, PP, PC, NN)                                                                                                \
+#define DQ_LVN(CC, PP, PC, NN) DQ_LVK((k_level_fwd<CC, PP, PC, NN>))
+#define DQ_LVK(KERNEL)                                                                                                        \
   {                                                                                                                           \
-    const int nb = occ_blocks_per_cu((const void*)k_level_fwd<CC, PP, PC, NN>, 256, lds);  /* keyed on (instantiation, lds, device) */ \
+    const int nb = occ_blocks_per_cu((const void*)KERNEL, 256, lds);  /* keyed on (instantiation, lds, device) */              \
     if (nb < 0) return 1;                                                                                                     \
     const int occ = std::min(nb, 6);                                                                                          \
     const int gx = std::max(1, std::min(occ * num_cus() / B, (tiles_ps + 3) / 4));  /* workgroups per sample */                \
-    hipLaunchKernelGGL((k_level_fwd<CC, PP, PC, NN>), dim3(gx, B), dim3(256), lds, s, k, a.params, ssb, tiles_ps, (int)total, ln, a.img); \
+    if (a.loss_z) {                                                                                                           \
+      DQ_REQUIRE((int64_t)gx * B * 4 <= LEVEL_LOSS_PARTS, "level_fwd: more waves than the loss partial-sum scratch holds");      \
+      *a.loss_parts_out = gx * B * 4;                                                                                         \
+    }                                                                                                                         \
+    hipLaunchKernelGGL(KERNEL, dim3(gx, B), dim3(256), lds, s, k, a.params, ssb, tiles_ps, (int)total, ln, a.img);             \
     DQ_LAUNCH_CHECK();                                                                                                        \
     return 0;                                                                                                                 \
   }
@@ -710,6 +736,11 @@ int launch_level_fwd(const LevelFwd& a, hipStream_t s) {
   if (a.C == CC && a.pre == PP && cp == PC) {                                                                                 \
     if (CC == 4 && a.n == 64) DQ_LVN(CC, PP, PC, (CC == 4))                                                                    \
     DQ_LVN(CC, PP, PC, false)                                                                                                 \
+  }
+  if (a.loss_z) {  // the training head has its own instantiations (the network's final block: k3 stage conv from 4 channels)
+    DQ_REQUIRE(a.C == 4 && a.pre == LEVEL_PRE_S1 && cp == 4, "level_fwd: the training head is built for the (4, k3 conv, 4) launch");
+    if (a.n == 64) DQ_LVK((k_level_fwd<4, LEVEL_PRE_S1, 4, true, true>))
+    DQ_LVK((k_level_fwd<4, LEVEL_PRE_S1, 4, false, true>))
   }
   DQ_LV(4, LEVEL_PRE_NONE, 4) DQ_LV(8, LEVEL_PRE_NONE, 4) DQ_LV(12, LEVEL_PRE_NONE, 4) DQ_LV(16, LEVEL_PRE_NONE, 4)
   DQ_LV(4, LEVEL_PRE_DOWN, 4) DQ_LV(8, LEVEL_PRE_DOWN, 4) DQ_LV(8, LEVEL_PRE_DOWN, 8) DQ_LV(12, LEVEL_PRE_DOWN, 8) DQ_LV(12, LEVEL_PRE_DOWN, 12)
@@ -721,6 +752,7 @@ int launch_level_fwd(const LevelFwd& a, hipStream_t s) {
   DQ_LV(16, LEVEL_PRE_S1, 16)
 #undef DQ_LV
 #undef DQ_LVN
+#undef DQ_LVK
   set_error("level_fwd: unsupported (C, stage, stage input width)");
   return 2;
 }

@@ -71,6 +71,16 @@ def test_side_stream_schedule_is_bitwise_neutral(tmp_path):
     assert np.array_equal(a["grads"], b["grads"]) and np.array_equal(a["eps"], b["eps"])
 
 
+def test_training_head_matches_the_three_launches_it_replaces(tmp_path):
+    """final_conv + squared error + d eps + final_conv's backward data path in the final block's launch (k_level_fwd's training head) against
+    k_conv_fwd / k_mse_fwd_bwd / k_conv_bwd_data (DQ_NO_HEAD_LOSS=1): the per-element arithmetic is the same, so every gradient is bit-identical;
+    the loss is summed in another (fixed) order."""
+    a = _run(tmp_path, "head", {})
+    b = _run(tmp_path, "nohead", {"DQ_NO_HEAD_LOSS": "1"})
+    assert np.array_equal(a["grads"], b["grads"])
+    assert abs(a["loss"] - b["loss"]) < 2e-6 * abs(b["loss"])
+
+
 def test_large_batch_keeps_the_per_kernel_backward(tmp_path):
     """More samples than a LinearAttention layer's slot reservation holds workgroups of the tiny backward (one slot each): the launch is declined
     and the per-kernel backward runs -- same loss, gradients within the fp32 tolerance of the small-batch comparison."""
