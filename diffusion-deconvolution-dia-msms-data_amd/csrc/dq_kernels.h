@@ -165,6 +165,9 @@ struct LevelFwd {
   // init_cond_proj's per-sample [scale, shift] at ss_init (same buffer / stride as the blocks' vectors); pw / pb = init_conv (4, 2, 7);
   // pre_out = h0 (always written)
   const float* cond = nullptr; float cm = 1.f, ca = 0.f; const float* ss_init = nullptr;
+  // ... in a train step the stage also stores its two input channels [conditioned mixture | x_t] as cat0 (rows, 2, n): the init conv's weight
+  // gradient and the input affine's backward read them (what k_prep_inputs + k_conv_fwd<4,7,0> produced in two launches in front of this one)
+  float* cat0_out = nullptr;
   // head epilogue (C == 4, inference; behind the last block): eps = final_conv(out) (ew (1, 4, 1), eb) -> eps_out (nullable), and with
   // x_t set the DDIM update of model.py:265-289 into x_out (coef: [sa, sb, sap, sbp] rows; step_ptr nullable: row index on the device)
   const float* ew = nullptr; const float* eb = nullptr; float* eps_out = nullptr;

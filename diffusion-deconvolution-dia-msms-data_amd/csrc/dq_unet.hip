@@ -837,7 +837,10 @@ LevelFwd level_desc(const Ctx& c, const LevelCall& lc) {
   LevelFwd f;
   f.params = c.P; f.in = lc.in; f.pre = lc.pre; f.nblocks = lc.nblocks; f.C = lc.C; f.rows = c.B * c.RT; f.n = lc.n; f.rows_per_sample = c.RT;
   if (lc.pc) { f.cp = lc.pc->cin; f.pw = c.prm(lc.pc->w); f.pb = lc.pc->b >= 0 ? c.prm(lc.pc->b) : nullptr; f.pre_out = c.save ? lc.pre_out : nullptr; }
-  if (lc.pre == LEVEL_PRE_INIT) { f.cond = lc.cond; f.cm = lc.cm; f.ca = lc.ca; f.ss_init = c.w(c.ar.ss) + c.p.ss_init; f.pre_out = lc.pre_out; }
+  if (lc.pre == LEVEL_PRE_INIT) {
+    f.cond = lc.cond; f.cm = lc.cm; f.ca = lc.ca; f.ss_init = c.w(c.ar.ss) + c.p.ss_init; f.pre_out = lc.pre_out;
+    f.cat0_out = c.save ? c.w(c.ar.cat0) : nullptr;  // (train step: kept for init_conv's weight gradient and the input affine's backward)
+  }
   if (lc.head) {
     f.ew = c.prm(lc.head->w); f.eb = c.prm(lc.head->b);
     if (c.step_io && c.step_io->x_t) {
@@ -875,7 +878,8 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     lc.C = l.r0.cout; lc.n = l.n; lc.nblocks = 2;
     lc.r[0] = &l.r0; lc.r[1] = &l.r1; lc.rb[0] = &a.downs[lv].r0; lc.rb[1] = &a.downs[lv].r1;
     if (lv == 0) {
-      if (!c.save && p.dim == 4 && p.init_conv.cout == 4 && p.init_conv.cin == 2 && p.init_conv.k == 7 && p.init_conv.b >= 0) {
+      static const bool train_init = [] { const char* e = std::getenv("DQ_NO_TRAIN_INIT"); return !(e && e[0] == '1'); }();  // A-B switch
+      if ((!c.save || train_init) && p.dim == 4 && p.init_conv.cout == 4 && p.init_conv.cin == 2 && p.init_conv.k == 7 && p.init_conv.b >= 0) {
         lc.pre = LEVEL_PRE_INIT; lc.pc = &p.init_conv; lc.in = x; lc.cond = init_cond; lc.cm = cm; lc.ca = ca; lc.pre_out = c.w(a.h0);
       } else {
         lc.in = c.w(a.h0);
@@ -994,7 +998,7 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
   DQ_TRY(launch_time_embed_fwd(p, dt, c.P, t, t_scalar, c.w(a.tbuf), c.w(a.ss), B, step_tab, step_ptr, c.s));
   // K2: mixture conditioning + concat (unet1d.py:1107-1115), then init_conv k7 (:1117)
   if (init_fused) {
-    if (!skip_ms1) DQ_TRY(launch_ms1_norm(attn_cond, cm, ca, c.w(a.ms1n), (int64_t)B * RT, c.s));
+    if (!skip_ms1) DQ_TRY(launch_ms1_norm(attn_cond, cm, ca, c.w(a.ms1n), (int64_t)B * RT, ps));  // (ps: the side stream of a forked train step, with the MS1 path)
   } else {
     // (forked: the MS1 normalisation goes with the MS1 path to the side stream)
     DQ_TRY(launch_prep_inputs(x, init_cond, attn_cond, c.w(a.ss), p.ss_total, p.ss_init, cm, ca, c.w(a.cat0), fwd_fork ? nullptr : c.w(a.ms1n), B, RT, p.mz, c.s));

@@ -67,6 +67,7 @@ struct LevelFwdK {
   LevelBlkK blk[2];
   // INIT stage: the mixture (rows, n), its normalisation cond * cm + ca, the offset of init_cond_proj's [scale, shift] in the ss vector
   const float* cond; float cm, ca; int ss_init;
+  float* cat0_out;  // (TH instantiation of the INIT stage)
   // head epilogue (ep_w >= 0): final_conv weight / bias offsets in P; eps_out nullable; DDIM update when x_t is set
   int ep_w, ep_b, pred_x0;
   float* eps_out; const float* x_t; float* x_out; const float* coef; const int* step_ptr;
@@ -302,6 +303,12 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
       load_skip(0);
       const float4 e4 = *reinterpret_cast<const float4*>(prm + C * 15 + 4);  // bias (unused here), scale + 1, shift
       float v[2] = {fmaf(cd, a.cm, a.ca) * e4.y + e4.z, xt};
+      if constexpr (TH) {  // train step: the concatenated input is kept for the backward
+        if (live) {
+          const unsigned coff = (((row * 2) << ln) + p) * 4u;
+          st(a.cat0_out, 0, coff, v[0]); st(a.cat0_out, 1, coff, v[1]);
+        }
+      }
       f32x4 acc[7];
 #pragma unroll
       for (int k = 0; k < 7; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -582,7 +589,7 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
             }
             if (a.eps_out) *reinterpret_cast<float*>(reinterpret_cast<char*>(a.eps_out) + eoff) = ep;
           }
-          if constexpr (TH) {  // training: model.py:361 and the first two steps of its backward, k_mse_fwd_bwd's arithmetic per element
+          if constexpr (TH && PRE != LEVEL_PRE_INIT) {  // training: model.py:361 and the first two steps of its backward, k_mse_fwd_bwd's arithmetic per element
             const float z = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.loss_z) + eoff);  // (not predicated: a clamped position)
             const float d = ev - z;
             if (live) {
@@ -599,7 +606,7 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
     }
     DQ_PSTAMP(C * 1000 + PRE * 100 + CP, 5);
   }
-  if constexpr (TH) {  // one partial sum per wave (fixed order inside the wave; the caller sums the waves in index order)
+  if constexpr (TH && PRE != LEVEL_PRE_INIT) {  // one partial sum per wave (fixed order inside the wave; the caller sums the waves in index order)
     const float t = wave_sum(lacc);
     if (lane == 0) a.loss_part[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = t;
   }
@@ -678,6 +685,8 @@ int launch_level_fwd(const LevelFwd& a, hipStream_t s) {
   DQ_REQUIRE(a.pre != LEVEL_PRE_INIT || (a.cond && a.ss_init && a.pre_out), "level_fwd: the first-layer stage needs the mixture, its scale / shift and h0");
   DQ_REQUIRE(!a.ew || (a.C == 4 && a.eb && (a.eps_out || a.x_t || a.loss_z) && (!a.x_t || (a.x_out && a.coef))), "level_fwd: incomplete head epilogue");
   DQ_REQUIRE(!a.loss_z || (a.ew && !a.x_t && a.loss_part && a.grad_out && a.dout && a.loss_parts_out), "level_fwd: incomplete training head");
+  DQ_REQUIRE(!a.cat0_out || (a.pre == LEVEL_PRE_INIT && !a.loss_z), "level_fwd: cat0_out belongs to the first-layer stage");
+  k.cat0_out = a.cat0_out;
   k.loss_z = a.loss_z; k.loss_part = a.loss_part; k.grad_out = a.grad_out; k.dout = a.dout; k.loss_gscale = a.loss_gscale;
   k.cond = a.cond; k.cm = a.cm; k.ca = a.ca; k.ss_init = a.ss_init ? (int)(a.ss_init - a.blk[0].ss) : 0;
   k.ep_w = poff(a.ew); k.ep_b = poff(a.eb); k.pred_x0 = a.pred_x0; k.eps_out = a.eps_out; k.x_t = a.x_t; k.x_out = a.x_out; k.coef = a.coef;
@@ -741,6 +750,11 @@ int launch_level_fwd(const LevelFwd& a, hipStream_t s) {
     DQ_REQUIRE(a.C == 4 && a.pre == LEVEL_PRE_S1 && cp == 4, "level_fwd: the training head is built for the (4, k3 conv, 4) launch");
     if (a.n == 64) DQ_LVK((k_level_fwd<4, LEVEL_PRE_S1, 4, true, true>))
     DQ_LVK((k_level_fwd<4, LEVEL_PRE_S1, 4, false, true>))
+  }
+  if (a.cat0_out) {  // the first level of a train step: the INIT stage that also stores its input
+    DQ_REQUIRE(a.C == 4 && cp == 2, "level_fwd: the first-layer stage is built for (4, init conv, 2)");
+    if (a.n == 64) DQ_LVK((k_level_fwd<4, LEVEL_PRE_INIT, 2, true, true>))
+    DQ_LVK((k_level_fwd<4, LEVEL_PRE_INIT, 2, false, true>))
   }
   DQ_LV(4, LEVEL_PRE_NONE, 4) DQ_LV(8, LEVEL_PRE_NONE, 4) DQ_LV(12, LEVEL_PRE_NONE, 4) DQ_LV(16, LEVEL_PRE_NONE, 4)
   DQ_LV(4, LEVEL_PRE_DOWN, 4) DQ_LV(8, LEVEL_PRE_DOWN, 4) DQ_LV(8, LEVEL_PRE_DOWN, 8) DQ_LV(12, LEVEL_PRE_DOWN, 8) DQ_LV(12, LEVEL_PRE_DOWN, 12)
