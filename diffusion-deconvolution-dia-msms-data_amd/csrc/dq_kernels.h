@@ -228,6 +228,9 @@ struct TinyBwd {
   float* dfold = nullptr;                                                                 // LEVEL_PRE_NONE: input gradient as (B, C, RT)
   float* din_rows = nullptr; float* dprev = nullptr; const float* stage_w = nullptr;      // LEVEL_PRE_DOWN: input gradient (rows, C); previous level's d la (rows, cp, 2) +=; Downsample weight
   const float* r0out_g = nullptr;                                                         // nullable: skip gradient already in d r0.out
+  // LEVEL_PRE_NONE, nullable pair: the Upsample conv BEHIND this level (nearest x2 + k3, 16 -> 16, rows of 2 positions) -- its backward data path runs
+  // in front of the LinearAttention part: d la = Upsample^T d rs with dup = d rs (rows, C, 2), and dy is not read
+  const float* up_w = nullptr; const float* dup = nullptr;
   struct Blk {
     const float* w1 = nullptr; const float* w2 = nullptr; const float* wr = nullptr; const float* g1 = nullptr; const float* g2 = nullptr;
     const float* ss = nullptr; int ss_stride = 0;

@@ -447,6 +447,12 @@ bool tiny_bwd_desc(const Ctx& c, bool up, TinyBwd* out) {
     if (c.G) { k.du1 = c.g(rb[i]->u1); k.du2 = c.g(rb[i]->u2); k.dout_st = r.res.cout ? c.g(rb[i]->out) : nullptr; }
   }
   if (up) {
+    // the Upsample conv behind the level (nearest x2 + k3, 16 -> 16): its backward data path in the same launch, its weight gradient on the side stream
+    static const bool upt_on = [] { const char* e = std::getenv("DQ_NO_TINY_UPT"); return !(e && e[0] == '1'); }();  // A-B switch
+    if (upt_on && !l.last && l.resample.k == 3 && l.resample.cin == 16 && l.resample.cout == 16 && l.n_next == 2) {
+      t.up_w = c.prm(l.resample.w);
+      if (c.G) t.dup = c.g(b.rs);
+    }
     if (c.G) {
       t.dy = c.g(b.la); t.dfold = c.g(a.mid2.out);
       t.blk[1].dB = c.g(a.downs[L - 1].r0.out); t.blk[1].dB_acc = 0;  // the up path is the first writer of the skip gradients (unet_backward)
@@ -1194,6 +1200,9 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     const int lv = L - 1 - ui;
     const int cx = l.r0.cout, cs = l.r0.cin - l.r0.cout;
     const int64_t in_off = ui == 0 ? a.mid_back : a.ups[ui - 1].rs;
+    if (ui == 0 && use_tb_up && tb_up.up_w)  // (the tiny backward applies Upsample^T itself: only the conv's weight / bias gradient is left, on the side stream)
+      DQ_TRY(conv_plain_bwd(c, l.resample, CONV_UP, c.w(b.la), c.g(b.rs), nullptr, R, l.n, l.n_next, 0));
+    else
     DQ_TRY(resample_bwd(c, l.resample, l.last ? LEVEL_PRE_S1 : LEVEL_PRE_UP, b, l.n, l.n_next, 0));  // only writer of d la (up): store
     if (ui == 0 && use_tb_up) {
       DQ_TRY(tiny_bwd_run(c, tb_up, true));  // LinearAttention + both ResnetBlocks; the input gradient lands in the bottleneck's layout

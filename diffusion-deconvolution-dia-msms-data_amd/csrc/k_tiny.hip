@@ -33,7 +33,7 @@ namespace dq {
 namespace {
 
 enum { TL_CONV3_N2 = 0, TL_DIAG = 1, TL_DOWN_N2 = 2, TL_DOWN_N1 = 3, TL_UP_N2 = 4, TL_LA1 = 5,
-       TL_DIAG_T = 6, TL_LA1_T = 7, TL_DOWN_N1_T = 8 };  // transposed forms of the backward data path (n == 1): step = output channel of the conv
+       TL_DIAG_T = 6, TL_LA1_T = 7, TL_DOWN_N1_T = 8, TL_UP_N2_T = 9 };  // transposed forms of the backward data path (n == 1): step = output channel of the conv
 // One dense layer of the chain = `steps` MFMAs.  Element (step s, lane) of its operand image:
 //   m = lane & 31 -> output (position pm = (m >> 2) & 1, channel co = (m & 3) + 4 (m >> 3)); k = lane >> 5 = the half that supplies B
 struct TinyLayer {
@@ -45,7 +45,7 @@ struct TinyLayer {
   int c0;     // first input channel this layer's steps walk (the skip half of cat(x, skip) starts at C)
   int steps, cout;
 };
-constexpr int TINY_MAX_LAYERS = 12;
+constexpr int TINY_MAX_LAYERS = 14;
 struct TinyImgItem { TinyLayer L[TINY_MAX_LAYERS]; int nl, total_steps; float* dst; };
 struct TinyImgMulti { TinyImgItem it[TINY_IMG_MAX]; };
 
@@ -80,6 +80,10 @@ __device__ __forceinline__ float tiny_img_value(const TinyLayer& L, int s, int l
     }
     case TL_DOWN_N1_T: {  // d in[ci][j] = sum_co W[co = s][ci][1 + j] d out[co]; j = L.w2
       return pm == k ? P[L.w + (s * L.cin + co) * 4 + 1 + L.w2] : 0.f;
+    }
+    case TL_UP_N2_T: {  // nearest x2 + k3, transposed: d in[ci] = sum_co W_p[co = s][ci] d out[co][p], W_0 = w1 + w2, W_1 = w0 + w1 (TL_UP_N2); p = L.w2
+      const float* q = P + L.w + (s * L.cin + co) * 3;
+      return pm == k ? q[1] + (L.w2 == 0 ? q[2] : q[0]) : 0.f;
     }
     case TL_LA1_T: {  // d xhat[ci = idx] = scale * sum_c' (Wo Wv)[c' = s][ci] d ypre[c']
       if (pm != k) return 0.f;
@@ -448,19 +452,22 @@ struct TinyBwdK {
   float* dfold;                                        // LEVEL_PRE_NONE: the level's input gradient as (B, C, RT)
   float* din_rows; float* dprev;                       // LEVEL_PRE_DOWN: the input gradient as (rows, C); the Downsample's data gradient += (rows, CP, 2)
   const float* r0out_g;                                // nullable: d r0.out already holds a skip gradient (down path): added to block 0's d out
+  const float* dup;                                    // UPT: d rs (rows, C, 2) of the Upsample conv behind the level
   TinyBwdBlkK blk[2];                                  // [0] = ResnetBlock 0, [1] = ResnetBlock 1
   int rows_per_sample, ss_stride;
 };
 constexpr int tiny_la_slot(int C) { return 256 * C + 4 * C * C + 3 * C; }  // = la_slot(C) of k_la_bwd.hip
 
-template <int C, int PRE, int CP, int CS>
+// UPT: the Upsample conv behind the level (its backward data path in front of everything else)
+template <int C, int PRE, int CP, int CS, bool UPT>
 __global__ void __launch_bounds__(256) k_tiny_bwd(TinyBwdK a, const float* __restrict__ P, const float* __restrict__ ssb, const float* __restrict__ img,
                                                  int tiles_ps) {
   static_assert(C == 16, "built for 16 channels");
   constexpr bool WR = CS > 0, POST = PRE == LEVEL_PRE_DOWN;
   constexpr int BLKT = 2 * C + (CS ? C : 0) + (WR ? 2 * C : 0);
   constexpr int B_POST = 0, B_LA = POST ? C : 0, B_R1 = B_LA + C, B_R0 = B_R1 + BLKT, B_ST = B_R0 + BLKT;
-  constexpr int TOTAL = B_ST + (PRE == LEVEL_PRE_DOWN ? 2 * C : 0);
+  constexpr int B_UP = B_ST + (PRE == LEVEL_PRE_DOWN ? 2 * C : 0);
+  constexpr int TOTAL = B_UP + (UPT ? 2 * C : 0);
   constexpr int NLD = tiny_rounds(TOTAL);
   constexpr int NACC = 3 * C + 8 * C;  // per-lane sums: d g_out | d b_out | d g_pre | per block d g2 | d g1 | d scale | d shift
   constexpr int PIDB = 400000 + PRE * 10 + (CS ? 1 : 0);  // tools/probe_step.py id
@@ -550,7 +557,20 @@ __global__ void __launch_bounds__(256) k_tiny_bwd(TinyBwdK a, const float* __res
     };
     // ---- loads of the whole tile up front
     float xv[16], uv[16], dv[16], dm[16], u2a[16], u1a[16], u2b[16], u1b[16], r0g[16];
-    ld16(a.x, xv); ld16(a.ypre, uv); ld16(a.dy, dv);
+    if constexpr (UPT) {
+      // d la = Upsample^T d rs: this row's 2 x 16 values [c][p], then two dense layers (one per output position of the conv); on its own
+      // memory round trip in front of the tile's other loads (32 more live registers at the peak otherwise)
+      float d0[16], d1[16];
+      const float4* q = reinterpret_cast<const float4*>(a.dup + row * (2 * C));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const float4 t = q[u]; d0[2 * u] = t.x; d1[2 * u] = t.y; d0[2 * u + 1] = t.z; d1[2 * u + 1] = t.w; }
+      const f32x16 t = dense(B_UP + C, d1, dense(B_UP, d0, zero16()));
+#pragma unroll
+      for (int c = 0; c < C; ++c) dv[c] = t[c];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ld16(a.x, xv); ld16(a.ypre, uv);
+    if constexpr (!UPT) ld16(a.dy, dv);
     if constexpr (POST) {
       const float* q = a.dmid + (int64_t)b * C * RT + rs_c;
 #pragma unroll
@@ -791,6 +811,10 @@ int tiny_bwd_layers(const TinyBwd& t, TinyLayer* L) {
     L[nl++] = TinyLayer{TL_DOWN_N1_T, poff(t.stage_w), 0, t.cp, 4, 0, C, t.cp};
     L[nl++] = TinyLayer{TL_DOWN_N1_T, poff(t.stage_w), 1, t.cp, 4, 0, C, t.cp};
   }
+  if (t.up_w) {  // (last in the image: the other bases do not move)
+    L[nl++] = TinyLayer{TL_UP_N2_T, poff(t.up_w), 0, C, 3, 0, C, C};
+    L[nl++] = TinyLayer{TL_UP_N2_T, poff(t.up_w), 1, C, 3, 0, C, C};
+  }
   return nl;
 }
 
@@ -922,7 +946,7 @@ bool tiny_bwd_usable(const TinyBwd& t) {
   // beyond ~1000 samples keep the per-kernel backward
   if ((int64_t)tiny_bwd_gx(t) * (t.rows / t.rows_per_sample) > 1000) return false;
   if (t.pre == LEVEL_PRE_DOWN) return t.cp == 12 && t.cs == 0;
-  if (t.pre == LEVEL_PRE_NONE) return t.cs == 16;
+  if (t.pre == LEVEL_PRE_NONE) return t.cs == 16 && !(t.dup && !t.up_w);
   return false;
 }
 static int tiny_bwd_gx(const TinyBwd& t) {
@@ -963,7 +987,8 @@ int launch_tiny_bwd_images(const TinyBwd* calls, int count, hipStream_t s) {
 
 int launch_tiny_bwd(const TinyBwd& t, hipStream_t s) {
   DQ_REQUIRE(tiny_bwd_usable(t), "tiny_bwd: unsupported shape");
-  DQ_REQUIRE(t.rows % t.rows_per_sample == 0 && t.img && t.x && t.ypre && t.dy && t.w_qkv && t.w_out && t.g_pre && t.g_out && t.la_part, "tiny_bwd: missing operand");
+  DQ_REQUIRE(!t.up_w || (t.pre == LEVEL_PRE_NONE && t.dup), "tiny_bwd: the Upsample stage needs d rs and belongs to the up level");
+  DQ_REQUIRE(t.rows % t.rows_per_sample == 0 && t.img && t.x && t.ypre && (t.dy || t.up_w) && t.w_qkv && t.w_out && t.g_pre && t.g_out && t.la_part, "tiny_bwd: missing operand");
   DQ_REQUIRE(t.pre != LEVEL_PRE_DOWN || (t.post_w && t.dmid && t.drs_out && t.din_rows && t.dprev && t.stage_w), "tiny_bwd: incomplete down-level operands");
   DQ_REQUIRE(t.pre != LEVEL_PRE_NONE || t.dfold, "tiny_bwd: missing input-gradient tensor");
   auto poff = [&](const float* ptr) -> int { return ptr ? (int)(ptr - t.params) : -1; };
@@ -971,7 +996,7 @@ int launch_tiny_bwd(const TinyBwd& t, hipStream_t s) {
   TinyBwdK k;
   k.x = t.x; k.ypre = t.ypre; k.dy = t.dy; k.la_gpre = poff(t.g_pre); k.la_go = poff(t.g_out); k.la_part = t.la_part;
   k.dmid = t.dmid; k.drs_out = t.drs_out; k.dfold = t.dfold; k.din_rows = t.din_rows; k.dprev = t.dprev; k.r0out_g = t.r0out_g;
-  k.rows_per_sample = t.rows_per_sample;
+  k.rows_per_sample = t.rows_per_sample; k.dup = t.dup;
   const float* ssb = t.blk[0].ss;
   k.ss_stride = t.blk[0].ss_stride;
   DQ_REQUIRE(t.la_part_floats >= (int64_t)gx * B * tiny_la_slot(C) + 4 * C * C, "tiny_bwd: LinearAttention slot region too small");
@@ -986,19 +1011,20 @@ int launch_tiny_bwd(const TinyBwd& t, hipStream_t s) {
   if (t.gblocks) *t.gblocks = gx;
   const int tiles_ps = cdiv(t.rows_per_sample, 64);
   const int blkt = 2 * C + (t.cs ? C : 0) + (t.cs ? 2 * C : 0);
-  const int total = (t.pre == LEVEL_PRE_DOWN ? C : 0) + C + 2 * blkt + (t.pre == LEVEL_PRE_DOWN ? 2 * C : 0);
+  const int total = (t.pre == LEVEL_PRE_DOWN ? C : 0) + C + 2 * blkt + (t.pre == LEVEL_PRE_DOWN ? 2 * C : 0) + (t.up_w ? 2 * C : 0);
   DQ_REQUIRE((int64_t)total * 64 == tiny_bwd_img_floats(t), "tiny_bwd: image layout mismatch");
   const size_t lds = (size_t)tiny_rounds(total) * 4096 + 256 * 4 + (size_t)4 * (2 * C * 65) * 4 + (size_t)(16 * 11 * C + 4 * C * C) * 4;
-#define DQ_TINYB(PP, PC, SS)                                                                                                  \
-  if (t.pre == PP && t.cs == SS) {                                                                                            \
-    const int nb = occ_blocks_per_cu((const void*)k_tiny_bwd<16, PP, PC, SS>, 256, lds);                                      \
+#define DQ_TINYB(PP, PC, SS, UU)                                                                                              \
+  if (t.pre == PP && t.cs == SS && (t.up_w != nullptr) == UU) {                                                               \
+    const int nb = occ_blocks_per_cu((const void*)k_tiny_bwd<16, PP, PC, SS, UU>, 256, lds);                                  \
     if (nb < 0) return 1;                                                                                                     \
-    hipLaunchKernelGGL((k_tiny_bwd<16, PP, PC, SS>), dim3(gx, B), dim3(256), lds, s, k, t.params, ssb, t.img, tiles_ps);      \
+    hipLaunchKernelGGL((k_tiny_bwd<16, PP, PC, SS, UU>), dim3(gx, B), dim3(256), lds, s, k, t.params, ssb, t.img, tiles_ps);  \
     DQ_LAUNCH_CHECK();                                                                                                        \
     return 0;                                                                                                                 \
   }
-  DQ_TINYB(LEVEL_PRE_DOWN, 12, 0)
-  DQ_TINYB(LEVEL_PRE_NONE, 0, 16)
+  DQ_TINYB(LEVEL_PRE_DOWN, 12, 0, false)
+  DQ_TINYB(LEVEL_PRE_NONE, 0, 16, false)
+  DQ_TINYB(LEVEL_PRE_NONE, 0, 16, true)
 #undef DQ_TINYB
   set_error("tiny_bwd: unsupported (stage, skip width)");
   return 2;

@@ -55,7 +55,7 @@ def _rel(a, b):
 
 def test_deep_level_kernels_match_the_launches_they_replace(tmp_path):
     new = _run(tmp_path, "new", {})
-    old = _run(tmp_path, "old", {"DQ_NO_TINY": "1", "DQ_NO_LA_SMALL": "1", "DQ_NO_FWD_FORK": "1", "DQ_NO_TAIL_FORK": "1"})
+    old = _run(tmp_path, "old", {"DQ_NO_TINY": "1", "DQ_NO_LA_SMALL": "1", "DQ_NO_FWD_FORK": "1", "DQ_NO_TAIL_FORK": "1", "DQ_NO_TRAIN_INIT": "1", "DQ_NO_HEAD_LOSS": "1"})
     assert _rel(new["eps"], old["eps"]) < 1e-5          # network output (inference path: head epilogue, no saved tensors)
     assert abs(new["loss"] - old["loss"]) < 2e-6 * abs(old["loss"])
     # gradients: the forward's saved tensors differ in the last bits; the heavily cancelling tensors bound the flat comparison
@@ -79,6 +79,15 @@ def test_training_head_matches_the_three_launches_it_replaces(tmp_path):
     b = _run(tmp_path, "nohead", {"DQ_NO_HEAD_LOSS": "1"})
     assert np.array_equal(a["grads"], b["grads"])
     assert abs(a["loss"] - b["loss"]) < 2e-6 * abs(b["loss"])
+
+
+def test_upsample_transpose_in_the_tiny_backward(tmp_path):
+    """The Upsample conv behind the deepest up level: its backward data path as a stage of k_tiny_bwd (+ the generic weight-gradient kernel on the
+    side stream) against k_conv_bwd_wg (DQ_NO_TINY_UPT=1)."""
+    a = _run(tmp_path, "upt", {})
+    b = _run(tmp_path, "noupt", {"DQ_NO_TINY_UPT": "1"})
+    assert a["loss"] == b["loss"]
+    assert _rel(a["grads"], b["grads"]) < 2e-5
 
 
 def test_large_batch_keeps_the_per_kernel_backward(tmp_path):
