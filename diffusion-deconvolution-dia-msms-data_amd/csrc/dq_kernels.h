@@ -168,6 +168,9 @@ struct LevelFwd {
   // ... in a train step the stage also stores its two input channels [conditioned mixture | x_t] as cat0 (rows, 2, n): the init conv's weight
   // gradient and the input affine's backward read them (what k_prep_inputs + k_conv_fwd<4,7,0> produced in two launches in front of this one)
   float* cat0_out = nullptr;
+  // ... and may form x_t itself (model.py:349-352, k_q_sample's arithmetic): in = x0 (rows, n), qs_noise (rows, n), qs_ab = the alpha-bar table,
+  // qs_t = the samples' timesteps, qs_norm: x0 -> 2 x0 - 1 first
+  const float* qs_noise = nullptr; const float* qs_ab = nullptr; const int64_t* qs_t = nullptr; int qs_norm = 0;
   // head epilogue (C == 4, inference; behind the last block): eps = final_conv(out) (ew (1, 4, 1), eb) -> eps_out (nullable), and with
   // x_t set the DDIM update of model.py:265-289 into x_out (coef: [sa, sb, sap, sbp] rows; step_ptr nullable: row index on the device)
   const float* ew = nullptr; const float* eb = nullptr; float* eps_out = nullptr;

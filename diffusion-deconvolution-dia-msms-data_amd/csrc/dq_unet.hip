@@ -214,6 +214,10 @@ struct Ctx {
   // the final block's launch when it can take them (k_level_fwd's training head); `done` / `nparts` tell the caller
   struct HeadLoss { const float* z = nullptr; float* grad_out = nullptr; float* part = nullptr; float gscale = 0.f; int nparts = 0; bool done = false; };
   HeadLoss* head_loss = nullptr;
+  // dq_train_step: x_t = q_sample(x0, t, noise) (model.py:349-352) is formed by level 0's INIT stage when that stage runs (`x` of unet_forward is
+  // then only the buffer x_t would have gone to); otherwise unet_forward launches k_q_sample into `x` first
+  struct QSample { const float* alpha_bars = nullptr; const float* x0 = nullptr; const int64_t* t = nullptr; const float* noise = nullptr; int normalize = 0; int64_t per = 0; };
+  const QSample* qsample = nullptr;
   float* w(int64_t off) const { return W + off; }
   float* g(int64_t off) const { return G + off; }
   const float* prm(int64_t off) const { return P + off; }
@@ -846,6 +850,9 @@ LevelFwd level_desc(const Ctx& c, const LevelCall& lc) {
   if (lc.pre == LEVEL_PRE_INIT) {
     f.cond = lc.cond; f.cm = lc.cm; f.ca = lc.ca; f.ss_init = c.w(c.ar.ss) + c.p.ss_init; f.pre_out = lc.pre_out;
     f.cat0_out = c.save ? c.w(c.ar.cat0) : nullptr;  // (train step: kept for init_conv's weight gradient and the input affine's backward)
+    if (c.qsample && f.cat0_out) {
+      f.in = c.qsample->x0; f.qs_noise = c.qsample->noise; f.qs_ab = c.qsample->alpha_bars; f.qs_t = c.qsample->t; f.qs_norm = c.qsample->normalize;
+    }
   }
   if (lc.head) {
     f.ew = c.prm(lc.head->w); f.eb = c.prm(lc.head->b);
@@ -1003,6 +1010,8 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
   // K1: time embedding + every scale/shift head (unet1d.py:1105, 315-318, 677)
   DQ_TRY(launch_time_embed_fwd(p, dt, c.P, t, t_scalar, c.w(a.tbuf), c.w(a.ss), B, step_tab, step_ptr, c.s));
   // K2: mixture conditioning + concat (unet1d.py:1107-1115), then init_conv k7 (:1117)
+  if (c.qsample && !(init_fused && c.save))  // (the INIT stage of a train step forms x_t itself)
+    DQ_TRY(launch_q_sample(c.qsample->alpha_bars, c.qsample->x0, c.qsample->t, c.qsample->noise, const_cast<float*>(x), B, c.qsample->per, c.qsample->normalize, c.s));
   if (init_fused) {
     if (!skip_ms1) DQ_TRY(launch_ms1_norm(attn_cond, cm, ca, c.w(a.ms1n), (int64_t)B * RT, ps));  // (ps: the side stream of a forked train step, with the MS1 path)
   } else {
@@ -1650,7 +1659,11 @@ int dq_train_step(dq_plan* plan, const float* params, const float* rope_freqs, c
   c.owner = (side_stream_enabled() && !plan->no_side) ? plan : nullptr;
   const int64_t per = (int64_t)RT * plan->plan.mz;
   const float cm = auto_normalize ? 2.f : 1.f, ca = auto_normalize ? -1.f : 0.f;
-  DQ_TRY(launch_q_sample(alpha_bars_dev, x0, t, noise, c.w(a.xa), B, per, auto_normalize, s));               // model.py:349-352
+  static const bool qs_fused_on = [] { const char* e = std::getenv("DQ_NO_QSAMPLE_FUSE"); return !(e && e[0] == '1'); }();  // A-B switch
+  Ctx::QSample qs;
+  qs.alpha_bars = alpha_bars_dev; qs.x0 = x0; qs.t = t; qs.noise = noise; qs.normalize = auto_normalize; qs.per = per;
+  if (qs_fused_on && ms1_loss_weight == 0.f) c.qsample = &qs;  // model.py:349-352 (the MS1 term reads x_t: it keeps the launch)
+  else DQ_TRY(launch_q_sample(alpha_bars_dev, x0, t, noise, c.w(a.xa), B, per, auto_normalize, s));
   static const bool head_loss_on = [] { const char* e = std::getenv("DQ_NO_HEAD_LOSS"); return !(e && e[0] == '1'); }();  // A-B switch
   Ctx::HeadLoss hl;
   if (head_loss_on && pred_type == DQ_PRED_EPS && ms1_loss_weight == 0.f) {

@@ -68,6 +68,7 @@ struct LevelFwdK {
   // INIT stage: the mixture (rows, n), its normalisation cond * cm + ca, the offset of init_cond_proj's [scale, shift] in the ss vector
   const float* cond; float cm, ca; int ss_init;
   float* cat0_out;  // (TH instantiation of the INIT stage)
+  const float* qs_noise; const float* qs_ab; const int64_t* qs_t; int qs_norm;  // (TH, nullable: x_t = sqrt(ab) x0 + sqrt(1 - ab) noise formed here)
   // head epilogue (ep_w >= 0): final_conv weight / bias offsets in P; eps_out nullable; DDIM update when x_t is set
   int ep_w, ep_b, pred_x0;
   float* eps_out; const float* x_t; float* x_out; const float* coef; const int* step_ptr;
@@ -257,6 +258,13 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
   // wave-uniform channel base pointers (the launcher checks every tensor stays below 2^31 elements), and NO load is predicated -- the
   // lanes beyond a sample's last position read its last position instead (their values reach no live lane: a sample ends at a row end)
   // -- so the only control flow is one branch around each group of stores.
+  float qsa = 1.f, qsb = 0.f;  // train step with q_sample in the INIT stage: this sample's sqrt(ab), sqrt(1 - ab)
+  if constexpr (TH && PRE == LEVEL_PRE_INIT) {
+    if (a.qs_noise) {
+      const float ab = a.qs_ab[a.qs_t[b]];
+      qsa = sqrtf(ab); qsb = sqrtf(1.0f - ab);
+    }
+  }
   float lacc = 0.f;  // training head: this lane's sum of squared errors
 #pragma unroll 1
   for (int tile = wid; tile < tiles_ps; tile += nwaves) {  // the workgroups of a sample share its tiles; the grid is one resident round
@@ -298,7 +306,14 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
     } else if constexpr (PRE == LEVEL_PRE_INIT) {
       // cat(conditioned mixture, x_t) -> init_conv k7 p3 (zero padding of the CONCATENATED tensor: the shifts bring zeros in)
       const unsigned ioff = ((row << ln) + p) * 4u;
-      const float xt = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.in) + ioff);
+      float xt = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.in) + ioff);
+      if constexpr (TH) {
+        if (a.qs_noise) {  // (wave-uniform) q_sample in place: a.in is x0
+          const float nz = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.qs_noise) + ioff);
+          if (a.qs_norm) xt = xt * 2.f - 1.f;
+          xt = qsa * xt + qsb * nz;
+        }
+      }
       const float cd = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.cond) + ioff);
       load_skip(0);
       const float4 e4 = *reinterpret_cast<const float4*>(prm + C * 15 + 4);  // bias (unused here), scale + 1, shift
@@ -687,6 +702,8 @@ int launch_level_fwd(const LevelFwd& a, hipStream_t s) {
   DQ_REQUIRE(!a.loss_z || (a.ew && !a.x_t && a.loss_part && a.grad_out && a.dout && a.loss_parts_out), "level_fwd: incomplete training head");
   DQ_REQUIRE(!a.cat0_out || (a.pre == LEVEL_PRE_INIT && !a.loss_z), "level_fwd: cat0_out belongs to the first-layer stage");
   k.cat0_out = a.cat0_out;
+  DQ_REQUIRE(!a.qs_noise || (a.cat0_out && a.qs_ab && a.qs_t), "level_fwd: q_sample in the first-layer stage needs the schedule, the timesteps and cat0_out");
+  k.qs_noise = a.qs_noise; k.qs_ab = a.qs_ab; k.qs_t = a.qs_t; k.qs_norm = a.qs_norm;
   k.loss_z = a.loss_z; k.loss_part = a.loss_part; k.grad_out = a.grad_out; k.dout = a.dout; k.loss_gscale = a.loss_gscale;
   k.cond = a.cond; k.cm = a.cm; k.ca = a.ca; k.ss_init = a.ss_init ? (int)(a.ss_init - a.blk[0].ss) : 0;
   k.ep_w = poff(a.ew); k.ep_b = poff(a.eb); k.pred_x0 = a.pred_x0; k.eps_out = a.eps_out; k.x_t = a.x_t; k.x_out = a.x_out; k.coef = a.coef;

@@ -81,6 +81,13 @@ def test_training_head_matches_the_three_launches_it_replaces(tmp_path):
     assert abs(a["loss"] - b["loss"]) < 2e-6 * abs(b["loss"])
 
 
+def test_q_sample_in_the_first_level_launch_is_bitwise_neutral(tmp_path):
+    """x_t = sqrt(ab) x0 + sqrt(1 - ab) noise formed by level 0's INIT stage (the arithmetic of k_q_sample) against the launch (DQ_NO_QSAMPLE_FUSE=1)."""
+    a = _run(tmp_path, "qsf", {})
+    b = _run(tmp_path, "noqsf", {"DQ_NO_QSAMPLE_FUSE": "1"})
+    assert a["loss"] == b["loss"] and np.array_equal(a["grads"], b["grads"])
+
+
 def test_upsample_transpose_in_the_tiny_backward(tmp_path):
     """The Upsample conv behind the deepest up level: its backward data path as a stage of k_tiny_bwd (+ the generic weight-gradient kernel on the
     side stream) against k_conv_bwd_wg (DQ_NO_TINY_UPT=1)."""
