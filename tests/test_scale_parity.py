@@ -114,6 +114,31 @@ def test_train_step_is_bitwise_repeatable():
         assert torch.equal(gr, runs[0][1]), int((gr != runs[0][1]).sum())
 
 
+def test_train_step_schedule_stress():
+    """The same fused step queued back to back WITHOUT a synchronisation in between, many times: loss and gradients stay bit-identical.  The step runs
+    on two queues that share scratch buffers; a missing ordering between them shows up as a run-to-run difference
+    (tools/race_stress.py is the long form: 4 shapes x 300 steps, profiles/r04_race_stress.log)."""
+    from dquartic.model.model import DDIMDiffusionModel
+
+    net, _ = _net(64, 14)
+    dm = DDIMDiffusionModel(model_class=net.cuda(), device="cuda")
+    for B, RT, reps in ((3, 70, 100), (8, 400, 50)):
+        g = torch.Generator().manual_seed(B)
+        x0, c2, c1 = (torch.rand(B, RT, 64, generator=g).cuda(), torch.rand(B, RT, 64, generator=g).cuda(), torch.rand(B, RT, generator=g).cuda())
+        t, nz = torch.randint(0, 1000, (B,), generator=g).cuda(), torch.randn(B, RT, 64, generator=g).cuda()
+        ref = None
+        bad = 0
+        for _ in range(reps):
+            loss = dm.train_step_fused(x0, c2, c1, t=t, noise=nz, zero_grads=True)
+            cur = (loss.clone(), net.flat_grads().clone())
+            if ref is None:
+                ref = cur
+            elif not (torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1])):
+                bad += 1
+        torch.cuda.synchronize()
+        assert bad == 0, (B, RT, bad)
+
+
 def test_sample_batch512_graph_vs_oracle_and_batch_independence():
     """configs[3]: 50-step DDIM sampling of 512 windows through the hipGraph-captured step."""
     from dquartic.model.model import DDIMDiffusionModel
