@@ -1132,7 +1132,8 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     LevelCall lh = up_call(L);
     const bool head_shape = p.dim == 4 && p.final_conv.cout == 1 && p.final_conv.cin == 4 && p.final_conv.k == 1 && p.final_conv.b >= 0 && level_ok(c, lh);
     const bool head_fused = !c.save && head_shape;
-    if (c.save && c.head_loss && c.G && head_shape && lh.pre == LEVEL_PRE_S1 && lh.pc && lh.pc->cin == 4) {
+    if (c.save && c.head_loss && c.G && head_shape && lh.pre == LEVEL_PRE_S1 && lh.pc && lh.pc->cin == 4 &&
+        (int64_t)B * 4 <= LEVEL_LOSS_PARTS) {  // (one partial sum per wave: beyond a resident round the grid is B workgroups)
       // train step: final_conv, loss and d fin.out in the final block's launch (its output IS stored); built for the (4, k3 conv, 4) launch
       lh.head = &p.final_conv; lh.eps_out = nullptr;
       LevelFwd f = with_img(lh, 2 * L);
@@ -1253,8 +1254,9 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
       nb.u = c.w(a.mid1.out); nb.dy = c.g(a.xn); nb.du = c.g(a.mid1.out); nb.accumulate = 1; nb.add_src = c.g(a.attn_out); nb.C = p.mid_c; nb.rows = B; nb.n = RT; nb.rows_per_sample = 1;
       nb.g = c.prm(p.ag); nb.dg = c.dprm(p.ag);
       nb.part = c.w(a.bb_part); nb.part_floats = a.bb_part_floats;
-      // (the gain's slot reduction feeds nothing on the chain: with the next side-stream flush; the slot's other user, the input-affine backward
-      // at the end of the pass, runs on the same stream behind it)
+      // (the gain's slot reduction feeds nothing on the chain: with the next side-stream flush.  The slot's other users: the MS1 path's backward, on
+      // the side stream behind it, and the input-affine backward at the end of the pass -- on the side stream too, or on the main stream behind the
+      // event that marks the side queue's state in front of the tail: unet_backward's `ev_ss`)
       PartReduce gred;
       const bool defer = c.owner && c.side_defer && !grad_x && tail_fork_enabled();
       if (defer) nb.defer_reduce = &gred;

@@ -131,8 +131,9 @@ __global__ void __launch_bounds__(256) k_level_images(LevelImgMulti mm, const fl
 // with the channel quads walked in a run-time load -> use loop a wave exposed one memory latency per quad and the launch ran at a
 // third of the rate its loads in flight allow)
 // N64: rows of exactly 64 positions = one row per wave: the wave shifts' zero fill at lanes 0 / 63 IS the conv's zero padding, no masks
-// TH: the training head (LevelFwd::loss_z) is compiled in -- its own instantiation, so that the inference kernels keep their registers (with a
-// run-time branch every C = 4 kernel went from 77 to 87: five instead of six workgroups per CU)
+// TH: the train step's code is compiled in -- the INIT stage that stores cat0 and may form x_t (LevelFwd::cat0_out, qs_*), the training head behind
+// the final block (LevelFwd::loss_z).  Instantiations of their own, so that the inference kernels keep their registers (as a run-time branch the
+// head took every C = 4 kernel from 77 to 87: five instead of six workgroups per CU)
 template <int C, int PRE, int CP, bool N64, bool TH = false>
 __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __restrict__ P, const float* __restrict__ ssb, int tiles_ps, int total_tiles,
                                                    int ln_rt, const float* __restrict__ img) {  // ssb: the per-sample scale / shift vectors; ln_rt = log2(n)
