@@ -4,6 +4,9 @@
 // mid_block1, mid_attn, mid_block2, final_res_block, final_conv.  The non-trainable RoPE frequencies
 // (mid_attn.fn.fn.rotary_emb.freqs) are NOT part of the flat buffer.
 #include "dq_plan.h"
+#include "dq_options.h"
+#include <atomic>
+#include <cstring>
 #include <cstdlib>
 
 namespace dq {
@@ -162,4 +165,23 @@ void build_resblock_plan(Plan& p, ResP& r, int cin, int cout) {
   r = b.res("block", cin, cout);
 }
 
+}  // namespace dq
+
+namespace dq {
+namespace {
+std::atomic<int64_t> g_options[OPT_COUNT] = {{-1}, {-1}};
+std::atomic<unsigned> g_options_epoch{0};
+const char* const g_option_keys[OPT_COUNT] = {"la_small_min_rows", "la_rows_bwd_min_rows"};
+}  // namespace
+int64_t option(Option o) { return g_options[o].load(std::memory_order_relaxed); }
+unsigned options_epoch() { return g_options_epoch.load(std::memory_order_relaxed); }
+int option_index(const char* key) {
+  for (int i = 0; key && i < OPT_COUNT; ++i)
+    if (!std::strcmp(key, g_option_keys[i])) return i;
+  return -1;
+}
+void set_option(int index, int64_t value) {
+  g_options[index].store(value, std::memory_order_relaxed);
+  g_options_epoch.fetch_add(1, std::memory_order_relaxed);
+}
 }  // namespace dq

@@ -73,4 +73,5 @@ struct dq_plan {
   hipStream_t cap_stream = nullptr;  // capture-only stream (the caller's may be the uncapturable legacy default stream)
   const void* g_params = nullptr; const void* g_rope = nullptr; const void* g_ws = nullptr;
   int g_B = 0, g_RT = 0, g_norm = -1, g_pred = -1;
+  unsigned g_opt_epoch = 0;  // dq::options_epoch() at capture time (a dq_set_option call may change the dispatch baked into the graph)
 };

@@ -5,6 +5,7 @@
 #include "dq_tfm.h"
 #include "dq_kernels.h"
 #include "dq_unet.h"
+#include "dq_options.h"
 #include "../../include/dq_hip.h"
 
 #include <algorithm>
@@ -1593,6 +1594,7 @@ int dq_unet_bwd(dq_plan* plan, const float* params, const float* rope_freqs, con
   float* W = (float*)workspace;
   Ctx c{plan->plan, plan->arena, params, W, W + plan->arena.floats, grads, B, RT, (hipStream_t)stream};
   c.owner = (side_stream_enabled() && !plan->no_side) ? plan : nullptr;
+  plan->twin_zeroed = nullptr;  // (only a forked forward of the SAME dq_train_step call clears the twin ahead of its backward)
   return unet_backward(c, rope_freqs, init_cond, cond_mul, cond_add, plan->dev, grad_out, grad_x);
 }
 
@@ -1636,6 +1638,18 @@ int dq_adamw_clip_step_dev(float* params, const float* grads, float* exp_avg, fl
                                step_dev, gnorm_out, (hipStream_t)stream);
 }
 
+int dq_set_option(const char* key, int64_t value) {
+  const int i = option_index(key);
+  DQ_REQUIRE(i >= 0, "dq_set_option: unknown key");
+  set_option(i, value);
+  return 0;
+}
+int64_t dq_get_option(const char* key) {
+  const int i = option_index(key);
+  if (i < 0) { set_error("dq_get_option: unknown key"); return INT64_MIN; }
+  return option((Option)i);
+}
+
 int dq_plan_set_side_stream(dq_plan* plan, int on) {
   DQ_REQUIRE(plan, "dq_plan_set_side_stream: null plan");
   plan->no_side = on ? false : true;
@@ -1652,6 +1666,7 @@ int dq_train_step(dq_plan* plan, const float* params, const float* rope_freqs, c
   DQ_REQUIRE(pred_type == DQ_PRED_EPS || loss_weight_dev, "dq_train_step: pred_type x0 needs the loss-weight (SNR) table");
   DQ_REQUIRE(B > 0 && RT > 0, "dq_train_step: B and RT must be positive");
   DQ_REQUIRE(ms1_loss_weight >= 0.f && ms1_loss_weight <= 1.f, "dq_train_step: ms1_loss_weight must lie in [0, 1]");
+  plan->twin_zeroed = nullptr;  // (a step that failed between its forked forward and its backward must not leave "already cleared" behind)
   DQ_TRY(ensure_arena(plan, B, RT));
   const Arena& a = plan->arena;
   DQ_REQUIRE(workspace_bytes >= 2 * (int64_t)sizeof(float) * a.floats, "dq_train_step: workspace too small (training=1)");
@@ -1773,7 +1788,7 @@ int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, 
     DQ_TRY(ms1_prologue(c, c.w(a.c1_stage)));
     io.x_t = xa; io.x_out = xa; io.step_ptr = step; io.want_eps = false;  // in place: element-wise, read and written by the same lane
     const bool valid = plan->step_exec && plan->g_params == params && plan->g_rope == rope_freqs && plan->g_ws == workspace &&
-                       plan->g_B == B && plan->g_RT == RT && plan->g_norm == auto_normalize && plan->g_pred == pred_type;
+                       plan->g_B == B && plan->g_RT == RT && plan->g_norm == auto_normalize && plan->g_pred == pred_type && plan->g_opt_epoch == options_epoch();
     if (!valid) {
       if (plan->step_exec) { (void)hipGraphExecDestroy(plan->step_exec); plan->step_exec = nullptr; }
       if (plan->step_graph) { (void)hipGraphDestroy(plan->step_graph); plan->step_graph = nullptr; }
@@ -1794,7 +1809,7 @@ int dq_ddim_sample(dq_plan* plan, const float* params, const float* rope_freqs, 
       DQ_HIP_OK(ce);
       plan->step_graph = g;
       DQ_HIP_OK(hipGraphInstantiate(&plan->step_exec, g, nullptr, nullptr, 0));
-      plan->g_params = params; plan->g_rope = rope_freqs; plan->g_ws = workspace; plan->g_B = B; plan->g_RT = RT; plan->g_norm = auto_normalize; plan->g_pred = pred_type;
+      plan->g_params = params; plan->g_rope = rope_freqs; plan->g_ws = workspace; plan->g_B = B; plan->g_RT = RT; plan->g_norm = auto_normalize; plan->g_pred = pred_type; plan->g_opt_epoch = options_epoch();
     }
     for (int i = 0; i < num_steps; ++i) DQ_HIP_OK(hipGraphLaunch(plan->step_exec, s));
     DQ_TRY(launch_sample_finish(xa, ms2_cond, out_x, out_noise, n, auto_normalize, s));

@@ -16,6 +16,8 @@
 #include "dq_common.h"
 #include "dq_kernels.h"
 #include "dq_mfma.h"
+#include "dq_options.h"
+#include <climits>
 #include <algorithm>
 #include <cstdlib>
 
@@ -250,12 +252,15 @@ bool la_small_usable(int C, int n) {
   if (!la_small_enabled()) return false;
   return ((n == 2 || n == 4) && (C == 12 || C == 16)) || (n == 8 && C == 12 && la_small8_enabled());  // (8 channels at 8 positions measured slower than the register-resident kernel: 297 vs 276 us at batch 512; 12 channels: 371 vs 429)
 }
-// Below this many rows the launch is a latency chain (a training batch of 32 windows: 400 tiles for 1,024 SIMDs) and the register-resident
-// kernel's shorter prologue wins (measured at 12,800 rows: 4 launches +35 us per step); above it the matrix pipe is the limit and this
-// form's ~3x fewer MFMA cycles per position pay.  DQ_LA_SMALL_MIN_ROWS: A-B switch.
+// Below one 32-row tile per SIMD the launch is a latency chain (a training batch of 32 windows: 400 tiles for 1,024 SIMDs) and the
+// register-resident kernel's shorter prologue wins (measured at 12,800 rows: 4 launches +35 us per step); above it the matrix pipe is the limit
+// and this form's ~3x fewer MFMA cycles per position pay.  The rule comes from the device (4 SIMDs per compute unit x 32 rows);
+// dq_set_option("la_small_min_rows", rows) overrides it (tests run both forms at every size).
 int la_small_min_rows() {
-  static const int v = [] { const char* e = std::getenv("DQ_LA_SMALL_MIN_ROWS"); return e ? std::atoi(e) : 40000; }();
-  return v;
+  const int64_t o = option(OPT_LA_SMALL_MIN_ROWS);
+  if (o >= 0) return (int)std::min<int64_t>(o, INT32_MAX);
+  static const int rule = [] { int d = 0; hipDeviceProp_t pr; return 32 * 4 * ((hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256); }();
+  return rule;
 }
 
 int launch_la_small_fwd(const LinAttn& a, hipStream_t s) {

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DQ_HIP_LIB", os.path.join(os.path.dirname(_HERE), "libdq_hip.so"))
 
 _lib = None
-ABI_VERSION = 9  # DQ_ABI_VERSION of include/dq_hip.h this table was written against
+ABI_VERSION = 10  # DQ_ABI_VERSION of include/dq_hip.h this table was written against
 PRED_TYPES = {"eps": 0, "x0": 1}  # DQ_PRED_EPS / DQ_PRED_X0
 PRECISIONS = {"fp32": 0, "bf16x3": 1}  # DQ_PRECISION_FP32 / DQ_PRECISION_BF16X3
 
@@ -35,6 +35,8 @@ PROTOTYPES = {
     "dq_adamw_clip_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_void_p,
                                        c_double, c_double, c_double, c_double, c_void_p, c_void_p, c_void_p]),
     "dq_plan_set_side_stream": (c_int, [c_void_p, c_int]),
+    "dq_set_option": (c_int, [c_char_p, c_int64]),
+    "dq_get_option": (c_int64, [c_char_p]),
     "dq_adamw_clip_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_double,
                                    c_double, c_double, c_double, c_double, c_int, c_void_p, c_void_p]),
     "dq_train_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
@@ -122,6 +124,15 @@ def build_id() -> str:
         with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def set_option(key: str, value: int) -> None:
+    """``dq_set_option``: a process-wide tuning option of the library (keys: include/dq_hip.h)."""
+    check(lib().dq_set_option(key.encode(), int(value)), f"dq_set_option({key!r})")
+
+
+def get_option(key: str) -> int:
+    return int(lib().dq_get_option(key.encode()))
 
 
 def check(rc, what):

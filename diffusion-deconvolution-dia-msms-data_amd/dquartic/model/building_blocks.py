@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from .. import _native as N
-from .unet1d import _attach
+from .unet1d import _attach, _FlatBuffers
 
 _BUCKET_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64)  # dq_tfm_bucket_fn
 
@@ -41,7 +41,7 @@ def time_embedding_freqs(hidden_dim: int):
     return torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1))).contiguous()
 
 
-class CustomTransformer(nn.Module):
+class CustomTransformer(_FlatBuffers, nn.Module):
     def __init__(self, input_dim=40000, hidden_dim=128, num_heads=1, num_layers=1):
         super().__init__()
         self.input_dim, self.hidden_dim, self.num_heads, self.num_layers = int(input_dim), int(hidden_dim), int(num_heads), int(num_layers)
@@ -99,39 +99,11 @@ class CustomTransformer(nn.Module):
         return [(n, self._by_name[n]) for n, _, _ in self._layout]
 
     def _ensure_flat(self):
-        first = self._by_name[self._layout[0][0]]
-        dev = first.device
-        ok = self._flat.device == dev
-        if ok:
-            base = self._flat.data_ptr()
-            ok = all(self._by_name[n].data_ptr() == base + 4 * o for n, o, _ in self._layout)
-        if not ok:
-            flat = torch.empty(self._flat.numel(), dtype=torch.float32, device=dev)
-            for pname, o, shape in self._layout:
-                p = self._by_name[pname]
-                flat[o:o + p.numel()].copy_(p.detach().reshape(-1).to(torch.float32))
-                p.data = flat[o:o + p.numel()].view(shape)
-            self._flat = flat
-            self._flat_grad = None
-        return self._flat
+        return self._flat_buffer()
 
     @property
     def flat_params(self) -> torch.Tensor:
-        return self._ensure_flat()
-
-    def flat_grads(self, zero: bool = False) -> torch.Tensor:
-        flat = self._ensure_flat()
-        if self._flat_grad is None or self._flat_grad.device != flat.device:
-            self._flat_grad = torch.zeros_like(flat)
-            zero = False
-        if zero:
-            self._flat_grad.zero_()
-        base = self._flat_grad.data_ptr()
-        for pname, o, shape in self._layout:
-            p = self._by_name[pname]
-            if p.grad is None or p.grad.data_ptr() != base + 4 * o:
-                p.grad = self._flat_grad[o:o + p.numel()].view(shape)
-        return self._flat_grad
+        return self._flat_buffer()
 
     def workspace(self, B, S1, S2, training):
         dev = self._flat.device

@@ -43,9 +43,20 @@ const char* dq_last_error(void);
  * 4: dq_tfm_bwd takes an accumulate flag.  5: dq_ddim_sample takes num_timesteps (the plan no longer fixes T); stand-alone
  * building blocks (dq_rmsnorm_fwd, dq_time_mlp_fwd, dq_scale_shift_fwd, dq_prep_inputs_fwd, dq_conv_fwd, dq_resblock_*,
  * dq_rope, dq_attn_*); dq_train_step takes ms1_loss_weight, dq_ms1_loss_fwd_bwd;
- * dq_tfm_set_precision, dq_gemm_bf16x3.  8: dq_tfm_bwd_buckets, dq_tfm_num_buckets, dq_tfm_bucket_info. */
+ * dq_tfm_set_precision, dq_gemm_bf16x3.  8: dq_tfm_bwd_buckets, dq_tfm_num_buckets, dq_tfm_bucket_info.  9: dq_linattn_prepare,
+ * dq_linattn_fwd_prepared.  10: dq_set_option, dq_get_option. */
 int dq_abi_version(void);
-#define DQ_ABI_VERSION 9
+#define DQ_ABI_VERSION 10
+
+/* Process-wide tuning options (no reference counterpart: the reference has one code path per op).  The library reads NO environment
+ * variable for its dispatch; what can be tuned is set here, takes effect from the next call on, and invalidates cached sampling graphs.
+ *   "la_small_min_rows"     rows (B * RT) from which LinearAttention over m/z rows of 2 / 4 / 8 positions runs in the
+ *                           one-register-group-per-position form (k_la_small.hip) instead of the register-resident one (k_linattn.hip);
+ *                           < 0 (default): the device rule, one 32-row tile per SIMD (32,768 rows on MI355X)
+ *   "la_rows_bwd_min_rows"  the same for its backward (k_la_rows_bwd.hip against k_la_bwd.hip); < 0 (default): every row count
+ * Both forms compute the same function (parity tests run both at every size).  Unknown key: non-zero / INT64_MIN. */
+int dq_set_option(const char* key, int64_t value);
+int64_t dq_get_option(const char* key);
 
 /* DDIMDiffusionModel.pred_type (model.py:205-213, 269-280, 354-389); any other value is rejected ("Unknown pred_type"). */
 enum { DQ_PRED_EPS = 0, DQ_PRED_X0 = 1 };

@@ -13,10 +13,31 @@ for p in (REPO, PKG):
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
-# The small-row LinearAttention kernel (k_la_small.hip) is dispatched from a row count on (latency vs throughput): the
-# suite runs it at EVERY row count, so that the small fixtures and the whole-net goldens cover it (the library reads the variable once).  The
-# register-resident kernel it replaces there stays covered by the stand-alone dq_linattn_fwd tests.
-os.environ.setdefault("DQ_LA_SMALL_MIN_ROWS", "0")
+# No environment default is set here: the suite runs the library the way bench.py runs it.  Tests that must see BOTH LinearAttention forms
+# (register-resident k_linattn.hip / k_la_bwd.hip against the one-register-group-per-position k_la_small.hip / k_la_rows_bwd.hip, chosen by row
+# count in the product) take the `la_form` fixture below, which flips the library's own tuning option (dq_set_option) in-process.
+LA_FORMS = {
+    # name: (la_small_min_rows, la_rows_bwd_min_rows); -1 = the library's default rule
+    "default": (-1, -1),          # what bench.py / a user gets: by row count (forward), every row count (backward)
+    "rows": (0, 0),               # the per-row forms at every row count
+    "register": (1 << 40, 1 << 40),  # the register-resident forms at every row count
+}
+
+
+def set_la_form(name):
+    from dquartic import _native as N
+
+    fwd, bwd = LA_FORMS[name]
+    N.set_option("la_small_min_rows", fwd)
+    N.set_option("la_rows_bwd_min_rows", bwd)
+
+
+@pytest.fixture(params=["default", "rows", "register"])
+def la_form(request):
+    """Runs the test once per LinearAttention dispatch; restores the default rule afterwards."""
+    set_la_form(request.param)
+    yield request.param
+    set_la_form("default")
 
 
 def pytest_configure(config):

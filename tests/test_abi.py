@@ -31,7 +31,7 @@ def test_header_symbols_exported_and_bound():
         assert name in N.PROTOTYPES, f"{name} has no ctypes prototype"
         assert len(N.PROTOTYPES[name][1]) == nargs, f"{name}: header has {nargs} parameters, binding {len(N.PROTOTYPES[name][1])}"
     assert set(N.PROTOTYPES) == set(decl), set(N.PROTOTYPES) ^ set(decl)
-    assert lib.dq_abi_version() == N.ABI_VERSION == 9  # DQ_ABI_VERSION in include/dq_hip.h
+    assert lib.dq_abi_version() == N.ABI_VERSION == 10  # DQ_ABI_VERSION in include/dq_hip.h
 
 
 def test_plan_layout_without_a_gpu():

@@ -1,5 +1,7 @@
-"""CPU: the committed benchmark line (profiles/bench_r01.json, written by `python bench.py` on an MI355X) carries every field the
-benchmark contract names, with consistent values; and bench.py's argument surface is the contract's."""
+"""CPU: the NEWEST committed benchmark line (profiles/bench_rNN.json, written by `python bench.py` on an MI355X) carries every field the
+benchmark contract names, with consistent values -- including the objects later rounds added (sampling leg with its own roofline,
+large-window leg, whole-step executed-FLOP fraction, small-batch legs); and bench.py's argument surface is the contract's."""
+import glob
 import json
 import os
 import re
@@ -9,8 +11,29 @@ import pytest
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _newest_bench_line():
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "bench_r[0-9][0-9].json")))
+    assert files, "no profiles/bench_rNN.json committed"
+    return files[-1], open(files[-1]).read().strip()
+
+
+def _check_roofline(r, bound=None):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and (bound is None or r["bound"] == bound)
+    assert r["unit"] == ("GB/s" if r["bound"] == "hbm" else "TFLOP/s")
+    assert r["peak"] == (8000.0 if r["bound"] == "hbm" else 157.3)
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
+    assert r["traffic"] is None or r["traffic"] > 0
+    if "launch_us" in r and "executed_flops_per_launch" in r:  # achieved = executed FLOPs per launch / HIP-event launch time
+        assert abs(r["achieved"] - r["executed_flops_per_launch"] / r["launch_us"] / 1e6) < 0.01 * r["achieved"]
+    if "launch_us" in r and r["bound"] == "hbm":
+        assert abs(r["achieved"] - r["bytes_per_launch"] / r["launch_us"] / 1e3) < 0.01 * r["achieved"]
+
+
 def test_committed_bench_line_has_the_contract_fields():
-    line = open(os.path.join(REPO, "profiles", "bench_r01.json")).read().strip()
+    path, line = _newest_bench_line()
+    assert int(re.search(r"bench_r(\d\d)\.json$", path).group(1)) >= 4, path  # (the newest one, not round 1's)
     assert "\n" not in line  # ONE line
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
@@ -18,18 +41,44 @@ def test_committed_bench_line_has_the_contract_fields():
         assert k in d, k
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
     assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert "configs[1]" in d["config"]["workload"] and d["config"]["global_batch"] == 32 * d["n_gpus"]
     assert abs(d["value"] - d["config"]["global_batch"] * 1e3 / d["ms_per_step"]) < 0.01 * d["value"]  # windows/s = batch / step time
-    r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
-        assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 0
+    _check_roofline(d["roofline"], "mfma")
+    assert d["roofline"]["traffic"] and d["roofline"]["traffic"] > 0  # the counter passes of THIS build id are committed with the line
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    # sustained leg: the same step over >= 5 s agrees with the K-step figure
+    su = d["sustained"]
+    assert su["seconds"] >= 4.5 and abs(su["ms_per_step"] - d["ms_per_step"]) < 0.1 * d["ms_per_step"]
+    # whole-step fractions: executed <= algorithmic (the re-association removes FLOPs, it adds none)
+    ws = d["whole_step"]
+    assert 0 < ws["executed_flop_frac"] <= ws["flop_frac"] and 0 < ws["hbm_frac"] < 1
+    # sampling leg (configs[3]) with its own roofline object
+    sm = d["sample"]
+    assert sm["batch_per_gpu"] == 512 and sm["steps"] == 50 and abs(sm["value"] - 512 * d["n_gpus"] / sm["seconds"]) < 0.01 * sm["value"]
+    _check_roofline(sm["roofline"], "mfma")
+    assert 0 < sm["whole_leg"]["executed_flop_frac"] <= sm["whole_leg"]["flop_frac"]
+    # the two HBM-bound kernels
+    for leg in ("train", "sample"):
+        _check_roofline(d["roofline_hbm"][leg], "hbm")
+    # configs[4]
+    lw = d["large_window"]
+    assert "configs[4]" in lw["workload"] and lw["batch"] == 8
+    assert abs(lw["train"]["windows_per_s"] - lw["batch"] * 1e3 / lw["train"]["ms_per_step"]) < 0.01 * lw["train"]["windows_per_s"]
+    assert 0 < lw["train"]["executed_flop_frac"] <= lw["train"]["flop_frac"] and lw["sample"]["ms_per_step"] > 0
+    # small batches (the reference's own batch_size 1, configs[0]'s 4): a figure per form that is reported
+    for b in ("b1", "b4"):
+        sb = d["small_batch"][b]
+        assert sb["ms_per_step"] > 0 and abs(sb["windows_per_s"] - int(b[1:]) * 1e3 / sb["ms_per_step"]) < 0.01 * sb["windows_per_s"]
+        if "graph_ms_per_step" in sb:
+            assert abs(sb["graph_speedup"] - sb["ms_per_step"] / sb["graph_ms_per_step"]) < 0.011
     t = d["transformer"]  # the CustomTransformer leg
     assert t["train_b1"]["value"] > 0 and t["train_b32"]["value"] > t["train_b1"]["value"]
     assert t["roofline"]["bound"] == "mfma" and 0 < t["roofline"]["frac"] < 1 and t["cpu_baseline"]["kind"] == "port"
+    # provenance: the line names the native build it was measured on
+    assert re.fullmatch(r"[0-9a-f]{16}", d["build_id"])
 
 
 def test_bench_cli_surface():

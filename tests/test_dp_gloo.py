@@ -228,11 +228,28 @@ def _gpu_dp_worker(rank, world, port, q):
             with torch.no_grad():
                 ref_net.flat_params.copy_(start)
             ref._prepare_training(1e-3)
-            ref_losses = [ref._train_one_batch(X.cuda(), ms2_cond=C2.cuda(), ms1_cond=C1.cuda(), noise=Nz.cuda(), t=Tt.cuda()) for _ in range(3)]
+            ref_losses, g_first = [], None
+            for i in range(3):
+                ref_losses.append(ref._train_one_batch(X.cuda(), ms2_cond=C2.cuda(), ms1_cond=C1.cuda(), noise=Nz.cuda(), t=Tt.cuda()))
+                if i == 0:
+                    g_first = ref_net.flat_grads().clone()  # the global batch's gradient of the first step
             moved = (ref_net.flat_params - start).abs().max()
-            err = float((net.flat_params - ref_net.flat_params).abs().max() / moved)
+            diff = (net.flat_params - ref_net.flat_params).abs()
+            # tensors whose reference gradient is above a floor (1e-3 of the largest entry of the whole gradient): AdamW moves a weight by
+            # ~lr * g / (|g| + 1e-8) -- the SIGN of g -- so a tensor whose gradient is analytically zero (rounding noise of ~1e-10) moves in a
+            # direction the summation order of the two half batches decides; those are measured apart
+            gmax = float(g_first.abs().max())
+            live = torch.zeros_like(diff, dtype=torch.bool)
+            for _, o, shape in ref_net._layout:
+                cnt = int(torch.tensor(shape).prod())
+                gt = g_first[o:o + cnt].abs()
+                if float(gt.max()) >= 1e-3 * gmax:
+                    live[o:o + cnt] = gt >= 1e-3 * gt.max()  # (and inside such a tensor, the entries that are not cancellation residue)
+            err = float(diff[live].max() / moved)
+            err_all = float(diff.max() / moved)
+            live_frac = float(live.float().mean())
             loss_err = abs(mean_loss - ref_losses[-1]) / abs(ref_losses[-1])
-        q.put((rank, same, err, loss_err))
+        q.put((rank, same, err, loss_err) if rank else (rank, same, err, loss_err, err_all, live_frac))
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -253,11 +270,12 @@ def test_two_ranks_on_the_gpu_equal_one_process_on_the_global_batch():
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert res[0][1] and res[1][1]                 # bit-identical replicas after three steps
-    # vs the single-process run: the parameter displacement agrees to a few 1e-3 of what three steps moved.  (The two half-batch gradients are
-    # summed in another order than the global batch's; AdamW divides by sqrt(v) + 1e-8, so a gradient that is analytically zero -- rounding
-    # noise of ~1e-10 -- still moves its weight by ~1 % of lr in a direction the summation order decides.  With unseeded replicas the figure
-    # scattered around 1e-3 from run to run: 1.2e-3 once in round 4 against a 1e-3 bound.)
-    assert 0 <= res[0][2] < 5e-3, res[0]
+    # vs the single-process run: over the tensors whose reference gradient is above the floor (see the worker) the parameter displacement
+    # agrees to 1e-3 of what three steps moved -- the summation order of two half-batch gradients against the global batch's.  The
+    # tensors below the floor move by the SIGN of rounding noise (AdamW divides by sqrt(v) + 1e-8): they only get a sanity bound.
+    print("two ranks vs one process: displacement error", res[0][2], "over", res[0][5], "of the elements; all elements:", res[0][4])
+    assert 0 <= res[0][2] < 1e-3, res[0]
+    assert res[0][5] > 0.3 and res[0][4] < 2e-2, res[0]
     assert res[0][3] < 1e-5, res[0]                # the all-reduced loss mean == the global-batch loss
 
 

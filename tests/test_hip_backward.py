@@ -87,7 +87,7 @@ def _default_net(g):
 
 
 @pytest.mark.parametrize("tag,use_rope", [("norope", False), ("rope", True)])
-def test_whole_net_grads_golden(golden, tag, use_rope):
+def test_whole_net_grads_golden(golden, tag, use_rope, la_form):
     """all 395 parameter gradients + d/dx through loss.backward() (autograd bridge -> dq_unet_bwd) vs the reference's"""
     g = golden("unet_default_rt16.npz")
     net = _default_net(g)

@@ -48,7 +48,7 @@ def test_linattn_fwd_golden(N, golden, C, n):
 
 
 @pytest.mark.parametrize("C,n", [(4, 64), (4, 32), (8, 16), (8, 8), (4, 2), (12, 4), (16, 1), (12, 2), (16, 2), (16, 4), (12, 8)])
-def test_linattn_fwd_prepared_equals_standalone(N, C, n):
+def test_linattn_fwd_prepared_equals_standalone(N, C, n, la_form):
     """dq_linattn_prepare + dq_linattn_fwd_prepared (the network's path: derived weights and the split-bf16 / fp32 operand images formed once
     per parameter state) == dq_linattn_fwd (every workgroup derives them itself), bit for bit; and against the oracle.
     Rows of 2 / 4 positions at 12 / 16 channels and of 8 positions at 12: the prepared path is another kernel (k_la_small: one group of registers per position, every
@@ -73,7 +73,7 @@ def test_linattn_fwd_prepared_equals_standalone(N, C, n):
     N.check(L.dq_linattn_prepare(args[0], args[1], args[3], C, N.ptr(prep), N.stream_ptr()), "dq_linattn_prepare")
     N.check(L.dq_linattn_fwd_prepared(N.ptr(xd), N.ptr(y1), None, *args, N.ptr(prep), C, rows, n, N.stream_ptr()), "dq_linattn_fwd_prepared")
     torch.cuda.synchronize()
-    if (n in (2, 4) and C in (12, 16)) or (n == 8 and C == 12):
+    if la_form == "rows" and ((n in (2, 4) and C in (12, 16)) or (n == 8 and C == 12)):  # (203 rows: the default rule keeps the register-resident form)
         assert rel_err(y1, y0.cpu()) < 1e-5
     else:
         assert torch.equal(y0, y1)
@@ -113,7 +113,7 @@ def _default_net(g):
 
 
 @pytest.mark.parametrize("tag,use_rope", [("rope", True), ("norope", False)])
-def test_whole_net_forward_golden(golden, tag, use_rope):
+def test_whole_net_forward_golden(golden, tag, use_rope, la_form):
     g = golden("unet_default_rt16.npz")
     net = _default_net(g)
     net.use_rope = use_rope
@@ -137,7 +137,7 @@ def test_tiny_net_batched_forward_golden(golden):
     assert rel_err(y, g["batch/y"]) < 2e-5
 
 
-def test_full_size_forward_vs_oracle(golden):
+def test_full_size_forward_vs_oracle(golden, la_form):
     """BASELINE config C1 shape: (B=4, RT=400, MZ=64), default network, against the oracle"""
     from oracle import dq_oracle as O
 

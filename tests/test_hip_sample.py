@@ -85,7 +85,7 @@ def test_predict_one_batch_golden(golden):
     assert isinstance(a, np.ndarray) and a.shape == tuple(x0.shape[1:]) and b.shape == a.shape
 
 
-def test_sample_full_size_vs_oracle(golden):
+def test_sample_full_size_vs_oracle(golden, la_form):
     """BASELINE shape (RT=400, MZ=64), default network, B=2, 5 steps: per-step eps and final sample vs the oracle"""
     from dquartic.model.model import DDIMDiffusionModel
     from dquartic.model.unet1d import UNet1d

@@ -2,9 +2,9 @@
 
   * configs[1]: ``_train_one_batch`` semantics at (32, 400, 64) -- loss and all 395 parameter gradients vs the per-sample oracle
     loop (batched semantics = the B = 1 reference applied to every sample, loss = mean over samples; DESIGN.md section 1);
-  * configs[3]: ``sample`` at B = 512, 50 steps, hipGraph replay -- windows 0..1 vs the oracle (per-step eps <= 1e-4 relative,
-    the tolerance north_star states), batch independence (windows 0..1 of the B = 512 run == a B = 2 run), x_T untouched,
-    second output == mixture - denoised;
+  * configs[3]: ``sample`` at B = 512, 50 steps, hipGraph replay -- windows 0 and 511 vs the oracle (per-step eps <= 1e-4 relative,
+    the tolerance north_star states), batch independence bit for bit at windows {0, 1, 255, 510, 511} (B = 2 / B = 1 re-runs), x_T
+    untouched, second output == mixture - denoised;
   * configs[4]: one (2000, 256) window -- forward eps, loss and all gradients vs the oracle;
   * determinism: two ``dq_train_step`` calls on the same inputs give bit-identical flat gradients and loss.
 
@@ -67,8 +67,20 @@ def _check_grads(net, po, tol=GRAD_TOL):
     return worst
 
 
-def test_train_one_batch_at_bench_size_vs_oracle():
-    """configs[1]: batch 32 of (400, 64) windows -- the exact workload ``bench.py``'s ``value`` is quoted on."""
+_ORACLE_CACHE = {}
+
+
+def _cached(key, fn):
+    """the oracle side of a test that runs once per LinearAttention dispatch (la_form): computed once per session"""
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = fn()
+    return _ORACLE_CACHE[key]
+
+
+def test_train_one_batch_at_bench_size_vs_oracle(la_form):
+    """configs[1]: batch 32 of (400, 64) windows -- the exact workload ``bench.py``'s ``value`` is quoted on, under every LinearAttention
+    dispatch: ``default`` is the kernel set of the bench line (the library's own rule at 12,800 rows), ``rows`` / ``register`` force either
+    form at every level it exists for."""
     from dquartic.model.model import DDIMDiffusionModel
 
     net, params = _net(64, 11)
@@ -79,12 +91,12 @@ def test_train_one_batch_at_bench_size_vs_oracle():
     t = torch.randint(0, 1000, (B,), generator=g)
     t[0], t[1] = 0, 999  # both ends of the schedule are in the batch
     nz = torch.randn(B, RT, MZ, generator=g)
-    lo, _, po = _oracle_grads(params, MZ, x0, c2, c1, t, nz)
+    lo, _, po = _cached("train32", lambda: _oracle_grads(params, MZ, x0, c2, c1, t, nz))
     net.train()
     loss = dm.train_step_fused(x0.cuda(), c2.cuda(), c1.cuda(), t=t.cuda(), noise=nz.cuda())
     assert abs(float(loss) - lo) < 2e-5 * abs(lo), (float(loss), lo)
     worst = _check_grads(net, po)
-    print("batch-32 train step: loss", float(loss), "oracle", lo, "worst grad", worst)
+    print("batch-32 train step [%s]: loss" % la_form, float(loss), "oracle", lo, "worst grad", worst)
     # the optimiser half of _train_one_batch on the same gradients: pre-clip norm vs the oracle's
     gn_ref = float(torch.sqrt(sum((po[k].grad.double() ** 2).sum() for k in po if po[k].grad is not None)))
     dm._set_optimizer(1e-5)
@@ -139,8 +151,13 @@ def test_train_step_schedule_stress():
         assert bad == 0, (B, RT, bad)
 
 
-def test_sample_batch512_graph_vs_oracle_and_batch_independence():
-    """configs[3]: 50-step DDIM sampling of 512 windows through the hipGraph-captured step."""
+def test_sample_batch512_graph_vs_oracle_and_batch_independence(la_form):
+    """configs[3]: 50-step DDIM sampling of 512 windows through the hipGraph-captured step, under every LinearAttention dispatch
+    (``default`` at 204,800 rows = the per-row forward at the deep levels, as bench.py's sampling leg runs it).
+
+    Every big kernel of the step is ONE resident round of workgroups that loops over tiles, so a dropped tail tile would be finite garbage
+    in a HIGH window: batch independence is checked bit for bit at windows {0, 1, 255, 510, 511} (B = 2 / B = 1 re-runs of exactly those
+    windows), and the oracle faces window 0 AND window 511."""
     from dquartic.model.model import DDIMDiffusionModel
     from oracle import dq_oracle as O
 
@@ -150,34 +167,43 @@ def test_sample_batch512_graph_vs_oracle_and_batch_independence():
     B, RT, MZ, NS = 512, 400, 64, 50
     g = torch.Generator().manual_seed(7)
     xT, c2, c1 = torch.randn(B, RT, MZ, generator=g), torch.rand(B, RT, MZ, generator=g), torch.rand(B, RT, generator=g)
-    xd = xT.cuda()
+    xd, c2d, c1d = xT.cuda(), c2.cuda(), c1.cuda()
     net.eval()
     with torch.no_grad():
-        s, pn = dm.sample(xd, c2.cuda(), c1.cuda(), num_steps=NS)
+        s, pn = dm.sample(xd, c2d, c1d, num_steps=NS)
     torch.cuda.synchronize()
     assert torch.equal(xd.cpu(), xT)                                         # x_T untouched
-    assert float((pn - (c2.cuda() - s)).abs().max()) < 1e-6                  # model.py:321-322: mixture - denoised
+    assert float((pn - (c2d - s)).abs().max()) < 1e-6                        # model.py:321-322: mixture - denoised
     assert bool(torch.isfinite(s).all())
-    # batch independence: windows 0..1 of the B = 512 run == a B = 2 run, graph on and off
-    with torch.no_grad():
-        s2, pn2 = dm.sample(xd[:2].contiguous(), c2[:2].cuda(), c1[:2].cuda(), num_steps=NS)
-        dm.use_graph = False
-        s2e, _, tx, te = dm.sample(xd[:2].contiguous(), c2[:2].cuda(), c1[:2].cuda(), num_steps=NS, return_trajectory=True)
-        dm.use_graph = True
-    assert torch.equal(s2, s2e)
-    assert torch.equal(s[:2], s2) and torch.equal(pn[:2], pn2)
-    # window 0 against the oracle (50 CPU steps per window: one is enough, window 1 is tied to it by the batch-independence
-    # checks above): per-step eps (<= 1e-4 of the step's eps scale) and the denoised window
-    tr = []
-    with torch.no_grad():
-        so, _ = O.Diffusion(params, O.UNetConfig(downsample_dim=64)).sample(xT[:1], c2[:1], c1[:1], NS, trace=tr)
-    worst = 0.0
-    for i, (_, _, e) in enumerate(tr):
-        worst = max(worst, float((te[i][:1].cpu() - e).abs().max() / e.abs().max()))
-    print("50-step sampling: worst per-step eps rel err", worst, "final MSE", float(((s[:1].cpu() - so) ** 2).mean()))
-    assert worst < EPS_TOL, worst
-    assert float(((s[:1].cpu() - so) ** 2).mean()) < 1e-8                    # denoised-MS2 MSE
-    assert float((s[:1].cpu() - so).abs().max() / so.abs().max()) < 5e-4
+    # batch independence, bit for bit: each group of windows re-run alone (graph on), the first group also without the graph
+    traj = {}
+    for idx in ([0, 1], [255], [510, 511]):
+        sel = torch.tensor(idx)
+        with torch.no_grad():
+            s2, pn2 = dm.sample(xd[sel].contiguous(), c2d[sel].contiguous(), c1d[sel].contiguous(), num_steps=NS)
+            dm.use_graph = False
+            s2e, _, tx, te = dm.sample(xd[sel].contiguous(), c2d[sel].contiguous(), c1d[sel].contiguous(), num_steps=NS, return_trajectory=True)
+            dm.use_graph = True
+        assert torch.equal(s2, s2e), idx
+        assert torch.equal(s[sel.cuda()], s2) and torch.equal(pn[sel.cuda()], pn2), idx
+        for j, w in enumerate(idx):
+            traj[w] = [e[j:j + 1].cpu() for e in te]
+    # windows 0 and 511 against the oracle (50 CPU steps per window): per-step eps (<= 1e-4 of the step's eps scale) and the denoised window;
+    # the windows in between are tied to their own small-batch runs above, and those to the same kernels
+    def oracle_window(w):
+        tr = []
+        with torch.no_grad():
+            so, _ = O.Diffusion(params, O.UNetConfig(downsample_dim=64)).sample(xT[w:w + 1], c2[w:w + 1], c1[w:w + 1], NS, trace=tr)
+        return so, [e for _, _, e in tr]
+    for w in (0, 511):
+        so, eps_o = _cached(("sample512", w), lambda: oracle_window(w))
+        worst = 0.0
+        for i, e in enumerate(eps_o):
+            worst = max(worst, float((traj[w][i] - e).abs().max() / e.abs().max()))
+        print("50-step sampling [%s], window %d: worst per-step eps rel err" % (la_form, w), worst, "final MSE", float(((s[w:w + 1].cpu() - so) ** 2).mean()))
+        assert worst < EPS_TOL, (w, worst)
+        assert float(((s[w:w + 1].cpu() - so) ** 2).mean()) < 1e-8           # denoised-MS2 MSE
+        assert float((s[w:w + 1].cpu() - so).abs().max() / so.abs().max()) < 5e-4
 
 
 def test_large_window_2000x256_vs_oracle():

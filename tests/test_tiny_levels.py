@@ -1,7 +1,7 @@
 """GPU parity of the round-4 deep-level kernels against the launches they replace, on the SAME seeded network and inputs:
 k_tiny (levels with rows of 1 / 2 positions: stage + ResnetBlocks + the n = 1 LinearAttention + the bottleneck folds) against
 k_level_fwd / k_linattn_fwd / k_conv_fwd / k_fold (DQ_NO_TINY=1), k_la_small against the register-resident LinearAttention
-(DQ_NO_LA_SMALL=1), and the side-stream scheduling of the train step against the single chain (DQ_NO_FWD_FORK=1 DQ_NO_TAIL_FORK=1).
+(dq_set_option: the register-resident forms at every row count), and the side-stream scheduling of the train step against the single chain (DQ_NO_FWD_FORK=1 DQ_NO_TAIL_FORK=1).
 The library reads its switches once per process, so every variant runs in its own child process (one at a time) and leaves an .npz.
 RT = 70 leaves the last tile of every sample partly filled (32-row and 64-row tiles)."""
 import os
@@ -20,6 +20,12 @@ import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[1])
 from dquartic.model.model import DDIMDiffusionModel
 from dquartic.model.unet1d import UNet1d
+import os
+from dquartic import _native as N
+if os.environ.get("TEST_LA_FORM") == "rows":  # the per-row LinearAttention forms at every row count (the product's rule picks by row count)
+    N.set_option("la_small_min_rows", 0); N.set_option("la_rows_bwd_min_rows", 0)
+elif os.environ.get("TEST_LA_FORM") == "register":
+    N.set_option("la_small_min_rows", 1 << 40); N.set_option("la_rows_bwd_min_rows", 1 << 40)
 torch.manual_seed(3)
 net = UNet1d(dim=4, channels=1, dim_mults=(1, 2, 2, 3, 3, 4, 4), conditional=True, init_cond_channels=1, attn_cond_channels=1, downsample_dim=64, simple=True).cuda()
 with torch.no_grad():
@@ -43,7 +49,7 @@ def _run(tmp_path, tag, env, shape=()):
     out = str(tmp_path / f"{tag}.npz")
     e = dict(os.environ)
     e.update(env)
-    e.setdefault("DQ_LA_SMALL_MIN_ROWS", "0")
+    e.setdefault("TEST_LA_FORM", "rows")  # (the deep-level kernels under test include the per-row LinearAttention forms)
     r = subprocess.run([sys.executable, "-c", CHILD, os.path.join(REPO, "diffusion-deconvolution-dia-msms-data_amd"), out] + [str(v) for v in shape], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     return dict(np.load(out))
@@ -55,7 +61,7 @@ def _rel(a, b):
 
 def test_deep_level_kernels_match_the_launches_they_replace(tmp_path):
     new = _run(tmp_path, "new", {})
-    old = _run(tmp_path, "old", {"DQ_NO_TINY": "1", "DQ_NO_LA_SMALL": "1", "DQ_NO_FWD_FORK": "1", "DQ_NO_TAIL_FORK": "1", "DQ_NO_TRAIN_INIT": "1", "DQ_NO_HEAD_LOSS": "1"})
+    old = _run(tmp_path, "old", {"DQ_NO_TINY": "1", "TEST_LA_FORM": "register", "DQ_NO_FWD_FORK": "1", "DQ_NO_TAIL_FORK": "1", "DQ_NO_TRAIN_INIT": "1", "DQ_NO_HEAD_LOSS": "1"})
     assert _rel(new["eps"], old["eps"]) < 1e-5          # network output (inference path: head epilogue, no saved tensors)
     assert abs(new["loss"] - old["loss"]) < 2e-6 * abs(old["loss"])
     # gradients: the forward's saved tensors differ in the last bits; the heavily cancelling tensors bound the flat comparison
