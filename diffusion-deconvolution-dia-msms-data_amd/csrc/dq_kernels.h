@@ -343,10 +343,20 @@ int launch_linattn_fwd(const LinAttn& a, hipStream_t s);
 bool la_small_usable(int C, int n);
 int la_small_min_rows();  // launch_linattn_fwd takes this path from that many rows on
 int launch_la_small_fwd(const LinAttn& a, hipStream_t s);
+// k_la_rows_bwd.hip: the backward in the same spirit (one m/z row per lane column, every product on v_mfma_f32_16x16x4_f32); one slot per
+// wave in the la_slot(C) layout; launch_linattn_bwd dispatches to it when the layer's prepared weights are at hand
+struct LinAttnBwd;
+bool la_rows_bwd_usable(int C, int n);
+int la_rows_bwd_min_rows();
+int launch_la_rows_bwd(const LinAttnBwd& a, int max_slots, int* slots_out, hipStream_t s);
 constexpr int LA_PREP_BOUNDED = 1024 + 4096;          // 1.0f when the layer's softmax logits are bounded by 64 for every input (k_linattn_prepare)
 constexpr int LA_PREP_BF16 = 1024 + 4096 + 8;         // split-bf16 operand image of Wq | Wk for 4 / 8 channels: 2048 la_nu(C) <= 6144 dwords (k_linattn.hip)
 constexpr int LA_PREP_SMALL = 1024 + 4096 + 8 + 6144;  // operand image of k_la_small (rows of <= 8 positions, C = 8 / 12 / 16): [q | k | W2][head][step < C / 2][64 lanes] <= 6144 floats
-constexpr int LA_PREP_FLOATS = 1024 + 4096 + 8 + 6144 + 6144;  // [w2: 4 * 16 * 16][wqk: 2 * 4 * 8 * 2 * 32][bounded, 7 unused][bf16 image][small-row image]
+// operand image of k_la_rows_bwd (rows of 2 / 4 positions, C = 8 / 12 / 16; v_mfma_f32_16x16x4_f32 A operands): [head][lane][LA_ROWS_LANE_FLOATS] =
+// [Wq log2(e): 2 CPL | Wk log2(e): 2 CPL | W2^T: CPL | Wq^T: 8 | Wk^T: 8 | padding], CPL = C / 4 (k_la_rows_bwd.hip has the index algebra)
+constexpr int LA_ROWS_LANE_FLOATS = 36;  // (b128 reads at this lane pitch are bank-conflict-free)
+constexpr int LA_PREP_ROWS = 1024 + 4096 + 8 + 6144 + 6144;
+constexpr int LA_PREP_FLOATS = LA_PREP_ROWS + 4 * 64 * LA_ROWS_LANE_FLOATS;  // [w2: 4 * 16 * 16][wqk: 2 * 4 * 8 * 2 * 32][bounded, 7 unused][bf16 image][small-row image][rows-backward image]
 struct LaPrepItem { const float* w_qkv; const float* w_out; int C; float* prep; const float* g_pre; };
 constexpr int LA_PREP_MAX = 16;
 struct PrepCopy { const float* src; float* dst; int n; };  // plain copies riding in the same launch (aligned weight slots)

@@ -30,6 +30,7 @@
 #include "dq_common.h"
 #include "dq_kernels.h"
 #include "dq_mfma.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace dq {
@@ -1416,6 +1417,20 @@ int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s) {
     b1.g = a.f.g_pre; b1.dg = a.dg_pre; b1.accumulate = 1;
     b1.part = a.part; b1.part_floats = a.part_floats;  // (free again: the slot reduce above has consumed it, in stream order)
     return launch_block_bwd(b1, s);
+  }
+  // rows of 2 / 4 positions at 8 / 12 / 16 channels: one m/z row per lane column (k_la_rows_bwd.hip), when the layer's prepared weights are at hand
+  if (a.f.prep && la_rows_bwd_usable(C, n) && rows >= la_rows_bwd_min_rows() &&
+      (((uintptr_t)a.f.x | (uintptr_t)a.ypre | (uintptr_t)a.dy | (uintptr_t)a.dx) & 15) == 0) {
+    const int slots_max = (int)std::min<int64_t>((a.part_floats - 4 * C * C) / la_slot(C), C <= 8 ? 2048 : 1024);
+    int slots = 0;
+    if (int rc = launch_la_rows_bwd(a, slots_max, &slots, s)) return rc;
+    if (a.defer_reduce) {
+      *a.waves_out = slots;
+      if (a.w2sum_out) *a.w2sum_out = a.part + (int64_t)slots * la_slot(C);
+      return 0;
+    }
+    const LaReduceItem it{a.part, slots, C, a.dw_qkv, a.dw_out, a.dg_out, a.db_out, a.dg_pre, a.part + (int64_t)slots * la_slot(C), a.f.w_qkv, a.f.w_out};
+    return launch_linattn_dw_reduce_multi(&it, 1, s);
   }
   LinAttnBwdK k;
   k.x = a.f.x; k.ypre = a.ypre; k.dy = a.dy; k.dx = a.dx; k.w_qkv = a.f.w_qkv; k.w_out = a.f.w_out;

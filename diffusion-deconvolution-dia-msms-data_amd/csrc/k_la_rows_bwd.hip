@@ -1,0 +1,499 @@
+// Backward of Residual(PreNorm(LinearAttention)) (reference forward dquartic/model/unet1d.py:446-496, 64-79, 143-176; the reference's
+// backward is autograd over those ops) for the DEEP levels -- m/z rows of 2 / 4 positions at 8 / 12 / 16 channels -- one m/z row per
+// LANE COLUMN, every product on v_mfma_f32_16x16x4_f32 (exact fp32, 32 cycles).  k_la_bwd.hip spends a 32-position unit of block-diagonal
+// 32 x 32 tiles on 8 .. 16 such rows: of a lane's 16 tile registers 1 - 2 mean anything, and its ~2,400 VALU instructions per unit and
+// head are tile-wide work on padding.
+//
+//   wave = 16 rows; lane = (g = lane / 16, row = lane % 16); CPL = C / 4 channels per lane
+//   c-layout : a C-channel tensor of position n lives in CPL registers, register r of lane (g, row) = channel CPL g + r of that row
+//   d-layout : a head's 32 channels live in 2 x 4 registers, register (t, r) of lane (g, row) = channel 16 t + 4 g + r
+// Both are at the same time the ACCUMULATOR layout of a 16 x 16 output tile whose rows are (a permutation of) the channels and a valid
+// B operand of a product that sums over the channels (K-step s takes register s of every lane: lane group g supplies k = g), so every
+// product chains register by register with no data movement, and everything per position -- the two RMSNorms, both softmaxes, the
+// N x N scalars S[n][m] = sum_d q[d][n] k[d][m] of a row -- is per-lane arithmetic plus a sum over the four lane groups (two
+// v_permlane swaps).  The algebra (per row and head; xh = PreNorm(x), W2 = Wo_h Wv_h, DY = d loss / d y_pre):
+//   forward (recomputed)   k = softmax_n(Wk xh), q = 32^-0.5 softmax_d(Wq xh), S[n][m] = sum_d q[d][n] k[d][m],
+//                          Z[:, n] = sum_m S[n][m] xh[:, m],  y_pre[:, n] += W2 Z[:, n]                       (k_la_small.hip)
+//   dZ[:, n] = W2^T DY[:, n]                          K = C   (A = W2^T image)
+//   dS[n][m] = sum_c dZ[c, n] xh[c, m]                per lane + group sum;      d xh[:, m] += sum_n S[n][m] dZ[:, n]
+//   dq[d][n] = sum_m dS[n][m] k[d][m] ; dk[d][m] = sum_n dS[n][m] q[d][n]        per lane
+//   softmax backward:  dql = q (dq - sum_d q dq / 32^-0.5) ;  dkl[d][m] = k[d][m] (dk[d][m] - T[d]),  T[d] = sum_m k dk = sum_n q[d][n] dq[d][n]
+//   d xh[:, n] += Wq^T dql[:, n] + Wk^T dkl[:, n]     K = 32  (A = transposed weight images, B = the d-layout registers)
+//   dWq += dql xh^T, dWk += dkl xh^T, dW2 += DY Z^T   K = rows = lanes: both operands through a wave-private LDS transpose
+// dWv = Wo^T dW2 and dWo = dW2 Wv^T follow once per layer from the slot sum (k_linattn_dwvo).  A wave keeps the weight gradients of all
+// four heads in registers over its tiles and leaves ONE slot in the layout of k_la_bwd.hip (la_slot(C)): the ordered slot reduce is
+// unchanged and the step stays bitwise repeatable.  No workgroup barrier after the prologue: the four waves of a workgroup share the
+// operand image and nothing else.
+#include "dq_common.h"
+#include "dq_kernels.h"
+#include "dq_options.h"
+#include <algorithm>
+#include <climits>
+
+namespace dq {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// sum / maximum over the four lanes {row, row + 16, row + 32, row + 48}: v_permlane16_swap (rows 0 <-> 1, 2 <-> 3), v_permlane32_swap
+// (halves) -- all VALU (tools/probe/blocks_sum.hip pins the semantics)
+__device__ __forceinline__ float gsum(float t) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_int(t), __float_as_int(t), false, false);
+  t = __int_as_float(a[0]) + __int_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_int(t), __float_as_int(t), false, false);
+  return __int_as_float(b[0]) + __int_as_float(b[1]);
+}
+__device__ __forceinline__ float gmax(float t) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_int(t), __float_as_int(t), false, false);
+  t = fmaxf(__int_as_float(a[0]), __int_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_int(t), __float_as_int(t), false, false);
+  return fmaxf(__int_as_float(b[0]), __int_as_float(b[1]));
+}
+__device__ __forceinline__ void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+// sum over the 16 lanes of a row (every lane receives it): four DPP adds
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));  // row_mirror
+  return v;
+}
+
+struct LaRowsBwdK {
+  const float* x; const float* ypre; const float* dy; float* dx;
+  const float* prep; const float* g_pre; const float* g_out;
+  float* part;  // one slot per wave, layout la_slot(C) of k_la_bwd.hip
+  int rows, ntiles, nslots, dx_store;
+};
+
+constexpr int la_slot_floats(int C) { return 256 * C + 4 * C * C + 3 * C; }
+
+template <int C, int N>
+__global__ void __launch_bounds__(256, 1) k_la_rows_bwd(LaRowsBwdK a) {
+  static_assert(C == 8 || C == 12 || C == 16, "channel widths of the deep levels");
+  static_assert(N == 2 || N == 4, "rows of 2 / 4 positions");
+  constexpr int CPL = C / 4;            // channels per lane
+  constexpr int RUN = CPL * N;          // a lane's contiguous run of a (row, C, N) tensor: channels CPL g .. CPL g + CPL - 1, all positions
+  constexpr int VW = RUN % 4 == 0 ? 4 : 2, NV = RUN / VW;
+  constexpr int LS = LA_ROWS_LANE_FLOATS;  // image floats per (head, lane)
+  constexpr int UP = 17;                // pitch of the [channel][row] transposes (conflict-free both ways)
+  constexpr int TP = 48;                // pitch of the [row][d] transposes: 16-byte stores, the two lane groups of a read phase 16 banks apart
+  constexpr float scale = 0.17677669529663687f;  // dim_head^-0.5 (unet1d.py:481)
+  __shared__ __attribute__((aligned(16))) float img[4 * 64 * LS];
+  // per wave: xh and DY of the tile as [n][c][row] (B / A operands of the K = rows products), Z of a head likewise, dql / dkl as [row][d]
+  constexpr int WS = 3 * N * 16 * UP + 2 * 16 * TP;
+  __shared__ __attribute__((aligned(16))) float wlds[4][WS];
+  {
+    constexpr int T4 = 4 * 64 * LS / 4, NLD = T4 / 256;
+    static_assert(T4 % 256 == 0, "whole rounds of 256 x 16 bytes");
+    const float4* src = reinterpret_cast<const float4*>(a.prep + LA_PREP_ROWS);
+    float4 v[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) v[u] = src[u * 256 + (int)threadIdx.x];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) reinterpret_cast<float4*>(img)[u * 256 + (int)threadIdx.x] = v[u];
+  }
+  const bool bounded = a.prep[LA_PREP_BOUNDED] != 0.f;
+  const int lane = threadIdx.x & 63, g = lane >> 4, row = lane & 15, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* ux = wlds[wv];
+  float* ud = ux + N * 16 * UP;
+  float* uz = ud + N * 16 * UP;
+  float* tq = uz + N * 16 * UP;
+  float* tk = tq + 16 * TP;
+  // channel rows of the transposes no lane writes (c >= C) are read as operand padding: zero them once
+  if (C < 16) {
+    for (int i = lane; i < 3 * N * 16 * UP; i += 64) ux[i] = 0.f;
+  }
+  float gpre[CPL], gout[CPL];
+#pragma unroll
+  for (int r = 0; r < CPL; ++r) { gpre[r] = a.g_pre[CPL * g + r]; gout[r] = a.g_out[CPL * g + r]; }
+  __syncthreads();
+  const int wid = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
+  if (wid >= a.nslots) return;  // (a wave without a slot has no tile either: nslots = min(ntiles, launched waves))
+  const float sqC = sqrtf((float)C);
+
+  // weight gradients of the four heads: dWq / dWk [d = 16 t + 4 g + r][c = row] ; dW2 [c' = 4 g + r][c = row]
+  f32x4 Gq[4][2], Gk[4][2], Gw[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    Gq[h][0] = Gq[h][1] = Gk[h][0] = Gk[h][1] = Gw[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float ngo[CPL], nbo[CPL], ngp[CPL];  // d g_out, d b_out, d g_pre partials of this lane's channels
+#pragma unroll
+  for (int r = 0; r < CPL; ++r) ngo[r] = nbo[r] = ngp[r] = 0.f;
+
+#pragma unroll 1
+  for (int tile = wid; tile < a.ntiles; tile += nwaves) {
+    const int grow = tile * 16 + row;
+    const bool live = grow < a.rows;
+    const int64_t base = ((int64_t)(live ? grow : a.rows - 1) * C + CPL * g) * N;
+    float xr[RUN], ur[RUN], dr[RUN];
+    {
+      typedef float vecf __attribute__((ext_vector_type(VW)));
+      vecf vx[NV], vu[NV], vd[NV];
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        vx[k] = *reinterpret_cast<const vecf*>(a.x + base + k * VW);
+        vu[k] = *reinterpret_cast<const vecf*>(a.ypre + base + k * VW);
+        vd[k] = *reinterpret_cast<const vecf*>(a.dy + base + k * VW);
+      }
+#pragma unroll
+      for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+          xr[k * VW + e] = live ? vx[k][e] : 0.f;  // (a row beyond the tensor contributes nothing: xh = DY = 0)
+          ur[k * VW + e] = live ? vu[k][e] : 0.f;
+          dr[k * VW + e] = live ? vd[k][e] : 0.f;
+        }
+    }
+    // ---- PreNorm recompute (unet1d.py:140, 171) and the post-norm backward (RMSNorm behind to_out, :470-473): DY = d loss / d y_pre
+    float xh[N][CPL], DY[N][CPL];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      float ssq = 0.f, usq = 0.f;
+#pragma unroll
+      for (int r = 0; r < CPL; ++r) { ssq = fmaf(xr[r * N + n], xr[r * N + n], ssq); usq = fmaf(ur[r * N + n], ur[r * N + n], usq); }
+      ssq = gsum(ssq);
+      usq = gsum(usq);
+      const float inv = rms_inv(ssq, sqC);
+      const float unrm = fast_sqrt(usq), uinv = fast_rcp(fmaxf(unrm, RMS_EPS));
+      float dot = 0.f, gdv[CPL], uh[CPL];
+#pragma unroll
+      for (int r = 0; r < CPL; ++r) {
+        xh[n][r] = xr[r * N + n] * inv * gpre[r];
+        uh[r] = ur[r * N + n] * uinv;
+        ngo[r] = fmaf(dr[r * N + n], uh[r] * sqC, ngo[r]);
+        gdv[r] = dr[r * N + n] * gout[r] * sqC;
+        dot = fmaf(gdv[r], uh[r], dot);
+      }
+      dot = gsum(dot);
+      const bool uclamped = unrm < RMS_EPS;  // F.normalize clamps the norm: below eps the map is linear
+#pragma unroll
+      for (int r = 0; r < CPL; ++r) {
+        DY[n][r] = uclamped ? gdv[r] * uinv : uinv * (gdv[r] - uh[r] * dot);
+        nbo[r] += DY[n][r];
+      }
+    }
+    // xh and DY as [n][c][row]: lane (g', j) then reads element (c = j, row = 4 s + g') for K-step s of a product over the rows
+    wsync();
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int r = 0; r < CPL; ++r) {
+        ux[(n * 16 + CPL * g + r) * UP + row] = xh[n][r];
+        ud[(n * 16 + CPL * g + r) * UP + row] = DY[n][r];
+      }
+    wsync();
+    float xhT[N][4];
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) xhT[n][s] = ux[(n * 16 + row) * UP + 4 * s + g];
+    float dxh[N][CPL];
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int r = 0; r < CPL; ++r) dxh[n][r] = 0.f;
+
+#pragma unroll 1
+    for (int hd = 0; hd < 4; ++hd) {
+      // this head's A operands: [q: 2 CPL | k: 2 CPL | W2^T: CPL | Wq^T: 8 | Wk^T: 8] of this lane, contiguous
+      float w[LS];
+      {
+        const float4* wp = reinterpret_cast<const float4*>(img + (hd * 64 + lane) * LS);
+#pragma unroll
+        for (int k = 0; k < LS / 4; ++k) { const float4 v = wp[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+      }
+      const float* aq = w;
+      const float* ak = w + 2 * CPL;
+      const float* aw2 = w + 4 * CPL;
+      const float* aqt = w + 5 * CPL;
+      const float* akt = w + 5 * CPL + 8;
+      // ---- k of every position; softmax over the positions, in the lane (unet1d.py:479)
+      f32x4 kk[N][2];
+#pragma unroll
+      for (int m = 0; m < N; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < CPL; ++s) acc = mfma16(ak[t * CPL + s], xh[m][s], acc);
+          kk[m][t] = acc;
+        }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float mx = 0.f;
+          if (!bounded) {
+            mx = kk[0][t][r];
+#pragma unroll
+            for (int m = 1; m < N; ++m) mx = fmaxf(mx, kk[m][t][r]);
+          }
+          float z = 0.f;
+#pragma unroll
+          for (int m = 0; m < N; ++m) { kk[m][t][r] = __builtin_amdgcn_exp2f(kk[m][t][r] - mx); z += kk[m][t][r]; }
+          const float rz = fast_rcp(z);
+#pragma unroll
+          for (int m = 0; m < N; ++m) kk[m][t][r] *= rz;
+        }
+      // ---- q of every position: softmax over the head's 32 channels (8 in the lane, the rest in the other lane groups), * 32^-0.5
+      f32x4 qs[N][2];
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < CPL; ++s) acc = mfma16(aq[t * CPL + s], xh[n][s], acc);
+          qs[n][t] = acc;
+        }
+        float mx = 0.f;
+        if (!bounded) {
+          mx = qs[n][0][0];
+#pragma unroll
+          for (int e = 1; e < 8; ++e) mx = fmaxf(mx, qs[n][e >> 2][e & 3]);
+          mx = gmax(mx);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qs[n][e >> 2][e & 3] = __builtin_amdgcn_exp2f(qs[n][e >> 2][e & 3] - mx); sum += qs[n][e >> 2][e & 3]; }
+        sum = gsum(sum);
+        const float sc = scale * fast_rcp(sum);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qs[n][e >> 2][e & 3] *= sc;
+      }
+      // ---- S[n][m] = sum_d q[d][n] k[d][m]
+      float S[N][N];
+#pragma unroll
+      for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+          float t = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t = fmaf(qs[n][e >> 2][e & 3], kk[m][e >> 2][e & 3], t);
+          S[n][m] = gsum(t);
+        }
+      // ---- Z[:, n] = sum_m S[n][m] xh[:, m] -> [n][c][row] for dW2 ; dZ[:, n] = W2^T DY[:, n]
+      wsync();  // (the previous head's readers of uz are done)
+      float dZ[N][CPL];
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) {
+          float z = 0.f;
+#pragma unroll
+          for (int m = 0; m < N; ++m) z = fmaf(S[n][m], xh[m][r], z);
+          uz[(n * 16 + CPL * g + r) * UP + row] = z;
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < CPL; ++s) acc = mfma16(aw2[s], DY[n][s], acc);
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) dZ[n][r] = acc[r];
+      }
+      // ---- dS[n][m] = sum_c dZ[c, n] xh[c, m] ; d xh[:, m] += sum_n S[n][m] dZ[:, n]
+      float dS[N][N];
+#pragma unroll
+      for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+          float t = 0.f;
+#pragma unroll
+          for (int r = 0; r < CPL; ++r) { t = fmaf(dZ[n][r], xh[m][r], t); dxh[m][r] = fmaf(S[n][m], dZ[n][r], dxh[m][r]); }
+          dS[n][m] = gsum(t);
+        }
+      // ---- q side: dq, the q-softmax backward, d xh += Wq^T dql, dWq += dql xh^T ; T[d] = sum_n q dq (= sum_m k dk) for the k softmax
+      f32x4 T[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 gq0 = {0.f, 0.f, 0.f, 0.f}, gq1 = gq0, gk0 = gq0, gk1 = gq0, gw = gq0;
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        f32x4 dq[2];
+        float D = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = 0.f;
+#pragma unroll
+            for (int m = 0; m < N; ++m) v = fmaf(dS[n][m], kk[m][t][r], v);
+            dq[t][r] = v;
+            const float qd = qs[n][t][r] * v;
+            D += qd;
+            T[t][r] += qd;
+          }
+        D = gsum(D) * (1.0f / scale);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) acc[r] = dxh[n][r];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            dq[t][r] = qs[n][t][r] * (dq[t][r] - D);  // d loss / d (natural-log q logit)
+            acc = mfma16(aqt[t * 4 + r], dq[t][r], acc);
+          }
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) dxh[n][r] = acc[r];
+        // dql as [row][d] -> A operand of dWq (M = d, K = rows)
+        wsync();
+        *reinterpret_cast<float4*>(tq + row * TP + 4 * g) = make_float4(dq[0][0], dq[0][1], dq[0][2], dq[0][3]);
+        *reinterpret_cast<float4*>(tq + row * TP + 16 + 4 * g) = make_float4(dq[1][0], dq[1][1], dq[1][2], dq[1][3]);
+        wsync();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          gq0 = mfma16(tq[(4 * s + g) * TP + row], xhT[n][s], gq0);
+          gq1 = mfma16(tq[(4 * s + g) * TP + 16 + row], xhT[n][s], gq1);
+        }
+      }
+      // ---- k side: dk, the k-softmax backward (over the positions), d xh += Wk^T dkl, dWk += dkl xh^T
+#pragma unroll
+      for (int m = 0; m < N; ++m) {
+        f32x4 dk[2];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) acc[r] = dxh[m][r];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = 0.f;
+#pragma unroll
+            for (int n = 0; n < N; ++n) v = fmaf(dS[n][m], qs[n][t][r], v);
+            dk[t][r] = kk[m][t][r] * (v - T[t][r]);
+            acc = mfma16(akt[t * 4 + r], dk[t][r], acc);
+          }
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) dxh[m][r] = acc[r];
+        wsync();
+        *reinterpret_cast<float4*>(tk + row * TP + 4 * g) = make_float4(dk[0][0], dk[0][1], dk[0][2], dk[0][3]);
+        *reinterpret_cast<float4*>(tk + row * TP + 16 + 4 * g) = make_float4(dk[1][0], dk[1][1], dk[1][2], dk[1][3]);
+        wsync();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          gk0 = mfma16(tk[(4 * s + g) * TP + row], xhT[m][s], gk0);
+          gk1 = mfma16(tk[(4 * s + g) * TP + 16 + row], xhT[m][s], gk1);
+        }
+      }
+      // ---- dW2[c'][c] += sum_rows DY[c'][row, n] Z[c][row, n]   (uz was written in front of the q side; the fences above order it)
+#pragma unroll
+      for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) gw = mfma16(ud[(n * 16 + row) * UP + 4 * s + g], uz[(n * 16 + row) * UP + 4 * s + g], gw);
+      // into this head's persistent accumulators (wave-uniform branch: statically indexed registers)
+#define DQ_ACC(H) { Gq[H][0] += gq0; Gq[H][1] += gq1; Gk[H][0] += gk0; Gk[H][1] += gk1; Gw[H] += gw; }
+      if (hd == 0) DQ_ACC(0) else if (hd == 1) DQ_ACC(1) else if (hd == 2) DQ_ACC(2) else DQ_ACC(3)
+#undef DQ_ACC
+    }
+
+    // ---- residual + PreNorm backward on the completed d xh ; dx (+)= dy + d/dx
+    {
+      typedef float vecf __attribute__((ext_vector_type(VW)));
+      float out[RUN];
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        float ssq = 0.f;
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) ssq = fmaf(xr[r * N + n], xr[r * N + n], ssq);
+        ssq = gsum(ssq);
+        const float nrm = fast_sqrt(ssq), pinv = fast_rcp(fmaxf(nrm, RMS_EPS));
+        float dot = 0.f, tot[CPL], uh[CPL];
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) {
+          uh[r] = xr[r * N + n] * pinv;
+          ngp[r] = fmaf(dxh[n][r], uh[r] * sqC, ngp[r]);
+          tot[r] = dxh[n][r] * gpre[r] * sqC;
+          dot = fmaf(tot[r], uh[r], dot);
+        }
+        dot = gsum(dot);
+        const bool clamped = nrm < RMS_EPS;
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) out[r * N + n] = dr[r * N + n] + (clamped ? tot[r] * pinv : pinv * (tot[r] - uh[r] * dot));
+      }
+      if (live) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+          vecf o;
+          if (a.dx_store) {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) o[e] = out[k * VW + e];
+          } else {
+            const vecf p = *reinterpret_cast<const vecf*>(a.dx + base + k * VW);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) o[e] = p[e] + out[k * VW + e];
+          }
+          *reinterpret_cast<vecf*>(a.dx + base + k * VW) = o;
+        }
+      }
+    }
+  }
+
+  // ---- flush: one slot per wave, layout la_slot(C) = dWq | dWk (256 C) | dW2 of the four heads (4 C C) | d g_out | d b_out | d g_pre
+  float* slot = a.part + (int64_t)wid * la_slot_floats(C);
+  if (row < C) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int d = 16 * t + 4 * g + r;
+          slot[(h * 32 + d) * C + row] = Gq[h][t][r];
+          slot[(128 + h * 32 + d) * C + row] = Gk[h][t][r];
+        }
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cp = 4 * g + r;
+        if (cp < C) slot[256 * C + h * C * C + cp * C + row] = Gw[h][r];
+      }
+  }
+  constexpr int GB = 256 * C + 4 * C * C;
+#pragma unroll
+  for (int r = 0; r < CPL; ++r) {
+    const float s0 = row16_sum(ngo[r]), s1 = row16_sum(nbo[r]), s2 = row16_sum(ngp[r]);
+    if (row == 0) {
+      const int c = CPL * g + r;
+      slot[GB + c] = s0; slot[GB + C + c] = s1; slot[GB + 2 * C + c] = s2;
+    }
+  }
+}
+
+}  // namespace
+
+bool la_rows_bwd_usable(int C, int n) { return (n == 2 || n == 4) && (C == 8 || C == 12 || C == 16); }
+int la_rows_bwd_min_rows() {
+  const int64_t o = option(OPT_LA_ROWS_BWD_MIN_ROWS);
+  return o < 0 ? 0 : (int)std::min<int64_t>(o, INT32_MAX);
+}
+
+// Launches the backward and reports the number of slots written (one per wave; at most max_slots).
+int launch_la_rows_bwd(const LinAttnBwd& a, int max_slots, int* slots_out, hipStream_t s) {
+  const int C = a.f.C, n = a.f.n, rows = a.f.rows;
+  DQ_REQUIRE(a.f.x && a.ypre && a.dy && a.dx && a.f.prep && a.f.g_pre && a.f.g_out && a.part && la_rows_bwd_usable(C, n), "la_rows_bwd: missing operand / unsupported shape");
+  DQ_REQUIRE((((uintptr_t)a.f.prep | (uintptr_t)a.f.x | (uintptr_t)a.ypre | (uintptr_t)a.dy | (uintptr_t)a.dx) & 15) == 0, "la_rows_bwd: misaligned tensor / prepared-weights buffer");
+  DQ_REQUIRE(max_slots >= 4, "la_rows_bwd: slot scratch too small");
+  const int ntiles = cdiv(rows, 16);
+  static const int cus = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+  const int waves = std::min(ntiles, std::min(max_slots, 4 * cus));  // one wave per SIMD at most (the LDS holds one workgroup per CU)
+  LaRowsBwdK k{a.f.x, a.ypre, a.dy, a.dx, a.f.prep, a.f.g_pre, a.f.g_out, a.part, rows, ntiles, waves, a.dx_store};
+  const int grid = cdiv(waves, 4);
+#define DQ_LRB(CC, NN)                                                                   \
+  if (C == CC && n == NN) {                                                              \
+    hipLaunchKernelGGL((k_la_rows_bwd<CC, NN>), dim3(grid), dim3(256), 0, s, k);         \
+    DQ_LAUNCH_CHECK();                                                                   \
+    *slots_out = waves;                                                                  \
+    return 0;                                                                            \
+  }
+  DQ_LRB(8, 2) DQ_LRB(8, 4) DQ_LRB(12, 2) DQ_LRB(12, 4) DQ_LRB(16, 2) DQ_LRB(16, 4)
+#undef DQ_LRB
+  set_error("la_rows_bwd: unsupported (C, n)");
+  return 2;
+}
+
+}  // namespace dq

@@ -708,6 +708,27 @@ __global__ void __launch_bounds__(256) k_linattn_prepare(LaPrepMulti m) {
       else v = (mrow < C && c < C) ? it.prep[((g - 8) * C + mrow) * C + c] : 0.f;
       it.prep[LA_PREP_SMALL + i] = v;
     }
+    // operand image of k_la_rows_bwd (k_la_rows_bwd.hip): A operands of v_mfma_f32_16x16x4_f32 -- lane (g, i) supplies A[i][k = g] -- per head and
+    // lane contiguous.  CPL = C / 4; channel of (lane group g, register r): CPL g + r; output row i = 4 g'' + r'' of an M = C product is channel
+    // CPL g'' + r'' (r'' < CPL), the other rows are padding.
+    const int CPL = C / 4;
+    for (int i = threadIdx.x; i < 4 * 64 * LA_ROWS_LANE_FLOATS; i += 256) {
+      const int k = i % LA_ROWS_LANE_FLOATS, l = (i / LA_ROWS_LANE_FLOATS) & 63, hd = i / (64 * LA_ROWS_LANE_FLOATS);
+      const int g = l >> 4, ii = l & 15;
+      const int ci = (ii & 3) < CPL ? CPL * (ii >> 2) + (ii & 3) : -1;  // channel of output row ii of an M = C product
+      float v = 0.f;
+      if (k < 4 * CPL) {  // q | k projections: M = head channel 16 t + ii, K-step s = channel CPL g + s
+        const int m = k / (2 * CPL), t = (k / CPL) & 1, s = k % CPL;
+        v = it.w_qkv[(m * 128 + hd * 32 + 16 * t + ii) * C + CPL * g + s] * 1.4426950408889634f;
+      } else if (k < 5 * CPL) {  // dZ = W2^T DY: M = channel c(ii) of Z, K-step s = channel c' = CPL g + s of DY
+        const int s = k - 4 * CPL;
+        if (ci >= 0) v = it.prep[(hd * C + CPL * g + s) * C + ci];
+      } else if (k < 5 * CPL + 16) {  // d xh += Wq^T dql / Wk^T dkl: M = channel c(ii), K-step (t, r) = head channel 16 t + 4 g + r (natural-log weights)
+        const int e = k - 5 * CPL, m = e >> 3, t = (e >> 2) & 1, r = e & 3;
+        if (ci >= 0) v = it.w_qkv[(m * 128 + hd * 32 + 16 * t + 4 * g + r) * C + ci];
+      }
+      it.prep[LA_PREP_ROWS + i] = v;
+    }
   }
 }
 int launch_linattn_prepare(const LaPrepItem* items, int count, hipStream_t s, const PrepCopy* copies, int n_copies) {

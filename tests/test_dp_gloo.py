@@ -270,12 +270,12 @@ def test_two_ranks_on_the_gpu_equal_one_process_on_the_global_batch():
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert res[0][1] and res[1][1]                 # bit-identical replicas after three steps
-    # vs the single-process run: over the tensors whose reference gradient is above the floor (see the worker) the parameter displacement
-    # agrees to 1e-3 of what three steps moved -- the summation order of two half-batch gradients against the global batch's.  The
-    # tensors below the floor move by the SIGN of rounding noise (AdamW divides by sqrt(v) + 1e-8): they only get a sanity bound.
-    print("two ranks vs one process: displacement error", res[0][2], "over", res[0][5], "of the elements; all elements:", res[0][4])
-    assert 0 <= res[0][2] < 1e-3, res[0]
-    assert res[0][5] > 0.3 and res[0][4] < 2e-2, res[0]
+    # vs the single-process run: the parameter displacement agrees to 2e-4 of what three steps moved, over ALL elements -- the summation
+    # order of two half-batch gradients against the global batch's (measured with seeded replicas: 3.5e-5 over all elements, 2.0e-5 over the
+    # 15 % of the entries whose first-step gradient is above 1e-3 of its tensor's largest; the 1.2e-3 reading of round 4 came from unseeded
+    # replicas, not from the data-parallel path).
+    print("two ranks vs one process: displacement error", res[0][4], "over all elements;", res[0][2], "over the", res[0][5], "above the gradient floor")
+    assert 0 <= res[0][4] < 2e-4 and 0 <= res[0][2] < 2e-4, res[0]
     assert res[0][3] < 1e-5, res[0]                # the all-reduced loss mean == the global-batch loss
 
 
