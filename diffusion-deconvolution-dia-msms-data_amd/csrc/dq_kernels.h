@@ -353,7 +353,7 @@ constexpr int LA_PREP_BOUNDED = 1024 + 4096;          // 1.0f when the layer's s
 constexpr int LA_PREP_BF16 = 1024 + 4096 + 8;         // split-bf16 operand image of Wq | Wk for 4 / 8 channels: 2048 la_nu(C) <= 6144 dwords (k_linattn.hip)
 constexpr int LA_PREP_SMALL = 1024 + 4096 + 8 + 6144;  // operand image of k_la_small (rows of <= 8 positions, C = 8 / 12 / 16): [q | k | W2][head][step < C / 2][64 lanes] <= 6144 floats
 // operand image of k_la_rows_bwd (rows of 2 / 4 positions, C = 8 / 12 / 16; v_mfma_f32_16x16x4_f32 A operands): [head][lane][LA_ROWS_LANE_FLOATS] =
-// [Wq log2(e): 2 CPL | Wk log2(e): 2 CPL | W2^T: CPL | Wq^T: 8 | Wk^T: 8 | padding], CPL = C / 4 (k_la_rows_bwd.hip has the index algebra)
+// [Wq log2(e): 8 | Wk log2(e): 8 | W2^T: 4 | Wq^T: 8 | Wk^T: 8] (the first three groups hold 2 CPL / 2 CPL / CPL values, CPL = C / 4; k_la_rows_bwd.hip has the index algebra)
 constexpr int LA_ROWS_LANE_FLOATS = 36;  // (b128 reads at this lane pitch are bank-conflict-free)
 constexpr int LA_PREP_ROWS = 1024 + 4096 + 8 + 6144 + 6144;
 constexpr int LA_PREP_FLOATS = LA_PREP_ROWS + 4 * 64 * LA_ROWS_LANE_FLOATS;  // [w2: 4 * 16 * 16][wqk: 2 * 4 * 8 * 2 * 32][bounded, 7 unused][bf16 image][small-row image][rows-backward image]

@@ -19,14 +19,13 @@
 //   dq[d][n] = sum_m dS[n][m] k[d][m] ; dk[d][m] = sum_n dS[n][m] q[d][n]        per lane
 //   softmax backward:  dql = q (dq - sum_d q dq / 32^-0.5) ;  dkl[d][m] = k[d][m] (dk[d][m] - T[d]),  T[d] = sum_m k dk = sum_n q[d][n] dq[d][n]
 //   d xh[:, n] += Wq^T dql[:, n] + Wk^T dkl[:, n]     K = 32  (A = transposed weight images, B = the d-layout registers)
-//   dWq += dql xh^T, dWk += dkl xh^T, dW2 += DY Z^T   K = rows = lanes: both operands through a wave-private LDS transpose
-// dWv = Wo^T dW2 and dWo = dW2 Wv^T follow once per layer from the slot sum (k_linattn_dwvo).  A wave keeps the weight gradients of all
-// four heads in registers over its tiles and leaves ONE slot in the layout of k_la_bwd.hip (la_slot(C)): the ordered slot reduce is
-// unchanged and the step stays bitwise repeatable.  No workgroup barrier after the prologue: the four waves of a workgroup share the
-// operand image and nothing else.
+//   dWq += dql xh^T, dWk += dkl xh^T, dW2 += DY Z^T   K = rows = lanes: both operands through an LDS transpose
+// dWv = Wo^T dW2 and dWo = dW2 Wv^T follow once per layer from the slot sum (k_linattn_dwvo).  A workgroup leaves ONE slot in the layout of
+// k_la_bwd.hip (la_slot(C)): the ordered slot reduce is unchanged and the step stays bitwise repeatable.
 #include "dq_common.h"
 #include "dq_kernels.h"
 #include "dq_options.h"
+#include "dq_probe.h"
 #include <algorithm>
 #include <climits>
 
@@ -36,14 +35,21 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-// sum / maximum over the four lanes {row, row + 16, row + 32, row + 48}: v_permlane16_swap (rows 0 <-> 1, 2 <-> 3), v_permlane32_swap
-// (halves) -- all VALU (tools/probe/blocks_sum.hip pins the semantics)
-__device__ __forceinline__ float gsum(float t) {
+// Sum over the four lanes {row, row + 16, row + 32, row + 48} (every lane receives it) ON THE MATRIX PIPE: a 16x16x4 product sums over
+// k = lane / 16, so with A = 1 every output row is sum_g B[g][row].  One MFMA (the pipe is two-thirds idle in this kernel) instead of two
+// v_permlane swaps, their register copies and two adds on the VALU, which is what bounds the kernel.
+// Measured (12,800 rows, kernel trace): the matrix-pipe form and the v_permlane form run within 3 % of each other at every shape (the
+// kernel is bound by the sum of VALU and MFMA issue at two waves per SIMD: 27,000 clocks per pair of head-tiles against 18,500 for one
+// alone); the VALU form keeps 20 registers more free at 4 positions (each MFMA result is a 4-register tuple) and is used there.
+template <bool ON_MFMA>
+__device__ __forceinline__ float gsum_t(float t) {
+  if (ON_MFMA) return mfma16(1.0f, t, f32x4{0.f, 0.f, 0.f, 0.f})[0];
   const auto a = __builtin_amdgcn_permlane16_swap(__float_as_int(t), __float_as_int(t), false, false);
   t = __int_as_float(a[0]) + __int_as_float(a[1]);
   const auto b = __builtin_amdgcn_permlane32_swap(__float_as_int(t), __float_as_int(t), false, false);
   return __int_as_float(b[0]) + __int_as_float(b[1]);
 }
+// the maximum stays on the VALU: v_permlane16_swap (rows 0 <-> 1, 2 <-> 3), v_permlane32_swap (halves) (tools/probe/blocks_sum.hip pins the semantics)
 __device__ __forceinline__ float gmax(float t) {
   const auto a = __builtin_amdgcn_permlane16_swap(__float_as_int(t), __float_as_int(t), false, false);
   t = fmaxf(__int_as_float(a[0]), __int_as_float(a[1]));
@@ -66,14 +72,20 @@ __device__ __forceinline__ float row16_sum(float v) {
 struct LaRowsBwdK {
   const float* x; const float* ypre; const float* dy; float* dx;
   const float* prep; const float* g_pre; const float* g_out;
-  float* part;  // one slot per wave, layout la_slot(C) of k_la_bwd.hip
-  int rows, ntiles, nslots, dx_store;
+  float* part;  // one slot per workgroup, layout la_slot(C) of k_la_bwd.hip
+  int rows, ntiles, dx_store;
 };
 
 constexpr int la_slot_floats(int C) { return 256 * C + 4 * C * C + 3 * C; }
 
+// A workgroup = four waves = the FOUR HEADS of the same 16-row tiles (as in k_la_bwd.hip): a wave keeps its head's 36 operand values per
+// lane and its head's weight-gradient accumulators in registers for the whole launch; the four d xh contributions meet in LDS behind one
+// barrier and the last head's wave finishes the tile.  ~50 KB of LDS and <= 256 registers: 2 - 3 workgroups per CU, so that at a training
+// batch (800 tiles x 4 heads for 1,024 SIMDs) several waves share a SIMD and cover each other's MFMA -> VALU hand-offs.  (The first
+// version ran the four heads one after the other in ONE wave per tile: 46 us per launch at (12 channels, 4 positions, 12,800 rows) against
+// 67 us for k_la_bwd.hip -- a chain of four heads on a single wave per SIMD.)
 template <int C, int N>
-__global__ void __launch_bounds__(256, 1) k_la_rows_bwd(LaRowsBwdK a) {
+__global__ void __launch_bounds__(256, 2) k_la_rows_bwd(LaRowsBwdK a) {
   static_assert(C == 8 || C == 12 || C == 16, "channel widths of the deep levels");
   static_assert(N == 2 || N == 4, "rows of 2 / 4 positions");
   constexpr int CPL = C / 4;            // channels per lane
@@ -83,10 +95,17 @@ __global__ void __launch_bounds__(256, 1) k_la_rows_bwd(LaRowsBwdK a) {
   constexpr int UP = 17;                // pitch of the [channel][row] transposes (conflict-free both ways)
   constexpr int TP = 48;                // pitch of the [row][d] transposes: 16-byte stores, the two lane groups of a read phase 16 banks apart
   constexpr float scale = 0.17677669529663687f;  // dim_head^-0.5 (unet1d.py:481)
+  auto gsum = [](float t) __attribute__((always_inline)) { return gsum_t<N == 2>(t); };
+  // LDS: the operand image of the four heads ([head][lane][LS]: a wave reads only its head's quarter, 16 bytes at a time, at the point of use --
+  // held in registers the 36 values per lane cost the second wave per SIMD at 4 positions; read from global memory per tile they were five
+  // exposed L2 round trips per tile); shared by the four waves: xh and DY of the tile as [n][c][row] (B / A operands of the K = rows products);
+  // per wave: two [row][d] tiles, which also carry the wave's d xh to the exchange at the end of a tile; the last wave's stash of x and dy.
   __shared__ __attribute__((aligned(16))) float img[4 * 64 * LS];
-  // per wave: xh and DY of the tile as [n][c][row] (B / A operands of the K = rows products), Z of a head likewise, dql / dkl as [row][d]
-  constexpr int WS = 3 * N * 16 * UP + 2 * 16 * TP;
-  __shared__ __attribute__((aligned(16))) float wlds[4][WS];
+  __shared__ __attribute__((aligned(16))) float ush[2 * N * 16 * UP];
+  __shared__ __attribute__((aligned(16))) float tls[4][2 * 16 * TP];
+  __shared__ __attribute__((aligned(16))) float stash[64 * 2 * RUN];
+  static_assert(64 * RUN <= 2 * 16 * TP, "a wave's d xh fits its tile region");
+  DQ_PSTAMP((500000 + C * 100 + N), 0);
   {
     constexpr int T4 = 4 * 64 * LS / 4, NLD = T4 / 256;
     static_assert(T4 % 256 == 0, "whole rounds of 256 x 16 bytes");
@@ -97,43 +116,46 @@ __global__ void __launch_bounds__(256, 1) k_la_rows_bwd(LaRowsBwdK a) {
 #pragma unroll
     for (int u = 0; u < NLD; ++u) reinterpret_cast<float4*>(img)[u * 256 + (int)threadIdx.x] = v[u];
   }
+  const int lane = threadIdx.x & 63, g = lane >> 4, row = lane & 15, hd = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* ux = ush;
+  float* ud = ush + N * 16 * UP;
+  float* t0 = tls[hd];
+  float* t1 = t0 + 16 * TP;
+  // this head's A operands of this lane, contiguous in the image: [q: 8 | k: 8 | W2^T: 4 | Wq^T: 8 | Wk^T: 8] (the first three hold
+  // 2 CPL / 2 CPL / CPL values)
+  const float4* wp = reinterpret_cast<const float4*>(img + (hd * 64 + lane) * LS);
+  auto ld8 = [&](int q4, float (&d)[8]) __attribute__((always_inline)) {
+    const float4 v0 = wp[q4], v1 = wp[q4 + 1];
+    d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w; d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w;
+  };
   const bool bounded = a.prep[LA_PREP_BOUNDED] != 0.f;
-  const int lane = threadIdx.x & 63, g = lane >> 4, row = lane & 15, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* ux = wlds[wv];
-  float* ud = ux + N * 16 * UP;
-  float* uz = ud + N * 16 * UP;
-  float* tq = uz + N * 16 * UP;
-  float* tk = tq + 16 * TP;
-  // channel rows of the transposes no lane writes (c >= C) are read as operand padding: zero them once
+  // channel rows of the shared transposes no lane writes (c >= C) are read as operand padding: zero them once
   if (C < 16) {
-    for (int i = lane; i < 3 * N * 16 * UP; i += 64) ux[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * N * 16 * UP; i += 256) ush[i] = 0.f;
   }
-  float gpre[CPL], gout[CPL];
-#pragma unroll
-  for (int r = 0; r < CPL; ++r) { gpre[r] = a.g_pre[CPL * g + r]; gout[r] = a.g_out[CPL * g + r]; }
   __syncthreads();
-  const int wid = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
-  if (wid >= a.nslots) return;  // (a wave without a slot has no tile either: nslots = min(ntiles, launched waves))
+  DQ_PSTAMP((500000 + C * 100 + N), 1);
   const float sqC = sqrtf((float)C);
 
-  // weight gradients of the four heads: dWq / dWk [d = 16 t + 4 g + r][c = row] ; dW2 [c' = 4 g + r][c = row]
-  f32x4 Gq[4][2], Gk[4][2], Gw[4];
+  // weight gradients of this head: dWq / dWk [d = 16 t + 4 g + r][c = row] ; dW2 [c' = 4 g + r][channel slot = row]
+  f32x4 gq0 = {0.f, 0.f, 0.f, 0.f}, gq1 = gq0, gk0 = gq0, gk1 = gq0, gw = gq0;
+  float na[CPL], nb[CPL];  // head 0's wave: d g_out, d b_out ; head 3's wave: d g_pre (in na)
 #pragma unroll
-  for (int h = 0; h < 4; ++h) {
-    Gq[h][0] = Gq[h][1] = Gk[h][0] = Gk[h][1] = Gw[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  float ngo[CPL], nbo[CPL], ngp[CPL];  // d g_out, d b_out, d g_pre partials of this lane's channels
-#pragma unroll
-  for (int r = 0; r < CPL; ++r) ngo[r] = nbo[r] = ngp[r] = 0.f;
+  for (int r = 0; r < CPL; ++r) na[r] = nb[r] = 0.f;
 
 #pragma unroll 1
-  for (int tile = wid; tile < a.ntiles; tile += nwaves) {
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int grow = tile * 16 + row;
     const bool live = grow < a.rows;
     const int64_t base = ((int64_t)(live ? grow : a.rows - 1) * C + CPL * g) * N;
-    float xr[RUN], ur[RUN], dr[RUN];
+    typedef float vecf __attribute__((ext_vector_type(VW)));
+    float xh[N][CPL], DY[N][CPL];
     {
-      typedef float vecf __attribute__((ext_vector_type(VW)));
+    float xr[RUN], ur[RUN], dr[RUN];
+    float gpre[CPL], gout[CPL];  // (per tile, L1-hot: not held across the head's work)
+#pragma unroll
+    for (int r = 0; r < CPL; ++r) { gpre[r] = a.g_pre[CPL * g + r]; gout[r] = a.g_out[CPL * g + r]; }
+    {
       vecf vx[NV], vu[NV], vd[NV];
 #pragma unroll
       for (int k = 0; k < NV; ++k) {
@@ -149,9 +171,19 @@ __global__ void __launch_bounds__(256, 1) k_la_rows_bwd(LaRowsBwdK a) {
           ur[k * VW + e] = live ? vu[k][e] : 0.f;
           dr[k * VW + e] = live ? vd[k][e] : 0.f;
         }
+      if (hd == 3) {  // the wave that finishes the tile keeps x and dy in LDS (its own lanes read them back: no fence beyond program order)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+          vecf sx, sd;
+#pragma unroll
+          for (int e = 0; e < VW; ++e) { sx[e] = xr[k * VW + e]; sd[e] = dr[k * VW + e]; }
+          *reinterpret_cast<vecf*>(stash + lane * 2 * RUN + k * VW) = sx;
+          *reinterpret_cast<vecf*>(stash + lane * 2 * RUN + RUN + k * VW) = sd;
+        }
+      }
     }
     // ---- PreNorm recompute (unet1d.py:140, 171) and the post-norm backward (RMSNorm behind to_out, :470-473): DY = d loss / d y_pre
-    float xh[N][CPL], DY[N][CPL];
+    // (every wave for itself: ~100 instructions against a second barrier and an LDS round trip)
 #pragma unroll
     for (int n = 0; n < N; ++n) {
       float ssq = 0.f, usq = 0.f;
@@ -166,7 +198,7 @@ __global__ void __launch_bounds__(256, 1) k_la_rows_bwd(LaRowsBwdK a) {
       for (int r = 0; r < CPL; ++r) {
         xh[n][r] = xr[r * N + n] * inv * gpre[r];
         uh[r] = ur[r * N + n] * uinv;
-        ngo[r] = fmaf(dr[r * N + n], uh[r] * sqC, ngo[r]);
+        if (hd == 0) na[r] = fmaf(dr[r * N + n], uh[r] * sqC, na[r]);  // d g_out
         gdv[r] = dr[r * N + n] * gout[r] * sqC;
         dot = fmaf(gdv[r], uh[r], dot);
       }
@@ -175,46 +207,38 @@ __global__ void __launch_bounds__(256, 1) k_la_rows_bwd(LaRowsBwdK a) {
 #pragma unroll
       for (int r = 0; r < CPL; ++r) {
         DY[n][r] = uclamped ? gdv[r] * uinv : uinv * (gdv[r] - uh[r] * dot);
-        nbo[r] += DY[n][r];
+        if (hd == 0) nb[r] += DY[n][r];  // d b_out
       }
     }
-    // xh and DY as [n][c][row]: lane (g', j) then reads element (c = j, row = 4 s + g') for K-step s of a product over the rows
-    wsync();
+    }
+    // xh (head 0's wave) and DY (head 1's) as [n][c][row]: lane (g', j) then reads element (c = j, row = 4 s + g') for K-step s of a product
+    // over the rows.  (The previous tile's readers are behind its second barrier.)
+    DQ_PSTAMP((500000 + C * 100 + N), 2);
+    if (hd == 0) {
 #pragma unroll
-    for (int n = 0; n < N; ++n)
+      for (int n = 0; n < N; ++n)
 #pragma unroll
-      for (int r = 0; r < CPL; ++r) {
-        ux[(n * 16 + CPL * g + r) * UP + row] = xh[n][r];
-        ud[(n * 16 + CPL * g + r) * UP + row] = DY[n][r];
-      }
-    wsync();
-    float xhT[N][4];
+        for (int r = 0; r < CPL; ++r) ux[(n * 16 + CPL * g + r) * UP + row] = xh[n][r];
+    } else if (hd == 1) {
 #pragma unroll
-    for (int n = 0; n < N; ++n)
+      for (int n = 0; n < N; ++n)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) xhT[n][s] = ux[(n * 16 + row) * UP + 4 * s + g];
+        for (int r = 0; r < CPL; ++r) ud[(n * 16 + CPL * g + r) * UP + row] = DY[n][r];
+    }
+    lds_barrier();
+    DQ_PSTAMP((500000 + C * 100 + N), 3);
     float dxh[N][CPL];
 #pragma unroll
     for (int n = 0; n < N; ++n)
 #pragma unroll
       for (int r = 0; r < CPL; ++r) dxh[n][r] = 0.f;
 
-#pragma unroll 1
-    for (int hd = 0; hd < 4; ++hd) {
-      // this head's A operands: [q: 2 CPL | k: 2 CPL | W2^T: CPL | Wq^T: 8 | Wk^T: 8] of this lane, contiguous
-      float w[LS];
-      {
-        const float4* wp = reinterpret_cast<const float4*>(img + (hd * 64 + lane) * LS);
-#pragma unroll
-        for (int k = 0; k < LS / 4; ++k) { const float4 v = wp[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
-      }
-      const float* aq = w;
-      const float* ak = w + 2 * CPL;
-      const float* aw2 = w + 4 * CPL;
-      const float* aqt = w + 5 * CPL;
-      const float* akt = w + 5 * CPL + 8;
+    {
       // ---- k of every position; softmax over the positions, in the lane (unet1d.py:479)
       f32x4 kk[N][2];
+      float ak[8], aq[8];
+      ld8(2, ak);
+      ld8(0, aq);
 #pragma unroll
       for (int m = 0; m < N; ++m)
 #pragma unroll
@@ -267,49 +291,51 @@ __global__ void __launch_bounds__(256, 1) k_la_rows_bwd(LaRowsBwdK a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) qs[n][e >> 2][e & 3] *= sc;
       }
-      // ---- S[n][m] = sum_d q[d][n] k[d][m]
-      float S[N][N];
+      // ---- per position n, one row of S at a time (the whole N x N of S and dZ of all positions live at once cost the second wave per SIMD):
+      //   S[n][m] = sum_d q[d][n] k[d][m] ;  Z[:, n] = sum_m S[n][m] xh[:, m] -> [row][channel slot] tile: dW2 += DY[:, n] Z[:, n]^T (K = rows) ;
+      //   dZ[:, n] = W2^T DY[:, n] ;  dS[n][m] = sum_c dZ[c, n] xh[c, m] ;  d xh[:, m] += S[n][m] dZ[:, n]
+      DQ_PSTAMP((500000 + C * 100 + N), 4);
+      float dS[N][N];
+      float aw2[4];
+      { const float4 v = wp[4]; aw2[0] = v.x; aw2[1] = v.y; aw2[2] = v.z; aw2[3] = v.w; }
 #pragma unroll
-      for (int n = 0; n < N; ++n)
+      for (int n = 0; n < N; ++n) {
+        float Sn[N];
 #pragma unroll
         for (int m = 0; m < N; ++m) {
           float t = 0.f;
 #pragma unroll
           for (int e = 0; e < 8; ++e) t = fmaf(qs[n][e >> 2][e & 3], kk[m][e >> 2][e & 3], t);
-          S[n][m] = gsum(t);
+          Sn[m] = gsum(t);
         }
-      // ---- Z[:, n] = sum_m S[n][m] xh[:, m] -> [n][c][row] for dW2 ; dZ[:, n] = W2^T DY[:, n]
-      wsync();  // (the previous head's readers of uz are done)
-      float dZ[N][CPL];
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int n = 0; n < N; ++n) {
+        for (int r = 0; r < CPL; ++r)
 #pragma unroll
-        for (int r = 0; r < CPL; ++r) {
-          float z = 0.f;
+          for (int m = 0; m < N; ++m) z[r] = fmaf(Sn[m], xh[m][r], z[r]);
+        float* tz = (n & 1) ? t1 : t0;
+        wsync();
+        *reinterpret_cast<float4*>(tz + row * TP + 4 * g) = make_float4(z[0], z[1], z[2], z[3]);
+        f32x4 dZ = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int m = 0; m < N; ++m) z = fmaf(S[n][m], xh[m][r], z);
-          uz[(n * 16 + CPL * g + r) * UP + row] = z;
-        }
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < CPL; ++s) dZ = mfma16(aw2[s], DY[n][s], dZ);
+        wsync();
 #pragma unroll
-        for (int s = 0; s < CPL; ++s) acc = mfma16(aw2[s], DY[n][s], acc);
-#pragma unroll
-        for (int r = 0; r < CPL; ++r) dZ[n][r] = acc[r];
-      }
-      // ---- dS[n][m] = sum_c dZ[c, n] xh[c, m] ; d xh[:, m] += sum_n S[n][m] dZ[:, n]
-      float dS[N][N];
-#pragma unroll
-      for (int n = 0; n < N; ++n)
+        for (int s = 0; s < 4; ++s) gw = mfma16(ud[(n * 16 + row) * UP + 4 * s + g], tz[(4 * s + g) * TP + row], gw);
 #pragma unroll
         for (int m = 0; m < N; ++m) {
           float t = 0.f;
 #pragma unroll
-          for (int r = 0; r < CPL; ++r) { t = fmaf(dZ[n][r], xh[m][r], t); dxh[m][r] = fmaf(S[n][m], dZ[n][r], dxh[m][r]); }
+          for (int r = 0; r < CPL; ++r) { t = fmaf(dZ[r], xh[m][r], t); dxh[m][r] = fmaf(Sn[m], dZ[r], dxh[m][r]); }
           dS[n][m] = gsum(t);
         }
+        if (N == 4) __builtin_amdgcn_sched_barrier(0);  // (interleaving the positions' chains costs the registers of the second wave per SIMD)
+      }
       // ---- q side: dq, the q-softmax backward, d xh += Wq^T dql, dWq += dql xh^T ; T[d] = sum_n q dq (= sum_m k dk) for the k softmax
+      DQ_PSTAMP((500000 + C * 100 + N), 5);
       f32x4 T[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-      f32x4 gq0 = {0.f, 0.f, 0.f, 0.f}, gq1 = gq0, gk0 = gq0, gk1 = gq0, gw = gq0;
+      float aqt[8];
+      ld8(5, aqt);
 #pragma unroll
       for (int n = 0; n < N; ++n) {
         f32x4 dq[2];
@@ -340,17 +366,23 @@ __global__ void __launch_bounds__(256, 1) k_la_rows_bwd(LaRowsBwdK a) {
 #pragma unroll
         for (int r = 0; r < CPL; ++r) dxh[n][r] = acc[r];
         // dql as [row][d] -> A operand of dWq (M = d, K = rows)
+        float* tq = (n & 1) ? t1 : t0;
         wsync();
         *reinterpret_cast<float4*>(tq + row * TP + 4 * g) = make_float4(dq[0][0], dq[0][1], dq[0][2], dq[0][3]);
         *reinterpret_cast<float4*>(tq + row * TP + 16 + 4 * g) = make_float4(dq[1][0], dq[1][1], dq[1][2], dq[1][3]);
         wsync();
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          gq0 = mfma16(tq[(4 * s + g) * TP + row], xhT[n][s], gq0);
-          gq1 = mfma16(tq[(4 * s + g) * TP + 16 + row], xhT[n][s], gq1);
+          const float xt = ux[(n * 16 + row) * UP + 4 * s + g];  // xh[c = row][batch row 4 s + g] (read here, not held: registers)
+          gq0 = mfma16(tq[(4 * s + g) * TP + row], xt, gq0);
+          gq1 = mfma16(tq[(4 * s + g) * TP + 16 + row], xt, gq1);
         }
+        if (N == 4) __builtin_amdgcn_sched_barrier(0);
       }
       // ---- k side: dk, the k-softmax backward (over the positions), d xh += Wk^T dkl, dWk += dkl xh^T
+      DQ_PSTAMP((500000 + C * 100 + N), 6);
+      float akt[8];
+      ld8(7, akt);
 #pragma unroll
       for (int m = 0; m < N; ++m) {
         f32x4 dk[2];
@@ -369,30 +401,56 @@ __global__ void __launch_bounds__(256, 1) k_la_rows_bwd(LaRowsBwdK a) {
           }
 #pragma unroll
         for (int r = 0; r < CPL; ++r) dxh[m][r] = acc[r];
+        float* tk = (m & 1) ? t1 : t0;
         wsync();
         *reinterpret_cast<float4*>(tk + row * TP + 4 * g) = make_float4(dk[0][0], dk[0][1], dk[0][2], dk[0][3]);
         *reinterpret_cast<float4*>(tk + row * TP + 16 + 4 * g) = make_float4(dk[1][0], dk[1][1], dk[1][2], dk[1][3]);
         wsync();
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          gk0 = mfma16(tk[(4 * s + g) * TP + row], xhT[m][s], gk0);
-          gk1 = mfma16(tk[(4 * s + g) * TP + 16 + row], xhT[m][s], gk1);
+          const float xt = ux[(m * 16 + row) * UP + 4 * s + g];
+          gk0 = mfma16(tk[(4 * s + g) * TP + row], xt, gk0);
+          gk1 = mfma16(tk[(4 * s + g) * TP + 16 + row], xt, gk1);
         }
+        if (N == 4) __builtin_amdgcn_sched_barrier(0);
       }
-      // ---- dW2[c'][c] += sum_rows DY[c'][row, n] Z[c][row, n]   (uz was written in front of the q side; the fences above order it)
-#pragma unroll
-      for (int n = 0; n < N; ++n)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) gw = mfma16(ud[(n * 16 + row) * UP + 4 * s + g], uz[(n * 16 + row) * UP + 4 * s + g], gw);
-      // into this head's persistent accumulators (wave-uniform branch: statically indexed registers)
-#define DQ_ACC(H) { Gq[H][0] += gq0; Gq[H][1] += gq1; Gk[H][0] += gk0; Gk[H][1] += gk1; Gw[H] += gw; }
-      if (hd == 0) DQ_ACC(0) else if (hd == 1) DQ_ACC(1) else if (hd == 2) DQ_ACC(2) else DQ_ACC(3)
-#undef DQ_ACC
     }
-
-    // ---- residual + PreNorm backward on the completed d xh ; dx (+)= dy + d/dx
+    DQ_PSTAMP((500000 + C * 100 + N), 7);
+    // ---- the four heads' d xh meet: [head][lane][RUN]
     {
-      typedef float vecf __attribute__((ext_vector_type(VW)));
+      wsync();  // (this wave's last readers of its tiles are done)
+      float* ex = t0 + lane * RUN;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        vecf o;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) { const int i = k * VW + e; o[e] = dxh[i % N][i / N]; }  // (run order: element r N + n)
+        *reinterpret_cast<vecf*>(ex + k * VW) = o;
+      }
+    }
+    lds_barrier();
+    DQ_PSTAMP((500000 + C * 100 + N), 8);
+    if (hd == 3) {
+      // ---- residual + PreNorm backward on the completed d xh (heads added in head order) ; dx (+)= dy + d/dx
+      float tot_[RUN];
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const vecf v0 = *reinterpret_cast<const vecf*>(tls[0] + lane * RUN + k * VW), v1 = *reinterpret_cast<const vecf*>(tls[1] + lane * RUN + k * VW);
+        const vecf v2 = *reinterpret_cast<const vecf*>(tls[2] + lane * RUN + k * VW), v3 = *reinterpret_cast<const vecf*>(tls[3] + lane * RUN + k * VW);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) tot_[k * VW + e] = ((v0[e] + v1[e]) + v2[e]) + v3[e];
+      }
+      // (x and dy come back from this wave's LDS stash instead of being held across the head's work: 2 RUN registers of every wave)
+      float xr[RUN], dr[RUN];
+      float gpre[CPL];
+#pragma unroll
+      for (int r = 0; r < CPL; ++r) gpre[r] = a.g_pre[CPL * g + r];
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const vecf sx = *reinterpret_cast<const vecf*>(stash + lane * 2 * RUN + k * VW), sd = *reinterpret_cast<const vecf*>(stash + lane * 2 * RUN + RUN + k * VW);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) { xr[k * VW + e] = sx[e]; dr[k * VW + e] = sd[e]; }
+      }
       float out[RUN];
 #pragma unroll
       for (int n = 0; n < N; ++n) {
@@ -405,8 +463,8 @@ __global__ void __launch_bounds__(256, 1) k_la_rows_bwd(LaRowsBwdK a) {
 #pragma unroll
         for (int r = 0; r < CPL; ++r) {
           uh[r] = xr[r * N + n] * pinv;
-          ngp[r] = fmaf(dxh[n][r], uh[r] * sqC, ngp[r]);
-          tot[r] = dxh[n][r] * gpre[r] * sqC;
+          na[r] = fmaf(tot_[r * N + n], uh[r] * sqC, na[r]);  // d g_pre
+          tot[r] = tot_[r * N + n] * gpre[r] * sqC;
           dot = fmaf(tot[r], uh[r], dot);
         }
         dot = gsum(dot);
@@ -432,36 +490,41 @@ __global__ void __launch_bounds__(256, 1) k_la_rows_bwd(LaRowsBwdK a) {
     }
   }
 
-  // ---- flush: one slot per wave, layout la_slot(C) = dWq | dWk (256 C) | dW2 of the four heads (4 C C) | d g_out | d b_out | d g_pre
-  float* slot = a.part + (int64_t)wid * la_slot_floats(C);
+  DQ_PSTAMP((500000 + C * 100 + N), 9);
+  // ---- flush: one slot per workgroup, layout la_slot(C) = dWq | dWk (256 C) | dW2 of the four heads (4 C C) | d g_out | d b_out | d g_pre;
+  // each wave its head's sections
+  float* slot = a.part + (int64_t)blockIdx.x * la_slot_floats(C);
   if (row < C) {
 #pragma unroll
-    for (int h = 0; h < 4; ++h)
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int d = 16 * t + 4 * g + r;
-          slot[(h * 32 + d) * C + row] = Gq[h][t][r];
-          slot[(128 + h * 32 + d) * C + row] = Gk[h][t][r];
-        }
-#pragma unroll
-    for (int h = 0; h < 4; ++h)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int cp = 4 * g + r;
-        if (cp < C) slot[256 * C + h * C * C + cp * C + row] = Gw[h][r];
-      }
-  }
-  constexpr int GB = 256 * C + 4 * C * C;
-#pragma unroll
-  for (int r = 0; r < CPL; ++r) {
-    const float s0 = row16_sum(ngo[r]), s1 = row16_sum(nbo[r]), s2 = row16_sum(ngp[r]);
-    if (row == 0) {
-      const int c = CPL * g + r;
-      slot[GB + c] = s0; slot[GB + C + c] = s1; slot[GB + 2 * C + c] = s2;
+    for (int r = 0; r < 4; ++r) {
+      const int d0 = 4 * g + r;
+      slot[(hd * 32 + d0) * C + row] = gq0[r];
+      slot[(hd * 32 + 16 + d0) * C + row] = gq1[r];
+      slot[(128 + hd * 32 + d0) * C + row] = gk0[r];
+      slot[(128 + hd * 32 + 16 + d0) * C + row] = gk1[r];
     }
   }
+  {
+    const int c = (row & 3) < CPL ? CPL * (row >> 2) + (row & 3) : -1;  // the channel of slot `row` of a [row][4 g + r] tile
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cp = 4 * g + r;
+      if (cp < C && c >= 0) slot[256 * C + hd * C * C + cp * C + c] = gw[r];
+    }
+  }
+  constexpr int GB = 256 * C + 4 * C * C;
+  if (hd == 0 || hd == 3) {
+#pragma unroll
+    for (int r = 0; r < CPL; ++r) {
+      const float s0 = row16_sum(na[r]), s1 = row16_sum(nb[r]);
+      if (row == 0) {
+        const int c = CPL * g + r;
+        if (hd == 0) { slot[GB + c] = s0; slot[GB + C + c] = s1; }
+        else slot[GB + 2 * C + c] = s0;
+      }
+    }
+  }
+  DQ_PSTAMP((500000 + C * 100 + N), 10);
 }
 
 }  // namespace
@@ -472,23 +535,24 @@ int la_rows_bwd_min_rows() {
   return o < 0 ? 0 : (int)std::min<int64_t>(o, INT32_MAX);
 }
 
-// Launches the backward and reports the number of slots written (one per wave; at most max_slots).
+// Launches the backward and reports the number of slots written (one per workgroup; at most max_slots).
 int launch_la_rows_bwd(const LinAttnBwd& a, int max_slots, int* slots_out, hipStream_t s) {
   const int C = a.f.C, n = a.f.n, rows = a.f.rows;
   DQ_REQUIRE(a.f.x && a.ypre && a.dy && a.dx && a.f.prep && a.f.g_pre && a.f.g_out && a.part && la_rows_bwd_usable(C, n), "la_rows_bwd: missing operand / unsupported shape");
   DQ_REQUIRE((((uintptr_t)a.f.prep | (uintptr_t)a.f.x | (uintptr_t)a.ypre | (uintptr_t)a.dy | (uintptr_t)a.dx) & 15) == 0, "la_rows_bwd: misaligned tensor / prepared-weights buffer");
-  DQ_REQUIRE(max_slots >= 4, "la_rows_bwd: slot scratch too small");
+  DQ_REQUIRE(max_slots >= 1, "la_rows_bwd: slot scratch too small");
   const int ntiles = cdiv(rows, 16);
   static const int cus = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
-  const int waves = std::min(ntiles, std::min(max_slots, 4 * cus));  // one wave per SIMD at most (the LDS holds one workgroup per CU)
-  LaRowsBwdK k{a.f.x, a.ypre, a.dy, a.dx, a.f.prep, a.f.g_pre, a.f.g_out, a.part, rows, ntiles, waves, a.dx_store};
-  const int grid = cdiv(waves, 4);
-#define DQ_LRB(CC, NN)                                                                   \
-  if (C == CC && n == NN) {                                                              \
-    hipLaunchKernelGGL((k_la_rows_bwd<CC, NN>), dim3(grid), dim3(256), 0, s, k);         \
-    DQ_LAUNCH_CHECK();                                                                   \
-    *slots_out = waves;                                                                  \
-    return 0;                                                                            \
+  LaRowsBwdK k{a.f.x, a.ypre, a.dy, a.dx, a.f.prep, a.f.g_pre, a.f.g_out, a.part, rows, ntiles, a.dx_store};
+#define DQ_LRB(CC, NN)                                                                                   \
+  if (C == CC && n == NN) {                                                                              \
+    const int nb = occ_blocks_per_cu((const void*)k_la_rows_bwd<CC, NN>, 256, 0);                        \
+    if (nb < 0) return 1;                                                                                \
+    const int grid = std::max(1, std::min(ntiles, std::min(max_slots, nb * cus)));  /* one resident round, a slot per workgroup */ \
+    hipLaunchKernelGGL((k_la_rows_bwd<CC, NN>), dim3(grid), dim3(256), 0, s, k);                         \
+    DQ_LAUNCH_CHECK();                                                                                   \
+    *slots_out = grid;                                                                                   \
+    return 0;                                                                                            \
   }
   DQ_LRB(8, 2) DQ_LRB(8, 4) DQ_LRB(12, 2) DQ_LRB(12, 4) DQ_LRB(16, 2) DQ_LRB(16, 4)
 #undef DQ_LRB

@@ -712,23 +712,40 @@ __global__ void __launch_bounds__(256) k_linattn_prepare(LaPrepMulti m) {
     // lane contiguous.  CPL = C / 4; channel of (lane group g, register r): CPL g + r; output row i = 4 g'' + r'' of an M = C product is channel
     // CPL g'' + r'' (r'' < CPL), the other rows are padding.
     const int CPL = C / 4;
-    for (int i = threadIdx.x; i < 4 * 64 * LA_ROWS_LANE_FLOATS; i += 256) {
+    constexpr int NR = 4 * 64 * LA_ROWS_LANE_FLOATS / 256;  // 36 values per thread: every load requested before the first store
+    float rv[NR];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      const int i = u * 256 + (int)threadIdx.x;
       const int k = i % LA_ROWS_LANE_FLOATS, l = (i / LA_ROWS_LANE_FLOATS) & 63, hd = i / (64 * LA_ROWS_LANE_FLOATS);
       const int g = l >> 4, ii = l & 15;
       const int ci = (ii & 3) < CPL ? CPL * (ii >> 2) + (ii & 3) : -1;  // channel of output row ii of an M = C product
-      float v = 0.f;
-      if (k < 4 * CPL) {  // q | k projections: M = head channel 16 t + ii, K-step s = channel CPL g + s
-        const int m = k / (2 * CPL), t = (k / CPL) & 1, s = k % CPL;
-        v = it.w_qkv[(m * 128 + hd * 32 + 16 * t + ii) * C + CPL * g + s] * 1.4426950408889634f;
-      } else if (k < 5 * CPL) {  // dZ = W2^T DY: M = channel c(ii) of Z, K-step s = channel c' = CPL g + s of DY
-        const int s = k - 4 * CPL;
-        if (ci >= 0) v = it.prep[(hd * C + CPL * g + s) * C + ci];
-      } else if (k < 5 * CPL + 16) {  // d xh += Wq^T dql / Wk^T dkl: M = channel c(ii), K-step (t, r) = head channel 16 t + 4 g + r (natural-log weights)
-        const int e = k - 5 * CPL, m = e >> 3, t = (e >> 2) & 1, r = e & 3;
-        if (ci >= 0) v = it.w_qkv[(m * 128 + hd * 32 + 16 * t + 4 * g + r) * C + ci];
+      // groups at fixed 16-byte aligned offsets: [q: 8 | k: 8 | W2^T: 4 | Wq^T: 8 | Wk^T: 8]; one unconditional load per value (a valid
+      // address is formed for the padding entries too), the select afterwards
+      const float* src = it.w_qkv;
+      int off = 0;
+      bool ok = false;
+      float mul = 1.f;
+      if (k < 16) {  // q | k projections: M = head channel 16 t + ii, K-step s = channel CPL g + s ; entry t CPL + s of the group
+        const int m = k >> 3, e = k & 7, t = e / CPL, s = e % CPL;
+        ok = e < 2 * CPL;
+        off = (m * 128 + hd * 32 + 16 * (ok ? t : 0) + ii) * C + CPL * g + s;
+        mul = 1.4426950408889634f;
+      } else if (k < 20) {  // dZ = W2^T DY: M = channel c(ii) of Z, K-step s = channel c' = CPL g + s of DY
+        const int s = k - 16;
+        ok = s < CPL && ci >= 0;
+        src = it.prep;
+        off = ok ? (hd * C + CPL * g + s) * C + ci : 0;
+      } else {  // d xh += Wq^T dql / Wk^T dkl: M = channel c(ii), K-step (t, r) = head channel 16 t + 4 g + r (natural-log weights)
+        const int e = k - 20, m = e >> 3, t = (e >> 2) & 1, r = e & 3;
+        ok = ci >= 0;
+        off = (m * 128 + hd * 32 + 16 * t + 4 * g + r) * C + (ok ? ci : 0);
       }
-      it.prep[LA_PREP_ROWS + i] = v;
+      const float v = src[off];
+      rv[u] = ok ? v * mul : 0.f;
     }
+#pragma unroll
+    for (int u = 0; u < NR; ++u) it.prep[LA_PREP_ROWS + u * 256 + (int)threadIdx.x] = rv[u];
   }
 }
 int launch_linattn_prepare(const LaPrepItem* items, int count, hipStream_t s, const PrepCopy* copies, int n_copies) {
