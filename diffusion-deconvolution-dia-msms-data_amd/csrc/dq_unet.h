@@ -69,6 +69,7 @@ struct dq_plan {
   unsigned ev_next = 0;
   bool side_used = false;
   const void* twin_zeroed = nullptr;  // the gradient twin a forked forward (dq_train_step) cleared on the side stream; consumed by unet_backward
+  float* debug_tail_addr = nullptr; float debug_tail_value = 0.f; int debug_tail_us = 0;  // dq_debug_side_tail_store (test hook)
   bool no_side = false;  // dq_plan_set_side_stream(plan, 0): weight-gradient launches on the caller's stream (captured train steps)
   hipStream_t cap_stream = nullptr;  // capture-only stream (the caller's may be the uncapturable legacy default stream)
   const void* g_params = nullptr; const void* g_rope = nullptr; const void* g_ws = nullptr;

@@ -1472,9 +1472,21 @@ int side_flush(const Ctx& c) {
   return 0;
 }
 
+// test hook (dq_debug_side_tail_store): the LAST thing the side stream does before the join is a delayed store -- a caller whose next
+// launch on its own stream sees the value has proof that dq_train_step / dq_unet_bwd order the side stream in front of their return
+__global__ void k_debug_delay_store(float* addr, float value, long long ticks) {
+  const long long t0 = wall_clock64();  // (100 MHz; the loop ends after `ticks` whatever the data)
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+  *addr = value;
+}
+
 int join_side(const Ctx& c) {
   dq_plan* pl = c.owner;
   if (!pl || !pl->side_used) return 0;
+  if (pl->debug_tail_addr) {
+    hipLaunchKernelGGL(k_debug_delay_store, dim3(1), dim3(1), 0, pl->side_stream, pl->debug_tail_addr, pl->debug_tail_value, (long long)pl->debug_tail_us * 100);
+    DQ_LAUNCH_CHECK();
+  }
   hipEvent_t ev = pl->events[pl->ev_next++ % dq_plan::NUM_EVENTS];
   DQ_HIP_OK(hipEventRecord(ev, pl->side_stream));
   DQ_HIP_OK(hipStreamWaitEvent(c.s, ev, 0));
@@ -1648,6 +1660,12 @@ int64_t dq_get_option(const char* key) {
   const int i = option_index(key);
   if (i < 0) { set_error("dq_get_option: unknown key"); return INT64_MIN; }
   return option((Option)i);
+}
+
+int dq_debug_side_tail_store(dq_plan* plan, float* addr, float value, int delay_us) {
+  DQ_REQUIRE(plan && delay_us >= 0 && delay_us <= 100000, "dq_debug_side_tail_store: null plan / delay out of range");
+  plan->debug_tail_addr = addr; plan->debug_tail_value = value; plan->debug_tail_us = delay_us;
+  return 0;
 }
 
 int dq_plan_set_side_stream(dq_plan* plan, int on) {

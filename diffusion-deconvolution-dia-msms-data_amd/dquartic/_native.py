@@ -50,6 +50,7 @@ PROTOTYPES = {
     "dq_pair_batch": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int64, c_float, c_float, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "dq_debug_tensor_offset": (c_int64, [c_void_p, c_char_p]),
+    "dq_debug_side_tail_store": (c_int, [c_void_p, c_void_p, c_float, c_int]),
     "dq_tfm_create": (c_void_p, [c_int, c_int, c_int, c_int]),
     "dq_tfm_destroy": (None, [c_void_p]),
     "dq_tfm_num_params": (c_int, [c_void_p]),

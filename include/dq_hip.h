@@ -44,7 +44,7 @@ const char* dq_last_error(void);
  * building blocks (dq_rmsnorm_fwd, dq_time_mlp_fwd, dq_scale_shift_fwd, dq_prep_inputs_fwd, dq_conv_fwd, dq_resblock_*,
  * dq_rope, dq_attn_*); dq_train_step takes ms1_loss_weight, dq_ms1_loss_fwd_bwd;
  * dq_tfm_set_precision, dq_gemm_bf16x3.  8: dq_tfm_bwd_buckets, dq_tfm_num_buckets, dq_tfm_bucket_info.  9: dq_linattn_prepare,
- * dq_linattn_fwd_prepared.  10: dq_set_option, dq_get_option. */
+ * dq_linattn_fwd_prepared.  10: dq_set_option, dq_get_option, dq_debug_side_tail_store. */
 int dq_abi_version(void);
 #define DQ_ABI_VERSION 10
 
@@ -324,6 +324,12 @@ int dq_attn_bwd(const float* q, const float* k, const float* v, const float* o, 
 /* Test hook: offset (in floats) of a named activation inside the workspace laid out by the last call on this plan
  * ("h0", "ms1f", "down3", "down3.la", "mid1", "attn_out", "up0", "fin", ...), or -1. */
 int64_t dq_debug_tensor_offset(dq_plan* plan, const char* name);
+
+/* Test hook: from now on the backward's side stream ends with a store of `value` to `addr`, delayed by delay_us microseconds, right in
+ * front of the join with the caller's stream (addr = NULL switches it off).  A launch the caller makes on its own stream after
+ * dq_train_step / dq_unet_bwd returned -- the flat gradient all-reduce of data-parallel training -- must see the value: that is the
+ * ordering the all-reduce relies on (tests/test_dp_gloo.py). */
+int dq_debug_side_tail_store(dq_plan* plan, float* addr, float value, int delay_us);
 
 #ifdef __cplusplus
 }

@@ -96,6 +96,40 @@ def test_single_rank_legs_issue_no_collective_alone():
     assert "cpu_baseline(net) if (rank == 0 and world == 1" in src and "if rank == 0 and world == 1 and not args.no_transformer" in src
 
 
+def _run_bench_under_torchrun(extra):
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(REPO, "bench.py"), "--gpus", "1"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_with_sampling_leg_under_torch_distributed_run_with_one_rank():
+    """The same launch mode WITH the sampling leg and the rank-0-only legs that a multi-GPU run keeps (no --train-only): between the train
+    leg's barriers and the final gather every rank runs the sampling leg on its shard of the 512 windows and the MAX over ranks of its time is
+    taken; the legs that call _train_one_batch on one rank alone (small batch, large window, CPU, transformer) stay gated on world == 1 -- here
+    the world IS 1 but the process group is live, so their collectives run too.  Bounded: 3 train steps, a 64-window sampling batch."""
+    d = _run_bench_under_torchrun(["--steps", "3", "--warmup", "1", "--no-cpu", "--no-transformer", "--no-large-window", "--sample-batch", "64"])
+    assert d["n_gpus"] == 1 and d["config"]["parallelism"] == "dp1" and d["steps"] == 3
+    assert d["value"] > 0 and abs(d["last_loss"]) < 1e3
+    sm = d["sample"]
+    assert sm["batch_per_gpu"] == 64 and sm["steps"] == 50 and sm["value"] > 0 and abs(sm["value"] - 64 / sm["seconds"]) < 0.01 * sm["value"]
+    assert d["small_batch"]["b1"]["ms_per_step"] > 0  # (a rank-0-only leg that issues the flat all-reduce inside the live group)
+
+
 @pytest.mark.gpu
 def test_bench_train_leg_under_torch_distributed_run_with_one_rank():
     """The driver's multi-GPU launch mode with the one GPU this box has: `python -m torch.distributed.run --nproc-per-node 1 bench.py

@@ -1,5 +1,7 @@
 """GPU parity, backward side: hand-written HIP backward kernels against torch autograd over the oracle and against the
 gradients / optimiser trajectories captured from the reference."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -428,16 +430,45 @@ def test_train_one_batch_under_rccl_process_group_world1():
         losses = [dm._train_one_batch(x0, ms2_cond=c2, ms1_cond=c1, noise=nz, t=t) for _ in range(3)]
         return losses, net.flat_params.clone(), float(dm.last_grad_norm), dm._global_mean(losses[-1])
 
+    def side_stream_is_joined_in_front_of_the_allreduce():
+        """dq_train_step runs its weight-gradient launches on a side stream and joins it to the caller's stream before it returns; the flat
+        gradient all-reduce that follows on the caller's stream relies on exactly that.  The test hook makes the side stream's LAST action a
+        store into the gradient buffer, delayed by 5 ms: the all-reduce (and a copy queued behind it, before any host synchronisation) must
+        already see the stored value."""
+        from dquartic import _native as N
+
+        torch.manual_seed(22)
+        net = UNet1d(dim=4, channels=1, dim_mults=(1, 2, 2, 3, 3, 4, 4), conditional=True, init_cond_channels=1,
+                     attn_cond_channels=1, downsample_dim=64, simple=True).cuda()
+        dm = DDIMDiffusionModel(model_class=net, device="cuda")
+        gen = torch.Generator().manual_seed(3)
+        x0, c2, c1 = torch.rand(2, 40, 64, generator=gen).cuda(), torch.rand(2, 40, 64, generator=gen).cuda(), torch.rand(2, 40, generator=gen).cuda()
+        grads = net.flat_grads()
+        dm.train_step_fused(x0, c2, c1)  # (warm-up: workspace, side stream, events)
+        torch.cuda.synchronize()
+        idx, poison = 7, 12345.0
+        N.check(N.lib().dq_debug_side_tail_store(net._plan, ctypes.c_void_p(grads.data_ptr() + 4 * idx), poison, 5000), "dq_debug_side_tail_store")
+        try:
+            dm.train_step_fused(x0, c2, c1)
+            dist.all_reduce(grads)              # the data-parallel exchange of model_interface.py, on the caller's stream
+            seen = grads[idx].clone()           # queued behind it, no host synchronisation in between
+        finally:
+            N.check(N.lib().dq_debug_side_tail_store(net._plan, None, 0.0, 0), "dq_debug_side_tail_store")
+        torch.cuda.synchronize()
+        return float(seen)
+
     ref = run(False)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         got = run(True)
+        seen = side_stream_is_joined_in_front_of_the_allreduce()
     finally:
         dist.destroy_process_group()
     assert got[0] == ref[0] and torch.equal(got[1], ref[1]) and got[2] == ref[2] and got[3] == ref[3]
     assert all(np.isfinite(l) for l in got[0])
+    assert seen == 12345.0, seen
 
 
 def test_captured_train_step_equals_eager_bit_for_bit():
