@@ -88,11 +88,8 @@ std::string build_plan(Plan& p, int dim, int n_mults, const int* mults, int mz, 
   // the 10,000 of the reference's shipped downsample_dim 40000 (unet1d.py:1027-1029) -- the wide path (im2col + matrix-core GEMM + channel-axis
   // norm, k_wide.hip).  Round 4 moved 64 channels there: a thread of the register-resident kernels ran 64 x 64 x 3 dependent FMAs per position
   // (k_conv_fwd<64, 3, 0> 241 us per conv, k_block_bwd<64> with 596 spilled registers); measured at batch 8: train step 19.5 -> 18.0 ms,
-  // sampling step 4.7 -> 4.0 ms.  DQ_WIDE_MID64=0 keeps the old path (A-B switch).
+  // sampling step 4.7 -> 4.0 ms.
   p.wide_mid = !(p.mid_c == 16 || p.mid_c == 32);
-  if (const char* e = std::getenv("DQ_WIDE_MID64")) {
-    if (e[0] == '0' && p.mid_c == 64) p.wide_mid = false;
-  }
   if (p.wide_mid && p.mid_c % 4) return "bottleneck width dims[-1]*MZ/2**(L-1) must be a multiple of 4";
   p.cond_dim = 2 * dim;
   if (p.cond_dim != 8) return "attn_cond_init_dim (2*dim) must be 8";

@@ -2,6 +2,7 @@
 // C ABI (include/dq_hip.h).  Follows UNet1d.forward (dquartic/model/unet1d.py:1086-1166) op by op; the comments
 // name the reference lines each stage replaces.
 #include "dq_common.h"
+#include "dq_dev.h"
 #include "dq_tfm.h"
 #include "dq_kernels.h"
 #include "dq_unet.h"
@@ -172,12 +173,10 @@ void layout_arena(const Plan& p, int B, int RT, Arena& a) {
 namespace {
 
 bool tail_fork_enabled() {
-  static const bool on = [] { const char* e = std::getenv("DQ_NO_TAIL_FORK"); return !(e && e[0] == '1'); }();  // A-B switch
-  return on;
+  return !DQ_DEV_FLAG("DQ_NO_TAIL_FORK", '1');  // (dev switch)
 }
 bool side_stream_enabled() {
-  static const bool on = [] { const char* e = std::getenv("DQ_NO_SIDE_STREAM"); return !(e && e[0] == '1'); }();
-  return on;
+  return !DQ_DEV_FLAG("DQ_NO_SIDE_STREAM", '1');  // (dev switch)
 }
 
 struct Ctx {
@@ -453,7 +452,7 @@ bool tiny_bwd_desc(const Ctx& c, bool up, TinyBwd* out) {
   }
   if (up) {
     // the Upsample conv behind the level (nearest x2 + k3, 16 -> 16): its backward data path in the same launch, its weight gradient on the side stream
-    static const bool upt_on = [] { const char* e = std::getenv("DQ_NO_TINY_UPT"); return !(e && e[0] == '1'); }();  // A-B switch
+    const bool upt_on = !DQ_DEV_FLAG("DQ_NO_TINY_UPT", '1');  // (dev switch)
     if (upt_on && !l.last && l.resample.k == 3 && l.resample.cin == 16 && l.resample.cout == 16 && l.n_next == 2) {
       t.up_w = c.prm(l.resample.w);
       if (c.G) t.dup = c.g(b.rs);
@@ -529,7 +528,7 @@ int la_flush(const Ctx& c) {
 // left take a third of that.  The slot cursor keeps running (every layer has its own reservation), so nothing the queued reduce reads is reused.
 int la_flush_side(const Ctx& c) {
   Ctx::LaDefer* d = c.la_defer;
-  static const bool off = [] { const char* e = std::getenv("DQ_NO_LA_FLUSH_SIDE"); return e && e[0] == '1'; }();  // A-B switch
+  const bool off = DQ_DEV_FLAG("DQ_NO_LA_FLUSH_SIDE", '1');  // (dev switch)
   if (off || !d || d->count == 0 || !c.owner || !c.side_defer || !tail_fork_enabled()) return 0;
   std::vector<LaReduceItem> items(d->items, d->items + d->count);
   Ctx::SideItem it{};
@@ -678,7 +677,7 @@ int conv_plain_bwd(const Ctx& c, const ConvP& cp, int mode, const float* in, con
 
 // backward of a level's resample conv: one launch for the data and the weight / bias gradient when the shape allows it
 int resample_bwd(const Ctx& c, const ConvP& cp, int pre, const LevelBuf& b, int n_in, int n_out, int accumulate) {
-  static const bool off = [] { const char* e = std::getenv("DQ_NO_CONV_WG"); return e && e[0] == '1'; }();  // A-B switch
+  const bool off = DQ_DEV_FLAG("DQ_NO_CONV_WG", '1');  // (dev switch)
   if (!off && b.cpart_floats && cp.b == cp.w + (int64_t)cp.cout * cp.cin * cp.k && conv_wg_usable(cp.cout, pre, cp.cin, n_out, c.RT)) {
     ConvBwdWg k;
     k.dy = c.g(b.rs); k.in = c.w(b.la); k.w = c.prm(cp.w); k.din = c.g(b.la); k.accumulate = accumulate;
@@ -821,7 +820,7 @@ int mid_backward_wide(const Ctx& c, const float* rope) {
 // one launch per level for [the resample conv that produces the level's input] + the level's ResnetBlocks (k_level.hip)
 // ---------------------------------------------------------------------------------------------------------------
 bool level_kernels_enabled() {
-  static const bool on = [] { const char* e = std::getenv("DQ_NO_LEVEL_FWD"); return !(e && e[0] == '1'); }();  // A-B switch
+  const bool on = !DQ_DEV_FLAG("DQ_NO_LEVEL_FWD", '1');  // (dev switch)
   return on;
 }
 // a block of the level kernel: its second input (skip channels) and where its results go
@@ -892,7 +891,7 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     lc.C = l.r0.cout; lc.n = l.n; lc.nblocks = 2;
     lc.r[0] = &l.r0; lc.r[1] = &l.r1; lc.rb[0] = &a.downs[lv].r0; lc.rb[1] = &a.downs[lv].r1;
     if (lv == 0) {
-      static const bool train_init = [] { const char* e = std::getenv("DQ_NO_TRAIN_INIT"); return !(e && e[0] == '1'); }();  // A-B switch
+      const bool train_init = !DQ_DEV_FLAG("DQ_NO_TRAIN_INIT", '1');  // (dev switch)
       if ((!c.save || train_init) && p.dim == 4 && p.init_conv.cout == 4 && p.init_conv.cin == 2 && p.init_conv.k == 7 && p.init_conv.b >= 0) {
         lc.pre = LEVEL_PRE_INIT; lc.pc = &p.init_conv; lc.in = x; lc.cond = init_cond; lc.cm = cm; lc.ca = ca; lc.pre_out = c.w(a.h0);
       } else {
@@ -977,7 +976,7 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
   // gradient twin's accumulated-into region (needed by the backward) were ~55 us at the head of the main queue, in front of or between
   // launches that do not depend on them.  One event forks; the main stream waits for `ev_prep` in front of the first LinearAttention and
   // for `ev_rest` in front of the first launch that reads the MS1 features.
-  static const bool fwd_fork_on = [] { const char* e = std::getenv("DQ_NO_FWD_FORK"); return !(e && e[0] == '1'); }();  // A-B switch
+  const bool fwd_fork_on = !DQ_DEV_FLAG("DQ_NO_FWD_FORK", '1');  // (dev switch)
   const bool fwd_fork = fwd_fork_on && c.owner && c.save && c.G && !c.step_io && !c.prepare_only;
   hipStream_t ps = c.s;
   hipEvent_t ev_prep = nullptr, ev_rest = nullptr;
@@ -1183,7 +1182,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
   else DQ_TRY(launch_zero(c.G, a.zero_floats, c.s));
   // the ResnetBlock / resample-conv slot reductions collected so far as one side-stream item
   auto wg_to_side = [&c, &wg_items, &side_items]() {
-    static const bool wg_off = [] { const char* e = std::getenv("DQ_NO_LA_FLUSH_SIDE"); return e && e[0] == '1'; }();
+    const bool wg_off = DQ_DEV_FLAG("DQ_NO_LA_FLUSH_SIDE", '1');  // (dev switch)
     if (wg_off || !c.owner || !c.side_defer || !tail_fork_enabled() || wg_items.empty()) return;
     std::vector<ResWgReduce> part(wg_items);
     Ctx::SideItem it{};
@@ -1327,7 +1326,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     return launch_prep_inputs_bwd(cc.g(a.cat0), init_cond, cm, ca, cc.g(a.ss), p.ss_total, p.ss_init, B, RT, p.mz, cc.w(a.bb_part),
                                   a.bb_part_floats, cc.s);
   };
-  static const bool tail_swap = [] { const char* e = std::getenv("DQ_NO_TAIL_SWAP"); return !(e && e[0] == '1'); }();  // A-B switch
+  const bool tail_swap = !DQ_DEV_FLAG("DQ_NO_TAIL_SWAP", '1');  // (dev switch)
   if (tail_swap && c.owner && c.side_defer && !grad_x && tail_fork_enabled()) {
     // The chain that ends the pass is  d h0 -> d cat0 (init conv, data) -> d(scale, shift) of init_cond_proj -> time-embedding backward -> norm -> update;
     // the LinearAttention slot reductions and the init conv's weight gradient only have to be there for the norm.  So the MAIN queue runs that chain and
@@ -1390,7 +1389,7 @@ int ensure_side(dq_plan* pl) {
     // compute units from it (three same-call pairs at batch 32: 3.695 / 3.681 / 3.679 ms against 3.697 / 3.696 / 3.954 with the highest priority, whose
     // occasional slow run is the side queue's kernels winning the arbitration against a resident-round grid of the main chain).  Either class is a
     // queue of its own.  DQ_SIDE_PRIO=h: the old setting (A-B switch).
-    static const bool low = [] { const char* e = std::getenv("DQ_SIDE_PRIO"); return !(e && e[0] == 'h'); }();
+    const bool low = !DQ_DEV_FLAG("DQ_SIDE_PRIO", 'h');  // (dev switch)
     DQ_HIP_OK(hipStreamCreateWithPriority(&pl->side_stream, hipStreamNonBlocking, low ? prio_least : prio_greatest));
     for (auto& e : pl->events) DQ_HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   return 0;
@@ -1694,12 +1693,12 @@ int dq_train_step(dq_plan* plan, const float* params, const float* rope_freqs, c
   c.owner = (side_stream_enabled() && !plan->no_side) ? plan : nullptr;
   const int64_t per = (int64_t)RT * plan->plan.mz;
   const float cm = auto_normalize ? 2.f : 1.f, ca = auto_normalize ? -1.f : 0.f;
-  static const bool qs_fused_on = [] { const char* e = std::getenv("DQ_NO_QSAMPLE_FUSE"); return !(e && e[0] == '1'); }();  // A-B switch
+  const bool qs_fused_on = !DQ_DEV_FLAG("DQ_NO_QSAMPLE_FUSE", '1');  // (dev switch)
   Ctx::QSample qs;
   qs.alpha_bars = alpha_bars_dev; qs.x0 = x0; qs.t = t; qs.noise = noise; qs.normalize = auto_normalize; qs.per = per;
   if (qs_fused_on && ms1_loss_weight == 0.f) c.qsample = &qs;  // model.py:349-352 (the MS1 term reads x_t: it keeps the launch)
   else DQ_TRY(launch_q_sample(alpha_bars_dev, x0, t, noise, c.w(a.xa), B, per, auto_normalize, s));
-  static const bool head_loss_on = [] { const char* e = std::getenv("DQ_NO_HEAD_LOSS"); return !(e && e[0] == '1'); }();  // A-B switch
+  const bool head_loss_on = !DQ_DEV_FLAG("DQ_NO_HEAD_LOSS", '1');  // (dev switch)
   Ctx::HeadLoss hl;
   if (head_loss_on && pred_type == DQ_PRED_EPS && ms1_loss_weight == 0.f) {
     hl.z = noise; hl.grad_out = c.w(a.xb); hl.part = c.w(a.head_part); hl.gscale = 2.0f / (float)(B * per);  // (launch_mse_fwd_bwd's scale)

@@ -16,6 +16,7 @@
 //   dK/dV     (keys on lanes):     S = xty(Qt, Kt), dP = xty(dOt, Vt) ; dV = xty(dOx, P) ; dK = xty(Qx, dS)
 // 3.4 % of the network FLOPs at 64x400.
 #include "dq_common.h"
+#include "dq_dev.h"
 #include "dq_kernels.h"
 #include "dq_mfma.h"
 #include <cstdlib>
@@ -220,20 +221,24 @@ __global__ void __launch_bounds__(64 * NW) k_attn_fwd(const float* __restrict__ 
 // waves per query block: ONE.  Four (each wave every fourth key block, partials merged in LDS) were measured at batch 32: forward 44 us
 // either way, dQ 62 -> 89 us (its 253 registers leave two waves per SIMD either way, and the merge comes on top).  The four-wave forms
 // stay selectable (DQ_ATTN_NW_F / DQ_ATTN_NW_Q = 4; tests/test_blocks_gpu.py is run with them).
+#ifdef DQ_DEV_SWITCHES
 static int attn_split(int B, int RT, bool query_side) {
-  static const int env_f = [] { const char* e = std::getenv("DQ_ATTN_NW_F"); return e && (e[0] == '1' || e[0] == '4') ? e[0] - '0' : 0; }();
-  static const int env_q = [] { const char* e = std::getenv("DQ_ATTN_NW_Q"); return e && (e[0] == '1' || e[0] == '4') ? e[0] - '0' : 0; }();
+  const int env_f = DQ_DEV_FLAG("DQ_ATTN_NW_F", '4') ? 4 : 0, env_q = DQ_DEV_FLAG("DQ_ATTN_NW_Q", '4') ? 4 : 0;  // (dev switches)
   (void)B; (void)RT;
   // (not chosen by grid size: a window's result must not depend on the batch it is computed in -- the four-wave merge adds the
   // partial softmaxes in another order, and tests/test_scale_parity.py holds batch 2 against batch 512 bit for bit)
   return query_side ? (env_q ? env_q : 1) : (env_f ? env_f : 1);
 }
+#endif
 
 int launch_attn_fwd(const float* q, int64_t q_bs, const float* k, int64_t k_bs, const float* v, int64_t v_bs, float* o, float* lse,
                     int B, int RT, hipStream_t s) {
   if (B == 0 || RT == 0) return 0;
+#ifdef DQ_DEV_SWITCHES
   if (attn_split(B, RT, false) == 4) hipLaunchKernelGGL(k_attn_fwd<4>, dim3(cdiv(RT, 32), B * 4), dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, o, lse, RT);
-  else hipLaunchKernelGGL(k_attn_fwd<1>, dim3(cdiv(RT, 32), B * 4), dim3(64), 0, s, q, q_bs, k, k_bs, v, v_bs, o, lse, RT);
+  else
+#endif
+  hipLaunchKernelGGL(k_attn_fwd<1>, dim3(cdiv(RT, 32), B * 4), dim3(64), 0, s, q, q_bs, k, k_bs, v, v_bs, o, lse, RT);
   DQ_LAUNCH_CHECK();
   return 0;
 }
@@ -379,8 +384,11 @@ int launch_attn_bwd(const float* q, int64_t q_bs, const float* k, int64_t k_bs, 
                     int64_t dv_bs, int B, int RT, hipStream_t s) {
   if (B == 0 || RT == 0) return 0;
   dim3 grid(cdiv(RT, 32), B * 4);
+#ifdef DQ_DEV_SWITCHES
   if (attn_split(B, RT, true) == 4) hipLaunchKernelGGL(k_attn_bwd_q<4>, grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, o, d_o, lse, delta, dq, dq_bs, RT);
-  else hipLaunchKernelGGL(k_attn_bwd_q<1>, grid, dim3(64), 0, s, q, q_bs, k, k_bs, v, v_bs, o, d_o, lse, delta, dq, dq_bs, RT);
+  else
+#endif
+  hipLaunchKernelGGL(k_attn_bwd_q<1>, grid, dim3(64), 0, s, q, q_bs, k, k_bs, v, v_bs, o, d_o, lse, delta, dq, dq_bs, RT);
   DQ_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_attn_bwd_kv, grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, d_o, lse, delta, dk, dk_bs, dv, dv_bs, RT);
   DQ_LAUNCH_CHECK();

@@ -181,7 +181,7 @@ int launch_conv_fwd(const ConvFwd& a, hipStream_t s) {
     case 12: return conv_fwd_dispatch<12>(a, 1, s);
     case 16: return conv_fwd_dispatch<16>(a, 1, s);
     case 32: return conv_fwd_dispatch<32>(a, 1, s);
-    case 64: return conv_fwd_dispatch<64>(a, 1, s);
+    // (64 output channels in one thread -- the 64-channel bottleneck of BASELINE configs[4] until round 4 -- went to the im2col + GEMM path: k_wide.hip)
     default:
       if (chunkable && a.cout % 32 == 0) return conv_fwd_dispatch<32>(a, a.cout / 32, s);
       set_error("conv_fwd: unsupported cout " + std::to_string(a.cout));
@@ -371,7 +371,7 @@ int launch_block_bwd(const BlockBwd& a, hipStream_t s) {
     hipLaunchKernelGGL((k_block_bwd<CC>), grid, block, 0, s, a_);     \
     break;
   switch (a.C) {
-    DQ_BB(1) DQ_BB(4) DQ_BB(8) DQ_BB(12) DQ_BB(16) DQ_BB(32) DQ_BB(64)
+    DQ_BB(1) DQ_BB(4) DQ_BB(8) DQ_BB(12) DQ_BB(16) DQ_BB(32)
     default:
       set_error("block_bwd: unsupported channel count " + std::to_string(a.C));
       return 2;
@@ -761,11 +761,8 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce_multi(WgradMulti m) {
   }
 }
 
-// blocks in flight per conv of a weight-gradient launch (A-B switch DQ_WGRAD_BLOCKS)
-static int wgrad_blocks() {
-  static const int v = [] { const char* e = std::getenv("DQ_WGRAD_BLOCKS"); return e ? std::max(64, std::atoi(e)) : 2048; }();
-  return v;
-}
+// blocks in flight per conv of a weight-gradient launch (2048: settled in round 2 over 512 .. 4096)
+static int wgrad_blocks() { return 2048; }
 
 // count <= 3 stride-1 convs with identical (rows, n_in == n_out); each descriptor carries its own scratch region
 int launch_conv_wgrad_multi(const ConvWgrad* w, int count, hipStream_t s) {
@@ -878,7 +875,6 @@ int launch_rmsnorm_fwd(const float* x, const float* g, float* y, int C, int rows
     case 12: hipLaunchKernelGGL((k_rmsnorm_fwd<12>), grid, block, 0, s, x, g, y, rows, n); break;
     case 16: hipLaunchKernelGGL((k_rmsnorm_fwd<16>), grid, block, 0, s, x, g, y, rows, n); break;
     case 32: hipLaunchKernelGGL((k_rmsnorm_fwd<32>), grid, block, 0, s, x, g, y, rows, n); break;
-    case 64: hipLaunchKernelGGL((k_rmsnorm_fwd<64>), grid, block, 0, s, x, g, y, rows, n); break;
     default: set_error("rmsnorm_fwd: unsupported channel count " + std::to_string(C)); return 2;
   }
   DQ_LAUNCH_CHECK();

@@ -1393,8 +1393,7 @@ int launch_linattn_bwd(const LinAttnBwd& a, hipStream_t s) {
   DQ_REQUIRE(a.part && a.part_floats >= (short_rows ? la_part_reserve(C) : (int64_t)LA_MAX_WAVES * 512 * C),
              "linattn_bwd: partial-sum scratch missing or too small");
   static_assert((int64_t)LA_MAX_WAVES * 512 * 4 >= 2048 * (int64_t)la_slot(4) + 64, "slot scratch: a resident round of slots must fit");
-  static const bool long_all = [] { const char* e = std::getenv("DQ_LA_BWD_LONG"); return e && e[0] == '1'; }();
-  if (n > 64 || (n & (n - 1)) != 0 || (long_all && n >= 32 && C <= 8)) {
+  if (n > 64 || (n & (n - 1)) != 0) {
     // rows of 128 / 256 positions: the sweep kernel between two pointwise norm-backward launches
     // (these launches accumulate into dx: a caller that asked for a plain store gets a cleared dx first)
     DQ_REQUIRE(a.part_floats >= (int64_t)LA_MAX_WAVES * 512 * C, "linattn_bwd: partial-sum scratch too small for the sweep kernel");

@@ -87,6 +87,9 @@ constexpr int la_slot_floats(int C) { return 256 * C + 4 * C * C + 3 * C; }
 template <int C, int N>
 __global__ void __launch_bounds__(256, 2) k_la_rows_bwd(LaRowsBwdK a) {
   static_assert(C == 8 || C == 12 || C == 16, "channel widths of the deep levels");
+  // (Rows of 8 positions: the straightforward instantiation holds k, q, S and dS of eight positions -- 256 + 256 registers and scratch, one workgroup
+  // per CU, no faster than k_la_bwd.hip's 121 us at 12,800 rows by the clocks of the 4-position kernel; this compiler's MFMA register-form
+  // pass also crashes on it.  Not built.)
   static_assert(N == 2 || N == 4, "rows of 2 / 4 positions");
   constexpr int CPL = C / 4;            // channels per lane
   constexpr int RUN = CPL * N;          // a lane's contiguous run of a (row, C, N) tensor: channels CPL g .. CPL g + CPL - 1, all positions

@@ -237,20 +237,11 @@ __global__ void __launch_bounds__(256, N <= 4 ? 2 : 1) k_la_small(LaSmallK a) { 
   }
 }
 
-bool la_small8_enabled() {
-  static const bool on = [] { const char* e = std::getenv("DQ_NO_LA_SMALL8"); return !(e && e[0] == '1'); }();  // A-B switch (rows of 8 positions)
-  return on;
-}
-bool la_small_enabled() {
-  static const bool on = [] { const char* e = std::getenv("DQ_NO_LA_SMALL"); return !(e && e[0] == '1'); }();  // A-B switch
-  return on;
-}
 
 }  // namespace
 
 bool la_small_usable(int C, int n) {
-  if (!la_small_enabled()) return false;
-  return ((n == 2 || n == 4) && (C == 12 || C == 16)) || (n == 8 && C == 12 && la_small8_enabled());  // (8 channels at 8 positions measured slower than the register-resident kernel: 297 vs 276 us at batch 512; 12 channels: 371 vs 429)
+  return ((n == 2 || n == 4) && (C == 12 || C == 16)) || (n == 8 && C == 12);  // (8 channels at 8 positions measured slower than the register-resident kernel: 297 vs 276 us at batch 512; 12 channels: 371 vs 429)
 }
 // Below one 32-row tile per SIMD the launch is a latency chain (a training batch of 32 windows: 400 tiles for 1,024 SIMDs) and the
 // register-resident kernel's shorter prologue wins (measured at 12,800 rows: 4 launches +35 us per step); above it the matrix pipe is the limit

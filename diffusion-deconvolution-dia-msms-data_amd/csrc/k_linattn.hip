@@ -20,6 +20,7 @@
 //   (again C rows, 4x4x1).  Both softmax normalisations are applied to the C-row results (M, P / R), not to the 32-row tiles.
 //   The W2 contraction and the post-norm run on the VALU for this lane's own channels; HBM traffic: x in, y out (+ ypre).
 #include "dq_common.h"
+#include "dq_dev.h"
 #include "dq_kernels.h"
 #include "dq_mfma.h"
 #include "dq_probe.h"
@@ -550,15 +551,13 @@ static int la_num_cus() {
   static const int v = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
   return v;
 }
-static int la_fwd_occ_cap() {  // DQ_LA_FWD_OCC = n > 0: the forward as ONE resident round of n workgroups per CU whose waves walk several units (A-B switch; default 0: one unit per wave)
-  static const int v = [] { const char* e = std::getenv("DQ_LA_FWD_OCC"); return e ? std::atoi(e) : 0; }();
-  return v;
-}
-// DQ_LA_PROJ=fp32: the K = C projections on v_mfma_f32_32x32x2_f32 as in rounds 1-3 (A-B switch; default: split-bf16 for 4 / 8 channels)
-bool la_proj_bf16() {
-  static const bool v = [] { const char* e = std::getenv("DQ_LA_PROJ"); return !(e && std::string(e) == "fp32"); }();
-  return v;
-}
+#ifdef DQ_DEV_SWITCHES
+#define DQ_LA_FP32_TOO 1
+#else
+#define DQ_LA_FP32_TOO 0
+#endif
+// split-bf16 K = C projections for 4 / 8 channels; DQ_LA_PROJ=fp32 in the dev build keeps the fp32 matrix-pipe form of rounds 1-3
+bool la_proj_bf16() { return !DQ_DEV_FLAG("DQ_LA_PROJ", 'f'); }
 template <int C>
 static int linattn_fwd_n(const LinAttn& a, hipStream_t s) {
 #define DQ_LA(NN)                                                                      \
@@ -567,23 +566,12 @@ static int linattn_fwd_n(const LinAttn& a, hipStream_t s) {
     /* 8 channels, rows of <= 8 positions: the 24 KB bf16 image costs the fourth workgroup per CU (278 -> 296 us at batch 512): fp32 form */ \
     constexpr bool CAN_BF = C <= 8 && NN > 1 && !(C == 8 && NN <= 8);                  \
     const int units = cdiv(a.rows, RW);                                                \
-    const int cap = la_fwd_occ_cap();                                                  \
-    int grid = cdiv(units, 4);                                                         \
-    if (CAN_BF && la_proj_bf16()) {                                                    \
-      if (cap > 0) {                                                                   \
-        const int nb = occ_blocks_per_cu((const void*)k_linattn_fwd<C, NN, CAN_BF>, 256, 0); \
-        if (nb < 0) return 1;                                                          \
-        grid = std::min(grid, std::min(nb, cap) * la_num_cus());                       \
-      }                                                                                \
+    const int grid = cdiv(units, 4);  /* one unit per wave: a wave walking several units with the next unit's x in flight was measured slower */ \
+    /* (the fp32-projection instantiation of a shape whose default is split-bf16 exists in the dev build only: DQ_LA_PROJ=fp32) */ \
+    if (DQ_LA_FP32_TOO && !(CAN_BF && la_proj_bf16()))                                 \
+      hipLaunchKernelGGL((k_linattn_fwd<C, NN, CAN_BF && !DQ_LA_FP32_TOO>), dim3(grid), dim3(256), 0, s, a); \
+    else                                                                               \
       hipLaunchKernelGGL((k_linattn_fwd<C, NN, CAN_BF>), dim3(grid), dim3(256), 0, s, a); \
-    } else {                                                                           \
-      if (cap > 0) {                                                                   \
-        const int nb = occ_blocks_per_cu((const void*)k_linattn_fwd<C, NN, false>, 256, 0); \
-        if (nb < 0) return 1;                                                          \
-        grid = std::min(grid, std::min(nb, cap) * la_num_cus());                       \
-      }                                                                                \
-      hipLaunchKernelGGL((k_linattn_fwd<C, NN, false>), dim3(grid), dim3(256), 0, s, a); \
-    }                                                                                  \
     break;                                                                             \
   }
   switch (a.n) {

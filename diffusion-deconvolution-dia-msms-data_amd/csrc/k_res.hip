@@ -195,9 +195,8 @@ int launch_res_fwd(const ResFwd& a, hipStream_t s) {
   DQ_REQUIRE(res_fusable(a.n, a.C, a.rows_per_sample), "res_fwd: row length must divide 256 (or one row of <= 512 per sample) and C be 4/8/12/16");
   DQ_REQUIRE(a.rows % a.rows_per_sample == 0, "res_fwd: rows must be a multiple of rows_per_sample");
   DQ_REQUIRE(a.wr || (a.cinA == a.C && a.cinB == 0), "res_fwd: identity residual needs C input channels");
-  // m/z rows of up to 64 positions: the convolutions on the matrix pipe (k_res_mm.hip).  DQ_RES_FWD=old keeps the VALU kernels (A-B switch)
-  static const bool old_fwd = [] { const char* e = std::getenv("DQ_RES_FWD"); return e && e[0] == 'o'; }();
-  if (!old_fwd && res_mm_usable(a.n, a.C, a.cinA, a.cinB, a.rows_per_sample, a.wr != nullptr)) return launch_res_fwd_mm(a, s);
+  // m/z rows of up to 64 positions: the convolutions on the matrix pipe (k_res_mm.hip)
+  if (res_mm_usable(a.n, a.C, a.cinA, a.cinB, a.rows_per_sample, a.wr != nullptr)) return launch_res_fwd_mm(a, s);
   if (a.rows_per_sample > 1 && res_cp_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_fwd_cp(a, s);
   if (a.rows_per_sample > 1 && res_v4_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_fwd_v4(a, s);
   DQ_REQUIRE(a.cinA == a.C && a.cinB <= a.C && (a.cinB == 0 || a.inB), "res_fwd: input must be C channels (+ at most C skip channels)");

@@ -23,6 +23,7 @@
 //     dshift] -- the order of the flat parameter buffer -- for k_res_wg_reduce to add up in block order: no atomics, bitwise
 //     repeatable.
 #include "dq_common.h"
+#include "dq_dev.h"
 #include "dq_kernels.h"
 #include "k_res_common.h"
 #include "dq_probe.h"
@@ -586,8 +587,7 @@ bool res_wg_usable(int n, int C, int cinA, int cinB, int rows_per_sample) {
   // step (B = 32) the 14 launches take 496 us against 279 us of k_res_bwd_cp + their weight-gradient launches on the side stream: one
   // 256-position tile per workgroup leaves staging (15,000 clocks), the channel-strided loads of rows of 2 positions (28,000) and the flush of
   // 47 accumulator quads (24,000) with nothing to overlap them.  DQ_WG_WIDE=1 selects it (tests/test_blocks_gpu.py runs both).
-  static const bool wide_on = [] { const char* e = std::getenv("DQ_WG_WIDE"); return e && e[0] == '1'; }();
-  if (C >= 12 && !wide_on) return false;
+  if (C >= 12 && !DQ_DEV_FLAG("DQ_WG_WIDE", '1')) return false;  // (dev switch; the 12 / 16-channel instantiations exist in the dev build only)
   const int nmin = C >= 12 ? 1 : 8;
   return n >= nmin && n <= 64 && (n & (n - 1)) == 0 && rows_per_sample > 1 && cinA == C && (cinB == 0 || (cinB % 4 == 0 && cinB <= C));
 }
@@ -606,9 +606,6 @@ void res_wg_grid(int B, int rows_per_sample, int n, int* tiles_ps, int* tpb, int
   *tiles_ps = cdiv((int64_t)rows_per_sample * n, TILE);
   const int64_t total = (int64_t)*tiles_ps * B;
   *tpb = (int)std::max<int64_t>(1, (total + 1023) / 1024);
-  static const int tpb_min = [] { const char* e = std::getenv("DQ_WG_TPB"); return e ? std::atoi(e) : 0; }();  // A-B switch
-  if (tpb_min > 0) *tpb = std::max(*tpb, tpb_min);
-  if (tpb_min < 0) *tpb = 1;
   *gx = cdiv(*tiles_ps, *tpb);
 }
 int res_wg_nv(int C, int cin, bool wr) { return C * cin * 3 + C + C + C * C * 3 + C + C + (wr ? C * cin + C : 0) + 2 * C; }
@@ -635,7 +632,10 @@ int launch_res_bwd_wg(const ResBwdWg& a_in, hipStream_t s, ResWgReduce* red_out)
   const void* fn = nullptr;
   size_t lds = 0;
 #define DQ_WGK(CC, WW) if (a.C == CC && wr == WW) { fn = (const void*)k_res_bwd_wg<CC, WW>; lds = res_wg_lds_bytes<CC, WW>(); }
-  DQ_WGK(4, true) DQ_WGK(4, false) DQ_WGK(8, true) DQ_WGK(8, false) DQ_WGK(12, true) DQ_WGK(12, false) DQ_WGK(16, true) DQ_WGK(16, false)
+  DQ_WGK(4, true) DQ_WGK(4, false) DQ_WGK(8, true) DQ_WGK(8, false)
+#ifdef DQ_DEV_SWITCHES  // (12 / 16 channels: built, parity-tested under DQ_WG_WIDE=1, slower than k_res_bwd_cp at those row lengths -- dev build only)
+  DQ_WGK(12, true) DQ_WGK(12, false) DQ_WGK(16, true) DQ_WGK(16, false)
+#endif
 #undef DQ_WGK
   DQ_REQUIRE(fn && lds <= 160 * 1024, "res_bwd_wg: no kernel for this shape");
   {
@@ -659,7 +659,10 @@ int launch_res_bwd_wg(const ResBwdWg& a_in, hipStream_t s, ResWgReduce* red_out)
   DQ_REQUIRE(a.part_floats >= (int64_t)gx * B * a.nv, "res_bwd_wg: slot scratch too small");
   dim3 grid(gx, B), block(256);
 #define DQ_WGL(CC, WW) if (a.C == CC && wr == WW) hipLaunchKernelGGL((k_res_bwd_wg<CC, WW>), grid, block, lds, s, a);
-  DQ_WGL(4, true) DQ_WGL(4, false) DQ_WGL(8, true) DQ_WGL(8, false) DQ_WGL(12, true) DQ_WGL(12, false) DQ_WGL(16, true) DQ_WGL(16, false)
+  DQ_WGL(4, true) DQ_WGL(4, false) DQ_WGL(8, true) DQ_WGL(8, false)
+#ifdef DQ_DEV_SWITCHES
+  DQ_WGL(12, true) DQ_WGL(12, false) DQ_WGL(16, true) DQ_WGL(16, false)
+#endif
 #undef DQ_WGL
   DQ_LAUNCH_CHECK();
   if (red_out) {

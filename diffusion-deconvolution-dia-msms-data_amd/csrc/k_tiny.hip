@@ -19,6 +19,7 @@
 // replacing k_level_fwd + k_linattn_fwd (+ k_conv_fwd + k_fold) at those levels: at batch 32 they were latency floors of 20-34 us each
 // (one 64-position wave per tile walking ~1,000 dependent 4x4x1 MFMAs at one wave per SIMD).
 #include "dq_common.h"
+#include "dq_dev.h"
 #include "dq_kernels.h"
 #include "dq_mfma.h"
 #include "dq_plan.h"
@@ -819,12 +820,12 @@ int tiny_bwd_layers(const TinyBwd& t, TinyLayer* L) {
 }
 
 bool tiny_bwd_enabled() {
-  static const bool on = [] { const char* e = std::getenv("DQ_NO_TINY_BWD"); return !(e && e[0] == '1'); }();  // A-B switch
+  const bool on = !DQ_DEV_FLAG("DQ_NO_TINY_BWD", '1');  // (dev switch)
   return on;
 }
 
 bool tiny_enabled() {
-  static const bool on = [] { const char* e = std::getenv("DQ_NO_TINY"); return !(e && e[0] == '1'); }();  // A-B switch
+  const bool on = !DQ_DEV_FLAG("DQ_NO_TINY", '1');  // (dev switch)
   return on;
 }
 

@@ -90,7 +90,7 @@ class DDIMDiffusionModel(ModelInterface):
         self.pred_type = pred_type
         self.ms1_loss_weight = ms1_loss_weight
         self._ab_host = None
-        self.use_graph = os.environ.get("DQ_NO_GRAPH", "0") != "1"  # sample(): replay one hipGraph-captured step per timestep
+        self.use_graph = True  # sample(): replay one hipGraph-captured step per timestep (an attribute, not an environment switch)
 
     # ------------------------------------------------------------------ helpers
     @property

@@ -242,12 +242,12 @@ class TrainStepGraph:
     count and lr are read from device memory by the optimiser kernel.  The backward's remaining weight-gradient launches run on the capture
     stream (``dq_plan_set_side_stream(plan, 0)``): a fork / join inside a graph was measured slower than the chain."""
 
-    def __init__(self, dm, x_0, ms2_cond, ms1_cond, ms1_loss_weight=0.0):
+    def __init__(self, dm, x_0, ms2_cond, ms1_cond, ms1_loss_weight=0.0, keep_side=False):
         self.dm, self.opt, self.net = dm, dm.optimizer, dm.model
         self.key = (tuple(x_0.shape), tuple(ms1_cond.shape), float(ms1_loss_weight or 0.0), float(dm.optimizer.grad_scale))
         self.x0, self.c2, self.c1 = (torch.empty_like(v, dtype=torch.float32).copy_(v) for v in (x_0, ms2_cond, ms1_cond))
         self.w = float(ms1_loss_weight or 0.0)
-        self.keep_side = os.environ.get("DQ_GRAPH_SIDE", "0") == "1"  # A-B switch: keep the fork / join inside the captured step
+        self.keep_side = bool(keep_side)  # keep the fork / join inside the captured step (measured slower than the single chain: off)
         N.check(N.lib().dq_plan_set_side_stream(self.net._plan, 1 if self.keep_side else 0), "dq_plan_set_side_stream")
         self.opt._dev_state()
         self.opt.sync_step_dev()
@@ -529,11 +529,14 @@ class ModelInterface(object):
             self.callback_handler.batch_callback(batch_idx, loss)
         return batch_loss
 
-    def enable_train_graph(self, on: bool = True):
+    def enable_train_graph(self, on: bool = True, keep_side: bool = False):
         """Run ``_train_one_batch`` as one captured hipGraph replay per step (``TrainStepGraph``): the reference trains at batch_size 1
         (dquartic_train_config.json:12), where a step is a chain of ~250 short launches and the host's launch rate is the limit.  Same
         kernels in the same order as the eager step (bit-identical given the same t / noise); single-process runs with drawn t / noise."""
         self.train_graph = bool(on)
+        if bool(keep_side) != getattr(self, "_train_graph_side", False):
+            self._train_graphs = {}
+        self._train_graph_side = bool(keep_side)  # capture the side-stream fork / join as a second branch of the graph
         if not on and getattr(self, "_train_graphs", None):
             self._train_graphs = {}
             N.check(N.lib().dq_plan_set_side_stream(self.model._plan, 1), "dq_plan_set_side_stream")  # eager steps fork their weight gradients again
@@ -554,7 +557,7 @@ class ModelInterface(object):
                 while len(graphs) >= 4:
                     del graphs[next(iter(graphs))]
                 self.optimizer.grad_scale = 1.0
-                tg = graphs[key] = TrainStepGraph(self, x_0, ms2_cond, ms1_cond, ms1_loss_weight)
+                tg = graphs[key] = TrainStepGraph(self, x_0, ms2_cond, ms1_cond, ms1_loss_weight, keep_side=getattr(self, "_train_graph_side", False))
             loss = tg.step(x_0, ms2_cond, ms1_cond)
             self.last_grad_norm = self.optimizer.last_grad_norm
             return loss.item() if sync else loss

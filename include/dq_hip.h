@@ -262,7 +262,7 @@ int dq_linattn_fwd_prepared(const float* x, float* y, float* ypre, const float* 
 int dq_linattn_bwd(const float* x, const float* ypre, const float* dy, float* dx, const float* w_qkv, const float* w_out,
                    const float* b_out, const float* g_pre, const float* g_out, float* dw_qkv, float* dw_out, float* db_out,
                    float* dg_pre, float* dg_out, float* scratch, int C, int rows, int n, void* stream);
-/* RMSNorm (unet1d.py:113-140): y = x / max(||x||_2 over C, 1e-12) * g * sqrt(C) on (rows, C, n); C in {4, 8, 12, 16, 32, 64}. */
+/* RMSNorm (unet1d.py:113-140): y = x / max(||x||_2 over C, 1e-12) * g * sqrt(C) on (rows, C, n); C in {4, 8, 12, 16, 32}. */
 int dq_rmsnorm_fwd(const float* x, const float* g, float* y, int C, int rows, int n, void* stream);
 /* SinusoidalPosEmb(4) -> Linear(4,16) -> GELU -> Linear(16,16) (unet1d.py:196-218, 956-960): t (B) int64 -> sinu_out (B,4),
  * temb_out (B,16) (either nullable).  scratch: 100 * B floats. */

@@ -2,7 +2,8 @@
 k_tiny (levels with rows of 1 / 2 positions: stage + ResnetBlocks + the n = 1 LinearAttention + the bottleneck folds) against
 k_level_fwd / k_linattn_fwd / k_conv_fwd / k_fold (DQ_NO_TINY=1), k_la_small against the register-resident LinearAttention
 (dq_set_option: the register-resident forms at every row count), and the side-stream scheduling of the train step against the single chain (DQ_NO_FWD_FORK=1 DQ_NO_TAIL_FORK=1).
-The library reads its switches once per process, so every variant runs in its own child process (one at a time) and leaves an .npz.
+The switches live in the DEVELOPMENT build of the library only (csrc/dq_dev.h; the product reads no environment variable) and are read once per
+process, so every variant runs in its own child process (one at a time) on build/dev/libdq_hip_dev.so and leaves an .npz.
 RT = 70 leaves the last tile of every sample partly filled (32-row and 64-row tiles)."""
 import os
 import subprocess
@@ -14,6 +15,7 @@ import pytest
 from conftest import REPO
 
 pytestmark = pytest.mark.gpu
+DEV_LIB = os.path.join(REPO, "diffusion-deconvolution-dia-msms-data_amd", "build", "dev", "libdq_hip_dev.so")
 
 CHILD = r"""
 import sys, numpy as np, torch
@@ -49,6 +51,10 @@ def _run(tmp_path, tag, env, shape=()):
     out = str(tmp_path / f"{tag}.npz")
     e = dict(os.environ)
     e.update(env)
+    # the A-B switches (DQ_NO_*) exist only in the development build of the library (csrc/dq_dev.h, `make dev`): the product build reads no
+    # environment variable.  BOTH sides of a comparison run the development build, whose default paths are the product's.
+    assert os.path.exists(DEV_LIB), "build the development library first: make -C diffusion-deconvolution-dia-msms-data_amd dev (or __graft_entry__.build())"
+    e["DQ_HIP_LIB"] = DEV_LIB
     e.setdefault("TEST_LA_FORM", "rows")  # (the deep-level kernels under test include the per-row LinearAttention forms)
     r = subprocess.run([sys.executable, "-c", CHILD, os.path.join(REPO, "diffusion-deconvolution-dia-msms-data_amd"), out] + [str(v) for v in shape], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]

@@ -3,6 +3,8 @@
 set -e -o pipefail
 VAR=${1:?variable name}
 mkdir -p gpurun_out
+# the switches exist in the development build only (csrc/dq_dev.h; make -C diffusion-deconvolution-dia-msms-data_amd dev)
+export DQ_HIP_LIB=${DQ_HIP_LIB:-$PWD/diffusion-deconvolution-dia-msms-data_amd/build/dev/libdq_hip_dev.so}
 env $VAR=1 python3 bench.py --no-cpu --no-transformer --no-large-window --steps 100 > gpurun_out/ab_${VAR}_on.json 2> gpurun_out/ab_${VAR}_on.err
 python3 bench.py --no-cpu --no-transformer --no-large-window --steps 100 > gpurun_out/ab_${VAR}_off.json 2> gpurun_out/ab_${VAR}_off.err
 python3 - <<PY
