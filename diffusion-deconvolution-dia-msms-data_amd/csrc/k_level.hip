@@ -427,11 +427,23 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
       const bool wr = r.wr >= 0;
       const int pq = 1 + 7 * bi;  // this block's rows of the parameter image: b1, g1, b2, g2, br, scale + 1, shift
       constexpr int NAR = G == 1 ? 4 : 2;  // independent accumulation chains of the residual conv per output quad
-      f32x4 acc[G][3], ar[G][NAR];
+      // ONE accumulation chain per output quad, started from the bias, at 4 / 8 channels: those levels always run with many waves per SIMD (rows
+      // of 8 .. 64 positions: thousands of tiles even at batch 1), which cover a dependent 4x4x1 chain (14.5 against 8.5 cycles per MFMA), and
+      // the three-chain form's `(a0 + a1) + (a2 + bias)` is 3 C VALU adds per conv in a kernel bound by VALU issue.  12 / 16 channels (deep
+      // levels, one wave per SIMD at a training batch) keep one chain per tap.
+      constexpr bool ONE = C <= 8;
+      constexpr int TK = ONE ? 1 : 3;
+      auto tapk = [](int k) constexpr { return ONE ? 0 : k; };
+      f32x4 acc[G][TK], ar[G][NAR];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
+        if constexpr (ONE) {
+          const float4 t = prm4(pq + 0, g);
+          acc[g][0] = f32x4{t.x, t.y, t.z, t.w};
+        } else {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) acc[g][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int k = 0; k < 3; ++k) acc[g][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int k = 0; k < NAR; ++k) ar[g][k] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -445,9 +457,9 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           const int js = (c * G + g) * 3;
-          acc[g][0] = mfma4(wjob(R, J.c1[bi], js + 0), xm, acc[g][0]);
-          acc[g][1] = mfma4(wjob(R, J.c1[bi], js + 1), x[c], acc[g][1]);
-          acc[g][2] = mfma4(wjob(R, J.c1[bi], js + 2), xp, acc[g][2]);
+          acc[g][tapk(0)] = mfma4(wjob(R, J.c1[bi], js + 0), xm, acc[g][tapk(0)]);
+          acc[g][tapk(1)] = mfma4(wjob(R, J.c1[bi], js + 1), x[c], acc[g][tapk(1)]);
+          acc[g][tapk(2)] = mfma4(wjob(R, J.c1[bi], js + 2), xp, acc[g][tapk(2)]);
         }
       }
       if (bi == 1) DQ_PSTAMP(C * 1000 + PRE * 100 + CP, 7);
@@ -465,9 +477,9 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
 #pragma unroll
             for (int g = 0; g < G; ++g) {
               const int js = ((C + c) * G + g) * 3;
-              acc[g][0] = mfma4(wjob(R, J.c1[bi], js + 0), xm, acc[g][0]);
-              acc[g][1] = mfma4(wjob(R, J.c1[bi], js + 1), xb[bi][c], acc[g][1]);
-              acc[g][2] = mfma4(wjob(R, J.c1[bi], js + 2), xp, acc[g][2]);
+              acc[g][tapk(0)] = mfma4(wjob(R, J.c1[bi], js + 0), xm, acc[g][tapk(0)]);
+              acc[g][tapk(1)] = mfma4(wjob(R, J.c1[bi], js + 1), xb[bi][c], acc[g][tapk(1)]);
+              acc[g][tapk(2)] = mfma4(wjob(R, J.c1[bi], js + 2), xp, acc[g][tapk(2)]);
             }
           }
         }
@@ -500,7 +512,7 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
         const float4 t = prm4(pq + 0, g);
         const float tv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) u[4 * g + i] = (acc[g][0][i] + acc[g][1][i]) + (acc[g][2][i] + tv[i]);
+        for (int i = 0; i < 4; ++i) u[4 * g + i] = ONE ? acc[g][0][i] : (acc[g][0][i] + acc[g][1][i]) + (acc[g][TK - 1][i] + tv[i]);
       }
       if (r.u1 && live) {
 #pragma unroll
@@ -526,9 +538,15 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
       if (bi == 1) DQ_PSTAMP(C * 1000 + PRE * 100 + CP, 10);
       // conv2 over the block-1 activation
 #pragma unroll
-      for (int g = 0; g < G; ++g)
+      for (int g = 0; g < G; ++g) {
+        if constexpr (ONE) {
+          const float4 t = prm4(pq + 2, g);
+          acc[g][0] = f32x4{t.x, t.y, t.z, t.w};
+        } else {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) acc[g][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int k = 0; k < 3; ++k) acc[g][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
       ring_start(R, J.c2[bi]);
 #pragma unroll
       for (int c = 0; c < C; ++c) {
@@ -537,9 +555,9 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           const int js = (c * G + g) * 3;
-          acc[g][0] = mfma4(wjob(R, J.c2[bi], js + 0), xm, acc[g][0]);
-          acc[g][1] = mfma4(wjob(R, J.c2[bi], js + 1), u[c], acc[g][1]);
-          acc[g][2] = mfma4(wjob(R, J.c2[bi], js + 2), xp, acc[g][2]);
+          acc[g][tapk(0)] = mfma4(wjob(R, J.c2[bi], js + 0), xm, acc[g][tapk(0)]);
+          acc[g][tapk(1)] = mfma4(wjob(R, J.c2[bi], js + 1), u[c], acc[g][tapk(1)]);
+          acc[g][tapk(2)] = mfma4(wjob(R, J.c2[bi], js + 2), xp, acc[g][tapk(2)]);
         }
       }
       if (bi == 1) DQ_PSTAMP(C * 1000 + PRE * 100 + CP, 11);
@@ -549,7 +567,7 @@ __global__ void __launch_bounds__(256) k_level_fwd(LevelFwdK a, const float* __r
         const float4 t = prm4(pq + 2, g);
         const float tv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[4 * g + i] = (acc[g][0][i] + acc[g][1][i]) + (acc[g][2][i] + tv[i]);
+        for (int i = 0; i < 4; ++i) o[4 * g + i] = ONE ? acc[g][0][i] : (acc[g][0][i] + acc[g][1][i]) + (acc[g][TK - 1][i] + tv[i]);
       }
       if (r.u2 && live) {
 #pragma unroll

@@ -72,7 +72,7 @@ def test_committed_bench_line_has_the_contract_fields():
     for b in ("b1", "b4"):
         sb = d["small_batch"][b]
         assert sb["ms_per_step"] > 0 and abs(sb["windows_per_s"] - int(b[1:]) * 1e3 / sb["ms_per_step"]) < 0.01 * sb["windows_per_s"]
-        if "graph_ms_per_step" in sb:
+        if "graph_ms_per_step" in sb:  # (lines up to round 4 carried the captured-graph replay of the step; round 5 dropped the figure)
             assert abs(sb["graph_speedup"] - sb["ms_per_step"] / sb["graph_ms_per_step"]) < 0.011
     t = d["transformer"]  # the CustomTransformer leg
     assert t["train_b1"]["value"] > 0 and t["train_b32"]["value"] > t["train_b1"]["value"]
