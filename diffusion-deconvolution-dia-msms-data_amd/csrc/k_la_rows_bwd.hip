@@ -107,6 +107,7 @@ __global__ void __launch_bounds__(256, 2) k_la_rows_bwd(LaRowsBwdK a) {
   __shared__ __attribute__((aligned(16))) float ush[2 * N * 16 * UP];
   __shared__ __attribute__((aligned(16))) float tls[4][2 * 16 * TP];
   __shared__ __attribute__((aligned(16))) float stash[64 * 2 * RUN];
+  __shared__ float gains[2 * 16];  // g_pre | g_out (read per tile from here: as per-lane global addresses they were 64-bit values held -- and spilled -- across the tile loop)
   static_assert(64 * RUN <= 2 * 16 * TP, "a wave's d xh fits its tile region");
   DQ_PSTAMP((500000 + C * 100 + N), 0);
   {
@@ -136,6 +137,7 @@ __global__ void __launch_bounds__(256, 2) k_la_rows_bwd(LaRowsBwdK a) {
   if (C < 16) {
     for (int i = threadIdx.x; i < 2 * N * 16 * UP; i += 256) ush[i] = 0.f;
   }
+  if (threadIdx.x < 32) gains[threadIdx.x] = (threadIdx.x & 15) < C ? (threadIdx.x < 16 ? a.g_pre : a.g_out)[threadIdx.x & 15] : 0.f;
   __syncthreads();
   DQ_PSTAMP((500000 + C * 100 + N), 1);
   const float sqC = sqrtf((float)C);
@@ -150,21 +152,23 @@ __global__ void __launch_bounds__(256, 2) k_la_rows_bwd(LaRowsBwdK a) {
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int grow = tile * 16 + row;
     const bool live = grow < a.rows;
-    const int64_t base = ((int64_t)(live ? grow : a.rows - 1) * C + CPL * g) * N;
+    // 32-bit BYTE offset of the lane's run against the wave-uniform tensor bases (the launcher checks 4 GB): no 64-bit per-lane address lives across the tile
+    const unsigned boff = (unsigned)(((live ? grow : a.rows - 1) * C + CPL * g) * N) * 4u;
+    auto at = [&](const float* t, int k) __attribute__((always_inline)) { return reinterpret_cast<const char*>(t) + boff + k * VW * 4; };
     typedef float vecf __attribute__((ext_vector_type(VW)));
     float xh[N][CPL], DY[N][CPL];
     {
     float xr[RUN], ur[RUN], dr[RUN];
     float gpre[CPL], gout[CPL];  // (per tile, L1-hot: not held across the head's work)
 #pragma unroll
-    for (int r = 0; r < CPL; ++r) { gpre[r] = a.g_pre[CPL * g + r]; gout[r] = a.g_out[CPL * g + r]; }
+    for (int r = 0; r < CPL; ++r) { gpre[r] = gains[CPL * g + r]; gout[r] = gains[16 + CPL * g + r]; }
     {
       vecf vx[NV], vu[NV], vd[NV];
 #pragma unroll
       for (int k = 0; k < NV; ++k) {
-        vx[k] = *reinterpret_cast<const vecf*>(a.x + base + k * VW);
-        vu[k] = *reinterpret_cast<const vecf*>(a.ypre + base + k * VW);
-        vd[k] = *reinterpret_cast<const vecf*>(a.dy + base + k * VW);
+        vx[k] = *reinterpret_cast<const vecf*>(at(a.x, k));
+        vu[k] = *reinterpret_cast<const vecf*>(at(a.ypre, k));
+        vd[k] = *reinterpret_cast<const vecf*>(at(a.dy, k));
       }
 #pragma unroll
       for (int k = 0; k < NV; ++k)
@@ -447,7 +451,7 @@ __global__ void __launch_bounds__(256, 2) k_la_rows_bwd(LaRowsBwdK a) {
       float xr[RUN], dr[RUN];
       float gpre[CPL];
 #pragma unroll
-      for (int r = 0; r < CPL; ++r) gpre[r] = a.g_pre[CPL * g + r];
+      for (int r = 0; r < CPL; ++r) gpre[r] = gains[CPL * g + r];
 #pragma unroll
       for (int k = 0; k < NV; ++k) {
         const vecf sx = *reinterpret_cast<const vecf*>(stash + lane * 2 * RUN + k * VW), sd = *reinterpret_cast<const vecf*>(stash + lane * 2 * RUN + RUN + k * VW);
@@ -483,11 +487,11 @@ __global__ void __launch_bounds__(256, 2) k_la_rows_bwd(LaRowsBwdK a) {
 #pragma unroll
             for (int e = 0; e < VW; ++e) o[e] = out[k * VW + e];
           } else {
-            const vecf p = *reinterpret_cast<const vecf*>(a.dx + base + k * VW);
+            const vecf p = *reinterpret_cast<const vecf*>(at(a.dx, k));
 #pragma unroll
             for (int e = 0; e < VW; ++e) o[e] = p[e] + out[k * VW + e];
           }
-          *reinterpret_cast<vecf*>(a.dx + base + k * VW) = o;
+          *reinterpret_cast<vecf*>(const_cast<char*>(at(a.dx, k))) = o;
         }
       }
     }
@@ -544,6 +548,7 @@ int launch_la_rows_bwd(const LinAttnBwd& a, int max_slots, int* slots_out, hipSt
   DQ_REQUIRE(a.f.x && a.ypre && a.dy && a.dx && a.f.prep && a.f.g_pre && a.f.g_out && a.part && la_rows_bwd_usable(C, n), "la_rows_bwd: missing operand / unsupported shape");
   DQ_REQUIRE((((uintptr_t)a.f.prep | (uintptr_t)a.f.x | (uintptr_t)a.ypre | (uintptr_t)a.dy | (uintptr_t)a.dx) & 15) == 0, "la_rows_bwd: misaligned tensor / prepared-weights buffer");
   DQ_REQUIRE(max_slots >= 1, "la_rows_bwd: slot scratch too small");
+  DQ_REQUIRE((int64_t)rows * C * n * 4 < (1ll << 32), "la_rows_bwd: tensors of 4 GB or more are not built (32-bit byte offsets)");
   const int ntiles = cdiv(rows, 16);
   static const int cus = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
   LaRowsBwdK k{a.f.x, a.ypre, a.dy, a.dx, a.f.prep, a.f.g_pre, a.f.g_out, a.part, rows, ntiles, a.dx_store};

@@ -28,6 +28,17 @@ if SAMPLE:
 for _ in range(5):
     N.check(L.dq_linattn_fwd_prepared(N.ptr(x), N.ptr(y), N.ptr(ypre), N.ptr(w), N.ptr(wo), N.ptr(bo), N.ptr(g1), N.ptr(g2), N.ptr(prep), C, rows, n, N.stream_ptr()), "f")
     N.check(L.dq_linattn_bwd(N.ptr(x), N.ptr(ypre), N.ptr(dy), N.ptr(dx), N.ptr(w), N.ptr(wo), N.ptr(bo), N.ptr(g1), N.ptr(g2), N.ptr(dw), N.ptr(dwo), N.ptr(dbo), N.ptr(dg1), N.ptr(dg2), N.ptr(scratch), C, rows, n, N.stream_ptr()), "b")
+# the deep levels' backward since round 5 (k_la_rows_bwd.hip): 12 channels, rows of 4 positions, the train step's 12,800 rows
+C2, n2 = 12, 4
+x2 = torch.randn(rows, C2, n2, generator=g).cuda(); dy2 = torch.randn(rows, C2, n2, generator=g).cuda()
+w2_ = (torch.randn(384, C2, generator=g) * .4).cuda(); wo2 = (torch.randn(C2, 128, generator=g) * .2).cuda()
+bo2, g12, g22 = torch.zeros(C2).cuda(), torch.ones(C2).cuda(), torch.ones(C2).cuda()
+y2, ypre2, dx2 = torch.empty_like(x2), torch.empty_like(x2), torch.zeros_like(x2)
+dw2_, dwo2, dbo2, dg12, dg22 = (torch.zeros_like(t) for t in (w2_, wo2, bo2, g12, g22))
+scratch2 = torch.empty(2 * x2.numel() + 2048 * 512 * C2, device="cuda")
+N.check(L.dq_linattn_fwd(N.ptr(x2), N.ptr(y2), N.ptr(ypre2), N.ptr(w2_), N.ptr(wo2), N.ptr(bo2), N.ptr(g12), N.ptr(g22), C2, rows, n2, N.stream_ptr()), "f2")
+for _ in range(5):
+    N.check(L.dq_linattn_bwd(N.ptr(x2), N.ptr(ypre2), N.ptr(dy2), N.ptr(dx2), N.ptr(w2_), N.ptr(wo2), N.ptr(bo2), N.ptr(g12), N.ptr(g22), N.ptr(dw2_), N.ptr(dwo2), N.ptr(dbo2), N.ptr(dg12), N.ptr(dg22), N.ptr(scratch2), C2, rows, n2, N.stream_ptr()), "b2")
 # calibration: q_sample streams 3 tensors of rows*C*n floats (2 reads + 1 write) with 16 B per lane
 ab = torch.linspace(0.9, 0.1, 1000).cuda(); t = torch.zeros(50, dtype=torch.long).cuda()
 for _ in range(5):

@@ -58,7 +58,7 @@ def main():
         m, _ = counter_means(outdir, ctr)
         for name, v in m.items():
             short = name.split("(")[0].replace("void ", "").replace("dq::", "")
-            if "k_linattn" in short:
+            if "k_linattn" in short or "k_la_" in short:
                 sq.setdefault(short, {})[ctr] = v
     res["sq"] = sq
     # the sampling-size launch (tools/pmc_linattn.py sample): k_linattn_fwd over 512 x 400 rows
