@@ -761,6 +761,118 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce_multi(WgradMulti m) {
   }
 }
 
+// ---- The same three weight gradients for the DEEP levels (m/z rows of 1 .. 8 positions, <= 16 output and <= 32 input channels) on the
+// matrix pipe: dW[co][ci][k] = sum_(row, p) dU[co][p] x[ci][p + k - 1] is a product whose K index is the m/z ROW, so with
+// v_mfma_f32_16x16x4_f32 (A: lane l supplies A[l % 16][l / 16], B: B[l / 16][l % 16]) a wave takes 16 rows per step and both operands are
+// loaded from memory ALREADY in operand order -- lane (g, i) reads dU[row 4 s + g][channel i][p] resp. x[row 4 s + g][channel i][q] for K-step
+// s: no staging, no transposes, every load of a 16-row tile in flight at once.  The four waves of a workgroup take the (conv, input-channel
+// tile) jobs of the block: conv2 | conv1, channels 0..15 | conv1, channels 16..31 | res_conv (both tiles); a workgroup walks its tiles and
+// leaves its sums in block `blockIdx.x` of each conv's scratch region, in the layout k_wgrad_reduce_multi sums.
+// k_conv_wgrad_multi walks the same tensors once per (4 x 4) channel block -- 18 .. 32 passes, per-thread accumulators, a block reduction --
+// and its per-lane 4-byte accesses at a row pitch of C n floats touch 32 cache lines per instruction: 30 .. 70 us per launch next to the main
+// chain's kernels for 2.4 MB of operands.  With those launches SKIPPED the train step is 0.114 ms shorter (3.472 -> 3.358 ms,
+// profiles/r05_ab_skip_deep_wgrad.log): that is what the side queue's largest tenant costs the main chain.
+typedef float wr_f32x4 __attribute__((ext_vector_type(4)));
+template <int N>
+__global__ void __launch_bounds__(256) k_wgrad_rows(WgradMulti m, int count, int ntiles) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // this wave's jobs: (conv z, input-channel tile t); wave 3 takes both tiles of the res_conv
+  int jz[2] = {-1, -1}, jt[2] = {0, 0};
+  if (wv == 0) { jz[0] = 0; if (m.c[0].cinA + m.c[0].cinB > 16) { jz[1] = 0; jt[1] = 1; } }
+  else if (wv == 1) { if (count > 1) jz[0] = 1; }
+  else if (wv == 2) { if (count > 1 && m.c[1].cinA + m.c[1].cinB > 16) { jz[0] = 1; jt[0] = 1; } }
+  else { if (count > 2) { jz[0] = 2; if (m.c[2].cinA + m.c[2].cinB > 16) { jz[1] = 2; jt[1] = 1; } } }
+  wr_f32x4 acc[2][3];
+  float bsum[2] = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc[j][k] = wr_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int rows = m.c[0].rows;
+#pragma unroll 1
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (jz[j] < 0) continue;  // (wave-uniform)
+      const ConvWgrad& a = m.c[jz[j]];
+      const int cin = a.cinA + a.cinB, ci = 16 * jt[j] + i;
+      const bool co_ok = i < a.cout, ci_ok = ci < cin;
+      const bool fromA = ci < a.cinA || !ci_ok;  // (a lane beyond the conv's input channels reads channel 0 of inA -- inB may be null -- and is zeroed)
+      float A[N][4], B[N][4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int row = tile * 16 + 4 * s + g;
+        const bool rok = row < rows;
+        const int rc = rok ? row : rows - 1;
+        // (no load is predicated: a clamped address, the select afterwards)
+        const float* du = a.du + ((int64_t)rc * a.cout + (co_ok ? i : 0)) * N;
+        const float* xs = fromA ? a.inA + ((int64_t)rc * a.cinA + (ci_ok ? ci : 0)) * N : a.inB + ((int64_t)rc * a.cinB + (ci - a.cinA)) * N;
+#pragma unroll
+        for (int p = 0; p < N; ++p) { A[p][s] = du[p]; B[p][s] = xs[p]; }
+#pragma unroll
+        for (int p = 0; p < N; ++p) { A[p][s] = (rok && co_ok) ? A[p][s] : 0.f; B[p][s] = (rok && ci_ok) ? B[p][s] : 0.f; }
+      }
+      if (a.K == 3) {
+#pragma unroll
+        for (int p = 0; p < N; ++p)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int q = p + k - 1;
+            if (q < 0 || q >= N) continue;  // (zero padding at the row ends; compile time)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[j][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[p][s], B[q][s], acc[j][k], 0, 0, 0);
+          }
+      } else {
+#pragma unroll
+        for (int p = 0; p < N; ++p)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[p][s], B[p][s], acc[j][0], 0, 0, 0);
+      }
+      if (jt[j] == 0) {
+#pragma unroll
+        for (int p = 0; p < N; ++p)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) bsum[j] += A[p][s];
+      }
+    }
+  }
+  // ---- this workgroup's block of each conv's partials: [dw (cout, cin, K) | dbias (cout)]; D register r of lane (g, j) = dW[co = 4 g + r][ci = 16 t + j]
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (jz[j] < 0) continue;
+    const ConvWgrad& a = m.c[jz[j]];
+    const int cin = a.cinA + a.cinB, ci = 16 * jt[j] + i, nelem_w = m.nelem_w[jz[j]];
+    float* part = a.scratch + (int64_t)blockIdx.x * (nelem_w + a.cout);
+    if (ci < cin) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (k >= a.K) break;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = 4 * g + r;
+          if (co < a.cout) part[((int64_t)co * cin + ci) * a.K + k] = acc[j][k][r];
+        }
+      }
+    }
+    if (jt[j] == 0) {  // bias: lane (g, i) holds the sum over its rows 4 s + g of channel i; the four lane groups meet through v_permlane swaps
+      float t = bsum[j];
+      const auto x1 = __builtin_amdgcn_permlane16_swap(__float_as_int(t), __float_as_int(t), false, false);
+      t = __int_as_float(x1[0]) + __int_as_float(x1[1]);
+      const auto x2 = __builtin_amdgcn_permlane32_swap(__float_as_int(t), __float_as_int(t), false, false);
+      t = __int_as_float(x2[0]) + __int_as_float(x2[1]);
+      if (g == 0 && i < a.cout) part[nelem_w + i] = t;
+    }
+  }
+}
+static bool wgrad_rows_usable(const ConvWgrad* w, int count) {
+  const int n = w[0].n_out;
+  if (!(n == 1 || n == 2 || n == 4 || n == 8)) return false;
+  for (int z = 0; z < count; ++z)
+    if (w[z].cout > 16 || w[z].cout < 12 || w[z].cinA + w[z].cinB > 32 || w[z].mode != CONV_S1 || !(w[z].K == 1 || w[z].K == 3) || (w[z].cinB > 0 && !w[z].inB)) return false;
+  // the job table: conv 0 and conv 1 are the block's k3 convs, conv 2 (if any) its 1x1 residual conv
+  return count >= 2 && w[0].K == 3 && w[1].K == 3 && (count < 3 || w[2].K == 1);
+}
+
 // blocks in flight per conv of a weight-gradient launch (2048: settled in round 2 over 512 .. 4096)
 static int wgrad_blocks() { return 2048; }
 
@@ -793,6 +905,22 @@ int launch_conv_wgrad_multi(const ConvWgrad* w, int count, hipStream_t s) {
     nelem_max = std::max(nelem_max, m.nelem_w[i] + a.cout);
   }
   for (int i = count; i < 3; ++i) { m.c[i] = w[0]; m.n_cib[i] = 1; m.nelem_w[i] = 0; m.gx[i] = 0; m.tiles[i] = 0; }
+  if (wgrad_rows_usable(w, count)) {  // the deep levels: 16 rows per K-step on the matrix pipe (k_wgrad_rows)
+    const int ntiles = cdiv(w[0].rows, 16);
+    int gx = std::min(ntiles, 256);
+    for (int i = 0; i < count; ++i) gx = (int)std::min<int64_t>(gx, w[i].scratch_floats / (m.nelem_w[i] + w[i].cout));
+    DQ_REQUIRE(gx >= 1, "conv_wgrad_multi: scratch too small");
+    for (int i = 0; i < count; ++i) m.gx[i] = gx;
+    const int n = w[0].n_out;
+    if (n == 1) hipLaunchKernelGGL(k_wgrad_rows<1>, dim3(gx), dim3(256), 0, s, m, count, ntiles);
+    else if (n == 2) hipLaunchKernelGGL(k_wgrad_rows<2>, dim3(gx), dim3(256), 0, s, m, count, ntiles);
+    else if (n == 4) hipLaunchKernelGGL(k_wgrad_rows<4>, dim3(gx), dim3(256), 0, s, m, count, ntiles);
+    else hipLaunchKernelGGL(k_wgrad_rows<8>, dim3(gx), dim3(256), 0, s, m, count, ntiles);
+    DQ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_wgrad_reduce_multi, dim3(cdiv(nelem_max, 16), 1, count), dim3(256), 0, s, m);
+    DQ_LAUNCH_CHECK();
+    return 0;
+  }
   dim3 grid(gx_max, tiles_max, count), block(256);
   if (vec4) hipLaunchKernelGGL(k_conv_wgrad_multi<true>, grid, block, 0, s, m);
   else hipLaunchKernelGGL(k_conv_wgrad_multi<false>, grid, block, 0, s, m);

@@ -34,7 +34,7 @@ def main():
     tensor_bytes = 12800 * 4 * 64 * 4  # tools/pmc_linattn.py: rows x C x n fp32
     res = {"build_id": N.build_id(), "shape": {"C": 4, "n": 64, "rows": 12800}, "tensor_bytes": tensor_bytes, "kernels": {}}
     for name in sorted(set(fetch) | set(write)):
-        short = name.split("(")[0].replace("void ", "").replace("dq::", "")
+        short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("dq::", "")
         if not any(k in short for k in ("k_linattn", "k_q_sample", "k_la_", "k_level_fwd", "k_res_bwd_wg", "k_res_wg_reduce", "k_rmsnorm")):
             continue
         f_kb, w_kb = fetch.get(name, 0.0), write.get(name, 0.0)
@@ -57,7 +57,7 @@ def main():
     for ctr in ("SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_VALU_MFMA_BUSY_CYCLES"):
         m, _ = counter_means(outdir, ctr)
         for name, v in m.items():
-            short = name.split("(")[0].replace("void ", "").replace("dq::", "")
+            short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("dq::", "")
             if "k_linattn" in short or "k_la_" in short:
                 sq.setdefault(short, {})[ctr] = v
     res["sq"] = sq
@@ -67,7 +67,7 @@ def main():
     res["sample_shape"] = {"C": 4, "n": 64, "rows": 512 * 400}
     res["sample_kernels"], res["sample_sq"] = {}, {}
     for name in sorted(set(sf) | set(sw)):
-        short = name.split("(")[0].replace("void ", "").replace("dq::", "")
+        short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("dq::", "")
         if "k_linattn_fwd" in short:
             f_kb, w_kb = sf.get(name, 0.0), sw.get(name, 0.0)
             res["sample_kernels"][short] = {"fetch_kb": round(f_kb, 1), "write_kb": round(w_kb, 1), "dispatches": snf.get(name, 0),
@@ -75,7 +75,7 @@ def main():
     for ctr in ("SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_VALU_MFMA_BUSY_CYCLES"):
         m, _ = counter_means(outdir, ctr, "S_")
         for name, v in m.items():
-            short = name.split("(")[0].replace("void ", "").replace("dq::", "")
+            short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("dq::", "")
             if "k_linattn_fwd" in short:
                 res["sample_sq"].setdefault(short, {})[ctr] = v
     with open(os.path.join(outdir, "pmc_linattn.json"), "w") as fh:

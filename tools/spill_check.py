@@ -16,10 +16,14 @@ def norm(n):
 res = {}
 for r in csv.DictReader(open(sys.argv[1])):
     res[norm(r["kernel"])] = r
-launched, missing, spilling = set(), [], []
+launched, missing, spilling, sspilling = set(), [], [], []
 for path in sys.argv[2:]:
-    for r in csv.DictReader(open(path)):
-        n = norm(r["Name"])
+    if path.endswith(".txt"):  # tools/kernel_census.sh output: "<calls>\t<name>"
+        names = [ln.rstrip("\n").split("\t", 1)[1] for ln in open(path) if "\t" in ln]
+    else:
+        names = [r["Name"] for r in csv.DictReader(open(path))]
+    for nm in names:
+        n = norm(nm)
         if not (n.startswith("dq::") or n.startswith("k_")):
             continue  # torch / runtime kernels
         launched.add(n)
@@ -27,9 +31,15 @@ for n in sorted(launched):
     r = res.get(n)
     if r is None:
         missing.append(n)
-    elif int(r["vgpr_spill"]) or int(r["scratch"]):
+        continue
+    if int(r["vgpr_spill"]) or int(r["scratch"]):
         spilling.append((n, r["vgpr"], r["scratch"], r["vgpr_spill"]))
+    if int(r["sgpr_spill"]):
+        sspilling.append((n, r["sgpr"], r["sgpr_spill"]))
 print(f"{len(launched)} distinct library kernels launched; {len(missing)} not matched by name in the table ({missing})")
 print(f"launched kernels with .vgpr_spill_count > 0 or scratch > 0: {len(spilling)}")
 for s in spilling:
+    print("  ", s)
+print(f"launched kernels with .sgpr_spill_count > 0 (scalars parked in VGPR lanes: v_writelane / v_readlane, no memory traffic): {len(sspilling)}")
+for s in sorted(sspilling, key=lambda t: -int(t[2])):
     print("  ", s)
