@@ -302,10 +302,6 @@ int res_bwd_side(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA,
     w[2].du = dout; w[2].K = 1; w[2].dw = c.dprm(r.res.w); w[2].dbias = c.dprm(r.res.b);
     count = 3;
   }
-#ifdef DQ_DEV_SWITCHES
-  // timing experiment (WRONG gradients): what would the step gain if the 12 / 16-channel blocks' weight gradients left the side queue?
-  if (!(DQ_DEV_FLAG("DQ_SKIP_DEEP_WGRAD", '1') && r.cout >= 12))
-#endif
   DQ_TRY(wgrad_async_multi(c, w, count));
   // the ordered sums of the per-block partials (norm gains, this block's d(scale), d(shift) of every sample): behind the
   // weight gradients on the side stream (which has waited for the event recorded after k_res_bwd), or on the main stream
