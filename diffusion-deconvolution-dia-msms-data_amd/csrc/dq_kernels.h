@@ -139,7 +139,12 @@ struct ResBwd {
   float* gpart = nullptr; int64_t gpart_floats = 0; int* gblocks = nullptr;
   int C = 0, rows = 0, n = 0, rows_per_sample = 1;
 };
-bool res_fusable(int n, int C, int rows_per_sample);  // rows_per_sample == 1: the bottleneck (one RT row per sample, <= 512 positions)
+bool res_fusable(int n, int C, int rows_per_sample);  // rows_per_sample == 1: the bottleneck (one RT row per sample: <= 512 positions, any length at 16 channels)
+// k_res_rt.hip: the bottleneck's 16-channel blocks (one RT row per sample, identity residual, no skip input) with the RT position as the lane
+// column of v_mfma_f32_16x16x4; launch_res_fwd / _bwd dispatch to it
+bool res_rt_usable(int C, int cinA, int cinB, bool has_wr, int rows_per_sample);
+int launch_res_rt_fwd(const ResFwd& a, hipStream_t s);
+int launch_res_rt_bwd(const ResBwd& a, hipStream_t s);
 // k_res_cp.hip: channel-parallel variant for the deep levels (n <= 8, C = 12 / 16); launch_res_fwd / _bwd dispatch to it
 bool res_cp_usable(int n, int C, int cinA, int cinB);
 int launch_res_fwd_cp(const ResFwd& a, hipStream_t s);

@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(BS) k_res_fwd(ResFwd a) {
 // up to 512 positions = one block per sample, whatever the length (no row can straddle a block then).
 bool res_fusable(int n, int C, int rows_per_sample) {
   if (!(C == 4 || C == 8 || C == 12 || C == 16) || n < 1) return false;
-  return rows_per_sample == 1 ? n <= 512 : (n <= 256 && (256 % n) == 0);
+  return rows_per_sample == 1 ? (n <= 512 || C == 16) : (n <= 256 && (256 % n) == 0);  // (C == 16: k_res_rt.hip takes any RT length)
 }
 namespace {
 int res_block_size(int n, int rows_per_sample) { return rows_per_sample == 1 && n > 256 ? 512 : 256; }
@@ -195,11 +195,13 @@ int launch_res_fwd(const ResFwd& a, hipStream_t s) {
   DQ_REQUIRE(res_fusable(a.n, a.C, a.rows_per_sample), "res_fwd: row length must divide 256 (or one row of <= 512 per sample) and C be 4/8/12/16");
   DQ_REQUIRE(a.rows % a.rows_per_sample == 0, "res_fwd: rows must be a multiple of rows_per_sample");
   DQ_REQUIRE(a.wr || (a.cinA == a.C && a.cinB == 0), "res_fwd: identity residual needs C input channels");
+  if (res_rt_usable(a.C, a.cinA, a.cinB, a.wr != nullptr, a.rows_per_sample)) return launch_res_rt_fwd(a, s);  // the bottleneck's blocks
   // m/z rows of up to 64 positions: the convolutions on the matrix pipe (k_res_mm.hip)
   if (res_mm_usable(a.n, a.C, a.cinA, a.cinB, a.rows_per_sample, a.wr != nullptr)) return launch_res_fwd_mm(a, s);
   if (a.rows_per_sample > 1 && res_cp_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_fwd_cp(a, s);
   if (a.rows_per_sample > 1 && res_v4_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_fwd_v4(a, s);
   DQ_REQUIRE(a.cinA == a.C && a.cinB <= a.C && (a.cinB == 0 || a.inB), "res_fwd: input must be C channels (+ at most C skip channels)");
+  DQ_REQUIRE(a.rows_per_sample > 1 || a.n <= 512, "res_fwd: one RT row per sample longer than 512 positions needs the 16-channel identity block");
   const int B = a.rows / a.rows_per_sample;
   const int BS = res_block_size(a.n, a.rows_per_sample);
   dim3 grid(cdiv((int64_t)a.rows_per_sample * a.n, BS), B), block(BS);
@@ -363,6 +365,8 @@ int launch_res_bwd(const ResBwd& a, hipStream_t s) {
   DQ_REQUIRE(a.wr || (a.cinA == a.C && a.cinB == 0), "res_bwd: identity residual needs C input channels");
   DQ_REQUIRE(a.cinA + a.cinB <= 2 * a.C, "res_bwd: a block input wider than two C-channel tensors is not built");
   if (a.gblocks) *a.gblocks = 0;
+  if (res_rt_usable(a.C, a.cinA, a.cinB, a.wr != nullptr, a.rows_per_sample)) return launch_res_rt_bwd(a, s);  // the bottleneck's blocks
+  DQ_REQUIRE(a.rows_per_sample > 1 || a.n <= 512, "res_bwd: one RT row per sample longer than 512 positions needs the 16-channel identity block");
   if (a.rows_per_sample > 1 && res_cp_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_bwd_cp(a, s);
   const int B = a.rows / a.rows_per_sample;
   const int BS = res_block_size(a.n, a.rows_per_sample);

@@ -153,7 +153,13 @@ def test_resnet_block_fixture_forward(N, golden, name, split):
                                                        # 12 / 16 channels with the weight gradients in the same launch (k_res_bwd_wg, wide path):
                                                        # identity residual, narrower skip than the block, several tiles per sample, rows of 1..8
                                                        (12, 12, 8, 66, 33, 0), (16, 16, 2, 130, 65, 0), (28, 16, 2, 160, 80, 16), (16, 12, 8, 70, 35, 12),
-                                                       (24, 12, 8, 200, 100, 12), (32, 16, 4, 300, 150, 16), (16, 16, 1, 600, 300, 0)])
+                                                       (24, 12, 8, 200, 100, 12), (32, 16, 4, 300, 150, 16), (16, 16, 1, 600, 300, 0),
+                                                       # the bottleneck's 16-channel blocks, RT position = lane column (k_res_rt.hip): RT axes shorter
+                                                       # than a tile, one short of / one over a tile and a workgroup (14 / 56 forward, 12 / 48 backward),
+                                                       # longer than the 512 the thread-per-position kernel took
+                                                       (16, 16, 1, 5, 1, 0), (16, 16, 2, 3, 1, 0), (16, 16, 11, 3, 1, 0), (16, 16, 12, 2, 1, 0), (16, 16, 13, 4, 1, 0),
+                                                       (16, 16, 14, 2, 1, 0), (16, 16, 15, 2, 1, 0), (16, 16, 47, 2, 1, 0), (16, 16, 49, 2, 1, 0), (16, 16, 57, 2, 1, 0),
+                                                       (16, 16, 413, 2, 1, 0), (16, 16, 700, 2, 1, 0), (16, 16, 2000, 1, 1, 0)])
 def test_resnet_block_backward_vs_oracle_autograd(N, cin, cout, n, rows, rps, split):
     """every dispatch of the ResnetBlock (fused m/z-row kernels, channel-parallel deep levels, the step-by-step bottleneck path
     with rows_per_sample = 1): forward, dX, all weight gradients and d(scale, shift) against autograd over the oracle"""
