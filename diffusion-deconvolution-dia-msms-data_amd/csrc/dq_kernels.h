@@ -143,7 +143,13 @@ bool res_fusable(int n, int C, int rows_per_sample);  // rows_per_sample == 1: t
 // k_res_rt.hip: the bottleneck's 16-channel blocks (one RT row per sample, identity residual, no skip input) with the RT position as the lane
 // column of v_mfma_f32_16x16x4; launch_res_fwd / _bwd dispatch to it
 bool res_rt_usable(int C, int cinA, int cinB, bool has_wr, int rows_per_sample);
-int launch_res_rt_fwd(const ResFwd& a, hipStream_t s);
+// the front of the bottleneck's Residual(PreNorm(Attention)) behind the first block: xn = RMSNorm(out) gn -> qv = W_qv xn (B, 256, RT), RoPE on
+// q; k = W_k ms1f (B, 128, RT) + RoPE when kk is given
+struct ResRtQkv {
+  const float* gn = nullptr; const float* wqv = nullptr; float* xn = nullptr; float* qv = nullptr; const float* rope = nullptr;
+  const float* wk = nullptr; const float* ms1f = nullptr; float* kk = nullptr;
+};
+int launch_res_rt_fwd(const ResFwd& a, hipStream_t s, const ResRtQkv* q = nullptr);
 int launch_res_rt_bwd(const ResBwd& a, hipStream_t s);
 // k_res_cp.hip: channel-parallel variant for the deep levels (n <= 8, C = 12 / 16); launch_res_fwd / _bwd dispatch to it
 bool res_cp_usable(int n, int C, int cinA, int cinB);

@@ -245,7 +245,7 @@ static inline bool side_flush_here(int lv) { return (lv & 1) == 0; }
 
 // ResnetBlock forward (unet1d.py:302-323): input = cat(A, B)
 int res_fwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, int cinA, const float* inB, int cinB, int rows, int n,
-            int rows_per_sample) {
+            int rows_per_sample, const ResRtQkv* qkv = nullptr) {  // qkv: the attention front rides behind the block (k_res_rt.hip; the caller checked res_rt_usable)
   if (res_fusable(n, r.cout, rows_per_sample)) {  // m/z levels, and a bottleneck of up to 512 RT positions: one fused launch
     ResFwd k;
     k.inA = inA; k.inB = inB; k.cinA = cinA; k.cinB = cinB;
@@ -256,8 +256,10 @@ int res_fwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, int 
     if (c.save) { k.u1 = c.w(b.u1); k.a1 = b.wpart_floats ? nullptr : c.w(b.a1); k.u2 = c.w(b.u2); }  // (wpart: the backward recomputes a1)
     k.out = c.w(b.out);
     k.C = r.cout; k.rows = rows; k.n = n; k.rows_per_sample = rows_per_sample;
+    if (qkv) return launch_res_rt_fwd(k, c.s, qkv);
     return launch_res_fwd(k, c.s);
   }
+  DQ_REQUIRE(!qkv, "res_fwd: the attention front needs the fused 16-channel block");
   ConvFwd f;
   f.inA = inA; f.inB = inB; f.cinA = cinA; f.cinB = cinB;
   f.w = c.prm(r.c1.w); f.bias = c.prm(r.c1.b); f.cout = r.cout; f.K = 3; f.mode = CONV_S1;
@@ -1070,9 +1072,20 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     DQ_TRY(mid_forward_wide(c, rope, cur));
   } else {
     if (!mid_in_done) DQ_TRY(launch_fold(cur, c.w(a.mid_in), B, RT, p.mid_c, 1, 0, c.s));
-    DQ_TRY(res_fwd(c, p.mid1, a.mid1, c.w(a.mid_in), p.mid_c, nullptr, 0, B, RT, 1));
+    // 16 channels (the default U-Net): PreNorm, to_qv, to_k and RoPE ride behind mid_block1 (k_res_rt.hip)
+    const bool qkv_fused = res_rt_usable(p.mid_c, p.mid_c, 0, p.mid1.res.cout != 0, 1) && HID == 128 && p.cond_dim == 8 &&
+                           !DQ_DEV_FLAG("DQ_NO_MID_QKV", '1');  // (dev switch)
+    if (qkv_fused) {
+      ResRtQkv q;
+      q.gn = c.prm(p.ag); q.wqv = c.prm(p.qv_w); q.xn = c.save ? c.w(a.xn) : nullptr; q.qv = c.w(a.qv); q.rope = rope;
+      if (!skip_ms1) { q.wk = c.prm(p.k_w); q.ms1f = c.w(a.ms1f); q.kk = c.w(a.kk); }
+      DQ_TRY(res_fwd(c, p.mid1, a.mid1, c.w(a.mid_in), p.mid_c, nullptr, 0, B, RT, 1, &q));
+    } else {
+      DQ_TRY(res_fwd(c, p.mid1, a.mid1, c.w(a.mid_in), p.mid_c, nullptr, 0, B, RT, 1));
+    }
     {
       // Residual(PreNorm(Attention(use_xattn))) (unet1d.py:552-567)
+      if (!qkv_fused) {
       DQ_TRY(launch_rmsnorm_fwd(c.w(a.mid1.out), c.prm(p.ag), c.w(a.xn), p.mid_c, B, RT, c.s));
       DQ_TRY(conv_plain_fwd(c, proj(p.qv_w, 2 * HID, p.mid_c), CONV_S1, c.w(a.xn), c.w(a.qv), B, RT, RT, prep_ok ? 0 : -1));
       if (!skip_ms1) DQ_TRY(conv_plain_fwd(c, proj(p.k_w, HID, p.cond_dim), CONV_S1, c.w(a.ms1f), c.w(a.kk), B, RT, RT, prep_ok ? 1 : -1));
@@ -1080,6 +1093,7 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
         // q = first 128 channels of each sample's 256; k rides in the same launch unless the sampling prologue rotated it already
         if (!skip_ms1) DQ_TRY(launch_rope2(c.w(a.qv), (int64_t)2 * HID * RT, c.w(a.kk), (int64_t)HID * RT, rope, B, RT, 1.f, c.s));
         else DQ_TRY(launch_rope(c.w(a.qv), rope, B, (int64_t)2 * HID * RT, RT, 1.f, c.s));
+      }
       }
       const int64_t qvbs = (int64_t)2 * HID * RT, kbs = (int64_t)HID * RT;
       DQ_TRY(launch_attn_fwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.w(a.lse), B, RT, c.s));

@@ -15,6 +15,10 @@
 // positions (d a1 and dU1 valid on lanes 1..14, d x on 2..13).  Only own positions are stored or counted in the norm-gain / scale-shift sums.
 // A workgroup = four waves = four consecutive tiles of one sample; its [d g2 | d g1 | d scale | d shift] sums go to slot
 // (sample, workgroup) of gpart for launch_part_reduce (ordered, bitwise repeatable), as k_res_bwd leaves them.
+// QKV (the first block only): the front of Residual(PreNorm(Attention)) (unet1d.py:552-561) rides behind the block -- its output is in
+// registers in exactly the B-operand layout: xn = RMSNorm(out) g, qv = W_qv xn (256 x 16: sixteen M-tiles of four K-steps), RoPE on the
+// first 16 channels of each of q's heads (adjacent pairs = registers (0, 1) and (2, 3) of a lane), and k = W_k ms1f (128 x 8) with its RoPE
+// when the caller has not prepared it (sampling computes k once in front of the loop).  Four launches (k_rmsnorm_fwd, two GEMMs, k_rope) less.
 // Any RT length (k_res.hip: <= 512; longer axes took the unfused five-launch path).  Weight gradients: unchanged (k_conv_wgrad_multi reads
 // the dU1 / dU2 / a1 tensors written here).
 #include "dq_common.h"
@@ -50,7 +54,8 @@ constexpr int C = 16;
 constexpr int FWD_OWN = 14, BWD_OWN = 12;  // own positions of a 16-lane tile
 constexpr float SQC = 4.0f;                // sqrt(C)
 
-__global__ void __launch_bounds__(256) k_res_rt_fwd(ResFwd a, int tiles_per_wave) {
+template <bool QKV>
+__global__ void __launch_bounds__(256) k_res_rt_fwd(ResFwd a, ResRtQkv q, int tiles_per_wave) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
   const int b = blockIdx.y, n = a.n;
   float w1[4][3], w2[4][3], b1[4], g1[4], b2[4], g2[4], sc[4], sh[4];
@@ -125,9 +130,70 @@ __global__ void __launch_bounds__(256) k_res_rt_fwd(ResFwd a, int tiles_per_wave
 #pragma unroll
       for (int r = 0; r < 4; ++r) ssq = fmaf(o[r], o[r], ssq);
       const float inv = rms_inv(gsum4(ssq), SQC);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = silu_f(o[r] * inv * g2[r]) + x[r][1];
       if (own) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a.out[base + (int64_t)r * n + p] = silu_f(o[r] * inv * g2[r]) + x[r][1];
+        for (int r = 0; r < 4; ++r) a.out[base + (int64_t)r * n + p] = o[r];
+      }
+    }
+    if constexpr (QKV) {
+      float xn[4];
+      {
+        float ssq = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ssq = fmaf(o[r], o[r], ssq);
+        const float inv = rms_inv(gsum4(ssq), SQC);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xn[r] = o[r] * inv * q.gn[4 * g + r];
+      }
+      if (q.xn && own) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q.xn[base + (int64_t)r * n + p] = xn[r];
+      }
+      // RoPE (k_attn.hip: k_rope): pair pr = 2 g + (r / 2) of a head's first 16 channels, angle = position * freqs[pr]
+      float cs[2] = {1.f, 1.f}, sn[2] = {0.f, 0.f};
+      if (q.rope) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) sincosf((float)p * q.rope[2 * g + h], &sn[h], &cs[h]);
+      }
+      auto rotate = [&](f32x4& v) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float xa = v[2 * h], xb = v[2 * h + 1];
+          v[2 * h] = xa * cs[h] - xb * sn[h];
+          v[2 * h + 1] = xb * cs[h] + xa * sn[h];
+        }
+      };
+      float* qvb = q.qv + (int64_t)b * 256 * n + (int64_t)(4 * g) * n + p;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const float* wr = q.wqv + (16 * t + j) * C + 4 * g;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma16(wr[r], xn[r], acc);
+        if (t < 8 && (t & 1) == 0) rotate(acc);  // q, channels 0..15 of head t / 2
+        if (own) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) qvb[(int64_t)(16 * t + r) * n] = acc[r];
+        }
+      }
+      if (q.kk) {  // (wave-uniform)
+        const float* mb = q.ms1f + (int64_t)b * 8 * n;
+        const float m0 = inr ? mb[(int64_t)g * n + p] : 0.f, m1 = inr ? mb[(int64_t)(4 + g) * n + p] : 0.f;
+        float* kb = q.kk + (int64_t)b * 128 * n + (int64_t)(4 * g) * n + p;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const float* wr = q.wk + (16 * t + j) * 8 + g;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          acc = mfma16(wr[0], m0, acc);
+          acc = mfma16(wr[4], m1, acc);
+          if ((t & 1) == 0) rotate(acc);
+          if (own) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) kb[(int64_t)(16 * t + r) * n] = acc[r];
+          }
+        }
       }
     }
   }
@@ -269,12 +335,17 @@ bool res_rt_usable(int C_, int cinA, int cinB, bool has_wr, int rows_per_sample)
   return rows_per_sample == 1 && C_ == C && cinA == C && cinB == 0 && !has_wr;
 }
 
-int launch_res_rt_fwd(const ResFwd& a, hipStream_t s) {
+int launch_res_rt_fwd(const ResFwd& a, hipStream_t s, const ResRtQkv* q) {
   DQ_REQUIRE(res_rt_usable(a.C, a.cinA, a.cinB, a.wr != nullptr, a.rows_per_sample) && a.n >= 1 && a.inA && a.out && a.ss,
              "res_rt_fwd: 16 channels, identity residual, one RT row per sample");
-  DQ_REQUIRE((int64_t)a.rows * C * a.n < ((int64_t)1 << 40), "res_rt_fwd: tensor too large");
   const int tpw = rt_tiles_per_wave(a.n, FWD_OWN);
-  hipLaunchKernelGGL(k_res_rt_fwd, dim3(cdiv(a.n, 4 * FWD_OWN * tpw), a.rows), dim3(256), 0, s, a, tpw);
+  const dim3 grid(cdiv(a.n, 4 * FWD_OWN * tpw), a.rows);
+  if (q) {
+    DQ_REQUIRE(q->gn && q->wqv && q->qv && (!q->kk || (q->wk && q->ms1f)), "res_rt_fwd: missing attention-front operand");
+    hipLaunchKernelGGL(k_res_rt_fwd<true>, grid, dim3(256), 0, s, a, *q, tpw);
+  } else {
+    hipLaunchKernelGGL(k_res_rt_fwd<false>, grid, dim3(256), 0, s, a, ResRtQkv{}, tpw);
+  }
   DQ_LAUNCH_CHECK();
   return 0;
 }
