@@ -327,7 +327,7 @@ int res_bwd_side(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA,
 // storeA / storeB: this block is the first writer of dA / dB in the backward pass (fused path only; the step-by-step path
 // below accumulates into the cleared buffers as before)
 int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, float* dA, int cinA, const float* inB, float* dB, int cinB,
-            int rows, int n, int rows_per_sample, int storeA = 0, int storeB = 0) {
+            int rows, int n, int rows_per_sample, int storeA = 0, int storeB = 0, const ResRtPre* pre = nullptr, int* gblocks_out = nullptr) {
   const float* dout = c.g(b.out);
   // (a block laid out for the fused weight-gradient kernel keeps no a1 tensor -- the arena assumes cat(x, skip) with x of cout channels, as
   // everywhere in the network; another split of the same cin cannot be served from that layout)
@@ -364,7 +364,9 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
     k.C = r.cout; k.rows = rows; k.n = n; k.rows_per_sample = rows_per_sample;
     int gblocks = 0;
     k.gpart = c.w(b.gpart); k.gpart_floats = b.gpart_floats; k.gblocks = &gblocks;
-    DQ_TRY(launch_res_bwd(k, c.s));
+    if (pre) DQ_TRY(launch_res_rt_bwd(k, c.s, pre));  // (the caller checked res_rt_usable: the block's d out is formed by the launch's prologue)
+    else DQ_TRY(launch_res_bwd(k, c.s));
+    if (gblocks_out) *gblocks_out = gblocks;
     return res_bwd_side(c, r, b, inA, cinA, inB, cinB, rows, n, rows_per_sample, gblocks);
   }
   // block2: norm -> silu
@@ -1246,6 +1248,8 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
   } else {
     if (!use_tb_up) DQ_TRY(launch_fold(c.g(a.mid_back), c.g(a.mid2.out), B, RT, p.mid_c, 1, 1, c.s));  // (the tiny backward wrote d mid2.out itself)
     DQ_TRY(res_bwd(c, p.mid2, a.mid2, c.w(a.attn_out), c.g(a.attn_out), p.mid_c, nullptr, nullptr, 0, B, RT, 1));
+    bool mid_pre = false;  // the back of the attention front rides in mid_block1's backward
+    std::function<int(hipStream_t)> mid_rest;  // ... and what the main chain then no longer waits for
     {
       const int64_t qvbs = (int64_t)2 * HID * RT, kbs = (int64_t)HID * RT;
       // to_out (1x1 + bias) and the residual
@@ -1257,6 +1261,25 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
       // was a k_axpy launch here plus one behind that kernel)
       DQ_TRY(launch_attn_bwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.g(a.o), c.w(a.lse), c.w(a.delta),
                              c.g(a.qv), qvbs, c.g(a.kk), kbs, c.g(a.qv) + kbs, qvbs, B, RT, c.s));
+      // 16 channels with a side queue at hand: RoPE^T, d xn = W_qv^T d qv, the PreNorm backward and the residual add run as the PROLOGUE of
+      // mid_block1's backward (k_res_rt.hip), which reads d q in the rotated frame.  What is left needs nothing of the main chain any more:
+      // RoPE^T in memory (the weight gradients of to_qv / to_k want d q, d k in the unrotated frame), d ms1f and both weight gradients go to
+      // the side queue -- behind the next flush's fork event, i.e. behind mid_block1's backward, which has read d q by then.
+      // (without a side queue -- the captured step, a plan without an owner -- the same launches follow mid_block1's backward on the main stream:
+      // the arithmetic, and with it every bit of the step, does not depend on the schedule)
+      const bool pre_fused = res_rt_usable(p.mid_c, p.mid_c, 0, p.mid1.res.cout != 0, 1) && HID == 128 &&
+                             a.bb_part_floats >= (int64_t)64 * B * p.mid_c && !DQ_DEV_FLAG("DQ_NO_MID_PRE", '1');  // (dev switch)
+      if (pre_fused) {
+        Ctx sc = c;
+        sc.owner = nullptr; sc.side_defer = nullptr;
+        const ConvP kp = proj(p.k_w, HID, p.cond_dim), qp = proj(p.qv_w, 2 * HID, p.mid_c);
+        mid_rest = [sc, &a, rope, B, RT, kp, qp, ws_ok](hipStream_t ss) mutable {
+          sc.s = ss;
+          if (rope) DQ_TRY(launch_rope2(sc.g(a.qv), (int64_t)2 * HID * RT, sc.g(a.kk), (int64_t)HID * RT, rope, B, RT, -1.f, ss));
+          DQ_TRY(conv_plain_bwd(sc, kp, CONV_S1, sc.w(a.ms1f), sc.g(a.kk), sc.g(a.ms1f), B, RT, RT, 0, ws_ok + 1));
+          return conv_plain_bwd(sc, qp, CONV_S1, sc.w(a.xn), sc.g(a.qv), nullptr, B, RT, RT, 0, ws_ok);  // (weight gradient only)
+        };
+      } else {
       if (rope) {
         DQ_TRY(launch_rope2(c.g(a.qv), (int64_t)2 * HID * RT, c.g(a.kk), (int64_t)HID * RT, rope, B, RT, -1.f, c.s));
       }
@@ -1280,8 +1303,31 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
         it.kind = 3; it.fn = [gred](hipStream_t ss) { return launch_part_reduce(gred, ss); };  // (kind 3: behind the flush's fork event whatever precedes it)
         c.side_defer->push_back(it);
       }
+          }
+      mid_pre = pre_fused;
     }
-    DQ_TRY(res_bwd(c, p.mid1, a.mid1, c.w(a.mid_in), c.g(a.mid_in), p.mid_c, nullptr, nullptr, 0, B, RT, 1));
+    if (mid_pre) {
+      ResRtPre q;
+      q.dqv = c.g(a.qv); q.wqv = c.prm(p.qv_w); q.x = c.w(a.mid1.out); q.gn = c.prm(p.ag); q.add = c.g(a.attn_out); q.rope = rope;
+      q.gn_part = c.w(a.bb_part); q.gn_part_floats = a.bb_part_floats;
+      int gblocks = 0;
+      DQ_TRY(res_bwd(c, p.mid1, a.mid1, c.w(a.mid_in), c.g(a.mid_in), p.mid_c, nullptr, nullptr, 0, B, RT, 1, 0, 0, &q, &gblocks));
+      PartReduce gred;  // d (PreNorm gain): the workgroups' sums in block order
+      gred.part = c.w(a.bb_part); gred.B = B; gred.gx = gblocks; gred.nv = p.mid_c; gred.nseg = 1;
+      gred.seg_start[0] = 0; gred.seg_len[0] = p.mid_c; gred.seg_dst[0] = c.dprm(p.ag);
+      if (c.owner && c.side_defer && tail_fork_enabled()) {
+        Ctx::SideItem it{};
+        it.kind = 3; it.fn = mid_rest;
+        c.side_defer->push_back(it);
+        it.fn = [gred](hipStream_t ss) { return launch_part_reduce(gred, ss); };
+        c.side_defer->push_back(it);
+      } else {
+        DQ_TRY(mid_rest(c.s));
+        DQ_TRY(launch_part_reduce(gred, c.s));
+      }
+    } else {
+      DQ_TRY(res_bwd(c, p.mid1, a.mid1, c.w(a.mid_in), c.g(a.mid_in), p.mid_c, nullptr, nullptr, 0, B, RT, 1));
+    }
     if (!use_tb_dn) DQ_TRY(launch_fold(c.g(a.mid_in), c.g(a.downs[L - 1].rs), B, RT, p.mid_c, 0, 0, c.s));  // first and only writer: store (the tiny backward reads d mid_in itself)
   }
   // MS1 feature path (unet1d.py:1120-1130): its gradient d ms1f is final behind the bottleneck (to_k is its only consumer) and nothing on

@@ -19,6 +19,9 @@
 // registers in exactly the B-operand layout: xn = RMSNorm(out) g, qv = W_qv xn (256 x 16: sixteen M-tiles of four K-steps), RoPE on the
 // first 16 channels of each of q's heads (adjacent pairs = registers (0, 1) and (2, 3) of a lane), and k = W_k ms1f (128 x 8) with its RoPE
 // when the caller has not prepared it (sampling computes k once in front of the loop).  Four launches (k_rmsnorm_fwd, two GEMMs, k_rope) less.
+// PRE (the first block's backward): the back of that front runs as the prologue -- RoPE^T on d q, d xn = W_qv^T d qv (K = 256: the K-slot order
+// m = 8 q + 2 g + h puts a RoPE pair into one lane's consecutive steps), the PreNorm backward and the residual branch's gradient give the
+// block's d out in registers, in the layout the backward wants (three launches less: k_rope, a GEMM, k_block_bwd; d mid1.out never exists).
 // Any RT length (k_res.hip: <= 512; longer axes took the unfused five-launch path).  Weight gradients: unchanged (k_conv_wgrad_multi reads
 // the dU1 / dU2 / a1 tensors written here).
 #include "dq_common.h"
@@ -229,8 +232,9 @@ __device__ __forceinline__ void norm_act_bwd_lc(const float (&u)[4], float (&d)[
   for (int r = 0; r < 4; ++r) d[r] = clamped ? d[r] * inv : inv * (d[r] - uh[r] * dot);
 }
 
-__global__ void __launch_bounds__(256) k_res_rt_bwd(ResBwd a, int tiles_per_wave) {
-  __shared__ float red[4][4 * C];
+template <bool PRE>
+__global__ void __launch_bounds__(256) k_res_rt_bwd(ResBwd a, ResRtPre q, int tiles_per_wave) {
+  __shared__ float red[4][5 * C];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
   const int b = blockIdx.y, n = a.n;
   // A operands of the transposed convolutions: d in[ci][p] = sum_(co, k) W[co][ci][k] dU[co][p + 1 - k]; K-step (r, k): lane group g
@@ -251,6 +255,12 @@ __global__ void __launch_bounds__(256) k_res_rt_bwd(ResBwd a, int tiles_per_wave
     }
   }
   float dg2[4] = {0.f, 0.f, 0.f, 0.f}, dg1[4] = {0.f, 0.f, 0.f, 0.f}, dsc[4] = {0.f, 0.f, 0.f, 0.f}, dsh[4] = {0.f, 0.f, 0.f, 0.f};
+  float dgn[4] = {0.f, 0.f, 0.f, 0.f};  // PRE: d (PreNorm gain)
+  float gn[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (PRE) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gn[r] = q.gn[4 * g + r];
+  }
   float none[4] = {0.f, 0.f, 0.f, 0.f};
   const int64_t base = (int64_t)b * C * n + (int64_t)(4 * g) * n;
   const bool rmw = a.dA && !a.dA_store;
@@ -264,12 +274,62 @@ __global__ void __launch_bounds__(256) k_res_rt_bwd(ResBwd a, int tiles_per_wave
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t o = base + (int64_t)r * n + p;
-      dout[r] = inr ? a.dout[o] : 0.f;
+      if constexpr (!PRE) dout[r] = inr ? a.dout[o] : 0.f;
       u2[r] = inr ? a.u2[o] : 1.f;
       u1[r] = inr ? a.u1[o] : 1.f;
       dold[r] = (own && rmw) ? a.dA[o] : 0.f;
-      d[r] = dout[r];
     }
+    if constexpr (PRE) {
+      // ---- d out of this block = d attn_out (the residual around the attention) + PreNorm^T (W_qv^T RoPE^T (d q | d v)); needed on every lane
+      // of the tile (the transposed convolutions read the neighbours), per position throughout
+      float xo[4], ad[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t o = base + (int64_t)r * n + p;
+        xo[r] = inr ? q.x[o] : 1.f;
+        ad[r] = inr ? q.add[o] : 0.f;
+      }
+      float cs[2] = {1.f, 1.f}, sn[2] = {0.f, 0.f};
+      if (q.rope) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) sincosf((float)p * q.rope[4 * h + g], &sn[h], &cs[h]);  // pair 4 h + g of a head's first 16 channels
+      }
+      const float* db = q.dqv + (int64_t)b * 256 * n + p;
+      f32x4 dn = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8  // (32 loads in flight per chunk; fully unrolled: 334 + 78 registers, one workgroup per CU)
+      for (int qq = 0; qq < 32; ++qq) {  // K-steps (2 qq, 2 qq + 1): lane group g supplies m = 8 qq + 2 g, + 1
+        const int m0 = 8 * qq + 2 * g;
+        float v0 = inr ? db[(int64_t)m0 * n] : 0.f, v1 = inr ? db[(int64_t)(m0 + 1) * n] : 0.f;
+        if (qq < 16 && (qq & 3) < 2) {  // d q, channels 0..15 of head qq / 4: the transpose of the rotation by angle p * freqs[4 (qq & 3) + g]
+          const float c_ = cs[qq & 1], s_ = sn[qq & 1];  // (qq & 3 is 0 or 1 here)
+          const float xa = v0, xb = v1;
+          v0 = xa * c_ + xb * s_;
+          v1 = xb * c_ - xa * s_;
+        }
+        dn = mfma16(q.wqv[m0 * C + j], v0, dn);
+        dn = mfma16(q.wqv[(m0 + 1) * C + j], v1, dn);
+      }
+      // PreNorm backward (RMSNorm with gain, no activation: k_block_bwd's arithmetic) ; + the residual branch
+      float ssq = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ssq = fmaf(xo[r], xo[r], ssq);
+      const float nrm = fast_sqrt(gsum4(ssq)), inv = fast_rcp(fmaxf(nrm, RMS_EPS));
+      float uh[4], dd[4];
+      float dot = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        uh[r] = xo[r] * inv;
+        dgn[r] = fmaf(own ? dn[r] : 0.f, uh[r] * SQC, dgn[r]);
+        dd[r] = dn[r] * gn[r] * SQC;
+        dot = fmaf(dd[r], uh[r], dot);
+      }
+      dot = gsum4(dot);
+      const bool clamped = nrm < RMS_EPS;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dout[r] = inr ? (ad[r] + (clamped ? dd[r] * inv : inv * (dd[r] - uh[r] * dot))) : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[r] = dout[r];
     // ---- block2: dU2 (zero outside the axis)
     norm_act_bwd_lc<false>(u2, d, g2, none, none, own, dg2, none, none);
 #pragma unroll
@@ -314,15 +374,20 @@ __global__ void __launch_bounds__(256) k_res_rt_bwd(ResBwd a, int tiles_per_wave
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const float s0 = row_sum16(dg2[r]), s1 = row_sum16(dg1[r]), s2 = row_sum16(dsc[r]), s3 = row_sum16(dsh[r]);
+    const float s4 = PRE ? row_sum16(dgn[r]) : 0.f;
     if (j == 0) {
       const int c = 4 * g + r;
       red[wv][c] = s0; red[wv][C + c] = s1; red[wv][2 * C + c] = s2; red[wv][3 * C + c] = s3;
+      if (PRE) red[wv][4 * C + c] = s4;
     }
   }
   __syncthreads();
   if (threadIdx.x < 4 * C) {
     const int i = threadIdx.x;
     a.gpart[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (4 * C) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+  } else if (PRE && threadIdx.x < 5 * C) {
+    const int i = threadIdx.x;
+    q.gn_part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * C + (i - 4 * C)] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
   }
 }
 
@@ -350,14 +415,20 @@ int launch_res_rt_fwd(const ResFwd& a, hipStream_t s, const ResRtQkv* q) {
   return 0;
 }
 
-int launch_res_rt_bwd(const ResBwd& a, hipStream_t s) {
-  DQ_REQUIRE(res_rt_usable(a.C, a.cinA, a.cinB, a.wr != nullptr, a.rows_per_sample) && a.n >= 1 && a.dout && a.u1 && a.u2 && a.du1 && a.du2 && a.ss,
+int launch_res_rt_bwd(const ResBwd& a, hipStream_t s, const ResRtPre* q) {
+  DQ_REQUIRE(res_rt_usable(a.C, a.cinA, a.cinB, a.wr != nullptr, a.rows_per_sample) && a.n >= 1 && (a.dout || q) && a.u1 && a.u2 && a.du1 && a.du2 && a.ss,
              "res_rt_bwd: 16 channels, identity residual, one RT row per sample");
   const int tpw = rt_tiles_per_wave(a.n, BWD_OWN);
   const dim3 grid(cdiv(a.n, 4 * BWD_OWN * tpw), a.rows);
   DQ_REQUIRE(a.gpart && a.gblocks && a.gpart_floats >= (int64_t)grid.x * grid.y * 4 * C, "res_rt_bwd: partial-sum slot missing or too small");
   *a.gblocks = (int)grid.x;  // workgroups per sample
-  hipLaunchKernelGGL(k_res_rt_bwd, grid, dim3(256), 0, s, a, tpw);
+  if (q) {
+    DQ_REQUIRE(q->dqv && q->wqv && q->x && q->gn && q->add && q->gn_part && q->gn_part_floats >= (int64_t)grid.x * grid.y * C,
+               "res_rt_bwd: missing attention-front operand");
+    hipLaunchKernelGGL(k_res_rt_bwd<true>, grid, dim3(256), 0, s, a, *q, tpw);
+  } else {
+    hipLaunchKernelGGL(k_res_rt_bwd<false>, grid, dim3(256), 0, s, a, ResRtPre{}, tpw);
+  }
   DQ_LAUNCH_CHECK();
   return 0;
 }
