@@ -161,6 +161,10 @@ int launch_res_rt_bwd(const ResBwd& a, hipStream_t s, const ResRtPre* q = nullpt
 bool res_cp_usable(int n, int C, int cinA, int cinB);
 int launch_res_fwd_cp(const ResFwd& a, hipStream_t s);
 int launch_res_bwd_cp(const ResBwd& a, hipStream_t s);
+// k_res_rows.hip: the deep levels' backward data path with the m/z row as the lane column of v_mfma_f32_16x16x4 (12 / 16 channels, rows of
+// 2 / 4 / 8 positions, 16-byte aligned tensors); launch_res_bwd dispatches to it
+bool res_rows_bwd_usable(const ResBwd& a);
+int launch_res_rows_bwd(const ResBwd& a, hipStream_t s);
 // k_res_v4.hip: 4-positions-per-thread forward for the wide levels (C = 4 / 8, n >= 8)
 bool res_v4_usable(int n, int C, int cinA, int cinB);
 int launch_res_fwd_v4(const ResFwd& a, hipStream_t s);

@@ -1249,7 +1249,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     if (!use_tb_up) DQ_TRY(launch_fold(c.g(a.mid_back), c.g(a.mid2.out), B, RT, p.mid_c, 1, 1, c.s));  // (the tiny backward wrote d mid2.out itself)
     DQ_TRY(res_bwd(c, p.mid2, a.mid2, c.w(a.attn_out), c.g(a.attn_out), p.mid_c, nullptr, nullptr, 0, B, RT, 1));
     bool mid_pre = false;  // the back of the attention front rides in mid_block1's backward
-    std::function<int(hipStream_t)> mid_rest;  // ... and what the main chain then no longer waits for
+    std::function<int(const Ctx&)> mid_rest;  // ... and what the main chain then no longer waits for
     {
       const int64_t qvbs = (int64_t)2 * HID * RT, kbs = (int64_t)HID * RT;
       // to_out (1x1 + bias) and the residual
@@ -1270,14 +1270,11 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
       const bool pre_fused = res_rt_usable(p.mid_c, p.mid_c, 0, p.mid1.res.cout != 0, 1) && HID == 128 &&
                              a.bb_part_floats >= (int64_t)64 * B * p.mid_c && !DQ_DEV_FLAG("DQ_NO_MID_PRE", '1');  // (dev switch)
       if (pre_fused) {
-        Ctx sc = c;
-        sc.owner = nullptr; sc.side_defer = nullptr;
         const ConvP kp = proj(p.k_w, HID, p.cond_dim), qp = proj(p.qv_w, 2 * HID, p.mid_c);
-        mid_rest = [sc, &a, rope, B, RT, kp, qp, ws_ok](hipStream_t ss) mutable {
-          sc.s = ss;
-          if (rope) DQ_TRY(launch_rope2(sc.g(a.qv), (int64_t)2 * HID * RT, sc.g(a.kk), (int64_t)HID * RT, rope, B, RT, -1.f, ss));
-          DQ_TRY(conv_plain_bwd(sc, kp, CONV_S1, sc.w(a.ms1f), sc.g(a.kk), sc.g(a.ms1f), B, RT, RT, 0, ws_ok + 1));
-          return conv_plain_bwd(sc, qp, CONV_S1, sc.w(a.xn), sc.g(a.qv), nullptr, B, RT, RT, 0, ws_ok);  // (weight gradient only)
+        mid_rest = [&a, rope, B, RT, kp, qp, ws_ok](const Ctx& cc) -> int {  // (on cc.s; weight gradients wherever cc sends them)
+          if (rope) DQ_TRY(launch_rope2(cc.g(a.qv), (int64_t)2 * HID * RT, cc.g(a.kk), (int64_t)HID * RT, rope, B, RT, -1.f, cc.s));
+          DQ_TRY(conv_plain_bwd(cc, kp, CONV_S1, cc.w(a.ms1f), cc.g(a.kk), cc.g(a.ms1f), B, RT, RT, 0, ws_ok + 1));
+          return conv_plain_bwd(cc, qp, CONV_S1, cc.w(a.xn), cc.g(a.qv), nullptr, B, RT, RT, 0, ws_ok);  // (weight gradient only)
         };
       } else {
       if (rope) {
@@ -1315,14 +1312,19 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
       PartReduce gred;  // d (PreNorm gain): the workgroups' sums in block order
       gred.part = c.w(a.bb_part); gred.B = B; gred.gx = gblocks; gred.nv = p.mid_c; gred.nseg = 1;
       gred.seg_start[0] = 0; gred.seg_len[0] = p.mid_c; gred.seg_dst[0] = c.dprm(p.ag);
-      if (c.owner && c.side_defer && tail_fork_enabled()) {
+      if (c.owner && c.side_defer && !grad_x && tail_fork_enabled()) {  // (the conditions under which the MS1 path's backward rides on the side queue too)
+        Ctx sc = c;
+        sc.owner = nullptr; sc.side_defer = nullptr;
         Ctx::SideItem it{};
-        it.kind = 3; it.fn = mid_rest;
+        it.kind = 3;
+        it.fn = [sc, mid_rest](hipStream_t ss) mutable { sc.s = ss; return mid_rest(sc); };
         c.side_defer->push_back(it);
         it.fn = [gred](hipStream_t ss) { return launch_part_reduce(gred, ss); };
         c.side_defer->push_back(it);
       } else {
-        DQ_TRY(mid_rest(c.s));
+        // on the main stream (d ms1f is read there next); the two weight gradients go where they always go (wgrad_async: the side queue's
+        // shared partial-sum scratch belongs to one stream)
+        DQ_TRY(mid_rest(c));
         DQ_TRY(launch_part_reduce(gred, c.s));
       }
     } else {

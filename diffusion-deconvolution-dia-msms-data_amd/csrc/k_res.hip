@@ -367,6 +367,7 @@ int launch_res_bwd(const ResBwd& a, hipStream_t s) {
   if (a.gblocks) *a.gblocks = 0;
   if (res_rt_usable(a.C, a.cinA, a.cinB, a.wr != nullptr, a.rows_per_sample)) return launch_res_rt_bwd(a, s);  // the bottleneck's blocks
   DQ_REQUIRE(a.rows_per_sample > 1 || a.n <= 512, "res_bwd: one RT row per sample longer than 512 positions needs the 16-channel identity block");
+  if (res_rows_bwd_usable(a)) return launch_res_rows_bwd(a, s);  // the deep levels: m/z row = lane column
   if (a.rows_per_sample > 1 && res_cp_usable(a.n, a.C, a.cinA, a.cinB)) return launch_res_bwd_cp(a, s);
   const int B = a.rows / a.rows_per_sample;
   const int BS = res_block_size(a.n, a.rows_per_sample);

@@ -59,6 +59,26 @@ constexpr float SQC = 4.0f;                // sqrt(C)
 
 template <bool QKV>
 __global__ void __launch_bounds__(256) k_res_rt_fwd(ResFwd a, ResRtQkv q, int tiles_per_wave) {
+  // QKV: W_qv (256 x 16) and W_k (128 x 8) staged once per workgroup -- read from memory tile by tile inside the epilogue they were sixteen
+  // memory round trips in a row (21 us per launch against 6 without the epilogue); the copy overlaps the block itself
+  __shared__ __attribute__((aligned(16))) float wqv_l[QKV ? 256 * C : 4];
+  __shared__ __attribute__((aligned(16))) float wk_l[QKV ? 128 * 8 : 4];
+  if constexpr (QKV) {
+    float v[16], vk[4];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = q.wqv[u * 256 + (int)threadIdx.x];
+    if (q.kk) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) vk[u] = q.wk[u * 256 + (int)threadIdx.x];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) wqv_l[u * 256 + (int)threadIdx.x] = v[u];
+    if (q.kk) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) wk_l[u * 256 + (int)threadIdx.x] = vk[u];
+    }
+    __syncthreads();  // (in front of the tile loop: every wave reaches it, whatever its tile)
+  }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
   const int b = blockIdx.y, n = a.n;
   float w1[4][3], w2[4][3], b1[4], g1[4], b2[4], g2[4], sc[4], sh[4];
@@ -171,10 +191,12 @@ __global__ void __launch_bounds__(256) k_res_rt_fwd(ResFwd a, ResRtQkv q, int ti
       float* qvb = q.qv + (int64_t)b * 256 * n + (int64_t)(4 * g) * n + p;
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
-        const float* wr = q.wqv + (16 * t + j) * C + 4 * g;
+        const float4 w4 = *reinterpret_cast<const float4*>(wqv_l + (16 * t + j) * C + 4 * g);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc = mfma16(wr[r], xn[r], acc);
+        acc = mfma16(w4.x, xn[0], acc);
+        acc = mfma16(w4.y, xn[1], acc);
+        acc = mfma16(w4.z, xn[2], acc);
+        acc = mfma16(w4.w, xn[3], acc);
         if (t < 8 && (t & 1) == 0) rotate(acc);  // q, channels 0..15 of head t / 2
         if (own) {
 #pragma unroll
@@ -187,7 +209,7 @@ __global__ void __launch_bounds__(256) k_res_rt_fwd(ResFwd a, ResRtQkv q, int ti
         float* kb = q.kk + (int64_t)b * 128 * n + (int64_t)(4 * g) * n + p;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          const float* wr = q.wk + (16 * t + j) * 8 + g;
+          const float* wr = wk_l + (16 * t + j) * 8 + g;
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
           acc = mfma16(wr[0], m0, acc);
           acc = mfma16(wr[4], m1, acc);
@@ -235,6 +257,17 @@ __device__ __forceinline__ void norm_act_bwd_lc(const float (&u)[4], float (&d)[
 template <bool PRE>
 __global__ void __launch_bounds__(256) k_res_rt_bwd(ResBwd a, ResRtPre q, int tiles_per_wave) {
   __shared__ float red[4][5 * C];
+  // PRE: W_qv staged once per workgroup (as the forward's epilogue does): the prologue's 64 weight operands per lane are LDS reads, its 64
+  // d qv operands ONE batch of loads (in four chunks of weights + gradients from memory the launch took 21 us against 6.5 without the prologue)
+  __shared__ __attribute__((aligned(16))) float wqv_l[PRE ? 256 * C : 4];
+  if constexpr (PRE) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = q.wqv[u * 256 + (int)threadIdx.x];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) wqv_l[u * 256 + (int)threadIdx.x] = v[u];
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
   const int b = blockIdx.y, n = a.n;
   // A operands of the transposed convolutions: d in[ci][p] = sum_(co, k) W[co][ci][k] dU[co][p + 1 - k]; K-step (r, k): lane group g
@@ -295,20 +328,31 @@ __global__ void __launch_bounds__(256) k_res_rt_bwd(ResBwd a, ResRtPre q, int ti
         for (int h = 0; h < 2; ++h) sincosf((float)p * q.rope[4 * h + g], &sn[h], &cs[h]);  // pair 4 h + g of a head's first 16 channels
       }
       const float* db = q.dqv + (int64_t)b * 256 * n + p;
-      f32x4 dn = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8  // (32 loads in flight per chunk; fully unrolled: 334 + 78 registers, one workgroup per CU)
-      for (int qq = 0; qq < 32; ++qq) {  // K-steps (2 qq, 2 qq + 1): lane group g supplies m = 8 qq + 2 g, + 1
-        const int m0 = 8 * qq + 2 * g;
-        float v0 = inr ? db[(int64_t)m0 * n] : 0.f, v1 = inr ? db[(int64_t)(m0 + 1) * n] : 0.f;
-        if (qq < 16 && (qq & 3) < 2) {  // d q, channels 0..15 of head qq / 4: the transpose of the rotation by angle p * freqs[4 (qq & 3) + g]
-          const float c_ = cs[qq & 1], s_ = sn[qq & 1];  // (qq & 3 is 0 or 1 here)
-          const float xa = v0, xb = v1;
-          v0 = xa * c_ + xb * s_;
-          v1 = xb * c_ - xa * s_;
+      f32x4 dn0 = {0.f, 0.f, 0.f, 0.f}, dn1 = {0.f, 0.f, 0.f, 0.f};  // (two chains)
+#pragma unroll 1
+      for (int hf = 0; hf < 2; ++hf) {  // d q (hf 0: the half with the rotation), then d v: 32 loads in flight each
+        float dv[32];  // K-steps (2 qq, 2 qq + 1): lane group g supplies m = 8 qq + 2 g, + 1
+#pragma unroll
+        for (int qi = 0; qi < 16; ++qi) {
+          const int m0 = 8 * (16 * hf + qi) + 2 * g;
+          dv[2 * qi] = inr ? db[(int64_t)m0 * n] : 0.f;
+          dv[2 * qi + 1] = inr ? db[(int64_t)(m0 + 1) * n] : 0.f;
         }
-        dn = mfma16(q.wqv[m0 * C + j], v0, dn);
-        dn = mfma16(q.wqv[(m0 + 1) * C + j], v1, dn);
+#pragma unroll
+        for (int qi = 0; qi < 16; ++qi) {
+          const int m0 = 8 * (16 * hf + qi) + 2 * g;
+          float v0 = dv[2 * qi], v1 = dv[2 * qi + 1];
+          if ((qi & 3) < 2) {  // d q, channels 0..15 of head qi / 4: the transpose of the rotation by angle p * freqs[4 (qi & 3) + g]
+            const float c_ = hf == 0 ? cs[qi & 1] : 1.f, s_ = hf == 0 ? sn[qi & 1] : 0.f;  // (qi & 3 is 0 or 1 here; d v is not rotated)
+            const float xa = v0, xb = v1;
+            v0 = xa * c_ + xb * s_;
+            v1 = xb * c_ - xa * s_;
+          }
+          dn0 = mfma16(wqv_l[m0 * C + j], v0, dn0);
+          dn1 = mfma16(wqv_l[(m0 + 1) * C + j], v1, dn1);
+        }
       }
+      const f32x4 dn = dn0 + dn1;
       // PreNorm backward (RMSNorm with gain, no activation: k_block_bwd's arithmetic) ; + the residual branch
       float ssq = 0.f;
 #pragma unroll
