@@ -369,6 +369,9 @@ int launch_la_small_fwd(const LinAttn& a, hipStream_t s);
 struct LinAttnBwd;
 bool la_rows_bwd_usable(int C, int n);
 int la_rows_bwd_min_rows();
+// k_la_rows_fwd.hip: the forward in the same layout (rows of 2 / 4 positions below la_small_min_rows; launch_linattn_fwd dispatches to it)
+bool la_rows_fwd_usable(int C, int n);
+int launch_la_rows_fwd(const LinAttn& a, hipStream_t s);
 int launch_la_rows_bwd(const LinAttnBwd& a, int max_slots, int* slots_out, hipStream_t s);
 constexpr int LA_PREP_BOUNDED = 1024 + 4096;          // 1.0f when the layer's softmax logits are bounded by 64 for every input (k_linattn_prepare)
 constexpr int LA_PREP_BF16 = 1024 + 4096 + 8;         // split-bf16 operand image of Wq | Wk for 4 / 8 channels: 2048 la_nu(C) <= 6144 dwords (k_linattn.hip)

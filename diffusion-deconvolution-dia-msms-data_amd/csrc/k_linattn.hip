@@ -758,6 +758,10 @@ int launch_linattn_fwd(const LinAttn& a, hipStream_t s) {
   if (a.prep && la_small_usable(a.C, a.n) && a.rows >= la_small_min_rows() &&
       (((uintptr_t)a.x | (uintptr_t)a.y | (uintptr_t)a.ypre) & 15) == 0)  // (its tiles move as 16-byte runs)
     return launch_la_small_fwd(a, s);
+  // rows of 2 / 4 positions below that threshold (training batches): one m/z row per lane column (k_la_rows_fwd.hip), wherever the rows
+  // backward is in use (the same option switches both: a run with the register-resident forms forced keeps the register forward)
+  if (a.prep && la_rows_fwd_usable(a.C, a.n) && a.rows >= la_rows_bwd_min_rows() && (((uintptr_t)a.x | (uintptr_t)a.prep) & 15) == 0)
+    return launch_la_rows_fwd(a, s);
   switch (a.C) {
     case 4: return linattn_fwd_n<4>(a, s);
     case 8: return linattn_fwd_n<8>(a, s);

@@ -44,7 +44,7 @@ def test_linattn_bwd_vs_autograd(N, C, n, rows):
     _la_bwd_case(N, C, n, rows)
 
 
-@pytest.mark.parametrize("form", ["rows", "register"])
+@pytest.mark.parametrize("form", ["default", "rows", "register"])
 @pytest.mark.parametrize("C,n,rows,wscale", [(12, 4, 50, 0.4), (12, 2, 33, 0.4), (16, 2, 16, 0.4), (16, 4, 3, 0.4), (8, 4, 9, 0.4), (8, 2, 17, 0.4),
                                              (12, 4, 1, 0.4), (16, 4, 15, 0.4), (16, 4, 17, 0.4), (12, 2, 4100, 0.4), (16, 2, 20000, 0.4), (12, 4, 12800, 0.4),
                                              # logits beyond the bounded-softmax criterion (k_linattn_prepare): the shifted form of both softmaxes
@@ -52,7 +52,9 @@ def test_linattn_bwd_vs_autograd(N, C, n, rows):
 def test_linattn_bwd_forms_vs_autograd(N, C, n, rows, wscale, form):
     """Rows of 2 / 4 positions at 8 / 12 / 16 channels in BOTH backward forms -- one m/z row per lane column on the 16x16x4 matrix pipe
     (k_la_rows_bwd.hip, the product's default) and the register-resident tiles (k_la_bwd.hip) -- against the oracle's autograd: ragged last
-    tiles, a single row, more tiles than one resident round of waves (20,000 rows = 1,250 tiles), the train step's own row count (12,800)."""
+    tiles, a single row, more tiles than one resident round of waves (20,000 rows = 1,250 tiles), the train step's own row count (12,800).
+    The PREPARED forward of the same case (the network's path) is held against the oracle too: under `default` that is k_la_rows_fwd.hip,
+    under `rows` k_la_small, under `register` the register-resident kernel."""
     from conftest import set_la_form
 
     set_la_form(form)
@@ -90,6 +92,15 @@ def _la_bwd_case(N, C, n, rows, wscale=0.4):
     N.check(L.dq_linattn_bwd(N.ptr(xd), N.ptr(ypre), N.ptr(gyd), N.ptr(dx), N.ptr(w), N.ptr(wo), N.ptr(bo), N.ptr(g1), N.ptr(g2),
                              N.ptr(dw), N.ptr(dwo), N.ptr(dbo), N.ptr(dg1), N.ptr(dg2), N.ptr(scratch), C, rows, n, N.stream_ptr()),
             "dq_linattn_bwd")
+    if n <= 64 and (n & (n - 1)) == 0:  # the network's forward: prepared weights / operand images (its kernel depends on the dispatch rule in force)
+        prep = torch.zeros(L.dq_linattn_prep_floats(), device="cuda")
+        yp, ypre_p = torch.empty_like(xd), torch.empty_like(xd)
+        N.check(L.dq_linattn_prepare(N.ptr(w), N.ptr(wo), N.ptr(g1), C, N.ptr(prep), N.stream_ptr()), "dq_linattn_prepare")
+        N.check(L.dq_linattn_fwd_prepared(N.ptr(xd), N.ptr(yp), N.ptr(ypre_p), N.ptr(w), N.ptr(wo), N.ptr(bo), N.ptr(g1), N.ptr(g2), N.ptr(prep),
+                                          C, rows, n, N.stream_ptr()), "dq_linattn_fwd_prepared")
+        torch.cuda.synchronize()
+        assert rel_err(yp, y) < 1e-5
+        assert rel_err(ypre_p, ypre.cpu()) < 1e-5
     torch.cuda.synchronize()
     assert rel_err(yd, y) < 1e-5
     tol = 2e-5 if (rows < 1000 and wscale < 1.0) else 1e-4  # long fp32 sums (in a fixed order: no atomics) lose a little; so do sharp softmaxes
