@@ -149,14 +149,20 @@ struct ResRtQkv {
   const float* gn = nullptr; const float* wqv = nullptr; float* xn = nullptr; float* qv = nullptr; const float* rope = nullptr;
   const float* wk = nullptr; const float* ms1f = nullptr; float* kk = nullptr;
 };
-int launch_res_rt_fwd(const ResFwd& a, hipStream_t s, const ResRtQkv* q = nullptr);
+// the back of the attention with the SECOND block: forward -- the block's input attn_out = res + W_o o + b_o is formed in the launch (and written
+// to `out`); backward -- d o = W_o^T d attn_out follows the block's d x
+struct ResRtOut {
+  const float* o = nullptr; const float* w = nullptr; const float* b = nullptr; const float* res = nullptr; float* out = nullptr;  // forward
+  float* d_o = nullptr;                                                                                                              // backward
+};
+int launch_res_rt_fwd(const ResFwd& a, hipStream_t s, const ResRtQkv* q = nullptr, const ResRtOut* ao = nullptr);
 // the back of that front in front of the first block's backward: d out = add + PreNorm^T(W_qv^T RoPE^T(dqv)); d gn partials to
 // gn_part[(sample * gblocks + workgroup) * 16 + c] (launch_part_reduce)
 struct ResRtPre {
   const float* dqv = nullptr; const float* wqv = nullptr; const float* x = nullptr; const float* gn = nullptr; const float* add = nullptr;
   const float* rope = nullptr; float* gn_part = nullptr; int64_t gn_part_floats = 0;
 };
-int launch_res_rt_bwd(const ResBwd& a, hipStream_t s, const ResRtPre* q = nullptr);
+int launch_res_rt_bwd(const ResBwd& a, hipStream_t s, const ResRtPre* q = nullptr, const ResRtOut* ao = nullptr);
 // k_res_cp.hip: channel-parallel variant for the deep levels (n <= 8, C = 12 / 16); launch_res_fwd / _bwd dispatch to it
 bool res_cp_usable(int n, int C, int cinA, int cinB);
 int launch_res_fwd_cp(const ResFwd& a, hipStream_t s);

@@ -245,7 +245,7 @@ static inline bool side_flush_here(int lv) { return (lv & 1) == 0; }
 
 // ResnetBlock forward (unet1d.py:302-323): input = cat(A, B)
 int res_fwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, int cinA, const float* inB, int cinB, int rows, int n,
-            int rows_per_sample, const ResRtQkv* qkv = nullptr) {  // qkv: the attention front rides behind the block (k_res_rt.hip; the caller checked res_rt_usable)
+            int rows_per_sample, const ResRtQkv* qkv = nullptr, const ResRtOut* aout = nullptr) {  // qkv / aout: the attention's front rides behind the block / its back in front of it (k_res_rt.hip; the caller checked res_rt_usable)
   if (res_fusable(n, r.cout, rows_per_sample)) {  // m/z levels, and a bottleneck of up to 512 RT positions: one fused launch
     ResFwd k;
     k.inA = inA; k.inB = inB; k.cinA = cinA; k.cinB = cinB;
@@ -256,10 +256,10 @@ int res_fwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, int 
     if (c.save) { k.u1 = c.w(b.u1); k.a1 = b.wpart_floats ? nullptr : c.w(b.a1); k.u2 = c.w(b.u2); }  // (wpart: the backward recomputes a1)
     k.out = c.w(b.out);
     k.C = r.cout; k.rows = rows; k.n = n; k.rows_per_sample = rows_per_sample;
-    if (qkv) return launch_res_rt_fwd(k, c.s, qkv);
+    if (qkv || aout) return launch_res_rt_fwd(k, c.s, qkv, aout);
     return launch_res_fwd(k, c.s);
   }
-  DQ_REQUIRE(!qkv, "res_fwd: the attention front needs the fused 16-channel block");
+  DQ_REQUIRE(!qkv && !aout, "res_fwd: the attention front / back needs the fused 16-channel block");
   ConvFwd f;
   f.inA = inA; f.inB = inB; f.cinA = cinA; f.cinB = cinB;
   f.w = c.prm(r.c1.w); f.bias = c.prm(r.c1.b); f.cout = r.cout; f.K = 3; f.mode = CONV_S1;
@@ -327,7 +327,8 @@ int res_bwd_side(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA,
 // storeA / storeB: this block is the first writer of dA / dB in the backward pass (fused path only; the step-by-step path
 // below accumulates into the cleared buffers as before)
 int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, float* dA, int cinA, const float* inB, float* dB, int cinB,
-            int rows, int n, int rows_per_sample, int storeA = 0, int storeB = 0, const ResRtPre* pre = nullptr, int* gblocks_out = nullptr) {
+            int rows, int n, int rows_per_sample, int storeA = 0, int storeB = 0, const ResRtPre* pre = nullptr, int* gblocks_out = nullptr,
+            const ResRtOut* aout = nullptr) {
   const float* dout = c.g(b.out);
   // (a block laid out for the fused weight-gradient kernel keeps no a1 tensor -- the arena assumes cat(x, skip) with x of cout channels, as
   // everywhere in the network; another split of the same cin cannot be served from that layout)
@@ -364,7 +365,7 @@ int res_bwd(const Ctx& c, const ResP& r, const ResBuf& b, const float* inA, floa
     k.C = r.cout; k.rows = rows; k.n = n; k.rows_per_sample = rows_per_sample;
     int gblocks = 0;
     k.gpart = c.w(b.gpart); k.gpart_floats = b.gpart_floats; k.gblocks = &gblocks;
-    if (pre) DQ_TRY(launch_res_rt_bwd(k, c.s, pre));  // (the caller checked res_rt_usable: the block's d out is formed by the launch's prologue)
+    if (pre || aout) DQ_TRY(launch_res_rt_bwd(k, c.s, pre, aout));  // (the caller checked res_rt_usable: d out formed by the launch's prologue / d o by its epilogue)
     else DQ_TRY(launch_res_bwd(k, c.s));
     if (gblocks_out) *gblocks_out = gblocks;
     return res_bwd_side(c, r, b, inA, cinA, inB, cinB, rows, n, rows_per_sample, gblocks);
@@ -1085,6 +1086,7 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
     } else {
       DQ_TRY(res_fwd(c, p.mid1, a.mid1, c.w(a.mid_in), p.mid_c, nullptr, 0, B, RT, 1));
     }
+    bool out_fused = false;
     {
       // Residual(PreNorm(Attention(use_xattn))) (unet1d.py:552-567)
       if (!qkv_fused) {
@@ -1099,6 +1101,9 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
       }
       const int64_t qvbs = (int64_t)2 * HID * RT, kbs = (int64_t)HID * RT;
       DQ_TRY(launch_attn_fwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.w(a.lse), B, RT, c.s));
+      // 16 channels: to_out (1x1 + bias) and the residual are formed in FRONT of mid_block2, inside its launch (k_res_rt.hip)
+      out_fused = res_rt_usable(p.mid_c, p.mid_c, 0, p.mid2.res.cout != 0, 1) && HID == 128 && !DQ_DEV_FLAG("DQ_NO_MID_OUT", '1');  // (dev switch)
+      if (!out_fused) {
       const ConvP ao = proj(p.ao_w, p.mid_c, HID);
       if (conv_is_gemm(c, ao, CONV_S1, RT, RT) && (prep_ok || ((uintptr_t)c.prm(ao.w) & 15) == 0)) {
         // to_out (1x1 conv, 128 -> mid_c channels, with bias) + the residual: attn_out = x ; attn_out += W o + b as a GEMM per sample
@@ -1115,8 +1120,15 @@ int unet_forward(const Ctx& c, const float* rope, const float* x, const int64_t*
         f.resA = c.w(a.mid1.out); f.rcinA = p.mid_c;
         DQ_TRY(launch_conv_fwd(f, c.s));
       }
+          }
     }
-    DQ_TRY(res_fwd(c, p.mid2, a.mid2, c.w(a.attn_out), p.mid_c, nullptr, 0, B, RT, 1));
+    if (out_fused) {
+      ResRtOut ao;
+      ao.o = c.w(a.o); ao.w = c.prm(p.ao_w); ao.b = c.prm(p.ao_b); ao.res = c.w(a.mid1.out); ao.out = c.w(a.attn_out);
+      DQ_TRY(res_fwd(c, p.mid2, a.mid2, c.w(a.attn_out), p.mid_c, nullptr, 0, B, RT, 1, nullptr, &ao));
+    } else {
+      DQ_TRY(res_fwd(c, p.mid2, a.mid2, c.w(a.attn_out), p.mid_c, nullptr, 0, B, RT, 1));
+    }
     if (!(is_tiny_up(0) && tiny_upc(0).in_folded)) DQ_TRY(launch_fold(c.w(a.mid2.out), c.w(a.mid_back), B, RT, p.mid_c, 0, 0, c.s));
   }
   cur = c.w(a.mid_back);
@@ -1247,7 +1259,15 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
     DQ_TRY(mid_backward_wide(c, rope));
   } else {
     if (!use_tb_up) DQ_TRY(launch_fold(c.g(a.mid_back), c.g(a.mid2.out), B, RT, p.mid_c, 1, 1, c.s));  // (the tiny backward wrote d mid2.out itself)
-    DQ_TRY(res_bwd(c, p.mid2, a.mid2, c.w(a.attn_out), c.g(a.attn_out), p.mid_c, nullptr, nullptr, 0, B, RT, 1));
+    // 16 channels: d o = W_o^T d attn_out follows mid_block2's d x inside its launch (k_res_rt.hip); to_out's weight gradient stays below
+    const bool out_bwd_fused = res_rt_usable(p.mid_c, p.mid_c, 0, p.mid2.res.cout != 0, 1) && HID == 128 && !DQ_DEV_FLAG("DQ_NO_MID_OUT", '1');  // (dev switch)
+    if (out_bwd_fused) {
+      ResRtOut ao;
+      ao.w = c.prm(p.ao_w); ao.d_o = c.g(a.o);
+      DQ_TRY(res_bwd(c, p.mid2, a.mid2, c.w(a.attn_out), c.g(a.attn_out), p.mid_c, nullptr, nullptr, 0, B, RT, 1, 0, 0, nullptr, nullptr, &ao));
+    } else {
+      DQ_TRY(res_bwd(c, p.mid2, a.mid2, c.w(a.attn_out), c.g(a.attn_out), p.mid_c, nullptr, nullptr, 0, B, RT, 1));
+    }
     bool mid_pre = false;  // the back of the attention front rides in mid_block1's backward
     std::function<int(const Ctx&)> mid_rest;  // ... and what the main chain then no longer waits for
     {
@@ -1256,7 +1276,7 @@ int unet_backward(const Ctx& c_in, const float* rope, const float* init_cond, fl
       ConvP ao = proj(p.ao_w, p.mid_c, HID);
       ao.b = p.ao_b;
       const int ws_ok = (int)(p.downs.size() + p.ups.size()) <= LA_PREP_MAX ? 0 : -3;  // aligned weight slots as the forward of this step filled them (0: q|v, 1: k, 2: to_out)
-      DQ_TRY(conv_plain_bwd(c, ao, CONV_S1, c.w(a.o), c.g(a.attn_out), c.g(a.o), B, RT, RT, 0, ws_ok + 2));
+      DQ_TRY(conv_plain_bwd(c, ao, CONV_S1, c.w(a.o), c.g(a.attn_out), out_bwd_fused ? nullptr : c.g(a.o), B, RT, RT, 0, ws_ok + 2));  // (fused: the weight / bias gradient only)
       // (d mid1.out = d attn_out [the residual] + the PreNorm path: formed by the PreNorm backward below, which reads d attn_out as its addend --
       // was a k_axpy launch here plus one behind that kernel)
       DQ_TRY(launch_attn_bwd(c.w(a.qv), qvbs, c.w(a.kk), kbs, c.w(a.qv) + kbs, qvbs, c.w(a.o), c.g(a.o), c.w(a.lse), c.w(a.delta),

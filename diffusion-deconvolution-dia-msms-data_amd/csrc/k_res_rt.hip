@@ -22,6 +22,9 @@
 // PRE (the first block's backward): the back of that front runs as the prologue -- RoPE^T on d q, d xn = W_qv^T d qv (K = 256: the K-slot order
 // m = 8 q + 2 g + h puts a RoPE pair into one lane's consecutive steps), the PreNorm backward and the residual branch's gradient give the
 // block's d out in registers, in the layout the backward wants (three launches less: k_rope, a GEMM, k_block_bwd; d mid1.out never exists).
+// OUT (the second block): the back of the attention rides in FRONT of the block: attn_out = mid1.out + W_o o + b_o (K = 128) is formed on the
+// tile's 16 lanes, conv1's outer taps come from the neighbouring lanes (12 own positions then), and in the block's BACKWARD d o = W_o^T d attn_out
+// follows d x as an epilogue (two GEMM launches less).
 // Any RT length (k_res.hip: <= 512; longer axes took the unfused five-launch path).  Weight gradients: unchanged (k_conv_wgrad_multi reads
 // the dU1 / dU2 / a1 tensors written here).
 #include "dq_common.h"
@@ -57,8 +60,9 @@ constexpr int C = 16;
 constexpr int FWD_OWN = 14, BWD_OWN = 12;  // own positions of a 16-lane tile
 constexpr float SQC = 4.0f;                // sqrt(C)
 
-template <bool QKV>
-__global__ void __launch_bounds__(256) k_res_rt_fwd(ResFwd a, ResRtQkv q, int tiles_per_wave) {
+template <bool QKV, bool OUT>
+__global__ void __launch_bounds__(256) k_res_rt_fwd(ResFwd a, ResRtQkv q, ResRtOut ao, int tiles_per_wave) {
+  constexpr int HALO = OUT ? 2 : 1, OWN = 16 - 2 * HALO;  // OUT: the block's input is formed in the lanes, its neighbours come from them too
   // QKV: W_qv (256 x 16) and W_k (128 x 8) staged once per workgroup -- read from memory tile by tile inside the epilogue they were sixteen
   // memory round trips in a row (21 us per launch against 6 without the epilogue); the copy overlaps the block itself
   __shared__ __attribute__((aligned(16))) float wqv_l[QKV ? 256 * C : 4];
@@ -99,18 +103,40 @@ __global__ void __launch_bounds__(256) k_res_rt_fwd(ResFwd a, ResRtQkv q, int ti
   const int64_t base = (int64_t)b * C * n + (int64_t)(4 * g) * n;  // (sample, channel 4 g, position 0)
 #pragma unroll 1
   for (int t = 0; t < tiles_per_wave; ++t) {
-    const int p0 = (((int)blockIdx.x * 4 + wv) * tiles_per_wave + t) * FWD_OWN;
+    const int p0 = (((int)blockIdx.x * 4 + wv) * tiles_per_wave + t) * OWN;
     if (p0 >= n) break;  // (wave-uniform)
-    const int p = p0 - 1 + j;
-    const bool inr = p >= 0 && p < n, own = j >= 1 && j <= FWD_OWN && p < n;
+    const int p = p0 - HALO + j;
+    const bool inr = p >= 0 && p < n, own = j >= HALO && j < HALO + OWN && p < n;
     const bool okl = p - 1 >= 0 && p - 1 < n, okr = p + 1 >= 0 && p + 1 < n;
     float x[4][3];
+    if constexpr (OUT) {
+      // ---- the block's input = attn_out = res + W_o o + b_o (unet1d.py:563-567 + the Residual): K-step s takes o channel 4 s + g
+      const float* ob = ao.o + (int64_t)b * 128 * n + p;
+      float ov[32];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float* src = a.inA + base + (int64_t)r * n;
-      x[r][0] = okl ? src[p - 1] : 0.f;
-      x[r][1] = inr ? src[p] : 0.f;
-      x[r][2] = okr ? src[p + 1] : 0.f;
+      for (int st = 0; st < 32; ++st) ov[st] = inr ? ob[(int64_t)(4 * st + g) * n] : 0.f;
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < 32; st += 2) {
+        acc0 = mfma16(ao.w[j * 128 + 4 * st + g], ov[st], acc0);
+        acc1 = mfma16(ao.w[j * 128 + 4 * (st + 1) + g], ov[st + 1], acc1);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = inr ? (acc0[r] + acc1[r]) + ao.b[4 * g + r] + ao.res[base + (int64_t)r * n + p] : 0.f;
+        x[r][1] = v;
+        if (own) ao.out[base + (int64_t)r * n + p] = v;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { x[r][0] = from_left(x[r][1]); x[r][2] = from_right(x[r][1]); }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* src = a.inA + base + (int64_t)r * n;
+        x[r][0] = okl ? src[p - 1] : 0.f;
+        x[r][1] = inr ? src[p] : 0.f;
+        x[r][2] = okr ? src[p + 1] : 0.f;
+      }
     }
     // ---- conv1 -> u1 ; RMSNorm, (scale + 1, shift), SiLU -> a1 (zero outside the axis: conv2's padding)
     f32x4 u = {b1[0], b1[1], b1[2], b1[3]};
@@ -254,8 +280,8 @@ __device__ __forceinline__ void norm_act_bwd_lc(const float (&u)[4], float (&d)[
   for (int r = 0; r < 4; ++r) d[r] = clamped ? d[r] * inv : inv * (d[r] - uh[r] * dot);
 }
 
-template <bool PRE>
-__global__ void __launch_bounds__(256) k_res_rt_bwd(ResBwd a, ResRtPre q, int tiles_per_wave) {
+template <bool PRE, bool OUT>
+__global__ void __launch_bounds__(256) k_res_rt_bwd(ResBwd a, ResRtPre q, ResRtOut ao, int tiles_per_wave) {
   __shared__ float red[4][5 * C];
   // PRE: W_qv staged once per workgroup (as the forward's epilogue does): the prologue's 64 weight operands per lane are LDS reads, its 64
   // d qv operands ONE batch of loads (in four chunks of weights + gradients from memory the launch took 21 us against 6.5 without the prologue)
@@ -413,6 +439,23 @@ __global__ void __launch_bounds__(256) k_res_rt_bwd(ResBwd a, ResRtPre q, int ti
 #pragma unroll
       for (int r = 0; r < 4; ++r) a.dA[base + (int64_t)r * n + p] = dold[r] + dx[r];
     }
+    if constexpr (OUT) {
+      // ---- d o = W_o^T d attn_out (M = 128: eight tiles; K-step r takes channel 4 g + r of the gradient just formed)
+      float dt[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dt[r] = dold[r] + dx[r];
+      float* dob = ao.d_o + (int64_t)b * 128 * n + (int64_t)(4 * g) * n + p;
+#pragma unroll
+      for (int tm = 0; tm < 8; ++tm) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma16(ao.w[(4 * g + r) * 128 + 16 * tm + j], dt[r], acc);
+        if (own) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dob[(int64_t)(16 * tm + r) * n] = acc[r];
+        }
+      }
+    }
   }
   // ---- this workgroup's [d g2 | d g1 | d scale | d shift]: over the row's 16 positions (DPP), then over the four waves (fixed order)
 #pragma unroll
@@ -444,24 +487,30 @@ bool res_rt_usable(int C_, int cinA, int cinB, bool has_wr, int rows_per_sample)
   return rows_per_sample == 1 && C_ == C && cinA == C && cinB == 0 && !has_wr;
 }
 
-int launch_res_rt_fwd(const ResFwd& a, hipStream_t s, const ResRtQkv* q) {
-  DQ_REQUIRE(res_rt_usable(a.C, a.cinA, a.cinB, a.wr != nullptr, a.rows_per_sample) && a.n >= 1 && a.inA && a.out && a.ss,
+int launch_res_rt_fwd(const ResFwd& a, hipStream_t s, const ResRtQkv* q, const ResRtOut* ao) {
+  DQ_REQUIRE(res_rt_usable(a.C, a.cinA, a.cinB, a.wr != nullptr, a.rows_per_sample) && a.n >= 1 && (a.inA || ao) && a.out && a.ss,
              "res_rt_fwd: 16 channels, identity residual, one RT row per sample");
-  const int tpw = rt_tiles_per_wave(a.n, FWD_OWN);
-  const dim3 grid(cdiv(a.n, 4 * FWD_OWN * tpw), a.rows);
+  DQ_REQUIRE(!(q && ao), "res_rt_fwd: the attention front and back ride with different blocks");
+  const int own = ao ? 12 : FWD_OWN;
+  const int tpw = rt_tiles_per_wave(a.n, own);
+  const dim3 grid(cdiv(a.n, 4 * own * tpw), a.rows);
   if (q) {
     DQ_REQUIRE(q->gn && q->wqv && q->qv && (!q->kk || (q->wk && q->ms1f)), "res_rt_fwd: missing attention-front operand");
-    hipLaunchKernelGGL(k_res_rt_fwd<true>, grid, dim3(256), 0, s, a, *q, tpw);
+    hipLaunchKernelGGL((k_res_rt_fwd<true, false>), grid, dim3(256), 0, s, a, *q, ResRtOut{}, tpw);
+  } else if (ao) {
+    DQ_REQUIRE(ao->o && ao->w && ao->b && ao->res && ao->out, "res_rt_fwd: missing to_out operand");
+    hipLaunchKernelGGL((k_res_rt_fwd<false, true>), grid, dim3(256), 0, s, a, ResRtQkv{}, *ao, tpw);
   } else {
-    hipLaunchKernelGGL(k_res_rt_fwd<false>, grid, dim3(256), 0, s, a, ResRtQkv{}, tpw);
+    hipLaunchKernelGGL((k_res_rt_fwd<false, false>), grid, dim3(256), 0, s, a, ResRtQkv{}, ResRtOut{}, tpw);
   }
   DQ_LAUNCH_CHECK();
   return 0;
 }
 
-int launch_res_rt_bwd(const ResBwd& a, hipStream_t s, const ResRtPre* q) {
+int launch_res_rt_bwd(const ResBwd& a, hipStream_t s, const ResRtPre* q, const ResRtOut* ao) {
   DQ_REQUIRE(res_rt_usable(a.C, a.cinA, a.cinB, a.wr != nullptr, a.rows_per_sample) && a.n >= 1 && (a.dout || q) && a.u1 && a.u2 && a.du1 && a.du2 && a.ss,
              "res_rt_bwd: 16 channels, identity residual, one RT row per sample");
+  DQ_REQUIRE(!(q && ao), "res_rt_bwd: the attention front and back ride with different blocks");
   const int tpw = rt_tiles_per_wave(a.n, BWD_OWN);
   const dim3 grid(cdiv(a.n, 4 * BWD_OWN * tpw), a.rows);
   DQ_REQUIRE(a.gpart && a.gblocks && a.gpart_floats >= (int64_t)grid.x * grid.y * 4 * C, "res_rt_bwd: partial-sum slot missing or too small");
@@ -469,9 +518,12 @@ int launch_res_rt_bwd(const ResBwd& a, hipStream_t s, const ResRtPre* q) {
   if (q) {
     DQ_REQUIRE(q->dqv && q->wqv && q->x && q->gn && q->add && q->gn_part && q->gn_part_floats >= (int64_t)grid.x * grid.y * C,
                "res_rt_bwd: missing attention-front operand");
-    hipLaunchKernelGGL(k_res_rt_bwd<true>, grid, dim3(256), 0, s, a, *q, tpw);
+    hipLaunchKernelGGL((k_res_rt_bwd<true, false>), grid, dim3(256), 0, s, a, *q, ResRtOut{}, tpw);
+  } else if (ao) {
+    DQ_REQUIRE(ao->w && ao->d_o && a.dA, "res_rt_bwd: missing to_out operand");
+    hipLaunchKernelGGL((k_res_rt_bwd<false, true>), grid, dim3(256), 0, s, a, ResRtPre{}, *ao, tpw);
   } else {
-    hipLaunchKernelGGL(k_res_rt_bwd<false>, grid, dim3(256), 0, s, a, ResRtPre{}, tpw);
+    hipLaunchKernelGGL((k_res_rt_bwd<false, false>), grid, dim3(256), 0, s, a, ResRtPre{}, ResRtOut{}, tpw);
   }
   DQ_LAUNCH_CHECK();
   return 0;
