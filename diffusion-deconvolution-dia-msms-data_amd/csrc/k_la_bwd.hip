@@ -488,6 +488,18 @@ __global__ void __launch_bounds__(256, (DQ_LA_4_3W && C == 4 && N == 64) ? 3 : (
         for (int r = 0; r < 16; ++r) q[r] *= qs;
         return q;
       };
+      // the same with the sum over d taken from the C-row side: sum_d q dq = sum_d q sum_c M[d][c] dP[c] = sum_c dP[c] P[c] (P = M^T q, both in every
+      // lane of the position already): C FMAs in place of 16 + a cross-half swap
+      auto q_softmax_bwd_pp = [&](const f32x16& q, const f32x16& dq, const float (&dP)[C], const float (&P)[C]) {
+        float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) t = fmaf(dP[c], P[c], t);
+        t *= (1.0f / scale);
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = q[r] * (dq[r] - t);
+        return o;
+      };
       auto q_softmax_bwd = [&](const f32x16& q, const f32x16& dq) {
         float t = 0.f;
 #pragma unroll
@@ -540,7 +552,7 @@ __global__ void __launch_bounds__(256, (DQ_LA_4_3W && C == 4 && N == 64) ? 3 : (
           f32x16 dq = {0};
 #pragma unroll
           for (int j = 0; j < NJ; ++j) dq = mfma32b(own(Mr, j), own(dP, j), dq);
-          const f32x16 dq_raw = q_softmax_bwd(q, dq);
+          const f32x16 dq_raw = q_softmax_bwd_pp(q, dq, dP, P);
           add_dxh(b, 0, dq_raw);
           add_dw(gq, b, tr32(dq_raw, tile, col, half));
           const f32x16 qT = tr32(q, tile, col, half);  // Q^T (rows n, col d); (the fences inside tr32 also complete this block's ps / dps stores)
@@ -644,7 +656,7 @@ __global__ void __launch_bounds__(256, (DQ_LA_4_3W && C == 4 && N == 64) ? 3 : (
             const float mv = c < C ? ms[s * MS_ROW + (c < C ? c : 0) * 32 + col] : 0.f;
             dq = mfma32b(mv, rl == s ? own(dP, j) : 0.f, dq);
           }
-        const f32x16 dq_raw = q_softmax_bwd(q, dq);
+        const f32x16 dq_raw = q_softmax_bwd_pp(q, dq, dP, P);
         add_dxh(0, 0, dq_raw);
         add_dw(gq, 0, tr32(dq_raw, tile, col, half));
         const f32x16 qT = tr32(q, tile, col, half);  // rows n, col d
