@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(REPO, "diffusion-deconvolution-dia-msms-data_amd
 import torch
 from dquartic import _native as N
 L = N.lib()
-for C, n in ((12, 4), (12, 2), (16, 2), (16, 4), (8, 4)):
+for C, n in ((12, 4), (12, 2), (16, 2), (16, 4), (8, 4), (12, 8)):  # (rows of 8 positions: k_la_small against the register-resident kernel)
     for B in (32, 128, 512):
         rows = B * 400
         g = torch.Generator().manual_seed(0)
